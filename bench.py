@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py -- Wide&Deep training examples/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (EmbeddingField lookup -> FcLayer
+forward/backward -> fused Adam/Ftrl sparse update) over one synthetic
+Criteo-shaped batch, inputs already resident in HBM.  N=1 runs BASELINE
+configs[1]: 26 sparse fields x 100k vocab x 16-dim, 13 dense, FC[512,256,1],
+batch 4096, WideDeepNN with wideSize 100000.  For N>1 the driver launches one
+rank per GPU with torch.distributed.run; rows are hash-sharded across ranks
+(configs[2]) -- see ps_amd/sharded.py.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA peak (exact f32; no TF32 on gfx950)
+
+C2 = dict(F=26, V=100000, D=16, X=13, fc=[512, 256, 1], B=4096, wide=100000, zipf=1.05, seed=0x5EED)
+
+
+def synth_batch(cfg, rng, B=None):
+    """ids ~ Zipf(1.05) over V per field, dense ~ N(0,1), labels ~ Bernoulli(0.25),
+    wide ids = id mod wideSize (CTR.java:65, MatrixUtil.hash)."""
+    B = B or cfg["B"]
+    E = np.minimum(rng.zipf(cfg["zipf"], size=(B, cfg["F"])) - 1, cfg["V"] - 1).astype(np.int64)
+    X = rng.standard_normal((B, cfg["X"])).astype(np.float32)
+    Y = (rng.random(B) < 0.25).astype(np.float32)
+    return E, X, Y, E % cfg["wide"]
+
+
+def fc_flops_per_step(cfg):
+    # fwd 2*B*sum(in*out), bwd 4*B*sum(in*out)
+    dims = [cfg["F"] * cfg["D"] + cfg["X"]] + cfg["fc"]
+    s = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    return 6.0 * cfg["B"] * s, dims
+
+
+def group_algorithmic(cfg, name, nnz, uniq):
+    """Algorithmic work of one launch group (bytes for HBM-bound, flop for MFMA-bound)."""
+    B, D, F = cfg["B"], cfg["D"], cfg["F"]
+    dims = [F * D + cfg["X"]] + cfg["fc"]
+    if name == "emb_fwd":
+        return "hbm", nnz * (4.0 * D + 8.0)                       # row + int64 id (read roofline)
+    if name == "emb_bwd_update":
+        return "hbm", nnz * 4.0 * D + uniq * (3 * 4.0 * D * 2) + nnz * 8.0
+    for l in range(len(cfg["fc"])):
+        if name == "fc_fwd%d" % l:
+            return "mfma", 2.0 * B * dims[l] * dims[l + 1]
+        if name == "fc_bwd_dw%d" % l:
+            return "mfma", 2.0 * B * dims[l] * dims[l + 1]
+        if name == "fc_bwd_data%d" % l:
+            return "mfma", 2.0 * B * (dims[l] if l > 0 else F * D) * dims[l + 1]
+    return None, 0.0
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The restated reference CPU path (oracle, string keys + hash maps, thread = 1 as CTR.java:72
+    forces) timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(cfg["seed"])
+    st = orc.Store(cfg["seed"])
+    om = orc.Model(st, orc.WIDEDEEP, cfg["F"], cfg["D"], cfg["X"], cfg["fc"], wide_size=cfg["wide"])
+    n, t_total = 0, 0.0
+    E, X, Y, W = synth_batch(cfg, rng)
+    om.train(E.astype(np.float32), X, Y, W.astype(np.float32))          # warm-up (creates keys)
+    while t_total < budget_s and n < 8:
+        E, X, Y, W = synth_batch(cfg, rng)
+        t0 = time.perf_counter()
+        om.train(E.astype(np.float32), X, Y, W.astype(np.float32))
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": cfg["B"] * n / t_total, "unit": "examples/s", "cores": 1, "kind": "port",
+            "sample": "%d Wide&Deep steps of batch %d (same synthetic config) after 1 warm-up, oracle/ps_oracle.c "
+                      "restatement in compat mode (string keys, hash maps, thread=1)" % (n, cfg["B"])}
+
+
+def run_single(args):
+    import ps_amd
+    cfg = dict(C2)
+    rng = np.random.default_rng(cfg["seed"])
+    kv = ps_amd.KVStore(0, cfg["seed"])
+    kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
+    gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv,
+                                      max_batch=cfg["B"], use_graph=int(args.graph))
+    nb = 8   # rotate a few resident batches so the step does not see one batch only
+    batches = []
+    for _ in range(nb):
+        E, X, Y, W = synth_batch(cfg, rng)
+        batches.append(ps_amd.DeviceBatch(kv, E, X, Y, W))
+    uniq = sum(len(np.unique(E[:, f])) for f in range(cfg["F"]))
+    nnz = cfg["B"] * cfg["F"]
+    # warm-up, with every kernel group bracketed by events: finds the dominant kernel
+    gm.set_profile(True)
+    for i in range(max(args.warmup, 1)):
+        gm.train_async(batches[i % nb])
+    gm.sync()
+    prof = gm.profile_report()
+    dom = max(prof.items(), key=lambda kv_: kv_[1][1] / max(kv_[1][0], 1))[0]
+    gm.set_profile(True, only=dom)   # two events per step around the dominant kernel only
+    gm.sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gm.train_async(batches[i % nb])
+    gm.sync()
+    dt = time.perf_counter() - t0
+    rep = gm.profile_report()
+    gm.set_profile(False)
+    loss = gm.train(batches[0])
+    cnt, ms = rep[dom]
+    kind, work = group_algorithmic(cfg, dom, nnz, uniq)
+    avg_s = ms / cnt / 1e3
+    if kind == "mfma":
+        roof = {"kernel": dom, "bound": "mfma", "achieved": work / avg_s / 1e12, "peak": F32_MFMA_PEAK_TFS,
+                "unit": "TFLOP/s", "traffic": None}
+    else:
+        roof = {"kernel": dom, "bound": "hbm", "achieved": work / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "traffic": None}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["avg_launch_us"] = avg_s * 1e6
+    groups = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in prof.items()}
+    out = {
+        "metric": "Wide&Deep training examples/sec", "value": cfg["B"] * args.steps / dt, "unit": "examples/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Wide&Deep synthetic, 26 sparse fields x 100k vocab x 16-dim emb, "
+                               "13 dense, FC[512,256,1], batch 4096, Zipf(1.05) ids, Adam + Ftrl(wide), 1 MI355X",
+                   "global_batch": cfg["B"], "parallelism": "single", "resident_inputs": True, "hip_graph": bool(args.graph)},
+        "roofline": roof,
+        "kernel_groups_warmup": groups,
+        "final_loss": loss,
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    if args.gather:
+        out["gather_hbm"] = gather_roofline(kv, args)
+    for b in batches:
+        b.close()
+    gm.close(); kv.close()
+    return out
+
+
+def gather_roofline(kv, args):
+    """BASELINE config 4 shape: one table >> 256 MiB Infinity Cache, D=64, 2^22 random ids / launch."""
+    import ctypes as C
+    from ps_amd import native as N
+    res = []
+    for rows, D, n, bag in ((args.gather_rows, 64, 1 << 22, 1), (args.gather_rows, 64, 1 << 17, 32)):
+        ms, br, bw = C.c_double(), C.c_double(), C.c_double()
+        N.check(N.lib().ps_bench_gather(kv.h, rows, D, n, bag, 20, 0x5EED, C.byref(ms), C.byref(br), C.byref(bw)))
+        res.append({"rows": rows, "D": D, "lookups": n * bag, "bag": bag, "table_GB": rows * D * 4 / 1e9,
+                    "avg_launch_us": ms.value * 1e3, "read_GBs": br.value / ms.value / 1e6,
+                    "read_plus_write_GBs": (br.value + bw.value) / ms.value / 1e6,
+                    "frac_of_8TBs_read": br.value / ms.value / 1e6 / HBM_PEAK_GBS,
+                    "frac_of_8TBs_read_plus_write": (br.value + bw.value) / ms.value / 1e6 / HBM_PEAK_GBS})
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather", type=int, default=1)
+    ap.add_argument("--gather-rows", type=int, default=64 * 1000 * 1000)   # 16.4 GB at D=64
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from ps_amd import sharded
+        out = sharded.run_bench(args, C2, synth_batch)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return
+    out = run_single(args)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+/*
+ * ps_native.h -- C ABI of libps_amd.so: the MI355X-native replacement for the
+ * wudikua/ps training hot path (EmbeddingField lookup -> FcLayer WX+B
+ * forward/backward -> Adam/FTRL sparse update -> key-sharded push/pull).
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI layer; its seams are four plain Java types, and every entry point
+ * below names the reference interface it replaces
+ * (paths relative to /root/reference/src/main/java/):
+ *
+ *   store.KVStore            store/KVStore.java:33-299     -> ps_store_*
+ *   update.Updater           update/Updater.java:6-11      -> ps_updater_*
+ *   layer.Layer (+ fields)   layer/Layer.java:12-78        -> ps_emb_* / ps_fc_* / ps_model_*
+ *   net.PSClient/Router      net/PSClient.java:47-186,
+ *                            net/PSRouterClient.java:55-151,
+ *                            net/Mod.java:13-15            -> ps_router_* / ps_shard_*
+ *
+ * Conventions
+ *  - every function returns an int status: PS_OK (== Resp.ec 200,
+ *    net/PServer.java:28), PS_MISSING (204, net/PServer.java:84),
+ *    PS_NO_UPDATER (500, net/PServer.java:172), or a negative PS_E_* code.
+ *    Nothing throws or aborts; ps_last_error() gives the text.
+ *  - plain pointers and sizes only.  Host float buffers use the reference's
+ *    byte layout: a FloatMatrix "features x B" (column-major) IS a row-major
+ *    [B][features] array; a weight "out x in" IS row-major [in][out].
+ *  - pointers named *_dev are HIP device pointers on the store's device;
+ *    everything else is host memory owned by the caller.
+ *  - ids are int64 (the reference carries them as float and formats them
+ *    with Float.toString -- exact only below 2^24; string keys such as
+ *    "emF13.28305.0" are accepted by ps_store_get/put for parity).
+ *  - one ps_store_t per GPU; calls on one store are serialised by the
+ *    caller (as the reference serialises on the KVStore monitor,
+ *    store/KVStore.java:109,136,192,202).
+ */
+#ifndef PS_NATIVE_H
+#define PS_NATIVE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------- */
+#define PS_OK 0            /* Resp.ec 200 */
+#define PS_MISSING 204     /* key / row absent            (net/PServer.java:84) */
+#define PS_NO_UPDATER 500  /* updater name unknown        (net/PServer.java:172) */
+#define PS_E_BAD_ARG (-1)
+#define PS_E_HIP (-2)      /* a HIP call failed / no device */
+#define PS_E_UNSUPPORTED (-3)
+#define PS_E_STATE (-4)    /* call order violated */
+
+const char *ps_last_error(void);
+/* library / build identification: "ps_amd <ver> gfx950 hip" */
+const char *ps_version(void);
+int ps_device_count(int *count);
+
+/* ---- update.Updater -------------------------------------------------- */
+enum { PS_UPD_ADAM = 0, PS_UPD_FTRL = 1, PS_UPD_SIMPLE = 2 };
+typedef struct ps_updater {
+    int kind;
+    float alfa;                 /* Adam / Ftrl learning rate ("alfa" sic) */
+    float beta1, beta2, epsilon;/* update/AdamUpdater.java:25-30          */
+    float beta, l1, l2;         /* update/FtrlUpdater.java:25-30          */
+    float eta;                  /* update/SimpleUpdater.java:11           */
+} ps_updater_t;
+/* model/DNN.java:95 : Adam(0.005, 0.9, 0.999, 1e-8) */
+void ps_updater_default_adam(ps_updater_t *u);
+/* model/WideDeepNN.java:109 : Ftrl(0.005, 1, 0.001, 0.001) */
+void ps_updater_default_ftrl(ps_updater_t *u);
+/* Updater.getName(): "adam@alfa:0.005@beta1:0.9@beta2:0.999@epsilon:1.0E-8@",
+ * Ftrl (also prefixed adam@, update/FtrlUpdater.java:78-80)
+ * "adam@alfa:0.005@beta:1.0@l1:0.001@l2:0.001@", "simple@eta:..@".
+ * The PS looks updaters up by exactly this string (net/PServer.java:169). */
+int ps_updater_name(const ps_updater_t *u, char *buf, int cap);
+/* AdamUpdater(String) / FtrlUpdater(String) / SimpleUpdater(String).
+ * Unknown name -> PS_NO_UPDATER. */
+int ps_updater_from_name(const char *name, ps_updater_t *out);
+
+/* ---- net.Router / net.Mod -------------------------------------------- */
+enum { PS_ROUTE_ID_MOD = 0,      /* native default: id mod n                      */
+       PS_ROUTE_JAVA_STRING = 1  /* floorMod(String.hashCode("emF<f>.<id>.0"), n) */ };
+/* java.lang.String.hashCode (net/Mod.java:14) */
+int32_t ps_java_string_hash(const char *key);
+/* net/Mod.java:13-15 with the floorMod fix (Java % can go negative). */
+int ps_router_shard_key(const char *key, int nshards);
+/* shard of embedding id `id` of field `field` under `route_mode` */
+int ps_router_shard_id(int route_mode, int field, int64_t id, int nshards);
+
+/* ---- store.KVStore : one GPU-resident shard -------------------------- */
+typedef struct ps_store ps_store_t;
+
+/* KVStore.ins() for device `device`; `seed` drives the counter-based row
+ * init that replaces util/MatrixUtil.java:62-74 (unseeded RandomUtils). */
+int ps_store_create(int device, uint64_t seed, ps_store_t **out);
+int ps_store_destroy(ps_store_t *s);
+int ps_store_device(const ps_store_t *s);
+
+/* Embedding tables "emF0".."emF<F-1>" (layer/EmbeddingLayer.java:50-57):
+ * F per-field tables of rows[f] x D floats, rows initialised
+ * +-U(0, 4*sqrt(6)/sqrt(1+D)) (layer/EmbeddingField.java:40-46) as a pure
+ * function of (seed, field, id).  Updater state lives beside the rows.
+ * shard/nshards: this store holds the ids with
+ * ps_router_shard_id(route_mode, f, id, nshards) == shard, densely packed.
+ * state_slots: 2 for Adam {M,V} / Ftrl {Z,N}, 0 = weights only (gather runs). */
+int ps_store_create_embedding(ps_store_t *s, int F, const int64_t *rows, int D,
+                              int state_slots, int shard, int nshards, int route_mode);
+/* Wide table "wide.weights.<id>" + "wide.bias" (layer/LRLayer.java:37-52): zeros. */
+int ps_store_create_wide(ps_store_t *s, int64_t wide_size);
+/* Dense tensors "fc<i>.weights" (out x in) / "fc<i>.bias" (out x 1),
+ * init +-U(0, 4*sqrt(6)/sqrt(in+out)) / (in+1)  (layer/FcLayer.java:34-50). */
+int ps_store_create_fc(ps_store_t *s, int layer, int in_dims, int out_dims);
+
+/* "default" / "wide.weights" / "wide.bias" / "emF" ... -> updater
+ * (the Map<String,Updater> of model/DNN.java:33, looked up exact-key, then
+ * prefix, then "default": store/KVStore.java:242-252). */
+int ps_store_set_updater(ps_store_t *s, const char *key_or_prefix, const ps_updater_t *u);
+
+/* KVStore.get(key) / put(key,val) by reference-style string key:
+ *   "emF<f>.<id>.0" (D floats), "wide.weights.<id>.0" (1), "wide.bias" (1),
+ *   "fc<i>.weights" (out*in, reference layout [in][out]), "fc<i>.bias" (out).
+ * get: *len receives the element count; PS_MISSING when the key is not
+ * held by this shard (store/KVStore.java:129-134 returns null). */
+int ps_store_get(ps_store_t *s, const char *key, float *out, int cap, int *len);
+int ps_store_put(ps_store_t *s, const char *key, const float *val, int len);
+/* Bulk row access: KVStore.get/put for n ids of one field
+ * (= PSClient.getList / updateList, net/PSClient.java:72-98,128-151).
+ * which: 0 weights, 1/2 = updater state slot 0/1 ({M,V} or {Z,N}). */
+int ps_store_get_rows(ps_store_t *s, int field, const int64_t *ids, int64_t n, int which, float *out);
+int ps_store_put_rows(ps_store_t *s, int field, const int64_t *ids, int64_t n, int which, const float *val);
+int ps_store_get_wide(ps_store_t *s, const int64_t *ids, int64_t n, int which, float *out);
+int ps_store_put_wide(ps_store_t *s, const int64_t *ids, int64_t n, int which, const float *val);
+/* AtomicLong globalStep (net/PServer.java:40): one per applied update round. */
+int64_t ps_store_global_step(const ps_store_t *s);
+/* bytes of HBM held by the store */
+int64_t ps_store_bytes(const ps_store_t *s);
+
+/* ---- layer.Layer : the model graph on one GPU ------------------------- */
+typedef struct ps_model ps_model_t;
+enum { PS_MODEL_DNN = 0,       /* model/DNN.java:92-128            */
+       PS_MODEL_WIDEDEEP = 1   /* model/WideDeepNN.java:105-161    */ };
+enum { PS_GRAD_COMPAT = 0,     /* reference arithmetic incl. the double-backward
+                                  factor (n+1)/(2n^2) and the
+                                  "every wide key ever seen" gradient (A.10)   */
+       PS_GRAD_INTENDED = 1    /* mean over occurrences / per-key presence sum */ };
+enum { PS_ACT_NONE = 0, PS_ACT_RELU = 1, PS_ACT_SIGMOID = 2 };
+
+typedef struct ps_model_config {
+    int kind;            /* PS_MODEL_*                                        */
+    int F, D, X;         /* embeddingFieldNum, embeddingSize, numberFieldNum  */
+    int nfc;             /* fcLayerDims.length (<= 8)                         */
+    int fc_dims[8];      /* e.g. {512,256,1}; last layer sigmoid (DNN) / none */
+    int64_t wide_size;   /* CTR.wideSize (CTR.java:35); 0 for DNN            */
+    int max_batch;       /* largest B ever passed                             */
+    int64_t max_nnz;     /* largest number of ids per batch (B*F if single-hot) */
+    int emb_grad_mode;   /* PS_GRAD_*                                         */
+    int wide_grad_mode;  /* PS_GRAD_*                                         */
+    int use_graph;       /* 1: replay the step as a hipGraph                  */
+} ps_model_config_t;
+
+/* One minibatch.  Single-hot (the reference): offsets == NULL and ids is
+ * [B][F] (the bytes of the F x B matrix "E", CTR.java:47-68).  Multi-hot:
+ * offsets[B*F+1] is a CSR over bags in (sample, field) order, sum pooling.
+ * on_device != 0: every pointer is a device pointer (inputs resident in HBM). */
+typedef struct ps_batch {
+    int B;
+    const int64_t *ids;       /* nnz ids, bag-major                          */
+    const int64_t *offsets;   /* NULL or [B*F+1]                             */
+    const float *dense;       /* [B][X]   ("X")                              */
+    const float *labels;      /* [B]      ("Y"); NULL for predict            */
+    const int64_t *wide_ids;  /* [B][F]   ("W" = E mod wideSize); WideDeep   */
+    int on_device;
+} ps_batch_t;
+
+/* DNN.buildModel / WideDeepNN.buildModel over the store's parameters
+ * (creates any of them that do not exist yet, as the lazy
+ * kvStore.get(key, init) does). */
+int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_model_t **out);
+int ps_model_destroy(ps_model_t *m);
+
+/* One training step for thread = 1:
+ *   TrainerThread.call (train/TrainerThread.java:29-39): pullWeights + Model.train
+ *   Trainer.train tail (train/Trainer.java:90-100): KVStore.update(updaters), clear, step++
+ * Asynchronous on the store's stream; *loss is written when loss != NULL
+ * (that forces a sync).  Training stops backward when loss <= 0.01 or NaN
+ * (model/DNN.java:58-63), exactly as the reference. */
+int ps_model_train(ps_model_t *m, const ps_batch_t *batch, float *loss);
+/* Split form of the same step, for hosts that drive Layer.forward /
+ * Layer.backward / KVStore.update themselves (and for the sharded path):
+ *   forward  = layers forward + loss            (model/DNN.java:44-49)
+ *   backward = loss.backward + layers backward  (model/DNN.java:50,64-68);
+ *              gradients are left in the store's pending set (= KVStore.sum)
+ *   update   = KVStore.update(Map) + clear      (store/KVStore.java:240-277) */
+int ps_model_forward(ps_model_t *m, const ps_batch_t *batch, float *loss);
+int ps_model_backward(ps_model_t *m);
+int ps_model_update(ps_model_t *m);
+/* Model.predict (model/DNN.java:78-90): forward only, P[B] to host. */
+int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p_out);
+int ps_model_sync(ps_model_t *m);
+/* last loss computed on device (syncs) */
+int ps_model_last_loss(ps_model_t *m, float *loss);
+
+/* Intermediates of the last step, copied to host in the reference layout
+ * (for parity tests: Layer.A / Layer.delta, layer/Layer.java:16-18).
+ * layer: 0 embedding A [B][F*D]; 1 concat A [B][F*D+X]; 2+i fc_i A [B][out_i].
+ * delta: 2+i = fc_i.delta = W^T delta [B][in_i] (layer/FcLayer.java:108);
+ *        for i = 0 the embedding columns are already masked by relu'. */
+int ps_model_get_act(ps_model_t *m, int layer, float *out, int64_t cap, int *rows, int *cols);
+int ps_model_get_delta(ps_model_t *m, int layer, float *out, int64_t cap, int *rows, int *cols);
+int ps_model_get_p(ps_model_t *m, float *out, int cap);
+/* Per-key gradient handed to the updater in the last step (after /cnt):
+ * unique embedding rows of field `field`: ids_out[n], grads_out[n][D];
+ * n_out receives the count (call with NULL outputs to size). */
+int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out, float *grads_out,
+                           int64_t cap_rows, int64_t *n_out);
+/* dense gradient of "fc<i>.weights" ([in][out]) / "fc<i>.bias" as given to the updater */
+int ps_model_get_fc_grad(ps_model_t *m, int layer, int bias, float *out, int cap);
+
+/* ---- stand-alone hot-path operators (what a GpuEmbeddingLayer /
+ *      GpuFcLayer JNI shim binds one-to-one) ------------------------------ */
+/* Device buffers for hosts without their own HIP binding (the JNI shim keeps
+ * these as long handles). */
+int ps_dev_alloc(ps_store_t *s, size_t bytes, void **out_dev);
+int ps_dev_free(ps_store_t *s, void *p_dev);
+int ps_dev_upload(ps_store_t *s, void *dst_dev, const void *src_host, size_t bytes);
+int ps_dev_download(ps_store_t *s, void *dst_host, const void *src_dev, size_t bytes);
+/* EmbeddingLayer.forward (layer/EmbeddingLayer.java:25-48) for all fields:
+ * out_dev[b][f*D + d] = act(sum over the bag of table_f[id][d]); ld = row
+ * stride of out_dev in floats.  ids/offsets as in ps_batch_t (device). */
+int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets_dev,
+                   int B, int act, float *out_dev, int ld);
+/* FcLayer.forward (layer/FcLayer.java:74-91): y = act(W x + b).
+ * x_dev [B][ldx]: ldx must be a multiple of 16 with ldx > in and
+ * x_dev[b][in] == 1.0 (the bias rides in the GEMM as a ones column; columns
+ * in+1..ldx-1 zero).  y_dev [B][ldy], ldy >= out. */
+int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx,
+                  int B, float *y_dev, int ldy);
+int ps_store_sync(ps_store_t *s);
+
+/* ---- measurement hooks ------------------------------------------------ */
+/* Large-table gather run (BASELINE config 4): one table of rows x D floats
+ * filled on device (no host copy), n bags of `bag` uniform-random ids,
+ * `iters` launches of the forward gather timed with HIP events on the
+ * store's stream.  Reports the average kernel time and the algorithmic
+ * bytes per launch (read = nnz*(4D+8) [+ 8*(n+1) offsets],
+ * written = 4*n*D). */
+int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, int iters,
+                    uint64_t seed, double *avg_ms_out, double *bytes_read_out,
+                    double *bytes_written_out);
+/* Run `steps` training steps on `batch` back to back, timed with HIP events
+ * on the store's stream (ms for all steps). */
+int ps_model_time_steps(ps_model_t *m, const ps_batch_t *batch, int steps, double *ms_out);
+/* Per-kernel-group HIP-event timing: while enabled every kernel group of the
+ * step is bracketed by events on the store's stream; the report is a
+ * ';'-separated list of name:launches:total_ms. */
+int ps_model_set_profile(ps_model_t *m, int enabled);
+/* bracket only the named kernel group (two events per step: cheap enough to
+ * leave on inside a timed region); NULL/"" = all groups */
+int ps_model_set_profile_filter(ps_model_t *m, const char *group);
+int ps_model_profile_report(ps_model_t *m, char *report, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

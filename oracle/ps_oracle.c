@@ -621,7 +621,8 @@ static void forward(orc_model *m, const float *E, const float *Xd, const float *
     m->P = m->fc[m->nfc - 1].A;
     if (m->kind == ORC_WIDEDEEP) {
         /* ---- LRLayer.forward  layer/LRLayer.java:62-98 ---- */
-        sent *bias = smap_get(&m->st->store, "wide.bias");
+        /* the matrix itself is stable; entry pointers are not (the map grows below) */
+        const float *biasd = smap_get(&m->st->store, "wide.bias")->data;
         m->wideZ = (float *)malloc(sizeof(float) * B);
         for (int i = 0; i < B; ++i) {
             float sumW = 0.f;
@@ -637,7 +638,7 @@ static void forward(orc_model *m, const float *E, const float *Xd, const float *
             }
             m->wideZ[i] = sumW;
         }
-        for (int i = 0; i < B; ++i) m->wideZ[i] += bias->data[0];               /* addiColumnVector :84 */
+        for (int i = 0; i < B; ++i) m->wideZ[i] += biasd[0];              /* addiColumnVector :84 */
         /* ---- AddLayer.forward  layer/AddLayer.java:33-48 ---- */
         m->addA = (float *)malloc(sizeof(float) * B);
         for (int i = 0; i < B; ++i) m->addA[i] = orc_sigmoid_clip(m->fc[m->nfc - 1].A[i] + m->wideZ[i]);

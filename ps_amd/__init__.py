@@ -1,0 +1,13 @@
+"""ps_amd -- MI355X-native hot path of the wudikua/ps parameter-server trainer.
+
+The package is a thin host mirror (api.py) over the C ABI of
+include/ps_native.h, implemented by hand-written HIP kernels for gfx950
+(csrc/).  Importing the package does not load the shared object; the first
+use does, and fails loudly if it was not built (`python -m ps_amd.build`).
+"""
+from . import native  # noqa: F401
+from .api import (AdamUpdater, Batch, DeviceBatch, DNN, FtrlUpdater, KVStore, Mod, SimpleUpdater, Trainer,  # noqa: F401
+                  Updater, WideDeepNN, java_string_hash)
+
+__all__ = ["AdamUpdater", "Batch", "DeviceBatch", "DNN", "FtrlUpdater", "KVStore", "Mod", "SimpleUpdater", "Trainer",
+           "Updater", "WideDeepNN", "java_string_hash", "native"]

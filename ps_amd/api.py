@@ -1,0 +1,434 @@
+"""Host-side mirror of the reference's interface for the hot path, over the
+C ABI (include/ps_native.h).  Same names, argument meaning and error
+behaviour as the Java types so the parity tests read like the reference:
+
+    update.AdamUpdater / FtrlUpdater / SimpleUpdater   update/*.java
+    net.Mod (Router)                                   net/Mod.java:13-15
+    store.KVStore                                      store/KVStore.java
+    model.DNN / model.WideDeepNN (buildModel, train,
+        predict, pullWeights, getUpdater)              model/DNN.java, model/WideDeepNN.java
+    train.Trainer (thread = 1)                         train/Trainer.java:70-101
+
+Arrays use the reference's byte layout: a FloatMatrix "features x B"
+(column-major) is a numpy [B, features] array.  The HIP library is the only
+compute path; nothing here falls back to numpy.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native as N
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+# ---------------------------------------------------------------------------
+# update.Updater
+# ---------------------------------------------------------------------------
+class Updater:
+    def __init__(self, st):
+        self._s = st
+
+    def getName(self):
+        buf = C.create_string_buffer(160)
+        N.check(N.lib().ps_updater_name(C.byref(self._s), buf, 160))
+        return buf.value.decode()
+
+    @staticmethod
+    def fromName(name):
+        """AdamUpdater(String) / FtrlUpdater(String) / SimpleUpdater(String);
+        an unknown name is Resp 500 (net/PServer.java:169-175)."""
+        st = N.ps_updater_t()
+        N.check(N.lib().ps_updater_from_name(name.encode(), C.byref(st)))
+        return Updater(st)
+
+    @property
+    def kind(self):
+        return self._s.kind
+
+
+class AdamUpdater(Updater):
+    def __init__(self, alfa=0.005, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        st = N.ps_updater_t()
+        st.kind = N.PS_UPD_ADAM
+        st.alfa, st.beta1, st.beta2, st.epsilon = alfa, beta1, beta2, epsilon   # (float) casts, AdamUpdater.java:43-48
+        super().__init__(st)
+
+
+class FtrlUpdater(Updater):
+    def __init__(self, alfa=0.005, beta=1.0, l1=0.001, l2=0.001):
+        st = N.ps_updater_t()
+        st.kind = N.PS_UPD_FTRL
+        st.alfa, st.beta, st.l1, st.l2 = alfa, beta, l1, l2
+        super().__init__(st)
+
+
+class SimpleUpdater(Updater):
+    def __init__(self, eta):
+        st = N.ps_updater_t()
+        st.kind = N.PS_UPD_SIMPLE
+        st.eta = eta
+        super().__init__(st)
+
+
+# ---------------------------------------------------------------------------
+# net.Router
+# ---------------------------------------------------------------------------
+class Mod:
+    """net/Mod.java with the floorMod fix (Java % goes negative)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def shard(self, key):
+        return N.lib().ps_router_shard_key(key.encode(), self.n)
+
+
+def java_string_hash(key):
+    return N.lib().ps_java_string_hash(key.encode())
+
+
+# ---------------------------------------------------------------------------
+# store.KVStore
+# ---------------------------------------------------------------------------
+class KVStore:
+    """One GPU-resident shard.  `KVStore.ins(device)` mirrors the singleton."""
+
+    _ins = {}
+
+    def __init__(self, device=0, seed=0):
+        h = C.c_void_p()
+        N.check(N.lib().ps_store_create(device, seed, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    @classmethod
+    def ins(cls, device=0, seed=0):
+        if device not in cls._ins:
+            cls._ins[device] = cls(device, seed)
+        return cls._ins[device]
+
+    def close(self):
+        if getattr(self, "h", None):
+            N.lib().ps_store_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- tables
+    def create_embedding(self, rows, D, state_slots=2, shard=0, nshards=1, route_mode=N.PS_ROUTE_ID_MOD):
+        rows = np.ascontiguousarray(rows, np.int64)
+        N.check(N.lib().ps_store_create_embedding(self.h, len(rows), _ip(rows), D, state_slots, shard, nshards, route_mode))
+        self.F, self.D = len(rows), D
+
+    def create_wide(self, wide_size):
+        N.check(N.lib().ps_store_create_wide(self.h, wide_size))
+
+    def create_fc(self, layer, in_dims, out_dims):
+        N.check(N.lib().ps_store_create_fc(self.h, layer, in_dims, out_dims))
+
+    def set_updater(self, key, updater):
+        N.check(N.lib().ps_store_set_updater(self.h, key.encode(), C.byref(updater._s)))
+
+    # -- KVStore.get / put
+    def get(self, key, cap=1 << 22):
+        """KVStore.get(key): None when the key is absent (store/KVStore.java:129-134)."""
+        out = np.empty(cap, np.float32)
+        n = C.c_int()
+        rc = N.lib().ps_store_get(self.h, key.encode(), _fp(out), cap, C.byref(n))
+        if rc == N.PS_MISSING:
+            return None
+        N.check(rc)
+        return out[:n.value].copy()
+
+    def put(self, key, val):
+        val = np.ascontiguousarray(val, np.float32).ravel()
+        N.check(N.lib().ps_store_put(self.h, key.encode(), _fp(val), val.size))
+
+    def get_rows(self, field, ids, which=0, D=None):
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.empty((len(ids), D or self.D), np.float32)
+        N.check(N.lib().ps_store_get_rows(self.h, field, _ip(ids), len(ids), which, _fp(out)))
+        return out
+
+    def put_rows(self, field, ids, val, which=0):
+        ids = np.ascontiguousarray(ids, np.int64)
+        val = np.ascontiguousarray(val, np.float32)
+        N.check(N.lib().ps_store_put_rows(self.h, field, _ip(ids), len(ids), which, _fp(val)))
+
+    def get_wide(self, ids, which=0):
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.empty(len(ids), np.float32)
+        N.check(N.lib().ps_store_get_wide(self.h, _ip(ids), len(ids), which, _fp(out)))
+        return out
+
+    def put_wide(self, ids, val, which=0):
+        ids = np.ascontiguousarray(ids, np.int64)
+        val = np.ascontiguousarray(val, np.float32)
+        N.check(N.lib().ps_store_put_wide(self.h, _ip(ids), len(ids), which, _fp(val)))
+
+    def global_step(self):
+        return N.lib().ps_store_global_step(self.h)
+
+    def bytes(self):
+        return N.lib().ps_store_bytes(self.h)
+
+    def sync(self):
+        N.check(N.lib().ps_store_sync(self.h))
+
+
+# ---------------------------------------------------------------------------
+# model.DNN / model.WideDeepNN
+# ---------------------------------------------------------------------------
+class Batch:
+    """Keeps the numpy arrays alive behind a ps_batch_t."""
+
+    def __init__(self, E, X, Y=None, W=None, offsets=None):
+        self.E = np.ascontiguousarray(E, np.int64)
+        self.X = None if X is None else np.ascontiguousarray(X, np.float32)
+        self.Y = None if Y is None else np.ascontiguousarray(Y, np.float32).ravel()
+        self.W = None if W is None else np.ascontiguousarray(W, np.int64)
+        self.offsets = None if offsets is None else np.ascontiguousarray(offsets, np.int64)
+        b = N.ps_batch_t()
+        if self.offsets is not None:
+            b.B = int(self.X.shape[0]) if self.X is not None else int(self.Y.size)
+        else:
+            b.B = int(self.E.shape[0])
+        b.ids = self.E.ctypes.data
+        b.offsets = None if self.offsets is None else self.offsets.ctypes.data
+        b.dense = None if self.X is None else self.X.ctypes.data
+        b.labels = None if self.Y is None else self.Y.ctypes.data
+        b.wide_ids = None if self.W is None else self.W.ctypes.data
+        b.on_device = 0
+        self.c = b
+
+
+class DeviceBatch:
+    """A minibatch resident in HBM (ps_batch_t.on_device = 1): what the bench
+    times against, so that `value` excludes the PCIe hand-over."""
+
+    def __init__(self, store, E, X, Y=None, W=None, offsets=None):
+        self.store = store
+        self._bufs = []
+        host = Batch(E, X, Y, W, offsets)
+
+        def up(a):
+            if a is None:
+                return None
+            p = C.c_void_p()
+            N.check(N.lib().ps_dev_alloc(store.h, a.nbytes, C.byref(p)))
+            N.check(N.lib().ps_dev_upload(store.h, p, a.ctypes.data, a.nbytes))
+            self._bufs.append(p)
+            return p.value
+
+        b = N.ps_batch_t()
+        b.B = host.c.B
+        b.ids, b.offsets, b.dense = up(host.E), up(host.offsets), up(host.X)
+        b.labels, b.wide_ids = up(host.Y), up(host.W)
+        b.on_device = 1
+        self.c = b
+        self.nnz = int(host.E.size)
+
+    def close(self):
+        for p in self._bufs:
+            N.lib().ps_dev_free(self.store.h, p)
+        self._bufs = []
+
+    def __del__(self):
+        try:
+            if getattr(self.store, "h", None):
+                self.close()
+        except Exception:
+            pass
+
+
+class _Model:
+    KIND = N.PS_MODEL_DNN
+
+    def __init__(self, store, F, D, X, fc_dims, wide_size=0, max_batch=4096, max_nnz=0,
+                 emb_grad_mode=N.PS_GRAD_COMPAT, wide_grad_mode=N.PS_GRAD_COMPAT, use_graph=0):
+        self.store = store
+        cfg = N.ps_model_config_t()
+        cfg.kind = self.KIND
+        cfg.F, cfg.D, cfg.X, cfg.nfc = F, D, X, len(fc_dims)
+        for i, d in enumerate(fc_dims):
+            cfg.fc_dims[i] = d
+        cfg.wide_size = wide_size
+        cfg.max_batch, cfg.max_nnz = max_batch, max_nnz
+        cfg.emb_grad_mode, cfg.wide_grad_mode, cfg.use_graph = emb_grad_mode, wide_grad_mode, use_graph
+        self.cfg = cfg
+        self.F, self.D, self.X, self.fc_dims = F, D, X, list(fc_dims)
+        h = C.c_void_p()
+        N.check(N.lib().ps_model_create(store.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._updater = {"default": AdamUpdater()}
+
+    def close(self):
+        if getattr(self, "h", None):
+            N.lib().ps_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def getUpdater(self):
+        return self._updater
+
+    def pullWeights(self):
+        """Model.pullWeights: parameters live in HBM behind the store; nothing to fetch."""
+
+    @staticmethod
+    def _batch(datas):
+        if isinstance(datas, (Batch, DeviceBatch)):
+            return datas
+        return Batch(datas["E"], datas.get("X"), datas.get("Y"), datas.get("W"), datas.get("offsets"))
+
+    def train(self, datas):
+        """TrainerThread.call + the KVStore.update/clear tail of Trainer.train; returns the loss."""
+        b = self._batch(datas)
+        loss = C.c_float()
+        N.check(N.lib().ps_model_train(self.h, C.byref(b.c), C.byref(loss)))
+        return loss.value
+
+    def train_async(self, batch):
+        N.check(N.lib().ps_model_train(self.h, C.byref(batch.c), None))
+
+    def forward(self, datas):
+        b = self._batch(datas)
+        self._last = b
+        loss = C.c_float()
+        N.check(N.lib().ps_model_forward(self.h, C.byref(b.c), C.byref(loss)))
+        return loss.value
+
+    def backward(self):
+        N.check(N.lib().ps_model_backward(self.h))
+
+    def update(self):
+        N.check(N.lib().ps_model_update(self.h))
+
+    def predict(self, datas):
+        b = self._batch(datas)
+        out = np.empty(b.c.B, np.float32)
+        N.check(N.lib().ps_model_predict(self.h, C.byref(b.c), _fp(out)))
+        return out
+
+    def sync(self):
+        N.check(N.lib().ps_model_sync(self.h))
+
+    # -- intermediates (Layer.A / Layer.delta) for parity tests
+    def _get2d(self, fn, layer):
+        r, c = C.c_int(), C.c_int()
+        N.check(fn(self.h, layer, None, 0, C.byref(r), C.byref(c)))
+        out = np.empty((c.value, r.value), np.float32)       # [B][features]
+        N.check(fn(self.h, layer, _fp(out), out.size, C.byref(r), C.byref(c)))
+        return out
+
+    def act(self, layer):
+        return self._get2d(N.lib().ps_model_get_act, layer)
+
+    def delta(self, layer):
+        return self._get2d(N.lib().ps_model_get_delta, layer)
+
+    def p(self, B):
+        out = np.empty(B, np.float32)
+        N.check(N.lib().ps_model_get_p(self.h, _fp(out), B))
+        return out
+
+    def emb_grads(self, field):
+        n = C.c_int64()
+        N.check(N.lib().ps_model_get_emb_grads(self.h, field, None, None, 0, C.byref(n)))
+        ids = np.empty(n.value, np.int64)
+        g = np.empty((n.value, self.D), np.float32)
+        N.check(N.lib().ps_model_get_emb_grads(self.h, field, _ip(ids), _fp(g), n.value, C.byref(n)))
+        return ids, g
+
+    def fc_grad(self, layer, bias=False):
+        inn = (self.F * self.D + self.X) if layer == 0 else self.fc_dims[layer - 1]
+        n = self.fc_dims[layer] if bias else inn * self.fc_dims[layer]
+        out = np.empty(n, np.float32)
+        N.check(N.lib().ps_model_get_fc_grad(self.h, layer, int(bias), _fp(out), n))
+        return out
+
+    # -- measurement
+    def time_steps(self, batch, steps):
+        ms = C.c_double()
+        N.check(N.lib().ps_model_time_steps(self.h, C.byref(batch.c), steps, C.byref(ms)))
+        return ms.value
+
+    def set_profile(self, on, only=None):
+        if on and only:
+            N.check(N.lib().ps_model_set_profile_filter(self.h, only.encode()))
+        else:
+            N.check(N.lib().ps_model_set_profile(self.h, int(on)))
+
+    def profile_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        N.check(N.lib().ps_model_profile_report(self.h, buf, 1 << 16))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                name, cnt, ms = item.split(":")
+                out[name] = (int(cnt), float(ms))
+        return out
+
+
+class DNN(_Model):
+    KIND = N.PS_MODEL_DNN
+
+    @staticmethod
+    def buildModel(embeddingFieldNum, embeddingSize, numberFieldNum, fcLayerDims, store=None, rows=None, **kw):
+        """DNN.buildModel (model/DNN.java:92-128).  `rows`: vocabulary per field
+        (the reference grows its maps lazily; HBM tables are sized up front)."""
+        store = store or KVStore.ins()
+        if not hasattr(store, "F"):
+            store.create_embedding(rows if rows is not None else [100000] * embeddingFieldNum, embeddingSize)
+        return DNN(store, embeddingFieldNum, embeddingSize, numberFieldNum, fcLayerDims, **kw)
+
+
+class WideDeepNN(_Model):
+    KIND = N.PS_MODEL_WIDEDEEP
+
+    @staticmethod
+    def buildModel(embeddingFieldNum, embeddingSize, numberFieldNum, fcLayerDims, wideSize, store=None, rows=None, **kw):
+        """WideDeepNN.buildModel (model/WideDeepNN.java:105-161): Ftrl on wide.*, Adam default."""
+        store = store or KVStore.ins()
+        if not hasattr(store, "F"):
+            store.create_embedding(rows if rows is not None else [100000] * embeddingFieldNum, embeddingSize)
+        m = WideDeepNN(store, embeddingFieldNum, embeddingSize, numberFieldNum, fcLayerDims, wide_size=wideSize, **kw)
+        ftrl = FtrlUpdater(0.005, 1.0, 0.001, 0.001)
+        m._updater["wide.weights"] = ftrl
+        m._updater["wide.bias"] = ftrl
+        return m
+
+
+class Trainer:
+    """train/Trainer.java for thread = 1 (what CTR.java:72 forces)."""
+
+    def __init__(self, nThreads, modelCallable):
+        if nThreads != 1:
+            raise ValueError("one replica per GPU: thread-DP is replaced by one process per GPU")
+        self.models = [modelCallable()]
+
+    def train(self, dataList):
+        if len(dataList) > len(self.models):
+            raise RuntimeError("dataList size > thread size")     # Trainer.java:72-74
+        return self.models[0].train(dataList[0])
+
+    def predict(self, dataList):
+        return [self.models[0].predict(d) for d in dataList]
+
+    def getTrainResult(self):
+        return self.models[0]

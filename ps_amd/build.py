@@ -1,0 +1,67 @@
+"""Build libps_amd.so (gfx950 only) in-tree with hipcc.
+
+    python -m ps_amd.build [--force]
+
+One hipcc -c per translation unit (cached by mtime), then one link.  The
+library is kept in-tree (ps_amd/lib/libps_amd.so): git-ignored, but it
+travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libps_amd.so")
+SOURCES = ["kernels_sort.hip", "kernels_gemm.hip", "kernels_emb.hip", "ps_store.hip", "ps_model.hip", "ps_ops.hip", "ps_shard.hip"]
+# -ffp-contract=off: the reference (JVM) rounds every float op separately;
+# the updater / reduce kernels must too, to stay bit-exact with the oracle.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newest_header():
+    t = 0.0
+    for d in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_t = _newest_header()
+    objs, relink = [], force or not os.path.exists(LIB)
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

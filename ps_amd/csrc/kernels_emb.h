@@ -1,0 +1,95 @@
+// kernels_emb.h -- argument blocks and launchers of kernels_emb.hip
+#pragma once
+#include "ps_common.h"
+
+#define PS_EMB_CHUNK 32  // per-key runs longer than this are summed as CH-chunks (oracle: orc_emb_geff chunk=32)
+
+struct EmbFwdArgs {
+    const float *W;            // [rows_total][D] all fields' tables back to back
+    const int64_t *row_base;   // [F+1] first global row of each field
+    const int64_t *ids;        // [nnz]
+    const int64_t *offsets;    // nullptr (single-hot, nnz = B*F) or [B*F+1]
+    int B, F, D, X, act;
+    float *out; int ld;        // [B][ld]
+    const float *dense;        // [B][X] or nullptr
+    uint32_t *key_out;         // [nnz] global row per entry (sort key) or nullptr
+    uint32_t *ent_bag;         // [nnz] bag of each entry (multi-hot) or nullptr
+    int *err;                  // out-of-range id counter
+    int LPR, gather_blocks;    // filled by the launcher
+};
+int launch_emb_fwd(EmbFwdArgs a, hipStream_t st);
+
+struct HeadArgs {
+    int B, F, wide, train;
+    const float *zlast; int ldz;       // last FcLayer output (logit, or P for DNN)
+    const int64_t *wide_ids; int64_t wide_rows;
+    const float *wide_w; const float *wide_bias; uint8_t *touched;
+    const float *labels;
+    float *P, *wide_z, *terms;
+    float *dlast; int ldd;             // delta at the last FcLayer's output
+    int *err;
+};
+int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);
+
+struct EmbBwdArgs {
+    int64_t nnz;
+    int F, D, grad_mode, apply;
+    const uint32_t *sorted_key, *sorted_ent, *seg_start, *seg_id, *nseg;
+    const uint32_t *ent_bag;           // nullptr => bag = entry
+    const float *delta; int ldd;       // [B][ldd], embedding columns already relu'-masked
+    float *partials;                   // [2*ceil(nnz/CH)][D]
+    float *W, *state;                  // [rows][D], [rows][2][D]
+    UpdParams upd;
+    float *grads_out; uint32_t *uniq_row; uint32_t *uniq_cnt;   // [nseg][D], [nseg], [nseg]
+    const int *skip;
+    int LPR;
+};
+int launch_emb_bwd(EmbBwdArgs a, hipStream_t st);
+
+struct DenseLayer {
+    float *W, *Wt, *S1, *S2;           // W' [K+1 rows][ldw], Wt [N rows][ldwt], state like W'
+    const float *part;                 // split-K partials [nsplit][..][ldp]
+    int64_t part_stride;
+    int K, N, ldw, ldwt, ldp, nsplit;
+    int64_t elem_begin, elem_end;      // flat [k][n] element range, k in [0,K]
+};
+struct DenseUpdArgs {
+    DenseLayer L[8];
+    int nlayers, B, apply;
+    UpdParams upd;
+    const float *flat_grad;            // when set: use this instead of partials/B
+    float *grad_out;                   // flat gradient as handed to the updater (or nullptr)
+    const int *skip;
+};
+int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
+
+struct WideUpdArgs {
+    int64_t rows;
+    float *W, *state;                  // [rows], [rows][2]
+    const uint8_t *touched;
+    float *bias, *bias_state;          // [1], [2]
+    const float *gbar;
+    UpdParams upd;
+    const int *skip;
+};
+int launch_wide_update(const WideUpdArgs &a, hipStream_t st);
+
+int launch_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
+                    int64_t id_first, int64_t id_stride, hipStream_t st);
+int launch_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldwt, uint64_t seed,
+                      uint64_t table_w, float scale_w, uint64_t table_b, float scale_b, hipStream_t st);
+int launch_fill(float *p, int64_t n, float v, hipStream_t st);
+int launch_fill_col(float *p, int rows, int ld, int col, float v, hipStream_t st);
+int launch_rows_copy(float *table, int64_t row_stride, int64_t col_off, const int64_t *rows_idx_dev,
+                     int64_t n, int D, float *buf_dev, int to_table, hipStream_t st);
+
+struct RowsApplyArgs {
+    int D, is_async, identity;
+    const uint32_t *sorted_key, *sorted_ent, *seg_start, *nseg;
+    const float *grads;                // [n][D], indexed by sorted_ent
+    float *W, *state;
+    UpdParams upd;
+    const int *skip;
+    int LPR;
+};
+int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st);

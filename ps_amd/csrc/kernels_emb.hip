@@ -1,0 +1,564 @@
+// kernels_emb.hip -- the sparse half of the hot path on gfx950:
+//   EmbeddingLayer/EmbeddingField.forward   layer/EmbeddingLayer.java:25-48, layer/EmbeddingField.java:66-78
+//   LRLayer.forward + AddLayer + CrossEntropy layer/LRLayer.java:62-98, layer/AddLayer.java:33-48, loss/CrossEntropy.java:10-28
+//   EmbeddingField.backward (twice) + KVStore.sum/update + Adam/Ftrl
+//                                            layer/EmbeddingField.java:86-104, store/KVStore.java:192-268,
+//                                            update/AdamUpdater.java:57-70, update/FtrlUpdater.java:51-76
+// These are HBM-bound gather/scatter kernels: rows move as 16-B lanes
+// (D/4 lanes per row, 64/(D/4) rows per wave instruction), outputs of one
+// sample are contiguous so a wave stores whole 1-KiB runs, and the per-key
+// reduction walks sorted runs in batch order (no float atomics; bit-exact
+// against the oracle's sequential order).  Compiled with -ffp-contract=off:
+// every reference op is individually rounded.
+#include "ps_common.h"
+#include "kernels_emb.h"
+
+namespace {
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+    float4 v;
+    __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.v = *reinterpret_cast<const float4 *>(p); return r; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+    __device__ __forceinline__ static Vec zero() { Vec r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
+    __device__ __forceinline__ float &at(int i) { return (&v.x)[i]; }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <> struct Vec<1> {
+    float v;
+    __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.v = *p; return r; }
+    __device__ __forceinline__ void store(float *p) const { *p = v; }
+    __device__ __forceinline__ static Vec zero() { Vec r; r.v = 0.f; return r; }
+    __device__ __forceinline__ float &at(int) { return v; }
+    __device__ __forceinline__ float get(int) const { return v; }
+};
+#define VFOR(i) _Pragma("unroll") for (int i = 0; i < VEC; ++i)
+
+// ---------------------------------------------------------------------------
+// forward gather (+ bag sum, + relu, + dense concat, + sort keys)
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x >= a.gather_blocks) {
+        // ConcatLayer.forward (layer/ConcatLayer.java:30-37): dense features behind the embeddings
+        const int64_t t = gt - (int64_t)a.gather_blocks * 256;
+        if (t < (int64_t)a.B * a.X) {
+            const int b = (int)(t / a.X), x = (int)(t % a.X);
+            a.out[(size_t)b * a.ld + a.F * a.D + x] = a.dense[t];
+        }
+        return;
+    }
+    const int64_t bag = gt / a.LPR;
+    const int part = (int)(gt % a.LPR);
+    if (bag >= (int64_t)a.B * a.F) return;
+    const int b = (int)(bag / a.F), f = (int)(bag % a.F);
+    const int64_t p0 = a.offsets ? a.offsets[bag] : bag;
+    const int64_t p1 = a.offsets ? a.offsets[bag + 1] : bag + 1;
+    const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
+    Vec<VEC> s = Vec<VEC>::zero();
+    for (int64_t p = p0; p < p1; ++p) {
+        int64_t id = a.ids[p];
+        if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
+        const int64_t row = rb + id;
+        const Vec<VEC> r = Vec<VEC>::load(a.W + (size_t)row * a.D + part * VEC);
+        if (p == p0) s = r;                       // rcopy of one row (EmbeddingField.java:73)
+        else { VFOR(i) s.at(i) = r.get(i) + s.at(i); }  // sum pooling, in bag order
+        if (part == 0 && a.key_out) {
+            a.key_out[p] = (uint32_t)row;
+            if (a.ent_bag) a.ent_bag[p] = (uint32_t)bag;
+        }
+    }
+    if (a.act == PS_ACT_RELU) { VFOR(i) s.at(i) = s.get(i) > 0.f ? s.get(i) : 0.f; }  // Relu.java:7-12
+    s.store(a.out + (size_t)b * a.ld + (size_t)f * a.D + part * VEC);
+}
+
+// ---------------------------------------------------------------------------
+// head: wide LR + add + clipped sigmoid + cross-entropy term + delta_L
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_clip_d(float x) {
+    return (float)(0.001f + (double)(.999f - 0.001f) / (1.0 + exp(-(double)x)));
+}
+
+__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.B) return;
+    float p;
+    if (a.wide) {
+        // LRLayer.forward (layer/LRLayer.java:73-84): sum over the F wide ids, sequential, then + bias
+        float sumW = 0.f;
+        for (int j = 0; j < a.F; ++j) {
+            int64_t id = a.wide_ids[(size_t)b * a.F + j];
+            if (id < 0 || id >= a.wide_rows) { atomicAdd(a.err, 1); id = 0; }
+            sumW += a.wide_w[id];
+            if (a.touched && a.train) a.touched[id] = 1;   // LRLayer.weights.put (never cleared)
+        }
+        sumW += a.wide_bias[0];
+        a.wide_z[b] = sumW;
+        const float z = a.zlast[(size_t)b * a.ldz] + sumW;  // AddLayer.forward l.add(r)
+        p = sigmoid_clip_d(z);
+    } else {
+        p = a.zlast[(size_t)b * a.ldz];                     // last FcLayer already applied the sigmoid
+    }
+    a.P[b] = p;
+    if (!a.labels) return;
+    const float l = a.labels[b];
+    // loss/CrossEntropy.java:15 (FastMath.log ~ log; double math, cast to float)
+    a.terms[b] = (float)(-l * log((double)p) - ((1 - l) * log((double)(1 - p))));
+    float d = (p - l) / (p * (1 - p));                      // loss/CrossEntropy.java:25
+    d *= p * (1 - p);                                       // Sigmoid.backward (activations/Sigmoid.java:18)
+    a.dlast[(size_t)b * a.ldd] = d;
+}
+
+// loss = sum(terms)/B, gbar = rowMeans(delta) ; sets the skip flag (model/DNN.java:58-63)
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float *terms, const float *dlast, int ldd, int B,
+                                                      float *loss_out, float *gbar_out, int *skip, int force_no_skip) {
+    __shared__ float s1[1024], s2[1024];
+    const int tid = threadIdx.x;
+    float a = 0.f, g = 0.f;
+    for (int i = tid; i < B; i += 1024) { a += terms[i]; g += dlast[(size_t)i * ldd]; }
+    s1[tid] = a; s2[tid] = g;
+    __syncthreads();
+    for (int off = 512; off; off >>= 1) {
+        if (tid < off) { s1[tid] += s1[tid + off]; s2[tid] += s2[tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float loss = s1[0] / B;
+        loss_out[0] = loss;
+        gbar_out[0] = s2[0] / (float)B;
+        skip[0] = (!force_no_skip && (loss <= 0.01f || loss != loss)) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// updaters (shared by sparse rows and dense tensors), one element
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sqrt_rn(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ float div_rn(float x, float y) { return __fdiv_rn(x, y); }
+
+__device__ __forceinline__ void adam_elem(const UpdParams &u, float g, float &w, float &M, float &V) {
+    // update/AdamUpdater.java:61-69, op for op
+    float m = g * u.c1;
+    float mo = M * u.beta1;
+    m = mo + m;
+    float v = g * g;
+    v = v * u.c2;
+    float vo = V * u.beta2;
+    v = vo + v;
+    M = m; V = v;
+    const float mm = div_rn(m, u.c1);
+    const float vv = div_rn(v, u.c2);
+    const float den = sqrt_rn(vv) + u.eps;
+    float q = div_rn(mm, den);
+    q = q * u.neg_alfa;
+    w = q + w;
+}
+
+__device__ __forceinline__ void ftrl_elem(const UpdParams &u, float g, float &w, float &z, float &n) {
+    // update/FtrlUpdater.java:64-74 (w from the OLD z,n; then z,n with the NEW w)
+    if (fabsf(z) <= u.l1) {
+        w = 0.f;
+    } else {
+        const float sign = z >= 0.f ? 1.f : -1.f;
+        const float den = div_rn(u.l2 + (u.beta + sqrt_rn(n)), u.alfa);
+        w = div_rn(-(z - sign * u.l1), den);
+    }
+    const float g2 = g * g;                                   // pow(dw,2): exact product, one rounding
+    const float s = sqrt_rn(n + g2) - sqrt_rn(div_rn(n, u.alfa));
+    const float t = g - s * w;
+    z = t + z;
+    n = g2 + n;
+}
+
+// ---------------------------------------------------------------------------
+// long-run partials: tile c of CH consecutive sorted entries computes the (at
+// most two) CH-chunks of long segments that START inside it
+// ---------------------------------------------------------------------------
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> load_g(const EmbBwdArgs &a, uint32_t p, int part) {
+    // masked per-sample gradient of entry p: relu'(A)*delta slice
+    // (EmbeddingField.java:91; the relu' mask was applied by the producing GEMM epilogue)
+    const uint32_t bag = a.ent_bag ? a.ent_bag[p] : p;
+    const uint32_t b = bag / (uint32_t)a.F, f = bag % (uint32_t)a.F;
+    return Vec<VEC>::load(a.delta + (size_t)b * a.ldd + (size_t)f * a.D + part * VEC);
+}
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> chunk_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part) {
+    Vec<VEC> acc = load_g<VEC>(a, a.sorted_ent[s], part);
+    for (uint32_t k = s + 1; k < e; ++k) {
+        const Vec<VEC> g = load_g<VEC>(a, a.sorted_ent[k], part);
+        VFOR(i) acc.at(i) = g.get(i) + acc.at(i);
+    }
+    return acc;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane64 = (int)(gt & 63);
+    const int gpw = 64 / a.LPR;                         // lane groups per wave (groups never straddle waves)
+    if (lane64 / a.LPR >= gpw) return;
+    const int64_t c = (gt >> 6) * gpw + lane64 / a.LPR;
+    const int part = lane64 % a.LPR;
+    const uint32_t CH = PS_EMB_CHUNK;
+    const uint32_t t0 = (uint32_t)(c * CH);
+    if ((int64_t)t0 >= a.nnz) return;
+    const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
+    const uint32_t u0 = a.seg_id[t0];
+    const uint32_t s0 = a.seg_start[u0], e0 = a.seg_start[u0 + 1];
+    if (e0 - s0 > CH) {
+        const uint32_t j = (t0 - s0 + CH - 1) / CH;
+        const uint32_t s = s0 + j * CH;
+        if (s <= t1 && s < e0) {
+            const uint32_t e = s + CH < e0 ? s + CH : e0;
+            const size_t slot = (size_t)2 * c + (j == 0 ? 1 : 0);
+            chunk_sum<VEC>(a, s, e, part).store(a.partials + slot * a.D + part * VEC);
+        }
+    }
+    const uint32_t u1 = a.seg_id[t1];
+    if (u1 != u0) {
+        const uint32_t s1 = a.seg_start[u1], e1 = a.seg_start[u1 + 1];
+        if (e1 - s1 > CH) {
+            const uint32_t e = s1 + CH;  // < e1
+            chunk_sum<VEC>(a, s1, e, part).store(a.partials + ((size_t)2 * c + 1) * a.D + part * VEC);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-key reduce (+ double-backward factor) (+ fused updater)
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane64 = (int)(gt & 63);
+    const int gpw = 64 / a.LPR;
+    if (lane64 / a.LPR >= gpw) return;
+    const int64_t u = (gt >> 6) * gpw + lane64 / a.LPR;
+    const int part = lane64 % a.LPR;
+    if (u >= (int64_t)*a.nseg) return;
+    const uint32_t CH = PS_EMB_CHUNK;
+    const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
+    const uint32_t n = e0 - s0;
+    const uint32_t row = a.sorted_key[s0];
+    Vec<VEC> S;
+    if (n <= CH) {
+        S = chunk_sum<VEC>(a, s0, e0, part);                       // put :91, addi :94 in batch order
+        if (a.grad_mode == PS_GRAD_COMPAT) {
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);          // divi(N) :100  (pass 1)
+            for (uint32_t k = s0; k < e0; ++k) {                   // pass 2: every g_k again
+                const Vec<VEC> g = load_g<VEC>(a, a.sorted_ent[k], part);
+                VFOR(i) S.at(i) = g.get(i) + S.at(i);
+            }
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));    // divi(2n); then x2 (sum.addi self), /2 (cnt) exact
+        } else {
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
+        }
+    } else {
+        const uint32_t nch = (n + CH - 1) / CH;
+        auto slot_of = [&](uint32_t j) -> size_t {
+            const uint32_t s = s0 + j * CH;
+            return (size_t)2 * (s / CH) + (j == 0 ? 1 : 0);
+        };
+        S = Vec<VEC>::load(a.partials + slot_of(0) * a.D + part * VEC);
+        for (uint32_t j = 1; j < nch; ++j) {
+            const Vec<VEC> p = Vec<VEC>::load(a.partials + slot_of(j) * a.D + part * VEC);
+            VFOR(i) S.at(i) = p.get(i) + S.at(i);
+        }
+        if (a.grad_mode == PS_GRAD_COMPAT) {
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
+            for (uint32_t j = 0; j < nch; ++j) {
+                const Vec<VEC> p = Vec<VEC>::load(a.partials + slot_of(j) * a.D + part * VEC);
+                VFOR(i) S.at(i) = p.get(i) + S.at(i);
+            }
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));
+        } else {
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
+        }
+    }
+    if (a.grads_out) {
+        S.store(a.grads_out + (size_t)u * a.D + part * VEC);
+        if (part == 0) { a.uniq_row[u] = row; if (a.uniq_cnt) a.uniq_cnt[u] = n; }
+    }
+    if (!a.apply) return;
+    float *wp = a.W + (size_t)row * a.D + part * VEC;
+    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
+    Vec<VEC> w = Vec<VEC>::load(wp);
+    if (a.upd.kind == PS_UPD_SIMPLE) {
+        VFOR(i) w.at(i) = (S.get(i) * -a.upd.eta) + w.get(i);      // update/SimpleUpdater.java:20-22
+        w.store(wp);
+        return;
+    }
+    Vec<VEC> s1 = Vec<VEC>::load(sp), s2 = Vec<VEC>::load(sp + a.D);
+    if (a.upd.kind == PS_UPD_ADAM) {
+        VFOR(i) adam_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+    } else {
+        // FtrlUpdater.java:52: skip the whole key when dw[0] == 0; element 0 lives in part 0
+        const int lane = threadIdx.x & 63;
+        const float g0 = __shfl(S.get(0), lane - part);
+        if (g0 == 0.f) return;
+        VFOR(i) ftrl_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+    }
+    w.store(wp); s1.store(sp); s2.store(sp + a.D);
+}
+
+// ---------------------------------------------------------------------------
+// PS owner side: apply a list of pushed (row, gradient) pairs
+//   net/PServer.java:164-195 push -> KVStore.sum ; :197-214 psUpdate -> KVStore.update(updater,key)
+//   BSP: g = (sum over the pushes of the key, in arrival order) / count, one updater step
+//   async (:176-184): one updater step per push, in arrival order, no averaging
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_rows_apply(RowsApplyArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane64 = (int)(gt & 63);
+    const int gpw = 64 / a.LPR;
+    if (lane64 / a.LPR >= gpw) return;
+    const int64_t u = (gt >> 6) * gpw + lane64 / a.LPR;
+    const int part = lane64 % a.LPR;
+    if (u >= (int64_t)*a.nseg) return;
+    // identity: the list is already unique (one push per key), runs are single entries
+    const uint32_t s0 = a.identity ? (uint32_t)u : a.seg_start[u];
+    const uint32_t e0 = a.identity ? (uint32_t)u + 1 : a.seg_start[u + 1];
+    const uint32_t row = a.sorted_key[s0];
+    auto ent = [&](uint32_t k) -> size_t { return a.identity ? (size_t)k : (size_t)a.sorted_ent[k]; };
+    float *wp = a.W + (size_t)row * a.D + part * VEC;
+    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
+    Vec<VEC> w = Vec<VEC>::load(wp), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
+    if (a.upd.kind != PS_UPD_SIMPLE) { s1 = Vec<VEC>::load(sp); s2 = Vec<VEC>::load(sp + a.D); }
+    const int lane = threadIdx.x & 63;
+    auto apply = [&](const Vec<VEC> &g) {
+        if (a.upd.kind == PS_UPD_ADAM) { VFOR(i) adam_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+        else if (a.upd.kind == PS_UPD_SIMPLE) { VFOR(i) w.at(i) = (g.get(i) * -a.upd.eta) + w.get(i); }
+        else {
+            const float g0 = __shfl(g.get(0), lane - part);
+            if (g0 != 0.f) { VFOR(i) ftrl_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+        }
+    };
+    if (a.is_async) {
+        for (uint32_t k = s0; k < e0; ++k)
+            apply(Vec<VEC>::load(a.grads + ent(k) * a.D + part * VEC));
+    } else {
+        Vec<VEC> S = Vec<VEC>::load(a.grads + ent(s0) * a.D + part * VEC);
+        for (uint32_t k = s0 + 1; k < e0; ++k) {
+            const Vec<VEC> g = Vec<VEC>::load(a.grads + ent(k) * a.D + part * VEC);
+            VFOR(i) S.at(i) = g.get(i) + S.at(i);
+        }
+        VFOR(i) S.at(i) = div_rn(S.get(i), (float)(e0 - s0));
+        apply(S);
+    }
+    w.store(wp);
+    if (a.upd.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
+}
+
+// ---------------------------------------------------------------------------
+// dense tensors: split-K reducer + /B + updater, writes W' ([in+1][out]) and its transpose
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // locate the layer
+    int l = 0;
+    while (l < a.nlayers - 1 && t >= a.L[l].elem_end) ++l;
+    if (t >= a.L[l].elem_end) return;
+    const DenseLayer &L = a.L[l];
+    const int64_t e = t - L.elem_begin;
+    const int k = (int)(e / L.N), n = (int)(e % L.N);   // k in [0, K] (K = bias row), n in [0, N)
+    float g;
+    if (a.flat_grad) {
+        // multi-worker path: the (all-reduced) mean gradient was materialised flat
+        g = a.flat_grad[t];
+    } else {
+        float s = 0.f;
+        for (int z = 0; z < L.nsplit; ++z) s += L.part[(size_t)z * L.part_stride + (size_t)k * L.ldp + n];
+        g = div_rn(s, (float)a.B);                       // divi(delta.columns) FcLayer.java:105 / rowMeans :103
+    }
+    if (a.grad_out) a.grad_out[t] = g;
+    if (!a.apply) return;
+    const size_t wi = (size_t)k * L.ldw + n;
+    float w = L.W[wi], s1 = L.S1[wi], s2 = L.S2[wi];
+    if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, s1, s2);
+    else if (a.upd.kind == PS_UPD_SIMPLE) w = (g * -a.upd.eta) + w;
+    else ftrl_elem(a.upd, g, w, s1, s2);   // per-tensor "dw[0]==0" skip is not meaningful for dense tensors
+    L.W[wi] = w; L.S1[wi] = s1; L.S2[wi] = s2;
+    L.Wt[(size_t)n * L.ldwt + k] = w;
+}
+
+// materialise the flat dense gradient (sum of split partials / B) without updating
+__global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float g = a.gbar[0];
+    if (r == a.rows) {
+        // "wide.bias": 1x1, same rowMeans(delta)  (layer/LRLayer.java:106-107)
+        if (a.upd.kind == PS_UPD_FTRL) { if (g != 0.f) ftrl_elem(a.upd, g, a.bias[0], a.bias_state[0], a.bias_state[1]); }
+        else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, a.bias[0], a.bias_state[0], a.bias_state[1]);
+        else a.bias[0] = (g * -a.upd.eta) + a.bias[0];
+        return;
+    }
+    if (r > a.rows) return;
+    // compat (layer/LRLayer.java:110-117): every key ever touched gets the same gbar
+    if (!a.touched[r]) return;
+    float w = a.W[r], z = a.state[2 * r], n = a.state[2 * r + 1];
+    if (a.upd.kind == PS_UPD_FTRL) { if (g == 0.f) return; ftrl_elem(a.upd, g, w, z, n); }
+    else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, z, n);
+    else w = (g * -a.upd.eta) + w;
+    a.W[r] = w; a.state[2 * r] = z; a.state[2 * r + 1] = n;
+}
+
+// ---------------------------------------------------------------------------
+// init / row access
+// ---------------------------------------------------------------------------
+__global__ void k_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
+                           int64_t id_first, int64_t id_stride) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * D) return;
+    const int64_t r = t / D; const int d = (int)(t % D);
+    W[t] = ps_init_value(seed, table, (uint64_t)(id_first + r * id_stride), (uint64_t)d, scale);
+}
+
+__global__ void k_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldwt, uint64_t seed,
+                             uint64_t table_w, float scale_w, uint64_t table_b, float scale_b) {
+    // reference layouts: weights out x in column-major => flat index n + N*k; bias flat index n
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)(K + 1) * N) return;
+    const int k = (int)(t / N), n = (int)(t % N);
+    const float v = k < K ? ps_init_value(seed, table_w, (uint64_t)((int64_t)n + (int64_t)N * k), 0, scale_w)
+                          : ps_init_value(seed, table_b, (uint64_t)n, 0, scale_b);
+    W[(size_t)k * ldw + n] = v;
+    Wt[(size_t)n * ldwt + k] = v;
+}
+
+__global__ void k_fill(float *p, int64_t n, float v) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = v;
+}
+__global__ void k_fill_col(float *p, int rows, int ld, int col, float v) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < rows) p[(size_t)t * ld + col] = v;
+}
+
+// rows[i][0..D) <-> table[row_of(ids[i])]; stride/offset select W or an interleaved state slot
+__global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, const int64_t *rows_idx,
+                            int64_t n, int D, float *buf, int to_table) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * D) return;
+    const int64_t i = t / D; const int d = (int)(t % D);
+    float *cell = table + rows_idx[i] * row_stride + col_off + d;
+    if (to_table) *cell = buf[t]; else buf[t] = *cell;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
+    const int vec = (a.D % 4 == 0) ? 4 : 1;
+    a.LPR = a.D / vec;
+    const int64_t threads = (int64_t)a.B * a.F * a.LPR;
+    a.gather_blocks = cdiv(threads, 256);
+    const int dense_blocks = a.dense ? cdiv((int64_t)a.B * a.X, 256) : 0;
+    const int grid = a.gather_blocks + dense_blocks;
+    if (grid == 0) return PS_OK;
+    if (vec == 4) hipLaunchKernelGGL(k_emb_fwd<4>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_emb_fwd<1>, dim3(grid), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st) {
+    hipLaunchKernelGGL(k_head, dim3(cdiv(a.B, 256)), dim3(256), 0, st, a);
+    if (a.labels)
+        hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, a.terms, a.dlast, a.ldd, a.B, loss_out, gbar_out, skip, force_no_skip);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
+    const int vec = (a.D % 4 == 0) ? 4 : 1;
+    a.LPR = a.D / vec;
+    if (a.nnz <= 0) return PS_OK;
+    const int64_t tiles = (a.nnz + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK;
+    const int gpw = 64 / a.LPR;                // lane groups per wave
+    if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
+    const int gp = cdiv((int64_t)cdiv(tiles, gpw) * 64, 256);
+    const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
+    if (vec == 4) {
+        hipLaunchKernelGGL(k_emb_partials<4>, dim3(gp), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_emb_reduce_update<4>, dim3(gr), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_emb_partials<1>, dim3(gp), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_emb_reduce_update<1>, dim3(gr), dim3(256), 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_dense_update(const DenseUpdArgs &a, hipStream_t st) {
+    const int64_t total = a.L[a.nlayers - 1].elem_end;
+    hipLaunchKernelGGL(k_dense_update, dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_wide_update(const WideUpdArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(k_wide_update, dim3(cdiv(a.rows + 1, 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
+                    int64_t id_first, int64_t id_stride, hipStream_t st) {
+    if (rows * D == 0) return PS_OK;
+    hipLaunchKernelGGL(k_init_emb, dim3(cdiv(rows * D, 256)), dim3(256), 0, st, W, rows, D, seed, table, scale, id_first, id_stride);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldwt, uint64_t seed,
+                      uint64_t table_w, float scale_w, uint64_t table_b, float scale_b, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_dense, dim3(cdiv((int64_t)(K + 1) * N, 256)), dim3(256), 0, st, W, Wt, K, N, ldw, ldwt, seed, table_w, scale_w, table_b, scale_b);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_fill(float *p, int64_t n, float v, hipStream_t st) {
+    if (n <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, v);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_fill_col(float *p, int rows, int ld, int col, float v, hipStream_t st) {
+    if (rows <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_fill_col, dim3(cdiv(rows, 256)), dim3(256), 0, st, p, rows, ld, col, v);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_rows_copy(float *table, int64_t row_stride, int64_t col_off, const int64_t *rows_idx_dev,
+                     int64_t n, int D, float *buf_dev, int to_table, hipStream_t st) {
+    if (n <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_rows_copy, dim3(cdiv(n * D, 256)), dim3(256), 0, st, table, row_stride, col_off, rows_idx_dev, n, D, buf_dev, to_table);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st) {
+    const int vec = (a.D % 4 == 0) ? 4 : 1;
+    a.LPR = a.D / vec;
+    if (n <= 0) return PS_OK;
+    const int gpw = 64 / a.LPR;
+    if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
+    const int g = cdiv((int64_t)cdiv(n, gpw) * 64, 256);
+    if (vec == 4) hipLaunchKernelGGL(k_rows_apply<4>, dim3(g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_rows_apply<1>, dim3(g), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}

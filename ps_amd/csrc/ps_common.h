@@ -1,0 +1,105 @@
+// ps_common.h -- internal declarations shared by the HIP translation units of
+// libps_amd.so (gfx950 only).  The public boundary is include/ps_native.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ps_native.h"
+
+int ps_set_err(int code, const char *fmt, ...);
+
+#define HIPCHK(x)                                                                       \
+    do {                                                                                \
+        hipError_t e__ = (x);                                                           \
+        if (e__ != hipSuccess)                                                          \
+            return ps_set_err(PS_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #x,       \
+                              hipGetErrorString(e__));                                  \
+    } while (0)
+#define PSCHK(x)                     \
+    do {                             \
+        int r__ = (x);               \
+        if (r__ != PS_OK) return r__; \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// counter-based row init: +-U(0, scale) as a pure function of
+// (seed, table, row, col).  Same definition as oracle/ps_oracle.c
+// orc_init_value (the oracle restates it; nothing is shared at link level).
+// Replaces util/MatrixUtil.java:62-74 (unseeded RandomUtils).
+// ---------------------------------------------------------------------------
+#define PS_TABLE_WIDE (1ull << 20)
+#define PS_TABLE_WIDE_B ((1ull << 20) + 1)
+#define PS_TABLE_FC(i) ((2ull << 20) + 2ull * (uint64_t)(i))
+
+__host__ __device__ inline uint64_t ps_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline float ps_init_value(uint64_t seed, uint64_t table, uint64_t row,
+                                               uint64_t col, float scale) {
+    uint64_t h = ps_splitmix64(seed + 0x9E3779B97F4A7C15ull * (table + 1));
+    h = ps_splitmix64(h ^ row);
+    h = ps_splitmix64(h ^ (col * 0xD6E8FEB86659FD93ull));
+    float u = (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+    float m = u * scale;
+    return ((h >> 39) & 1) ? -m : m;
+}
+float ps_xavier_scale(int in_dims, int out_dims);
+
+// ---------------------------------------------------------------------------
+// device-side updater parameters
+// ---------------------------------------------------------------------------
+struct UpdParams {
+    int kind;  // PS_UPD_*
+    float alfa, beta1, beta2, eps, c1, c2, neg_alfa;  // adam (c1 = 1-beta1, c2 = 1-beta2 in f32)
+    float beta, l1, l2;                               // ftrl
+    float eta;
+};
+UpdParams make_upd_params(const ps_updater_t &u);
+
+// ---------------------------------------------------------------------------
+// sort / segment primitives (kernels_sort.hip)
+// ---------------------------------------------------------------------------
+struct SortWorkspace {
+    uint32_t *keys_alt = nullptr, *vals_alt = nullptr;  // ping-pong buffers [cap]
+    uint32_t *counts = nullptr;                         // [256 * nblk]
+    uint32_t *blk_heads = nullptr;                      // [nblk]
+    int64_t cap = 0;
+    int nblk = 0;
+};
+int sort_ws_alloc(SortWorkspace &ws, int64_t cap);
+void sort_ws_free(SortWorkspace &ws);
+// Stable LSD radix sort of (key, val) pairs on `key_bits` low bits.
+// iota_vals: vals start as 0..n-1 (not read).  The sorted pairs end up in
+// *keys_res / *vals_res (either keys/vals or the workspace's alt buffers,
+// depending on the pass count) -- no copy back.
+int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t n, int key_bits,
+                     bool iota_vals, uint32_t **keys_res, uint32_t **vals_res, hipStream_t st);
+// Segments of equal keys in a sorted key array: seg_start[nseg+1], seg_id[n],
+// *nseg_dev.
+int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, uint32_t *seg_start,
+                   uint32_t *seg_id, uint32_t *nseg_dev, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// GEMM (kernels_gemm.hip): f32 MFMA 32x32x2, exact f32
+// ---------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_MASK_POS = 3 };
+// C[M][N] = epi( A[M][K] * Bt[N][K]^T )   (both operands K-contiguous)
+//   EPI_MASK_POS: C = acc * (mask[row][col] > 0 ? 1 : 0) for col < mask_cols, acc otherwise
+int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
+            int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
+            const int *skip_flag, hipStream_t st);
+// Cpart[z][Kout][ldc] = sum over m in split z of A[m][kout] * D[m][n]  (split-K over M)
+int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
+                   float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
+                   const int *skip_flag, hipStream_t st);
+int gemm_tn_choose_split(int Kout, int N, int M);

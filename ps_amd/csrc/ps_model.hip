@@ -1,0 +1,603 @@
+// ps_model.hip -- the layer graph of model/DNN.java / model/WideDeepNN.java
+// laid out for one MI355X: activations [B][features] with every FcLayer's
+// bias folded into its GEMM through a ones column, the whole step issued on
+// one HIP stream (optionally replayed as a hipGraph).
+//
+// Step = TrainerThread.call (train/TrainerThread.java:29-39) + the tail of
+// Trainer.train (train/Trainer.java:90-100) for thread = 1:
+//   forward : EmbeddingLayer -> ConcatLayer -> FcLayer x nfc [-> LRLayer -> AddLayer] -> CrossEntropy
+//   backward: CrossEntropy' -> [AddLayer', LRLayer'] -> FcLayer' x nfc -> EmbeddingLayer' (twice, App. A.6)
+//   update  : KVStore.update(updaters) (Adam / Ftrl fused into the reducers) ; clear
+#include <string.h>
+
+#include "ps_store.h"
+
+namespace {
+
+int model_alloc(ps_model *m, void **p, size_t bytes, bool zero) { return store_dev_alloc(m->s, p, bytes, zero); }
+
+// event bracket around one kernel group when profiling is on
+struct Prof {
+    ps_model *m;
+    long idx = -1;
+    Prof(ps_model *mm, const char *name) : m(mm) {
+        if (!m->profile) return;
+        if (!m->prof_filter.empty() && m->prof_filter != name) return;
+        ps_model::ProfEvent e;
+        e.name = name;
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
+        (void)hipEventRecord(e.a, m->s->stream);
+        m->prof_events.push_back(e);
+        idx = (long)m->prof_events.size() - 1;
+    }
+    ~Prof() {
+        if (idx >= 0) (void)hipEventRecord(m->prof_events[idx].b, m->s->stream);
+    }
+};
+
+int bits_for(int64_t n) {
+    int b = 1;
+    while (b < 32 && (1ll << b) < n) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_model_t **out) {
+    if (!s || !cfg || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->F <= 0 || cfg->D <= 0 || cfg->X < 0 || cfg->nfc <= 0 || cfg->nfc > 8 || cfg->max_batch <= 0)
+        return ps_set_err(PS_E_BAD_ARG, "bad model config");
+    if (cfg->fc_dims[cfg->nfc - 1] != 1) return ps_set_err(PS_E_UNSUPPORTED, "the last FcLayer must have 1 output (CrossEntropy is binary)");
+    if (!s->emb.W) return ps_set_err(PS_E_STATE, "create the embedding tables first (ps_store_create_embedding)");
+    if (s->emb.F != cfg->F || s->emb.D != cfg->D) return ps_set_err(PS_E_BAD_ARG, "store embedding is %dx%d, model wants %dx%d", s->emb.F, s->emb.D, cfg->F, cfg->D);
+    HIPCHK(hipSetDevice(s->device));
+    if (cfg->kind == PS_MODEL_WIDEDEEP) {
+        if (cfg->wide_size <= 0) return ps_set_err(PS_E_BAD_ARG, "WideDeep needs wide_size");
+        if (!s->wide.W) PSCHK(ps_store_create_wide(s, cfg->wide_size));
+        if (s->wide.rows != cfg->wide_size) return ps_set_err(PS_E_BAD_ARG, "wide table size mismatch");
+    }
+    ps_model *m = new ps_model();
+    m->s = s;
+    m->cfg = *cfg;
+    m->Bcap = cfg->max_batch;
+    m->nnz_cap = cfg->max_nnz > 0 ? cfg->max_nnz : (int64_t)cfg->max_batch * cfg->F;
+    const int F = cfg->F, D = cfg->D, X = cfg->X, nfc = cfg->nfc, B = m->Bcap;
+    // FcLayer.build (layer/FcLayer.java:53-70)
+    int in = F * D + X;
+    for (int l = 0; l < nfc; ++l) {
+        PSCHK(ps_store_create_fc(s, l, in, cfg->fc_dims[l]));
+        in = cfg->fc_dims[l];
+    }
+    m->fc.resize(nfc);
+    m->dense_elems = 0;
+    for (int l = 0; l < nfc; ++l) {
+        FcParams &p = s->fc[l];
+        FcBuf &b = m->fc[l];
+        b.ldA = p.Kpad;
+        PSCHK(model_alloc(m, (void **)&b.A, sizeof(float) * (size_t)B * b.ldA, true));
+        PSCHK(launch_fill_col(b.A, B, b.ldA, p.K, 1.0f, s->stream));       // the ones column that carries the bias
+        b.ldD = p.ldw;
+        PSCHK(model_alloc(m, (void **)&b.dOut, sizeof(float) * (size_t)B * b.ldD, true));
+        b.nsplit = gemm_tn_choose_split(p.K + 1, p.N, B);
+        b.ldp = p.ldw;
+        b.part_stride = (int64_t)p.Kpad * b.ldp;
+        PSCHK(model_alloc(m, (void **)&b.part, sizeof(float) * (size_t)b.nsplit * b.part_stride, true));
+        m->dense_elems += (int64_t)(p.K + 1) * p.N;
+    }
+    m->ld_last = (int)round_up(cfg->fc_dims[nfc - 1] + 1, 16);
+    PSCHK(model_alloc(m, (void **)&m->out_last, sizeof(float) * (size_t)B * m->ld_last, true));
+    m->ldx = (int)round_up(F * D, 16);
+    PSCHK(model_alloc(m, (void **)&m->dx, sizeof(float) * (size_t)B * m->ldx, true));
+    PSCHK(model_alloc(m, (void **)&m->P, sizeof(float) * B, true));
+    PSCHK(model_alloc(m, (void **)&m->wide_z, sizeof(float) * B, true));
+    PSCHK(model_alloc(m, (void **)&m->terms, sizeof(float) * B, true));
+    PSCHK(model_alloc(m, (void **)&m->loss_dev, sizeof(float) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->gbar_dev, sizeof(float) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->skip_dev, sizeof(int) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->ids_dev, sizeof(int64_t) * (size_t)m->nnz_cap, false));
+    PSCHK(model_alloc(m, (void **)&m->offsets_dev, sizeof(int64_t) * ((size_t)B * F + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->wide_ids_dev, sizeof(int64_t) * (size_t)B * F, false));
+    PSCHK(model_alloc(m, (void **)&m->dense_dev, sizeof(float) * (size_t)B * (X > 0 ? X : 1), false));
+    PSCHK(model_alloc(m, (void **)&m->labels_dev, sizeof(float) * B, false));
+    const int64_t nc = m->nnz_cap;
+    PSCHK(sort_ws_alloc(m->ws, nc));
+    PSCHK(model_alloc(m, (void **)&m->keys, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->ent_bag, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->seg_start, sizeof(uint32_t) * (size_t)(nc + 2), false));
+    PSCHK(model_alloc(m, (void **)&m->seg_id, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->nseg_dev, sizeof(uint32_t) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
+    PSCHK(model_alloc(m, (void **)&m->grads_out, sizeof(float) * (size_t)(nc + 1) * D, false));
+    PSCHK(model_alloc(m, (void **)&m->dense_grad_flat, sizeof(float) * (size_t)m->dense_elems, true));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *out = m;
+    return PS_OK;
+}
+
+extern "C" int ps_model_destroy(ps_model_t *m) {
+    if (!m) return PS_OK;
+    (void)hipSetDevice(m->s->device);
+    (void)hipStreamSynchronize(m->s->stream);
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
+    fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
+    fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
+    sort_ws_free(m->ws);
+    fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
+    fr(m->partials); fr(m->grads_out); fr(m->dense_grad_flat);
+    delete m;
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batch staging
+// ---------------------------------------------------------------------------
+static int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
+    const ps_model_config_t &c = m->cfg;
+    if (!b || b->B <= 0 || b->B > m->Bcap) return ps_set_err(PS_E_BAD_ARG, "batch size %d out of (0,%d]", b ? b->B : 0, m->Bcap);
+    if (!b->ids) return ps_set_err(PS_E_BAD_ARG, "batch.ids is NULL");
+    if (c.X > 0 && !b->dense) return ps_set_err(PS_E_BAD_ARG, "batch.dense is NULL");
+    if (need_labels && !b->labels) return ps_set_err(PS_E_BAD_ARG, "batch.labels is NULL");
+    if (c.kind == PS_MODEL_WIDEDEEP && !b->wide_ids) return ps_set_err(PS_E_BAD_ARG, "batch.wide_ids is NULL");
+    hipStream_t st = m->s->stream;
+    const int64_t nbags = (int64_t)b->B * c.F;
+    int64_t nnz = nbags;
+    if (b->offsets) {
+        if (b->on_device) {
+            int64_t last = 0;
+            HIPCHK(hipMemcpyAsync(&last, b->offsets + nbags, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            nnz = last;
+        } else {
+            nnz = b->offsets[nbags];
+        }
+    }
+    if (nnz < 0 || nnz > m->nnz_cap) return ps_set_err(PS_E_BAD_ARG, "nnz %lld exceeds max_nnz %lld", (long long)nnz, (long long)m->nnz_cap);
+    m->cur_B = b->B; m->cur_nnz = nnz;
+    if (b->on_device) {
+        m->cur_ids = b->ids; m->cur_offsets = b->offsets; m->cur_dense = b->dense;
+        m->cur_labels = b->labels; m->cur_wide = b->wide_ids;
+        return PS_OK;
+    }
+    HIPCHK(hipMemcpyAsync(m->ids_dev, b->ids, sizeof(int64_t) * nnz, hipMemcpyHostToDevice, st));
+    m->cur_ids = m->ids_dev;
+    m->cur_offsets = nullptr;
+    if (b->offsets) {
+        HIPCHK(hipMemcpyAsync(m->offsets_dev, b->offsets, sizeof(int64_t) * (nbags + 1), hipMemcpyHostToDevice, st));
+        m->cur_offsets = m->offsets_dev;
+    }
+    m->cur_dense = nullptr;
+    if (c.X > 0) {
+        HIPCHK(hipMemcpyAsync(m->dense_dev, b->dense, sizeof(float) * (size_t)b->B * c.X, hipMemcpyHostToDevice, st));
+        m->cur_dense = m->dense_dev;
+    }
+    m->cur_labels = nullptr;
+    if (b->labels) {
+        HIPCHK(hipMemcpyAsync(m->labels_dev, b->labels, sizeof(float) * b->B, hipMemcpyHostToDevice, st));
+        m->cur_labels = m->labels_dev;
+    }
+    m->cur_wide = nullptr;
+    if (c.kind == PS_MODEL_WIDEDEEP) {
+        HIPCHK(hipMemcpyAsync(m->wide_ids_dev, b->wide_ids, sizeof(int64_t) * nbags, hipMemcpyHostToDevice, st));
+        m->cur_wide = m->wide_ids_dev;
+    }
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the three phases, enqueued on the store's stream
+// ---------------------------------------------------------------------------
+static int enqueue_forward(ps_model *m, bool train) {
+    ps_store *s = m->s;
+    const ps_model_config_t &c = m->cfg;
+    hipStream_t st = s->stream;
+    const int B = m->cur_B, nfc = c.nfc;
+    // EmbeddingLayer.forward + ConcatLayer.forward
+    EmbFwdArgs e;
+    memset(&e, 0, sizeof e);
+    e.W = s->emb.W; e.row_base = s->emb.row_base_dev; e.ids = m->cur_ids; e.offsets = m->cur_offsets;
+    e.B = B; e.F = c.F; e.D = c.D; e.X = c.X; e.act = PS_ACT_RELU;   // EmbeddingLayer.build: Relu (EmbeddingLayer.java:53)
+    e.out = m->fc[0].A; e.ld = m->fc[0].ldA; e.dense = m->cur_dense;
+    e.key_out = train ? m->keys : nullptr;
+    e.ent_bag = (train && m->cur_offsets) ? m->ent_bag : nullptr;
+    e.err = s->err_dev;
+    { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
+    // FcLayer.forward x nfc
+    for (int l = 0; l < nfc; ++l) {
+        FcParams &p = s->fc[l];
+        float *out = l + 1 < nfc ? m->fc[l + 1].A : m->out_last;
+        const int ldo = l + 1 < nfc ? m->fc[l + 1].ldA : m->ld_last;
+        int epi = EPI_RELU;
+        if (l == nfc - 1) epi = c.kind == PS_MODEL_WIDEDEEP ? EPI_NONE : EPI_SIGMOID;   // FcLayer.java:58-62, WideDeepNN.java:128
+        static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
+        Prof pf(m, names[l]);
+        PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
+                      nullptr, 0, 0, nullptr, st));
+    }
+    // LRLayer.forward + AddLayer.forward + loss
+    HeadArgs h;
+    memset(&h, 0, sizeof h);
+    h.B = B; h.F = c.F; h.wide = c.kind == PS_MODEL_WIDEDEEP; h.train = train;
+    h.zlast = m->out_last; h.ldz = m->ld_last;
+    h.wide_ids = m->cur_wide; h.wide_rows = s->wide.rows; h.wide_w = s->wide.W; h.wide_bias = s->wide.bias;
+    h.touched = s->wide.touched;
+    h.labels = m->cur_labels;
+    h.P = m->P; h.wide_z = m->wide_z; h.terms = m->terms;
+    h.dlast = m->fc[nfc - 1].dOut; h.ldd = m->fc[nfc - 1].ldD;
+    h.err = s->err_dev;
+    { Prof pf(m, "head_loss"); PSCHK(launch_head(h, m->loss_dev, m->gbar_dev, m->skip_dev, 0, st)); }
+    return PS_OK;
+}
+
+static int enqueue_backward(ps_model *m, bool apply) {
+    ps_store *s = m->s;
+    const ps_model_config_t &c = m->cfg;
+    hipStream_t st = s->stream;
+    const int B = m->cur_B, nfc = c.nfc;
+    const int *skip = m->skip_dev;
+    // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
+    for (int l = nfc - 1; l >= 0; --l) {
+        FcParams &p = s->fc[l];
+        FcBuf &b = m->fc[l];
+        // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
+        static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
+        static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
+        if (l > 0) {
+            Prof pf(m, nd[l]);
+            PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
+                          EPI_MASK_POS, b.A, b.ldA, p.K, skip, st));
+        } else {
+            Prof pf(m, nd[l]);
+            PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
+                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, skip, st));
+        }
+        Prof pf2(m, nw[l]);
+        // dW (+ db through the ones column), split over the batch
+        PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
+                             b.nsplit, skip, st));
+    }
+    // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
+    DenseUpdArgs d;
+    memset(&d, 0, sizeof d);
+    d.nlayers = nfc; d.B = B; d.apply = apply ? 1 : 0; d.skip = skip;
+    ps_updater_t u;
+    PSCHK(store_resolve_updater(s, "fc0.weights", &u));
+    d.upd = make_upd_params(u);
+    d.grad_out = m->dense_grad_flat;
+    int64_t off = 0;
+    for (int l = 0; l < nfc; ++l) {
+        FcParams &p = s->fc[l];
+        DenseLayer &L = d.L[l];
+        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+        L.part = m->fc[l].part; L.part_stride = m->fc[l].part_stride; L.ldp = m->fc[l].ldp; L.nsplit = m->fc[l].nsplit;
+        L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
+        L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
+    }
+    { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }
+    // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
+    if (c.kind == PS_MODEL_WIDEDEEP && apply) {
+        if (c.wide_grad_mode != PS_GRAD_COMPAT)
+            return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is not implemented on the device path yet");
+        WideUpdArgs w;
+        memset(&w, 0, sizeof w);
+        w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
+        w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = skip;
+        PSCHK(store_resolve_updater(s, "wide.weights", &u));
+        w.upd = make_upd_params(u);
+        Prof pf(m, "wide_update");
+        PSCHK(launch_wide_update(w, st));
+    }
+    // EmbeddingLayer.backward (twice): sort entries by row, per-key run reduce, fused updater
+    const int64_t nnz = m->cur_nnz;
+    {
+        Prof pf(m, "emb_sort");
+        PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
+                               &m->sorted_ents, st));
+    }
+    {
+        Prof pf(m, "emb_segments");
+        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
+    }
+    EmbBwdArgs g;
+    memset(&g, 0, sizeof g);
+    g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = (apply && s->emb.state) ? 1 : 0;
+    g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
+    g.nseg = m->nseg_dev; g.ent_bag = m->cur_offsets ? m->ent_bag : nullptr;
+    g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.W = s->emb.W; g.state = s->emb.state;
+    PSCHK(store_resolve_updater(s, "emF", &u));
+    g.upd = make_upd_params(u);
+    g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
+    { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st)); }
+    return PS_OK;
+}
+
+// KVStore.update for the split form: apply the gradients left by backward(apply = false)
+static int enqueue_update(ps_model *m) {
+    ps_store *s = m->s;
+    const ps_model_config_t &c = m->cfg;
+    hipStream_t st = s->stream;
+    const int nfc = c.nfc;
+    ps_updater_t u;
+    DenseUpdArgs d;
+    memset(&d, 0, sizeof d);
+    d.nlayers = nfc; d.B = m->cur_B; d.apply = 1; d.skip = m->skip_dev; d.flat_grad = m->dense_grad_flat;
+    PSCHK(store_resolve_updater(s, "fc0.weights", &u));
+    d.upd = make_upd_params(u);
+    int64_t off = 0;
+    for (int l = 0; l < nfc; ++l) {
+        FcParams &p = s->fc[l];
+        DenseLayer &L = d.L[l];
+        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+        L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
+        L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
+    }
+    PSCHK(launch_dense_update(d, st));
+    if (c.kind == PS_MODEL_WIDEDEEP) {
+        WideUpdArgs w;
+        memset(&w, 0, sizeof w);
+        w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
+        w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = m->skip_dev;
+        PSCHK(store_resolve_updater(s, "wide.weights", &u));
+        w.upd = make_upd_params(u);
+        PSCHK(launch_wide_update(w, st));
+    }
+    if (s->emb.state) {
+        // the per-key gradients are unique already: one "push" per key
+        RowsApplyArgs r;
+        memset(&r, 0, sizeof r);
+        r.D = c.D; r.is_async = 0; r.identity = 1;
+        r.sorted_key = m->uniq_row; r.nseg = m->nseg_dev; r.grads = m->grads_out;
+        r.W = s->emb.W; r.state = s->emb.state; r.skip = m->skip_dev;
+        PSCHK(store_resolve_updater(s, "emF", &u));
+        r.upd = make_upd_params(u);
+        PSCHK(launch_rows_apply(r, m->cur_nnz, st));
+    }
+    return PS_OK;
+}
+
+static int finish_step(ps_model *m, float *loss) {
+    ps_store *s = m->s;
+    if (!loss) return PS_OK;
+    HIPCHK(hipMemcpyAsync(loss, m->loss_dev, sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, s->err_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        HIPCHK(hipMemset(s->err_dev, 0, sizeof(int)));
+        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err);
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_model_train(ps_model_t *m, const ps_batch_t *batch, float *loss) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(stage_batch(m, batch, true));
+    PSCHK(enqueue_forward(m, true));
+    PSCHK(enqueue_backward(m, true));
+    m->fwd_done = true; m->bwd_done = true;
+    m->s->global_step++;                               // Context.step / PServer.globalStep
+    return finish_step(m, loss);
+}
+
+extern "C" int ps_model_forward(ps_model_t *m, const ps_batch_t *batch, float *loss) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(stage_batch(m, batch, true));
+    PSCHK(enqueue_forward(m, true));
+    m->fwd_done = true; m->bwd_done = false;
+    return finish_step(m, loss);
+}
+
+extern "C" int ps_model_backward(ps_model_t *m) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    if (!m->fwd_done) return ps_set_err(PS_E_STATE, "backward before forward");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(enqueue_backward(m, false));
+    m->bwd_done = true;
+    return PS_OK;
+}
+
+extern "C" int ps_model_update(ps_model_t *m) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    if (!m->bwd_done) return ps_set_err(PS_E_STATE, "update before backward");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(enqueue_update(m));
+    m->s->global_step++;
+    m->bwd_done = false;
+    return PS_OK;
+}
+
+extern "C" int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p_out) {
+    if (!m || !p_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->s->device));
+    ps_batch_t b = *batch;
+    b.labels = nullptr;
+    PSCHK(stage_batch(m, &b, false));
+    PSCHK(enqueue_forward(m, false));
+    m->fwd_done = false;
+    HIPCHK(hipMemcpyAsync(p_out, m->P, sizeof(float) * b.B, hipMemcpyDeviceToHost, m->s->stream));
+    HIPCHK(hipStreamSynchronize(m->s->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_model_sync(ps_model_t *m) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    HIPCHK(hipStreamSynchronize(m->s->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_model_last_loss(ps_model_t *m, float *loss) {
+    if (!m || !loss) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->s->device));
+    return finish_step(m, loss);
+}
+
+// ---------------------------------------------------------------------------
+// intermediates for parity tests
+// ---------------------------------------------------------------------------
+static int copy_out_2d(ps_model *m, const float *src, int ld, int rows, int cols, float *out, int64_t cap, int *r, int *c) {
+    if (r) *r = cols;     // reference orientation: features x B
+    if (c) *c = rows;
+    if (!out) return PS_OK;
+    if (cap < (int64_t)rows * cols) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(float) * cols, src, sizeof(float) * ld, sizeof(float) * cols, rows,
+                            hipMemcpyDeviceToHost, m->s->stream));
+    HIPCHK(hipStreamSynchronize(m->s->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_model_get_act(ps_model_t *m, int layer, float *out, int64_t cap, int *rows, int *cols) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    const ps_model_config_t &c = m->cfg;
+    const int B = m->cur_B;
+    if (layer == 0) return copy_out_2d(m, m->fc[0].A, m->fc[0].ldA, B, c.F * c.D, out, cap, rows, cols);
+    if (layer == 1) return copy_out_2d(m, m->fc[0].A, m->fc[0].ldA, B, c.F * c.D + c.X, out, cap, rows, cols);
+    const int l = layer - 2;
+    if (l < 0 || l >= c.nfc) return ps_set_err(PS_E_BAD_ARG, "no such layer %d", layer);
+    if (l + 1 < c.nfc) return copy_out_2d(m, m->fc[l + 1].A, m->fc[l + 1].ldA, B, c.fc_dims[l], out, cap, rows, cols);
+    return copy_out_2d(m, m->out_last, m->ld_last, B, c.fc_dims[l], out, cap, rows, cols);
+}
+
+extern "C" int ps_model_get_delta(ps_model_t *m, int layer, float *out, int64_t cap, int *rows, int *cols) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    const ps_model_config_t &c = m->cfg;
+    const int B = m->cur_B, l = layer - 2;
+    if (l < 0 || l >= c.nfc) return ps_set_err(PS_E_BAD_ARG, "no such layer %d", layer);
+    if (l == 0) return copy_out_2d(m, m->dx, m->ldx, B, c.F * c.D, out, cap, rows, cols);
+    return copy_out_2d(m, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, m->s->fc[l].K, out, cap, rows, cols);
+}
+
+extern "C" int ps_model_get_p(ps_model_t *m, float *out, int cap) {
+    if (!m || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    if (cap < m->cur_B) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
+    HIPCHK(hipSetDevice(m->s->device));
+    HIPCHK(hipMemcpyAsync(out, m->P, sizeof(float) * m->cur_B, hipMemcpyDeviceToHost, m->s->stream));
+    HIPCHK(hipStreamSynchronize(m->s->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out, float *grads_out,
+                                      int64_t cap_rows, int64_t *n_out) {
+    if (!m || !n_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    ps_store *s = m->s;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    uint32_t nseg = 0;
+    HIPCHK(hipMemcpy(&nseg, m->nseg_dev, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> rows(nseg);
+    if (nseg) HIPCHK(hipMemcpy(rows.data(), m->uniq_row, sizeof(uint32_t) * nseg, hipMemcpyDeviceToHost));
+    const EmbTables &e = s->emb;
+    if (field < 0 || field >= e.F) return ps_set_err(PS_E_BAD_ARG, "no field %d", field);
+    int64_t lo = 0, hi = 0;
+    for (uint32_t i = 0; i < nseg; ++i) {
+        if ((int64_t)rows[i] < e.row_base[field]) lo = i + 1;
+        if ((int64_t)rows[i] < e.row_base[field + 1]) hi = i + 1;
+    }
+    const int64_t n = hi - lo;
+    *n_out = n;
+    if (!ids_out || !grads_out) return PS_OK;
+    if (cap_rows < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
+    for (int64_t i = 0; i < n; ++i) ids_out[i] = e.shard + ((int64_t)rows[lo + i] - e.row_base[field]) * e.nshards;
+    if (n) HIPCHK(hipMemcpy(grads_out, m->grads_out + (size_t)lo * e.D, sizeof(float) * n * e.D, hipMemcpyDeviceToHost));
+    return PS_OK;
+}
+
+extern "C" int ps_model_get_fc_grad(ps_model_t *m, int layer, int bias, float *out, int cap) {
+    if (!m || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    ps_store *s = m->s;
+    if (layer < 0 || layer >= m->cfg.nfc) return ps_set_err(PS_E_BAD_ARG, "no such layer");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int64_t off = 0;
+    for (int l = 0; l < layer; ++l) off += (int64_t)(s->fc[l].K + 1) * s->fc[l].N;
+    const FcParams &p = s->fc[layer];
+    const int n = bias ? p.N : p.K * p.N;
+    if (cap < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
+    if (bias) off += (int64_t)p.K * p.N;
+    HIPCHK(hipMemcpy(out, m->dense_grad_flat + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// measurement hooks
+// ---------------------------------------------------------------------------
+static int prof_collect(ps_model *m) {
+    HIPCHK(hipStreamSynchronize(m->s->stream));
+    for (auto &e : m->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            auto &acc = m->prof_acc[e.name];
+            acc.first += 1; acc.second += ms;
+        }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    m->prof_events.clear();
+    return PS_OK;
+}
+
+extern "C" int ps_model_set_profile(ps_model_t *m, int enabled) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(prof_collect(m));
+    if (enabled) m->prof_acc.clear();
+    m->profile = enabled != 0;
+    m->prof_filter.clear();
+    return PS_OK;
+}
+
+extern "C" int ps_model_set_profile_filter(ps_model_t *m, const char *group) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(prof_collect(m));
+    m->prof_acc.clear();
+    m->prof_filter = group ? group : "";
+    m->profile = true;
+    return PS_OK;
+}
+
+extern "C" int ps_model_profile_report(ps_model_t *m, char *report, int cap) {
+    if (!m || !report || cap <= 0) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(prof_collect(m));
+    std::string out;
+    char line[160];
+    for (auto &kv : m->prof_acc) {
+        snprintf(line, sizeof line, "%s:%ld:%.6f;", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    snprintf(report, cap, "%s", out.c_str());
+    return PS_OK;
+}
+
+extern "C" int ps_model_time_steps(ps_model_t *m, const ps_batch_t *batch, int steps, double *ms_out) {
+    if (!m || !batch || !ms_out || steps <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    ps_store *s = m->s;
+    HIPCHK(hipSetDevice(s->device));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipEventRecord(a, s->stream));
+    for (int i = 0; i < steps; ++i) {
+        int r = ps_model_train(m, batch, nullptr);
+        if (r != PS_OK) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); return r; }
+        if (m->profile && m->prof_events.size() > 4096) PSCHK(prof_collect(m));
+    }
+    HIPCHK(hipEventRecord(b, s->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_out = ms;
+    return finish_step(m, nullptr);
+}

@@ -1,0 +1,163 @@
+// ps_ops.hip -- stand-alone operators and measurement hooks of the C ABI:
+// device buffers, EmbeddingLayer.forward / FcLayer.forward as single calls
+// (what a JNI GpuEmbeddingLayer / GpuFcLayer binds), and the large-table
+// gather benchmark of BASELINE config 4.
+#include <string.h>
+
+#include "ps_store.h"
+
+extern "C" int ps_dev_alloc(ps_store_t *s, size_t bytes, void **out_dev) {
+    if (!s || !out_dev) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMalloc(out_dev, bytes ? bytes : 16));
+    HIPCHK(hipMemsetAsync(*out_dev, 0, bytes ? bytes : 16, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PS_OK;
+}
+extern "C" int ps_dev_free(ps_store_t *s, void *p) {
+    if (!s) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (p) HIPCHK(hipFree(p));
+    return PS_OK;
+}
+extern "C" int ps_dev_upload(ps_store_t *s, void *dst, const void *src, size_t bytes) {
+    if (!s || !dst || !src) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PS_OK;
+}
+extern "C" int ps_dev_download(ps_store_t *s, void *dst, const void *src, size_t bytes) {
+    if (!s || !dst || !src) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PS_OK;
+}
+extern "C" int ps_store_sync(ps_store_t *s) {
+    if (!s) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, s->err_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        HIPCHK(hipMemset(s->err_dev, 0, sizeof(int)));
+        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err);
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets_dev, int B,
+                              int act, float *out_dev, int ld) {
+    if (!s || !ids_dev || !out_dev || B <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
+    if (ld < s->emb.F * s->emb.D || (s->emb.D % 4 == 0 && (ld & 3))) return ps_set_err(PS_E_BAD_ARG, "bad ld %d", ld);
+    HIPCHK(hipSetDevice(s->device));
+    EmbFwdArgs e;
+    memset(&e, 0, sizeof e);
+    e.W = s->emb.W; e.row_base = s->emb.row_base_dev; e.ids = ids_dev; e.offsets = offsets_dev;
+    e.B = B; e.F = s->emb.F; e.D = s->emb.D; e.X = 0; e.act = act;
+    e.out = out_dev; e.ld = ld; e.err = s->err_dev;
+    return launch_emb_fwd(e, s->stream);
+}
+
+extern "C" int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx, int B,
+                             float *y_dev, int ldy) {
+    if (!s || !x_dev || !y_dev || B <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    if (layer < 0 || layer >= (int)s->fc.size() || !s->fc[layer].present) return ps_set_err(PS_MISSING, "fc%d absent", layer);
+    FcParams &p = s->fc[layer];
+    if (ldx != p.Kpad) return ps_set_err(PS_E_BAD_ARG, "fc%d wants ldx = %d (in+1 rounded up to 16, ones column at %d)", layer, p.Kpad, p.K);
+    if (ldy < p.N) return ps_set_err(PS_E_BAD_ARG, "ldy %d < out %d", ldy, p.N);
+    HIPCHK(hipSetDevice(s->device));
+    const int epi = act == PS_ACT_RELU ? EPI_RELU : act == PS_ACT_SIGMOID ? EPI_SIGMOID : EPI_NONE;
+    return gemm_nt(x_dev, ldx, B, p.Wt, p.Kpad, p.N, y_dev, ldy, B, p.N, p.Kpad, epi, nullptr, 0, 0, nullptr, s->stream);
+}
+
+// ---------------------------------------------------------------------------
+// BASELINE config 4: one huge table, random gather, HBM roofline
+// ---------------------------------------------------------------------------
+namespace {
+__global__ void k_fill_table(float *W, int64_t n4, uint64_t seed) {
+    // cheap device hash fill, float4 per thread (no host copy of a 256 GB table)
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const uint64_t h = ps_splitmix64(seed ^ (uint64_t)i);
+        float4 v;
+        v.x = (float)(uint32_t)(h & 0xFFFF) * (1.0f / 65536.0f) - 0.5f;
+        v.y = (float)(uint32_t)((h >> 16) & 0xFFFF) * (1.0f / 65536.0f) - 0.5f;
+        v.z = (float)(uint32_t)((h >> 32) & 0xFFFF) * (1.0f / 65536.0f) - 0.5f;
+        v.w = (float)(uint32_t)((h >> 48) & 0xFFFF) * (1.0f / 65536.0f) - 0.5f;
+        reinterpret_cast<float4 *>(W)[i] = v;
+    }
+}
+__global__ void k_rand_ids(int64_t *ids, int64_t n, int64_t rows, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[i] = (int64_t)(ps_splitmix64(seed + (uint64_t)i * 0x9E3779B97F4A7C15ull) % (uint64_t)rows);
+}
+__global__ void k_iota_offsets(int64_t *off, int64_t nbags, int bag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nbags) off[i] = i * bag;
+}
+}  // namespace
+
+extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, int iters, uint64_t seed,
+                               double *avg_ms_out, double *bytes_read_out, double *bytes_written_out) {
+    if (!s || rows <= 0 || D <= 0 || (D & 3) || n <= 0 || bag <= 0 || iters <= 0 || !avg_ms_out)
+        return ps_set_err(PS_E_BAD_ARG, "bad argument (D must be a multiple of 4)");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    float *W = nullptr, *out = nullptr;
+    int64_t *ids = nullptr, *off = nullptr, *rb = nullptr;
+    int *err = nullptr;
+    const int64_t nnz = n * bag;
+    const size_t wbytes = sizeof(float) * (size_t)rows * D;
+    hipError_t e = hipMalloc((void **)&W, wbytes);
+    if (e != hipSuccess) return ps_set_err(PS_E_HIP, "hipMalloc of the %.1f GB table failed: %s", wbytes / 1e9, hipGetErrorString(e));
+    int rc = PS_OK;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        if (W) (void)hipFree(W); if (out) (void)hipFree(out); if (ids) (void)hipFree(ids);
+        if (off) (void)hipFree(off); if (rb) (void)hipFree(rb); if (err) (void)hipFree(err);
+    };
+#define BG(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rc = ps_set_err(PS_E_HIP, "%s -> %s", #x, hipGetErrorString(e__)); cleanup(); return rc; } } while (0)
+    BG(hipMalloc((void **)&out, sizeof(float) * (size_t)n * D));
+    BG(hipMalloc((void **)&ids, sizeof(int64_t) * (size_t)nnz));
+    BG(hipMalloc((void **)&off, sizeof(int64_t) * (size_t)(n + 1)));
+    BG(hipMalloc((void **)&rb, sizeof(int64_t) * 2));
+    BG(hipMalloc((void **)&err, sizeof(int)));
+    BG(hipMemsetAsync(err, 0, sizeof(int), st));
+    const int64_t base[2] = {0, rows};
+    BG(hipMemcpyAsync(rb, base, sizeof base, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fill_table, dim3(256 * 32), dim3(256), 0, st, W, (int64_t)(rows * (int64_t)D / 4), seed);
+    hipLaunchKernelGGL(k_rand_ids, dim3(cdiv(nnz, 256)), dim3(256), 0, st, ids, nnz, rows, seed ^ 0xABCDEFull);
+    hipLaunchKernelGGL(k_iota_offsets, dim3(cdiv(n + 1, 256)), dim3(256), 0, st, off, n, bag);
+    BG(hipGetLastError());
+    EmbFwdArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = W; a.row_base = rb; a.ids = ids; a.offsets = bag > 1 ? off : nullptr;
+    a.B = (int)n; a.F = 1; a.D = D; a.X = 0; a.act = PS_ACT_RELU; a.out = out; a.ld = D; a.err = err;
+    if (n > 0x7fffffff) { cleanup(); return ps_set_err(PS_E_BAD_ARG, "n too large"); }
+    rc = launch_emb_fwd(a, st);   // warm-up
+    if (rc != PS_OK) { cleanup(); return rc; }
+    hipEvent_t ea, eb;
+    BG(hipEventCreate(&ea)); BG(hipEventCreate(&eb));
+    BG(hipStreamSynchronize(st));
+    BG(hipEventRecord(ea, st));
+    for (int i = 0; i < iters; ++i) {
+        rc = launch_emb_fwd(a, st);
+        if (rc != PS_OK) { cleanup(); return rc; }
+    }
+    BG(hipEventRecord(eb, st));
+    BG(hipEventSynchronize(eb));
+    float ms = 0.f;
+    BG(hipEventElapsedTime(&ms, ea, eb));
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    *avg_ms_out = (double)ms / iters;
+    if (bytes_read_out) *bytes_read_out = (double)nnz * (4.0 * D + 8.0) + (bag > 1 ? 8.0 * (double)(n + 1) : 0.0);
+    if (bytes_written_out) *bytes_written_out = 4.0 * (double)n * D;
+    cleanup();
+#undef BG
+    return PS_OK;
+}

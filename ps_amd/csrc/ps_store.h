@@ -1,0 +1,102 @@
+// ps_store.h -- the GPU-resident KVStore shard (store/KVStore.java) and the
+// model graph built over it (model/DNN.java, model/WideDeepNN.java).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels_emb.h"
+#include "ps_common.h"
+
+struct EmbTables {
+    int F = 0, D = 0, state_slots = 0;
+    int shard = 0, nshards = 1, route_mode = PS_ROUTE_ID_MOD;
+    std::vector<int64_t> rows;      // vocabulary per field
+    std::vector<int64_t> row_base;  // [F+1] first LOCAL global row of each field
+    int64_t total_rows = 0;         // rows held by this shard
+    float *W = nullptr;             // [total_rows][D]
+    float *state = nullptr;         // [total_rows][2][D]  {M,V} or {Z,N}
+    int64_t *row_base_dev = nullptr;
+};
+
+struct WideTable {
+    int64_t rows = 0;
+    float *W = nullptr, *state = nullptr;  // [rows], [rows][2] {Z,N}
+    uint8_t *touched = nullptr;            // LRLayer.weights membership (never cleared)
+    float *bias = nullptr, *bias_state = nullptr;
+};
+
+struct FcParams {
+    bool present = false;
+    int K = 0, N = 0;        // in, out
+    int Kpad = 0;            // round_up(K+1,16): rows of W' (row K = bias), row stride of Wt
+    int ldw = 0;             // round_up(N,16): row stride of W'
+    float *W = nullptr;      // W'  [Kpad][ldw]   (reference layout [in][out] + bias row)
+    float *Wt = nullptr;     // W'^T [N][Kpad]
+    float *S1 = nullptr, *S2 = nullptr;  // updater state, W' layout
+};
+
+struct ps_store {
+    int device = 0;
+    uint64_t seed = 0;
+    hipStream_t stream = nullptr;
+    EmbTables emb;
+    WideTable wide;
+    std::vector<FcParams> fc;
+    std::map<std::string, ps_updater_t> updaters;
+    int64_t global_step = 0;
+    int64_t bytes = 0;
+    int *err_dev = nullptr;     // device-side bad-id counter
+    // scratch for row get/put
+    int64_t *idx_dev = nullptr; float *rowbuf_dev = nullptr; int64_t scratch_rows = 0; int scratch_D = 0;
+    // scratch for push application
+    SortWorkspace push_ws; uint32_t *push_keys = nullptr, *push_ents = nullptr, *push_seg_start = nullptr,
+                              *push_seg_id = nullptr, *push_nseg = nullptr; int64_t push_cap = 0;
+};
+
+int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero);
+// updater resolution as KVStore.update(Map): exact key, then prefix, then "default"
+int store_resolve_updater(const ps_store *s, const char *key, ps_updater_t *out);
+// local global row of (field, id) on this shard, or -1 when not held here
+int64_t store_local_row(const ps_store *s, int field, int64_t id);
+int store_ensure_scratch(ps_store *s, int64_t rows, int D);
+
+struct FcBuf {
+    float *A = nullptr;  int ldA = 0;     // input activations of layer l: [Bcap][ldA]
+    float *dOut = nullptr; int ldD = 0;   // delta at the output of layer l: [Bcap][ldD]
+    float *part = nullptr; int nsplit = 1; int64_t part_stride = 0; int ldp = 0;
+};
+
+struct ps_model {
+    ps_store *s = nullptr;
+    ps_model_config_t cfg;
+    int Bcap = 0;
+    int64_t nnz_cap = 0;
+    std::vector<FcBuf> fc;      // nfc entries
+    float *out_last = nullptr; int ld_last = 0;   // output of the last FcLayer [Bcap][ld_last]
+    float *dx = nullptr; int ldx = 0;             // delta wrt the embedding columns [Bcap][ldx]
+    float *P = nullptr, *wide_z = nullptr, *terms = nullptr, *loss_dev = nullptr, *gbar_dev = nullptr;
+    int *skip_dev = nullptr;
+    // staged inputs
+    int64_t *ids_dev = nullptr, *offsets_dev = nullptr, *wide_ids_dev = nullptr;
+    float *dense_dev = nullptr, *labels_dev = nullptr;
+    // current batch (device views)
+    const int64_t *cur_ids = nullptr, *cur_offsets = nullptr, *cur_wide = nullptr;
+    const float *cur_dense = nullptr, *cur_labels = nullptr;
+    int cur_B = 0; int64_t cur_nnz = 0; bool fwd_done = false, bwd_done = false;
+    // embedding backward workspaces
+    SortWorkspace ws;
+    uint32_t *keys = nullptr, *ents = nullptr, *ent_bag = nullptr, *seg_start = nullptr, *seg_id = nullptr,
+             *nseg_dev = nullptr, *uniq_row = nullptr, *uniq_cnt = nullptr;
+    uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
+    float *partials = nullptr, *grads_out = nullptr;
+    float *dense_grad_flat = nullptr; int64_t dense_elems = 0;
+    // per-kernel-group event timing (ps_model_set_profile)
+    struct ProfEvent { const char *name; hipEvent_t a, b; };
+    bool profile = false;
+    std::string prof_filter;    // when set: only this kernel group is bracketed
+    std::vector<ProfEvent> prof_events;
+    std::map<std::string, std::pair<long, double>> prof_acc;
+    // graph replay
+    hipGraphExec_t graph_exec = nullptr; int graph_B = -1; int64_t graph_nnz = -1; const void *graph_sig[6] = {0, 0, 0, 0, 0, 0};
+};

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI) against the oracle, on the same
+seeded inputs.  Bit-exact for everything that is integer/copy/elementwise
+(gather, relu, per-key reduction incl. the double-backward factor, Adam,
+Ftrl); FP32 GEMM-fed quantities within 1e-5 relative (the tolerance
+BASELINE.json's north_star states; jblas' sgemm order is unknowable)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+SEED = 0x5EED
+RTOL = 1e-5
+
+
+def close(a, b, scale=None, rtol=RTOL, what=""):
+    """|a-b| <= rtol*|b| + rtol*scale  (scale: magnitude of the terms summed into b)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = np.abs(b).max() if scale is None else scale
+    err = np.abs(a - b) - rtol * np.abs(b) - rtol * s
+    assert err.max() <= 0, "%s: max excess %.3e (max|b| %.3e)" % (what, err.max(), np.abs(b).max())
+
+
+def make_pair(orc, wide, F, D, X, fc, V, B, seed=SEED, **kw):
+    import ps_amd
+    st = orc.Store(seed)
+    om = orc.Model(st, orc.WIDEDEEP if wide else orc.DNN, F, D, X, fc, wide_size=kw.get("wide_size", 1000))
+    kv = ps_amd.KVStore(0, seed)
+    kv.create_embedding([V] * F, D)
+    if wide:
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, kw.get("wide_size", 1000), store=kv, max_batch=B)
+    else:
+        gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    return st, om, kv, gm
+
+
+def data(rng, B, F, X, V, zipf=False):
+    if zipf:
+        E = np.minimum(rng.zipf(1.3, size=(B, F)) - 1, V - 1).astype(np.int64)
+    else:
+        E = rng.integers(0, V, size=(B, F)).astype(np.int64)
+    if B >= 4:
+        E[1] = E[0]
+        E[3, 0] = E[0, 0]
+    Xd = rng.standard_normal((B, X)).astype(f32)
+    Y = (rng.random(B) < 0.3).astype(f32)
+    return E, Xd, Y
+
+
+def test_init_matches_oracle(orc):
+    """Counter-based init is the same pure function on both sides (bit-exact)."""
+    import ps_amd
+    F, D, V = 3, 8, 50
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    kv.create_fc(0, F * D + 2, 5)
+    xav = orc.xavier_scale(1, D)
+    for f in range(F):
+        ids = np.arange(0, V, 7)
+        np.testing.assert_array_equal(kv.get_rows(f, ids), orc.init_rows(SEED, f, ids, D, xav))
+    w = kv.get("fc0.weights")
+    np.testing.assert_array_equal(w, orc.init_dense(SEED, orc.TABLE_FC(0), 5 * (F * D + 2), orc.xavier_scale(F * D + 2, 5)))
+    b = kv.get("fc0.bias")
+    np.testing.assert_array_equal(b, orc.init_dense(SEED, orc.TABLE_FC(0) + 1, 5, orc.xavier_scale(F * D + 2, 1)))
+    # string keys: "emF1.14.0"
+    np.testing.assert_array_equal(kv.get(orc.emb_key(1, 14.0)), orc.init_rows(SEED, 1, [14], D, xav)[0])
+    assert kv.get("emF1.%d.0" % (V + 3)) is None                  # absent key -> null
+    kv.put("emF2.3.0", np.arange(D, dtype=f32))
+    np.testing.assert_array_equal(kv.get_rows(2, [3])[0], np.arange(D, dtype=f32))
+    kv.close()
+
+
+CASES = [
+    # wide, F, D, X, fc, V, B, zipf
+    (False, 3, 4, 2, [5, 3, 1], 5, 6, False),          # tiny, heavy duplicates
+    (True, 3, 4, 2, [5, 3, 1], 5, 6, False),
+    (False, 23, 10, 45, [150, 10, 1], 40, 100, False), # CTR.java shape (C1): D=10 -> scalar lanes
+    (True, 26, 16, 13, [64, 32, 1], 300, 256, True),   # Criteo-like, zipf duplicates, runs > 32 (chunked order)
+]
+
+
+@pytest.mark.parametrize("wide,F,D,X,fc,V,B,zipf", CASES)
+def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
+    rng = np.random.default_rng(7)
+    st, om, kv, gm = make_pair(orc, wide, F, D, X, fc, V, B, wide_size=97)
+    om.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 32)      # runs > 32 use the chunked order on both sides
+    nfc = len(fc)
+    for step in range(3):
+        E, Xd, Y = data(rng, B, F, X, V, zipf)
+        Wd = (E % 97) if wide else None
+        # state before the step (for the bit-exact updater check)
+        uniq = [np.unique(E[:, f]) for f in range(F)]
+        w0 = [kv.get_rows(f, uniq[f]) for f in range(F)]
+        m0 = [kv.get_rows(f, uniq[f], 1) for f in range(F)]
+        v0 = [kv.get_rows(f, uniq[f], 2) for f in range(F)]
+        loss_o = om.train(E.astype(f32), Xd, Y, None if Wd is None else Wd.astype(f32), do_update=False)
+        loss_g = gm.forward({"E": E, "X": Xd, "Y": Y, "W": Wd})
+        # ---- forward: gather + relu + concat are copies -> bit-exact (when weights are)
+        if step == 0:
+            np.testing.assert_array_equal(gm.act(0), om.act(0))
+            np.testing.assert_array_equal(gm.act(1), om.act(1))
+        else:
+            close(gm.act(0), om.act(0), what="emb A")
+        for li in range(nfc):
+            close(gm.act(2 + li) if not (wide and li == nfc - 1) else gm.act(2 + li), om.act(2 + li), what="fc%d A" % li)
+        close(gm.p(B), om.p(), what="P")
+        close(loss_g, loss_o, what="loss")
+        gm.backward()
+        # ---- backward deltas (GEMM-fed): tolerance
+        for li in range(nfc):
+            d_o = om.delta(2 + li)
+            if li == 0:
+                d_o = d_o[:, :F * D] * (om.act(0) > 0)       # our dx is already relu'-masked, embedding columns only
+            close(gm.delta(2 + li), d_o, what="delta fc%d" % li)
+        for li in range(nfc):
+            close(gm.fc_grad(li), om.grad("fc%d.weights" % li), what="dW%d" % li)
+            close(gm.fc_grad(li, True), om.grad("fc%d.bias" % li), what="db%d" % li)
+        # ---- per-key embedding gradient: BIT-EXACT against the oracle's reduction of OUR delta
+        dx = gm.delta(2)
+        g_gpu = []
+        for f in range(F):
+            ids, g = gm.emb_grads(f)
+            np.testing.assert_array_equal(ids, uniq[f])
+            for i, idv in enumerate(ids):
+                ks = np.nonzero(E[:, f] == idv)[0]
+                gk = dx[ks, f * D:(f + 1) * D]
+                np.testing.assert_array_equal(g[i], orc.emb_geff(gk, orc.GRAD_COMPAT, 32), err_msg="emF%d.%d" % (f, idv))
+                close(g[i], om.grad(orc.emb_key(f, float(idv))), scale=np.abs(gk).sum(), what="g emF%d.%d" % (f, idv))
+            g_gpu.append(g)
+        gm.update()
+        om.apply_update()
+        # ---- Adam on rows: BIT-EXACT given our gradient
+        for f in range(F):
+            w1 = kv.get_rows(f, uniq[f]); m1 = kv.get_rows(f, uniq[f], 1); v1 = kv.get_rows(f, uniq[f], 2)
+            for i in range(len(uniq[f])):
+                we, me, ve = orc.adam_update(w0[f][i], g_gpu[f][i], m0[f][i], v0[f][i])
+                np.testing.assert_array_equal(w1[i], we); np.testing.assert_array_equal(m1[i], me); np.testing.assert_array_equal(v1[i], ve)
+        # ---- weights after the step vs the oracle's own run.  One Adam step moves a weight by
+        # ~alfa*g/(|g|+eps): where |g| ~ eps the quotient is ill-conditioned, so compare with an
+        # absolute floor of a fraction of alfa.
+        for f in range(F):
+            w1 = kv.get_rows(f, uniq[f])
+            wo = np.stack([st.get(orc.emb_key(f, float(i))) for i in uniq[f]])
+            assert np.abs(w1 - wo).max() <= 2e-5 * (step + 1), "emb rows drifted: %g" % np.abs(w1 - wo).max()
+        for li in range(nfc):
+            assert np.abs(kv.get("fc%d.weights" % li) - st.get("fc%d.weights" % li)).max() <= 2e-5 * (step + 1)
+            assert np.abs(kv.get("fc%d.bias" % li) - st.get("fc%d.bias" % li)).max() <= 2e-5 * (step + 1)
+        if wide:
+            touched = np.unique(E % 97)
+            wo = np.array([st.get(orc.wide_key(float(i)))[0] for i in touched], f32)
+            assert np.abs(kv.get_wide(touched) - wo).max() <= 2e-5 * (step + 1)
+            assert abs(kv.get("wide.bias")[0] - st.get("wide.bias")[0]) <= 2e-5 * (step + 1)
+    gm.close(); kv.close()
+
+
+def test_fused_train_equals_split_form(orc):
+    """ps_model_train (fused updaters) == forward/backward/update (split form), bit for bit."""
+    import ps_amd
+    F, D, X, fc, V, B = 4, 8, 3, [16, 8, 1], 30, 64
+    rng = np.random.default_rng(3)
+    res = []
+    for fused in (True, False):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, 50, store=kv, max_batch=B)
+        r2 = np.random.default_rng(3)
+        for _ in range(4):
+            E, Xd, Y = data(r2, B, F, X, V, True)
+            d = {"E": E, "X": Xd, "Y": Y, "W": E % 50}
+            if fused:
+                gm.train(d)
+            else:
+                gm.forward(d); gm.backward(); gm.update()
+        res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)],
+                    kv.get_wide(np.arange(50)), kv.get("wide.bias"), kv.global_step()))
+        gm.close(); kv.close()
+    a, b = res
+    for x, y in zip(a[0], b[0]):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(a[1], b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
+    assert a[4] == b[4] == 4
+
+
+def test_ftrl_rows_bit_exact(orc):
+    """Ftrl fused into the sparse scatter (config 5's updater) is bit-exact with the oracle,
+    including the dw[0]==0 skip and w lagging z,n by one update."""
+    import ps_amd
+    F, D, X, fc, V, B = 2, 8, 1, [8, 1], 12, 32
+    rng = np.random.default_rng(9)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    kv.set_updater("emF", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    for step in range(4):
+        E, Xd, Y = data(rng, B, F, X, V)
+        uniq = [np.unique(E[:, f]) for f in range(F)]
+        w0 = [kv.get_rows(f, uniq[f]) for f in range(F)]
+        z0 = [kv.get_rows(f, uniq[f], 1) for f in range(F)]
+        n0 = [kv.get_rows(f, uniq[f], 2) for f in range(F)]
+        gm.train({"E": E, "X": Xd, "Y": Y})
+        for f in range(F):
+            ids, g = gm.emb_grads(f)
+            w1 = kv.get_rows(f, ids); z1 = kv.get_rows(f, ids, 1); n1 = kv.get_rows(f, ids, 2)
+            for i in range(len(ids)):
+                we, ze, ne, _ = orc.ftrl_update(w0[f][i], g[i], z0[f][i], n0[f][i])
+                np.testing.assert_array_equal(w1[i], we); np.testing.assert_array_equal(z1[i], ze); np.testing.assert_array_equal(n1[i], ne)
+    gm.close(); kv.close()
+
+
+def test_loss_slim_stops_backward(orc):
+    """model/DNN.java:58-63: loss <= 0.01 (or NaN) returns before backward: nothing is updated."""
+    import ps_amd
+    F, D, X, fc, V, B = 2, 4, 1, [4, 1], 6, 8
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    # force P -> 0.999 for label 1: huge positive bias on the last layer
+    kv.put("fc1.bias", np.array([50.0], f32))
+    E = np.zeros((B, F), np.int64); Xd = np.zeros((B, X), f32); Y = np.ones(B, f32)
+    before = kv.get_rows(0, [0]).copy(); wb = kv.get("fc0.weights").copy()
+    loss = gm.train({"E": E, "X": Xd, "Y": Y})
+    assert loss <= 0.01
+    np.testing.assert_array_equal(kv.get_rows(0, [0]), before)
+    np.testing.assert_array_equal(kv.get("fc0.weights"), wb)
+    gm.close(); kv.close()
+
+
+def test_predict_matches_forward(orc):
+    import ps_amd
+    F, D, X, fc, V, B = 3, 4, 2, [6, 1], 9, 16
+    rng = np.random.default_rng(1)
+    st, om, kv, gm = make_pair(orc, False, F, D, X, fc, V, B)
+    E, Xd, Y = data(rng, B, F, X, V)
+    close(gm.predict({"E": E, "X": Xd}), om.predict(E.astype(f32), Xd), what="predict")
+    gm.close(); kv.close()
