@@ -247,6 +247,11 @@ int ps_store_sync(ps_store_t *s);
 int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, int iters,
                     uint64_t seed, double *avg_ms_out, double *bytes_read_out,
                     double *bytes_written_out);
+/* GEMM micro-benchmark: kind 0 = C[M][N] = A[M][K] * Bt[N][K]^T (FcLayer forward / delta),
+ * kind 1 = split-K dW[K][N] = A[M][K]^T * D[M][N].  Average ms per launch (HIP events). */
+int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int nsplit, int iters, double *avg_ms_out);
+/* tuning knobs for experiments ("gemm_nt_cfg": 0 auto, 1 128x128, 2 64x128, 3 64x64, 4 128x32 tiles) */
+int ps_tune_set(const char *knob, int value);
 /* Run `steps` training steps on `batch` back to back, timed with HIP events
  * on the store's stream (ms for all steps). */
 int ps_model_time_steps(ps_model_t *m, const ps_batch_t *batch, int steps, double *ms_out);

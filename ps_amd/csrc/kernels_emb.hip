@@ -80,26 +80,36 @@ __device__ __forceinline__ float sigmoid_clip_d(float x) {
     return (float)(0.001f + (double)(.999f - 0.001f) / (1.0 + exp(-(double)x)));
 }
 
+// One wave per sample: lane j fetches wide id j and its weight (F independent gathers in
+// flight, coalesced id reads), then every lane folds the F weights in field order through
+// shuffles -- the reference's sequential f32 sum, without a serial chain of memory latencies.
 __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (b >= a.B) return;
     float p;
     if (a.wide) {
         // LRLayer.forward (layer/LRLayer.java:73-84): sum over the F wide ids, sequential, then + bias
         float sumW = 0.f;
-        for (int j = 0; j < a.F; ++j) {
-            int64_t id = a.wide_ids[(size_t)b * a.F + j];
-            if (id < 0 || id >= a.wide_rows) { atomicAdd(a.err, 1); id = 0; }
-            sumW += a.wide_w[id];
-            if (a.touched && a.train) a.touched[id] = 1;   // LRLayer.weights.put (never cleared)
+        for (int j0 = 0; j0 < a.F; j0 += 64) {
+            float w = 0.f;
+            if (j0 + lane < a.F) {
+                int64_t id = a.wide_ids[(size_t)b * a.F + j0 + lane];
+                if (id < 0 || id >= a.wide_rows) { atomicAdd(a.err, 1); id = 0; }
+                w = a.wide_w[id];
+                if (a.touched && a.train) a.touched[id] = 1;   // LRLayer.weights.put (never cleared)
+            }
+            const int n = a.F - j0 < 64 ? a.F - j0 : 64;
+            for (int j = 0; j < n; ++j) sumW += __shfl(w, j);
         }
         sumW += a.wide_bias[0];
-        a.wide_z[b] = sumW;
+        if (lane == 0) a.wide_z[b] = sumW;
         const float z = a.zlast[(size_t)b * a.ldz] + sumW;  // AddLayer.forward l.add(r)
         p = sigmoid_clip_d(z);
     } else {
         p = a.zlast[(size_t)b * a.ldz];                     // last FcLayer already applied the sigmoid
     }
+    if (lane != 0) return;
     a.P[b] = p;
     if (!a.labels) return;
     const float l = a.labels[b];
@@ -134,8 +144,12 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float *terms, const 
 // ---------------------------------------------------------------------------
 // updaters (shared by sparse rows and dense tensors), one element
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float sqrt_rn(float x) { return __fsqrt_rn(x); }
-__device__ __forceinline__ float div_rn(float x, float y) { return __fdiv_rn(x, y); }
+// IEEE round-to-nearest sqrt and divide.  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS
+// the HIP header maps it to __ocml_native_sqrt_f32 (v_sqrt_f32, ~1 ulp) -- measured 1-ulp
+// mismatches against the oracle.  llvm.sqrt.f32 / fdiv are correctly rounded under hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt (= Java's (float)Math.sqrt((double)x) and '/').
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float div_rn(float x, float y) { return x / y; }
 
 __device__ __forceinline__ void adam_elem(const UpdParams &u, float g, float &w, float &M, float &V) {
     // update/AdamUpdater.java:61-69, op for op
@@ -175,26 +189,51 @@ __device__ __forceinline__ void ftrl_elem(const UpdParams &u, float g, float &w,
 // long-run partials: tile c of CH consecutive sorted entries computes the (at
 // most two) CH-chunks of long segments that START inside it
 // ---------------------------------------------------------------------------
-template <int VEC>
+// BAG is a template parameter on purpose: a run-time "a.ent_bag ? load : p" inside the unrolled
+// batches makes hipcc branch around every load and wait for each one separately (the guide's
+// ".s-level trap (c)"): measured 30 us of serialized round trips per kernel before the hoist.
+template <int VEC, bool BAG>
 __device__ __forceinline__ Vec<VEC> load_g(const EmbBwdArgs &a, uint32_t p, int part) {
     // masked per-sample gradient of entry p: relu'(A)*delta slice
     // (EmbeddingField.java:91; the relu' mask was applied by the producing GEMM epilogue)
-    const uint32_t bag = a.ent_bag ? a.ent_bag[p] : p;
+    uint32_t bag = p;
+    if (BAG) bag = a.ent_bag[p];
     const uint32_t b = bag / (uint32_t)a.F, f = bag % (uint32_t)a.F;
     return Vec<VEC>::load(a.delta + (size_t)b * a.ldd + (size_t)f * a.D + part * VEC);
 }
 
-template <int VEC>
-__device__ __forceinline__ Vec<VEC> chunk_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part) {
-    Vec<VEC> acc = load_g<VEC>(a, a.sorted_ent[s], part);
-    for (uint32_t k = s + 1; k < e; ++k) {
-        const Vec<VEC> g = load_g<VEC>(a, a.sorted_ent[k], part);
-        VFOR(i) acc.at(i) = g.get(i) + acc.at(i);
+// acc (+)= g[s] + g[s+1] + ... in index order.  The adds are a strict chain (the reference
+// order), but the loads are not: entries are fetched PS_EMB_ILP at a time -- 16 independent
+// index loads, then 16 independent row loads -- so a run costs ~2 memory latencies per 16
+// entries instead of 2 per entry (measured 30 us -> the latency chain was the whole kernel).
+#define PS_EMB_ILP 16
+template <int VEC, bool BAG>
+__device__ __forceinline__ void run_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part, Vec<VEC> &acc, bool have) {
+    for (uint32_t k = s; k < e; k += PS_EMB_ILP) {
+        uint32_t ent[PS_EMB_ILP];
+#pragma unroll
+        for (int j = 0; j < PS_EMB_ILP; ++j) ent[j] = a.sorted_ent[k + j < e ? k + j : e - 1];
+        Vec<VEC> g[PS_EMB_ILP];
+#pragma unroll
+        for (int j = 0; j < PS_EMB_ILP; ++j) g[j] = load_g<VEC, BAG>(a, ent[j], part);
+#pragma unroll
+        for (int j = 0; j < PS_EMB_ILP; ++j) {
+            if (k + j < e) {
+                if (have) { VFOR(i) acc.at(i) = g[j].get(i) + acc.at(i); }
+                else { acc = g[j]; have = true; }
+            }
+        }
     }
+}
+
+template <int VEC, bool BAG>
+__device__ __forceinline__ Vec<VEC> chunk_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part) {
+    Vec<VEC> acc = Vec<VEC>::zero();
+    run_sum<VEC, BAG>(a, s, e, part, acc, false);     // first touch: put :91; then addi :94
     return acc;
 }
 
-template <int VEC>
+template <int VEC, bool BAG>
 __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
     if (a.skip && *a.skip) return;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -215,7 +254,7 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
         if (s <= t1 && s < e0) {
             const uint32_t e = s + CH < e0 ? s + CH : e0;
             const size_t slot = (size_t)2 * c + (j == 0 ? 1 : 0);
-            chunk_sum<VEC>(a, s, e, part).store(a.partials + slot * a.D + part * VEC);
+            chunk_sum<VEC, BAG>(a, s, e, part).store(a.partials + slot * a.D + part * VEC);
         }
     }
     const uint32_t u1 = a.seg_id[t1];
@@ -223,7 +262,7 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
         const uint32_t s1 = a.seg_start[u1], e1 = a.seg_start[u1 + 1];
         if (e1 - s1 > CH) {
             const uint32_t e = s1 + CH;  // < e1
-            chunk_sum<VEC>(a, s1, e, part).store(a.partials + ((size_t)2 * c + 1) * a.D + part * VEC);
+            chunk_sum<VEC, BAG>(a, s1, e, part).store(a.partials + ((size_t)2 * c + 1) * a.D + part * VEC);
         }
     }
 }
@@ -231,7 +270,7 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
 // ---------------------------------------------------------------------------
 // per-key reduce (+ double-backward factor) (+ fused updater)
 // ---------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool BAG>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     if (a.skip && *a.skip) return;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -246,17 +285,32 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     const uint32_t n = e0 - s0;
     const uint32_t row = a.sorted_key[s0];
     Vec<VEC> S;
-    if (n <= CH) {
-        S = chunk_sum<VEC>(a, s0, e0, part);                       // put :91, addi :94 in batch order
+    if (n <= PS_EMB_ILP) {
+        // the common case (most keys occur a handful of times): one batch of independent loads
+        // serves both passes from registers
+        uint32_t ent[PS_EMB_ILP];
+#pragma unroll
+        for (int j = 0; j < PS_EMB_ILP; ++j) ent[j] = a.sorted_ent[s0 + ((uint32_t)j < n ? j : n - 1)];
+        Vec<VEC> g[PS_EMB_ILP];
+#pragma unroll
+        for (int j = 0; j < PS_EMB_ILP; ++j) g[j] = load_g<VEC, BAG>(a, ent[j], part);
+        S = g[0];                                                   // put :91
+#pragma unroll
+        for (int j = 1; j < PS_EMB_ILP; ++j)
+            if ((uint32_t)j < n) { VFOR(i) S.at(i) = g[j].get(i) + S.at(i); }   // addi :94, batch order
+        VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);               // divi(N) :100  (pass 1)
         if (a.grad_mode == PS_GRAD_COMPAT) {
-            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);          // divi(N) :100  (pass 1)
-            for (uint32_t k = s0; k < e0; ++k) {                   // pass 2: every g_k again
-                const Vec<VEC> g = load_g<VEC>(a, a.sorted_ent[k], part);
-                VFOR(i) S.at(i) = g.get(i) + S.at(i);
-            }
-            VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));    // divi(2n); then x2 (sum.addi self), /2 (cnt) exact
-        } else {
-            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
+#pragma unroll
+            for (int j = 0; j < PS_EMB_ILP; ++j)                    // pass 2: every g_k again
+                if ((uint32_t)j < n) { VFOR(i) S.at(i) = g[j].get(i) + S.at(i); }
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));     // divi(2n); then x2 (sum.addi self), /2 (cnt) exact
+        }
+    } else if (n <= CH) {
+        S = chunk_sum<VEC, BAG>(a, s0, e0, part);
+        VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
+        if (a.grad_mode == PS_GRAD_COMPAT) {
+            run_sum<VEC, BAG>(a, s0, e0, part, S, true);
+            VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));
         }
     } else {
         const uint32_t nch = (n + CH - 1) / CH;
@@ -264,20 +318,26 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
             const uint32_t s = s0 + j * CH;
             return (size_t)2 * (s / CH) + (j == 0 ? 1 : 0);
         };
-        S = Vec<VEC>::load(a.partials + slot_of(0) * a.D + part * VEC);
-        for (uint32_t j = 1; j < nch; ++j) {
-            const Vec<VEC> p = Vec<VEC>::load(a.partials + slot_of(j) * a.D + part * VEC);
-            VFOR(i) S.at(i) = p.get(i) + S.at(i);
-        }
-        if (a.grad_mode == PS_GRAD_COMPAT) {
-            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
-            for (uint32_t j = 0; j < nch; ++j) {
-                const Vec<VEC> p = Vec<VEC>::load(a.partials + slot_of(j) * a.D + part * VEC);
-                VFOR(i) S.at(i) = p.get(i) + S.at(i);
+        auto add_partials = [&](bool have) {                        // chunk partials in chunk order, 8 loads in flight
+            for (uint32_t j0 = 0; j0 < nch; j0 += PS_EMB_ILP) {
+                Vec<VEC> p[PS_EMB_ILP];
+#pragma unroll
+                for (int j = 0; j < PS_EMB_ILP; ++j)
+                    p[j] = Vec<VEC>::load(a.partials + slot_of(j0 + j < nch ? j0 + j : nch - 1) * a.D + part * VEC);
+#pragma unroll
+                for (int j = 0; j < PS_EMB_ILP; ++j) {
+                    if (j0 + j < nch) {
+                        if (have) { VFOR(i) S.at(i) = p[j].get(i) + S.at(i); }
+                        else { S = p[j]; have = true; }
+                    }
+                }
             }
+        };
+        add_partials(false);
+        VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
+        if (a.grad_mode == PS_GRAD_COMPAT) {
+            add_partials(true);
             VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));
-        } else {
-            VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
         }
     }
     if (a.grads_out) {
@@ -312,7 +372,7 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
 //   BSP: g = (sum over the pushes of the key, in arrival order) / count, one updater step
 //   async (:176-184): one updater step per push, in arrival order, no averaging
 // ---------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool IDENT>
 __global__ __launch_bounds__(256) void k_rows_apply(RowsApplyArgs a) {
     if (a.skip && *a.skip) return;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -323,10 +383,10 @@ __global__ __launch_bounds__(256) void k_rows_apply(RowsApplyArgs a) {
     const int part = lane64 % a.LPR;
     if (u >= (int64_t)*a.nseg) return;
     // identity: the list is already unique (one push per key), runs are single entries
-    const uint32_t s0 = a.identity ? (uint32_t)u : a.seg_start[u];
-    const uint32_t e0 = a.identity ? (uint32_t)u + 1 : a.seg_start[u + 1];
+    uint32_t s0 = (uint32_t)u, e0 = (uint32_t)u + 1;
+    if (!IDENT) { s0 = a.seg_start[u]; e0 = a.seg_start[u + 1]; }
     const uint32_t row = a.sorted_key[s0];
-    auto ent = [&](uint32_t k) -> size_t { return a.identity ? (size_t)k : (size_t)a.sorted_ent[k]; };
+    auto ent = [&](uint32_t k) -> size_t { return IDENT ? (size_t)k : (size_t)a.sorted_ent[k]; };
     float *wp = a.W + (size_t)row * a.D + part * VEC;
     float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
     Vec<VEC> w = Vec<VEC>::load(wp), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
@@ -473,7 +533,7 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
 }
 
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st) {
-    hipLaunchKernelGGL(k_head, dim3(cdiv(a.B, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_head, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);   // one wave per sample
     if (a.labels)
         hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, a.terms, a.dlast, a.ldd, a.B, loss_out, gbar_out, skip, force_no_skip);
     HIPCHK(hipGetLastError());
@@ -489,13 +549,15 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
     const int gp = cdiv((int64_t)cdiv(tiles, gpw) * 64, 256);
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
-    if (vec == 4) {
-        hipLaunchKernelGGL(k_emb_partials<4>, dim3(gp), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_emb_reduce_update<4>, dim3(gr), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(k_emb_partials<1>, dim3(gp), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_emb_reduce_update<1>, dim3(gr), dim3(256), 0, st, a);
-    }
+    const bool bag = a.ent_bag != nullptr;
+#define EMB_BWD_LAUNCH(V, BG)                                                                  \
+    do {                                                                                       \
+        hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gp), dim3(256), 0, st, a);            \
+        hipLaunchKernelGGL((k_emb_reduce_update<V, BG>), dim3(gr), dim3(256), 0, st, a);       \
+    } while (0)
+    if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }
+    else { if (bag) EMB_BWD_LAUNCH(1, true); else EMB_BWD_LAUNCH(1, false); }
+#undef EMB_BWD_LAUNCH
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -557,8 +619,13 @@ int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st) {
     const int gpw = 64 / a.LPR;
     if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
     const int g = cdiv((int64_t)cdiv(n, gpw) * 64, 256);
-    if (vec == 4) hipLaunchKernelGGL(k_rows_apply<4>, dim3(g), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_rows_apply<1>, dim3(g), dim3(256), 0, st, a);
+    if (vec == 4) {
+        if (a.identity) hipLaunchKernelGGL((k_rows_apply<4, true>), dim3(g), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_rows_apply<4, false>), dim3(g), dim3(256), 0, st, a);
+    } else {
+        if (a.identity) hipLaunchKernelGGL((k_rows_apply<1, true>), dim3(g), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_rows_apply<1, false>), dim3(g), dim3(256), 0, st, a);
+    }
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -11,19 +11,16 @@
 //
 // Tiling is for 64-wide waves: a workgroup is 4 waves in a WM x WN grid, each
 // wave owns TM x TN accumulator tiles of 32x32 (16 acc VGPRs each).  K is
-// walked in BK=16 slabs staged through double-buffered LDS with a register
+// walked in BKT-wide slabs staged through double-buffered LDS with a register
 // prefetch of the next slab, one barrier per slab.  At the f32 MFMA rate
 // (64 cycles per instruction per SIMD) LDS bandwidth is far from binding, so
 // the fragment reads stay simple: ds_read_b128 along k with a k-permutation
-// (lanes 0-31 take k 0-3 / 8-11, lanes 32-63 take k 4-7 / 12-15 of a slab).
+// (per 8 k's: lanes 0-31 take k 0-3, lanes 32-63 take k 4-7).
 #include "ps_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 16;
-constexpr int LDS_LD = 20;  // 16 + 4 pad floats: 16-B aligned rows, conflict-free ds_read_b128
 
 struct NtArgs {
     const float *A; int lda; int a_rows;
@@ -35,57 +32,61 @@ struct NtArgs {
     const int *skip;
 };
 
-__device__ __forceinline__ float4 ld4_rows(const float *p, int ld, int row, int nrows, int col) {
-    if (row < nrows) return *reinterpret_cast<const float4 *>(p + (size_t)row * ld + col);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 __device__ __forceinline__ float sigmoid_clip_dev(float x) {
     // activations/Sigmoid.java:11 -- float constants, double exp, cast to float
     return (float)(0.001f + (double)(.999f - 0.001f) / (1.0 + exp(-(double)x)));
 }
 
-template <int WM, int WN, int TM, int TN>
+// C[M][N] = epi(A[M][K] * Bt[N][K]^T); LDS rows are BKT+4 floats (16-B aligned,
+// conflict-free ds_read_b128 for both BKT=16 (stride 20) and BKT=32 (stride 36)).
+template <int WM, int WN, int TM, int TN, int BKT>
 __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_F4 = BM * 4 / 256 > 0 ? BM * 4 / 256 : 1;  // float4 per thread per slab
-    constexpr int B_F4 = BN * 4 / 256 > 0 ? BN * 4 / 256 : 1;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+    constexpr int LD = BKT + 4;
+    constexpr int RF4 = BKT / 4;                               // float4 per tile row
+    constexpr int A_F4 = (BM * RF4 + 255) / 256, B_F4 = (BN * RF4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int nk = a.K / BK;
+    const int nk = (a.K + BKT - 1) / BKT;
 
     float4 ra[A_F4], rb[B_F4];
     auto gload = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
-            if (BM * 4 >= 256 || e < BM * 4)
-                ra[i] = ld4_rows(a.A, a.lda, m0 + (e >> 2), a.a_rows, k0 + (e & 3) * 4);
+            const int r = m0 + e / RF4, c = k0 + (e % RF4) * 4;
+            // unconditional load from a clamped (always valid) address, zeroed by select:
+            // a branch around the load would serialise the slab's loads (one wait each)
+            const bool ok = ((BM * RF4) % 256 == 0 || e < BM * RF4) && r < a.a_rows && c < a.K;
+            const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)(r < a.a_rows ? r : a.a_rows - 1) * a.lda + (c < a.K ? c : a.K - 4));
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
-            if (BN * 4 >= 256 || e < BN * 4)
-                rb[i] = ld4_rows(a.Bt, a.ldb, n0 + (e >> 2), a.b_rows, k0 + (e & 3) * 4);
+            const int r = n0 + e / RF4, c = k0 + (e % RF4) * 4;
+            const bool ok = ((BN * RF4) % 256 == 0 || e < BN * RF4) && r < a.b_rows && c < a.K;
+            const float4 v = *reinterpret_cast<const float4 *>(a.Bt + (size_t)(r < a.b_rows ? r : a.b_rows - 1) * a.ldb + (c < a.K ? c : a.K - 4));
+            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto swrite = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
-            if (BM * 4 >= 256 || e < BM * 4)
-                *reinterpret_cast<float4 *>(&As[buf][(e >> 2) * LDS_LD + (e & 3) * 4]) = ra[i];
+            if ((BM * RF4) % 256 == 0 || e < BM * RF4)
+                *reinterpret_cast<float4 *>(&As[buf][(e / RF4) * LD + (e % RF4) * 4]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
-            if (BN * 4 >= 256 || e < BN * 4)
-                *reinterpret_cast<float4 *>(&Bs[buf][(e >> 2) * LDS_LD + (e & 3) * 4]) = rb[i];
+            if ((BN * RF4) % 256 == 0 || e < BN * RF4)
+                *reinterpret_cast<float4 *>(&Bs[buf][(e / RF4) * LD + (e % RF4) * 4]) = rb[i];
         }
     };
 
@@ -100,20 +101,20 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     gload(0);
     swrite(0);
     __syncthreads();
-    const int arow = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-    const int brow = (wn * TN * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < BKT / 8; ++q) {
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4 *>(&As[buf][arow + i * 32 * LDS_LD + q * 8]);
+                fa[i] = *reinterpret_cast<const float4 *>(&As[buf][arow + i * 32 * LD + q * 8]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][brow + j * 32 * LDS_LD + q * 8]);
+                fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][brow + j * 32 * LD + q * 8]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -135,18 +136,25 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
             const int rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+            // relu' mask: all 16 loads issued up front with clamped (always valid) addresses --
+            // a load inside the per-element `if` would be waited for one by one
+            float mk[16];
+            if (a.epi == EPI_MASK_POS) {
+                const int mc = col < a.mask_cols ? col : a.mask_cols - 1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    mk[r] = a.mask[(size_t)(row < a.M ? row : a.M - 1) * a.ldmask + mc];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < a.M && col < a.N) {
-                    float v = acc[i][j][r];
-                    if (a.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
-                    else if (a.epi == EPI_SIGMOID) v = sigmoid_clip_dev(v);
-                    else if (a.epi == EPI_MASK_POS) {
-                        if (col < a.mask_cols) v *= a.mask[(size_t)row * a.ldmask + col] > 0.f ? 1.f : 0.f;
-                    }
-                    a.C[(size_t)row * a.ldc + col] = v;
-                }
+                float v = acc[i][j][r];
+                if (a.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
+                else if (a.epi == EPI_SIGMOID) v = sigmoid_clip_dev(v);
+                else if (a.epi == EPI_MASK_POS) v *= (col >= a.mask_cols || mk[r] > 0.f) ? 1.f : 0.f;
+                if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
             }
         }
 }
@@ -160,51 +168,52 @@ struct TnArgs {
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int BKT>
 __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_F4 = BM * 4 / 256 > 0 ? BM * 4 / 256 : 1;  // 16 rows * B?/4 float4 / 256 threads
-    constexpr int B_F4 = BN * 4 / 256 > 0 ? BN * 4 / 256 : 1;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Ds[2][BK * BN];
+    constexpr int A_F4 = (BKT * BM / 4 + 255) / 256, B_F4 = (BKT * BN / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BKT * BM];
+    __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
     const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int m_begin = blockIdx.z * a.mchunk;
     const int m_end = m_begin + a.mchunk < a.M ? m_begin + a.mchunk : a.M;
-    const int nk = m_end > m_begin ? (m_end - m_begin + BK - 1) / BK : 0;
+    const int nk = m_end > m_begin ? (m_end - m_begin + BKT - 1) / BKT : 0;
 
     float4 ra[A_F4], rb[B_F4];
     auto gload = [&](int kt) {
-        const int mb = m_begin + kt * BK;
+        const int mb = m_begin + kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
             const int r = e / (BM / 4), c = (e % (BM / 4)) * 4;
             const int gm = mb + r, gc = k0 + c;
-            ra[i] = (e < BM * 4 && gm < m_end && gc < a.a_cols) ? *reinterpret_cast<const float4 *>(a.A + (size_t)gm * a.lda + gc)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = e < BKT * BM / 4 && gm < m_end && gc < a.a_cols;
+            const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)(gm < a.M ? gm : a.M - 1) * a.lda + (gc < a.a_cols ? gc : a.a_cols - 4));
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
             const int r = e / (BN / 4), c = (e % (BN / 4)) * 4;
             const int gm = mb + r, gc = n0 + c;
-            rb[i] = (e < BN * 4 && gm < m_end && gc < a.d_cols) ? *reinterpret_cast<const float4 *>(a.D + (size_t)gm * a.ldd + gc)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = e < BKT * BN / 4 && gm < m_end && gc < a.d_cols;
+            const float4 v = *reinterpret_cast<const float4 *>(a.D + (size_t)(gm < a.M ? gm : a.M - 1) * a.ldd + (gc < a.d_cols ? gc : a.d_cols - 4));
+            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto swrite = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
-            if (e < BM * 4) *reinterpret_cast<float4 *>(&As[buf][(e / (BM / 4)) * BM + (e % (BM / 4)) * 4]) = ra[i];
+            if (e < BKT * BM / 4) *reinterpret_cast<float4 *>(&As[buf][(e / (BM / 4)) * BM + (e % (BM / 4)) * 4]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
-            if (e < BN * 4) *reinterpret_cast<float4 *>(&Ds[buf][(e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = rb[i];
+            if (e < BKT * BN / 4) *reinterpret_cast<float4 *>(&Ds[buf][(e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = rb[i];
         }
     };
 
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
+        for (int s = 0; s < BKT / 2; ++s) {
             float fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = As[buf][(2 * s + kh) * BM + acol + i * 32];
@@ -260,22 +269,39 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
 
 }  // namespace
 
+// tuning knobs (ps_tune_set): 0 = automatic
+int g_gemm_nt_cfg = 0;   // 1 128x128/16, 2 64x128/16, 3 64x64/16, 4 128x32/16, 5 64x64/32, 6 64x128/32, 7 128x128/32, 8 128x32/32
+int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5 128x32/32
+
+#define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
+    hipLaunchKernelGGL((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32), cdiv(N, WN * TN * 32)), \
+                       dim3(256), 0, st, a)
+
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
             const int *skip_flag, hipStream_t st) {
-    if (K % BK != 0 || (lda & 3) || (ldb & 3))
-        return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 16/4/4", K, lda, ldb);
+    if ((K & 3) || (lda & 3) || (ldb & 3))
+        return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
     NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag};
-    auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
-    if (N <= 32) {
-        hipLaunchKernelGGL((k_gemm_nt<4, 1, 1, 1>), dim3(cdiv(M, 128), cdiv(N, 32)), dim3(256), 0, st, a);
-    } else if (tiles(128, 128) >= 256) {
-        hipLaunchKernelGGL((k_gemm_nt<2, 2, 2, 2>), dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
-    } else if (tiles(64, 128) >= 256) {
-        hipLaunchKernelGGL((k_gemm_nt<2, 2, 1, 2>), dim3(cdiv(M, 64), cdiv(N, 128)), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((k_gemm_nt<2, 2, 1, 1>), dim3(cdiv(M, 64), cdiv(N, 64)), dim3(256), 0, st, a);
+    int cfg = g_gemm_nt_cfg;
+    if (cfg == 0) {
+        // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
+        // (measured best on MI355X for M=4096, N in 256..512, K in 256..528); narrow N: 128x32.
+        auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
+        if (N <= 32) cfg = 8;
+        else if (tiles(64, 128) >= 2048) cfg = 6;
+        else cfg = 5;
+    }
+    switch (cfg) {
+    case 1: NT_LAUNCH(2, 2, 2, 2, 16); break;
+    case 2: NT_LAUNCH(2, 2, 1, 2, 16); break;
+    case 3: NT_LAUNCH(2, 2, 1, 1, 16); break;
+    case 4: NT_LAUNCH(4, 1, 1, 1, 16); break;
+    case 5: NT_LAUNCH(2, 2, 1, 1, 32); break;
+    case 6: NT_LAUNCH(2, 2, 1, 2, 32); break;
+    case 7: NT_LAUNCH(2, 2, 2, 2, 32); break;
+    default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -283,13 +309,17 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 
 int gemm_tn_choose_split(int Kout, int N, int M) {
     const long long tiles = N <= 32 ? (long long)cdiv(Kout, 128) * cdiv(N, 32) : (long long)cdiv(Kout, 64) * cdiv(N, 64);
-    int s = (int)((384 + tiles - 1) / tiles);          // aim at ~1.5 workgroups per CU
-    const int max_s = M / 128 > 0 ? M / 128 : 1;       // keep >= 128 batch rows per split
+    int s = (int)((768 + tiles - 1) / tiles);           // ~3 workgroups per CU; more splits = more partial traffic
+    const int max_s = M / 128 > 0 ? M / 128 : 1;        // keep >= 128 batch rows per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     return s;
 }
+
+#define TN_LAUNCH(WM, WN, TM, TN, BKT)                                                                      \
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT>),                                                    \
+                       dim3(cdiv(Kout, WM * TM * 32), cdiv(N, WN * TN * 32), nsplit), dim3(256), 0, st, a)
 
 int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
@@ -297,12 +327,17 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     if ((lda & 3) || (ldd & 3) || (a_cols & 3) || (d_cols & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_tn: leading dims / cols must be multiples of 4");
     if (Kout <= 0 || N <= 0 || nsplit <= 0) return PS_OK;
-    const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), BK);
+    const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), 32);
     TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag};
-    if (N <= 32)
-        hipLaunchKernelGGL((k_gemm_tn<4, 1, 1, 1>), dim3(cdiv(Kout, 128), cdiv(N, 32), nsplit), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_gemm_tn<2, 2, 1, 1>), dim3(cdiv(Kout, 64), cdiv(N, 64), nsplit), dim3(256), 0, st, a);
+    int cfg = g_gemm_tn_cfg;
+    if (cfg == 0) cfg = N <= 32 ? 5 : 2;
+    switch (cfg) {
+    case 1: TN_LAUNCH(2, 2, 1, 1, 16); break;
+    case 2: TN_LAUNCH(2, 2, 1, 1, 32); break;
+    case 3: TN_LAUNCH(2, 2, 2, 2, 16); break;
+    case 4: TN_LAUNCH(4, 1, 1, 1, 16); break;
+    default: TN_LAUNCH(4, 1, 1, 1, 32); break;
+    }
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -2,6 +2,11 @@
 // segment (run-of-equal-keys) builder that the deterministic embedding
 // backward stands on (per-key sums in batch order, no
 // float atomics).  gfx950: 64-wide waves, ballot-based stable ranking.
+//
+// Every kernel first issues ALL of its global loads unconditionally (indices
+// clamped, not branched): a load inside an `if` of an unrolled loop makes
+// hipcc wait for each one separately, and at these sizes (1e5 keys) a kernel
+// is nothing but a chain of memory round trips.
 #include "ps_common.h"
 
 namespace {
@@ -18,12 +23,18 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restric
     __shared__ uint32_t h[256];
     const int tid = threadIdx.x;
     h[tid] = 0;
-    __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    uint32_t k[RS_IPT];
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = base + j * RS_TPB + tid;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+        k[j] = keys[idx < n ? idx : n - 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const int64_t idx = base + j * RS_TPB + tid;
+        if (idx < n) atomicAdd(&h[(k[j] >> shift) & 255u], 1u);
     }
     __syncthreads();
     counts[(size_t)tid * nblk + blockIdx.x] = h[tid];
@@ -31,25 +42,27 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restric
 
 // in-place exclusive scan of `total` u32 by ONE workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t *__restrict__ a, int total) {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (total + 1023) / 1024;
     const int lo = tid * per;
     const int hi = lo + per < total ? lo + per : total;
     uint32_t s = 0;
     for (int i = lo; i < hi; ++i) s += a[i];
-    part[tid] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // wave-level inclusive scan with shuffles, then across the 16 waves
+    uint32_t inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
     }
-    uint32_t run = part[tid] - s;  // exclusive prefix of this thread's chunk
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int i = 0; i < w; ++i) wbase += wsum[i];
+    uint32_t run = wbase + inc - s;  // exclusive prefix of this thread's chunk
     for (int i = lo; i < hi; ++i) {
-        uint32_t v = a[i];
+        const uint32_t v = a[i];
         a[i] = run;
         run += v;
     }
@@ -59,6 +72,7 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t *__restrict__ 
 // walks them in 16 batches of 64 in index order, ranking equal digits inside
 // a batch with ballots (lanes in increasing order) and across batches with a
 // running per-(wave,digit) cursor in LDS.
+template <bool IOTA>
 __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__restrict__ kin,
                                                           const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout,
@@ -69,22 +83,25 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
     __shared__ uint32_t cur[4][256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 1024; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
-    __syncthreads();
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_SPAN;
     uint32_t k[RS_IPT], v[RS_IPT];
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = wbase + j * 64 + lane;
-        k[j] = 0; v[j] = 0;
-        if (idx < n) {
-            k[j] = kin[idx];
-            v[j] = vin ? vin[idx] : (uint32_t)idx;
-            atomicAdd(&cur[w][(k[j] >> shift) & 255u], 1u);
-        }
+        const int64_t ci = idx < n ? idx : n - 1;
+        k[j] = kin[ci];
+        v[j] = IOTA ? (uint32_t)idx : vin[ci];
+    }
+    const uint32_t goff = offs[(size_t)tid * nblk + blockIdx.x];   // digit tid's global cursor for this block
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const int64_t idx = wbase + j * 64 + lane;
+        if (idx < n) atomicAdd(&cur[w][(k[j] >> shift) & 255u], 1u);
     }
     __syncthreads();
     {   // thread tid owns digit tid: turn per-wave counts into per-wave global cursors
-        uint32_t g = offs[(size_t)tid * nblk + blockIdx.x];
+        uint32_t g = goff;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
             const uint32_t c = cur[ww][tid];
@@ -119,8 +136,9 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
 }
 
 // ---- segments -------------------------------------------------------------
-__device__ __forceinline__ bool is_head(const uint32_t *keys, int64_t idx) {
-    return idx == 0 || keys[idx] != keys[idx - 1];
+// head(idx) = idx == 0 || keys[idx] != keys[idx-1], from two unconditional loads
+__device__ __forceinline__ bool head_of(uint32_t cur, uint32_t prev, int64_t idx, int64_t n) {
+    return idx < n && (idx == 0 || cur != prev);
 }
 
 __global__ __launch_bounds__(RS_TPB) void k_seg_count(const uint32_t *__restrict__ keys, int64_t n,
@@ -128,12 +146,17 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_count(const uint32_t *__restrict
     __shared__ uint32_t red[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
-    uint32_t c = 0;
+    uint32_t kc[RS_IPT], kp[RS_IPT];
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = base + j * RS_TPB + tid;
-        if (idx < n && is_head(keys, idx)) ++c;
+        const int64_t ci = idx < n ? idx : n - 1;
+        kc[j] = keys[ci];
+        kp[j] = keys[ci > 0 ? ci - 1 : 0];
     }
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) c += head_of(kc[j], kp[j], base + j * RS_TPB + tid, n) ? 1u : 0u;
     for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
     if (lane == 0) red[w] = c;
     __syncthreads();
@@ -148,17 +171,24 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict_
     __shared__ uint32_t red[4];
     __shared__ uint32_t wave_heads[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_SPAN;
+    uint32_t kc[RS_IPT], kp[RS_IPT];
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const int64_t idx = wbase + j * 64 + lane;
+        const int64_t ci = idx < n ? idx : n - 1;
+        kc[j] = keys[ci];
+        kp[j] = keys[ci > 0 ? ci - 1 : 0];
+    }
     // heads in all earlier blocks
     uint32_t acc = 0;
     for (int i = tid; i < (int)blockIdx.x; i += RS_TPB) acc += blk_heads[i];
     for (int off = 32; off; off >>= 1) acc += __shfl_down(acc, off);
     if (lane == 0) red[w] = acc;
-    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_SPAN;
     uint32_t hbits = 0, wcount = 0;
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
-        const int64_t idx = wbase + j * 64 + lane;
-        const bool h = idx < n && is_head(keys, idx);
+        const bool h = head_of(kc[j], kp[j], wbase + j * 64 + lane, n);
         hbits |= (h ? 1u : 0u) << j;
         wcount += (uint32_t)__popcll(__ballot(h));
     }
@@ -220,9 +250,10 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
         hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.counts, 256 * nblk);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RS_TPB), 0, st, kin,
-                           (p == 0 && iota_vals) ? (const uint32_t *)nullptr : (const uint32_t *)vin,
-                           kout, vout, n, shift, ws.counts, nblk);
+        if (p == 0 && iota_vals)
+            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, nblk);
+        else
+            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, nblk);
         uint32_t *t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

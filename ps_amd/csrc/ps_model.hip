@@ -36,6 +36,18 @@ struct Prof {
     }
 };
 
+// side chains: while profiling (events on the main stream) or with multi_stream off, everything
+// stays on the main stream and fork/join are no-ops
+hipStream_t side_stream(ps_model *m, int i) { return (m->profile || !m->multi_stream) ? m->s->stream : m->side[i]; }
+int fork(ps_model *m, hipStream_t from, hipStream_t to) {
+    if (from == to) return PS_OK;
+    hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+    HIPCHK(hipEventRecord(e, from));
+    HIPCHK(hipStreamWaitEvent(to, e, 0));
+    return PS_OK;
+}
+int join(ps_model *m, hipStream_t from, hipStream_t to) { return fork(m, from, to); }
+
 int bits_for(int64_t n) {
     int b = 1;
     while (b < 32 && (1ll << b) < n) ++b;
@@ -114,6 +126,9 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->grads_out, sizeof(float) * (size_t)(nc + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->dense_grad_flat, sizeof(float) * (size_t)m->dense_elems, true));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+    m->events.resize(64);
+    for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));
     *out = m;
     return PS_OK;
@@ -124,7 +139,9 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     (void)hipSetDevice(m->s->device);
     (void)hipStreamSynchronize(m->s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (int i = 0; i < 2; ++i) if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
+    for (auto &e : m->events) (void)hipEventDestroy(e);
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
@@ -146,6 +163,10 @@ static int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
     if (need_labels && !b->labels) return ps_set_err(PS_E_BAD_ARG, "batch.labels is NULL");
     if (c.kind == PS_MODEL_WIDEDEEP && !b->wide_ids) return ps_set_err(PS_E_BAD_ARG, "batch.wide_ids is NULL");
     hipStream_t st = m->s->stream;
+    if (m->side0_pending) {      // a forward without its backward: do not let the next gather race the old sort
+        PSCHK(join(m, m->side[0], st));
+        m->side0_pending = false;
+    }
     const int64_t nbags = (int64_t)b->B * c.F;
     int64_t nnz = nbags;
     if (b->offsets) {
@@ -208,6 +229,22 @@ static int enqueue_forward(ps_model *m, bool train) {
     e.ent_bag = (train && m->cur_offsets) ? m->ent_bag : nullptr;
     e.err = s->err_dev;
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
+    if (train) {
+        // the sort only needs the row keys the gather just emitted: run it beside the FC chain
+        hipStream_t ss = side_stream(m, 0);
+        PSCHK(fork(m, st, ss));
+        const int64_t nnz = m->cur_nnz;
+        {
+            Prof pf(m, "emb_sort");
+            PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
+                                   &m->sorted_ents, ss));
+        }
+        {
+            Prof pf(m, "emb_segments");
+            PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss));
+        }
+        m->side0_pending = true;
+    }
     // FcLayer.forward x nfc
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
@@ -241,10 +278,28 @@ static int enqueue_backward(ps_model *m, bool apply) {
     hipStream_t st = s->stream;
     const int B = m->cur_B, nfc = c.nfc;
     const int *skip = m->skip_dev;
+    // side chain 1: wide update, then every dW GEMM as soon as its delta exists, then the dense update
+    hipStream_t sw = side_stream(m, 1);
+    PSCHK(fork(m, st, sw));
+    ps_updater_t u;
+    // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
+    if (c.kind == PS_MODEL_WIDEDEEP && apply) {
+        if (c.wide_grad_mode != PS_GRAD_COMPAT)
+            return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is not implemented on the device path yet");
+        WideUpdArgs w;
+        memset(&w, 0, sizeof w);
+        w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
+        w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = skip;
+        PSCHK(store_resolve_updater(s, "wide.weights", &u));
+        w.upd = make_upd_params(u);
+        Prof pf(m, "wide_update");
+        PSCHK(launch_wide_update(w, sw));
+    }
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
         FcParams &p = s->fc[l];
         FcBuf &b = m->fc[l];
+        if (l < nfc - 1) PSCHK(fork(m, st, sw));     // delta_l was just produced on the main chain
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
@@ -260,13 +315,12 @@ static int enqueue_backward(ps_model *m, bool apply) {
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
-                             b.nsplit, skip, st));
+                             b.nsplit, skip, sw));
     }
     // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
     DenseUpdArgs d;
     memset(&d, 0, sizeof d);
     d.nlayers = nfc; d.B = B; d.apply = apply ? 1 : 0; d.skip = skip;
-    ps_updater_t u;
     PSCHK(store_resolve_updater(s, "fc0.weights", &u));
     d.upd = make_upd_params(u);
     d.grad_out = m->dense_grad_flat;
@@ -279,31 +333,12 @@ static int enqueue_backward(ps_model *m, bool apply) {
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }
-    { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }
-    // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
-    if (c.kind == PS_MODEL_WIDEDEEP && apply) {
-        if (c.wide_grad_mode != PS_GRAD_COMPAT)
-            return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is not implemented on the device path yet");
-        WideUpdArgs w;
-        memset(&w, 0, sizeof w);
-        w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
-        w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = skip;
-        PSCHK(store_resolve_updater(s, "wide.weights", &u));
-        w.upd = make_upd_params(u);
-        Prof pf(m, "wide_update");
-        PSCHK(launch_wide_update(w, st));
-    }
-    // EmbeddingLayer.backward (twice): sort entries by row, per-key run reduce, fused updater
+    { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }   // in order behind the dW GEMMs
+    // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
+    // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
-    {
-        Prof pf(m, "emb_sort");
-        PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
-                               &m->sorted_ents, st));
-    }
-    {
-        Prof pf(m, "emb_segments");
-        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
-    }
+    PSCHK(join(m, side_stream(m, 0), st));
+    m->side0_pending = false;
     EmbBwdArgs g;
     memset(&g, 0, sizeof g);
     g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = (apply && s->emb.state) ? 1 : 0;
@@ -314,6 +349,7 @@ static int enqueue_backward(ps_model *m, bool apply) {
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
     { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st)); }
+    PSCHK(join(m, sw, st));       // the step is complete when the main stream is
     return PS_OK;
 }
 
@@ -375,12 +411,49 @@ static int finish_step(ps_model *m, float *loss) {
     return PS_OK;
 }
 
+// One training step as a replayed hipGraph: the kernel arguments bake in the batch pointers,
+// so there is one instantiated graph per (pointers, B, nnz); host batches are staged into the
+// model's fixed device buffers first (outside the graph) and share one graph.
+static int train_graph(ps_model *m) {
+    ps_store *s = m->s;
+    const void *sig[5] = {m->cur_ids, m->cur_offsets, m->cur_dense, m->cur_labels, m->cur_wide};
+    for (auto &g : m->graphs)
+        if (g.B == m->cur_B && g.nnz == m->cur_nnz && memcmp(g.sig, sig, sizeof sig) == 0) {
+            HIPCHK(hipGraphLaunch(g.exec, s->stream));
+            return PS_OK;
+        }
+    if (m->graphs.size() >= 64) {        // do not grow without bound on ever-changing pointers
+        for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear();
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_forward(m, true);
+    if (rc == PS_OK) rc = enqueue_backward(m, true);
+    hipError_t e = hipStreamEndCapture(s->stream, &graph);
+    if (rc != PS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return ps_set_err(PS_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    ps_model::GraphEntry ge;
+    memcpy(ge.sig, sig, sizeof sig);
+    ge.B = m->cur_B; ge.nnz = m->cur_nnz; ge.exec = nullptr;
+    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return ps_set_err(PS_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    m->graphs.push_back(ge);
+    HIPCHK(hipGraphLaunch(ge.exec, s->stream));
+    return PS_OK;
+}
+
 extern "C" int ps_model_train(ps_model_t *m, const ps_batch_t *batch, float *loss) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     HIPCHK(hipSetDevice(m->s->device));
     PSCHK(stage_batch(m, batch, true));
-    PSCHK(enqueue_forward(m, true));
-    PSCHK(enqueue_backward(m, true));
+    if (m->cfg.use_graph && !m->profile) {
+        PSCHK(train_graph(m));
+    } else {
+        PSCHK(enqueue_forward(m, true));
+        PSCHK(enqueue_backward(m, true));
+    }
     m->fwd_done = true; m->bwd_done = true;
     m->s->global_step++;                               // Context.step / PServer.globalStep
     return finish_step(m, loss);

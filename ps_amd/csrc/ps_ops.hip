@@ -161,3 +161,44 @@ extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, in
 #undef BG
     return PS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// tuning knobs and the GEMM micro-benchmark (measurement only)
+// ---------------------------------------------------------------------------
+extern "C" int ps_tune_set(const char *knob, int value) {
+    if (!knob) return ps_set_err(PS_E_BAD_ARG, "null knob");
+    if (strcmp(knob, "gemm_nt_cfg") == 0) { g_gemm_nt_cfg = value; return PS_OK; }
+    if (strcmp(knob, "gemm_tn_cfg") == 0) { g_gemm_tn_cfg = value; return PS_OK; }
+    return ps_set_err(PS_E_BAD_ARG, "unknown knob %s", knob);
+}
+
+extern "C" int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int nsplit, int iters, double *avg_ms_out) {
+    if (!s || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !avg_ms_out) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    const int Kp = (int)round_up(K, 16), Np = (int)round_up(N, 16);
+    float *A = nullptr, *B = nullptr, *Cc = nullptr;
+    const size_t ea = (size_t)M * (kind == 0 ? Kp : (size_t)round_up(K, 16));
+    HIPCHK(hipMalloc((void **)&A, sizeof(float) * (size_t)M * Kp));
+    HIPCHK(hipMalloc((void **)&B, sizeof(float) * (size_t)(kind == 0 ? (size_t)N * Kp : (size_t)M * Np)));
+    HIPCHK(hipMalloc((void **)&Cc, sizeof(float) * (kind == 0 ? (size_t)M * Np : (size_t)nsplit * Kp * Np)));
+    (void)ea;
+    PSCHK(launch_fill(A, (int64_t)M * Kp, 0.5f, st));
+    PSCHK(launch_fill(B, kind == 0 ? (int64_t)N * Kp : (int64_t)M * Np, 0.25f, st));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    int rc = PS_OK;
+    for (int it = -2; it < iters && rc == PS_OK; ++it) {
+        if (it == 0) HIPCHK(hipEventRecord(e0, st));
+        if (kind == 0) rc = gemm_nt(A, Kp, M, B, Kp, N, Cc, Np, M, N, Kp, EPI_RELU, nullptr, 0, 0, nullptr, st);
+        else rc = gemm_tn_splitk(A, Kp, Kp, B, Np, Np, Cc, Np, (int64_t)Kp * Np, K, N, M, nsplit, nullptr, st);
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(Cc);
+    return rc;
+}

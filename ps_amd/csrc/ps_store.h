@@ -97,6 +97,13 @@ struct ps_model {
     std::string prof_filter;    // when set: only this kernel group is bracketed
     std::vector<ProfEvent> prof_events;
     std::map<std::string, std::pair<long, double>> prof_acc;
-    // graph replay
-    hipGraphExec_t graph_exec = nullptr; int graph_B = -1; int64_t graph_nnz = -1; const void *graph_sig[6] = {0, 0, 0, 0, 0, 0};
+    // side streams: independent chains of the step (sort | dW + dense update | wide update) run
+    // beside the main FC chain; fork/join through events (also what the captured graph records)
+    hipStream_t side[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> events; size_t next_event = 0;
+    bool multi_stream = true;
+    bool side0_pending = false;   // a forward forked the sort chain and no backward joined it yet
+    // graph replay: one instantiated graph per (batch pointers, B, nnz)
+    struct GraphEntry { const void *sig[5]; int B; int64_t nnz; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
 };

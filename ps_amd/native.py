@@ -96,6 +96,8 @@ SIGNATURES = {
     "ps_emb_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i]),
     "ps_fc_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),
+    "ps_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _pd]),
+    "ps_tune_set": (_i, [_cp, _i]),
     "ps_model_time_steps": (_i, [_vp, C.POINTER(ps_batch_t), _i, _pd]),
     "ps_model_set_profile": (_i, [_vp, _i]),
     "ps_model_set_profile_filter": (_i, [_vp, _cp]),
