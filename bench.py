@@ -188,11 +188,13 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--zipf", type=float, default=1.05, help="id distribution exponent; <= 1 means uniform")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="run the sharded (multi-GPU) path even at N=1")
+    ap.add_argument("--is-async", type=int, default=0, help="async push (-DisPsAsync=1): no averaging, arrival order")
     ap.add_argument("--gather", type=int, default=1)
     ap.add_argument("--gather-rows", type=int, default=64 * 1000 * 1000)   # 16.4 GB at D=64
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.sharded:
         from ps_amd import sharded
         out = sharded.run_bench(args, C2, synth_batch)
         if out is not None:

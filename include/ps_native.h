@@ -237,6 +237,59 @@ int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx
                   int B, float *y_dev, int ldy);
 int ps_store_sync(ps_store_t *s);
 
+/* ---- net.PSClient / PSRouterClient / PServer over a sharded store ------
+ * One ps_store_t per GPU holds the embedding rows with id mod N == shard
+ * (net/Mod.java routing, PS_ROUTE_ID_MOD); dense FC tensors and the wide
+ * table are replicated and kept identical by an all-reduce.  These are the
+ * device-side halves of the exchange; the host moves the buffers between
+ * ranks (RCCL all-to-all-v / all-reduce over xGMI: torch.distributed in
+ * bench.py, any binding in a Java host).  Per step and rank:
+ *
+ *   ps_shard_plan            = PSRouterClient.getList fan-out  (net/PSRouterClient.java:60-85)
+ *     all-to-all counts, all-to-all-v send_rows -> recv_rows
+ *   ps_shard_serve_pull      = PServer.getList                 (net/PServer.java:102-117)
+ *     all-to-all-v rows back  -> cache [U][D]  (the worker cache, store/KVStore.java:96)
+ *   ps_shard_forward_backward= Model.train on the cached rows  (model/DNN.java:35-70)
+ *   ps_shard_grads           = the per-key gradients PSClient.push sends (net/PSClient.java:154-174)
+ *     all-to-all-v grads      -> recv_grads (same order as recv_rows)
+ *   ps_shard_apply_push      = PServer.push + barrier + psUpdate (net/PServer.java:164-283)
+ *   ps_shard_flat_grad / all-reduce(sum) / ps_shard_apply_flat
+ *                            = push + psUpdate of every dense tensor and wide key
+ *
+ * The step never stops early on loss <= 0.01 in this mode (a worker that
+ * skipped its backward would stall the collective). */
+/* Adopt the host framework's HIP stream (hipStream_t) for everything this
+ * store enqueues, so kernels and the host's collectives are stream-ordered. */
+int ps_store_set_stream(ps_store_t *s, void *hip_stream);
+/* Worker: stage the batch, find its unique (field,id) keys grouped by owner
+ * shard.  counts_out[nshards] = keys per owner; *send_rows_dev = the
+ * owner-local row of every unique key (uint32, owner-major, ascending row). */
+int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards, int64_t *counts_out,
+                  uint32_t **send_rows_dev, int64_t *n_unique);
+/* Owner: rows_out_dev[i][0..D) = weights of local row rows_dev[i]. */
+int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int64_t n, float *rows_out_dev);
+/* Worker: forward + loss + backward reading embedding rows from cache_dev
+ * [n_unique][D] (order of send_rows).  Leaves the per-key gradients, the
+ * flat dense/wide gradient, and writes *loss when non-NULL (syncs). */
+int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, float *loss);
+/* Worker: *grads_dev = [n_unique][D] gradients in the order of send_rows
+ * (each already carries this worker's double-backward factor, App. A.6). */
+int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_unique);
+/* Owner: rows_dev[n] / grads_dev[n][D] as received from all workers
+ * (worker-major).  BSP (is_async = 0): mean over the workers that pushed a
+ * key, one updater step per key.  Async (-DisPsAsync=1,
+ * net/PServer.java:176-184): every push applied on its own, in arrival
+ * (= worker) order.  globalStep++ either way. */
+int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev,
+                        int64_t n, int is_async);
+/* Replicated tensors: one flat device buffer
+ * [fc weights+biases | wide G | wide C | wide.bias g] to all-reduce(sum);
+ * G[k] = this worker's mean delta if it ever touched key k, C[k] = 1 if so. */
+int ps_shard_flat_grad(ps_model_t *m, float **flat_dev, int64_t *nfloats);
+/* Apply the all-reduced flat buffer: dense g = sum / nworkers (every worker
+ * pushes every dense tensor), wide g[k] = G[k] / C[k] over the touching workers. */
+int ps_shard_apply_flat(ps_model_t *m, int nworkers);
+
 /* ---- measurement hooks ------------------------------------------------ */
 /* Large-table gather run (BASELINE config 4): one table of rows x D floats
  * filled on device (no host copy), n bags of `bag` uniform-random ids,

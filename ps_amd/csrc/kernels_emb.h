@@ -14,6 +14,7 @@ struct EmbFwdArgs {
     const float *dense;        // [B][X] or nullptr
     uint32_t *key_out;         // [nnz] global row per entry (sort key) or nullptr
     uint32_t *ent_bag;         // [nnz] bag of each entry (multi-hot) or nullptr
+    const uint32_t *slot;      // when set: row of entry p is slot[p] (W = pulled-row cache), ids unused
     int *err;                  // out-of-range id counter
     int LPR, gather_blocks;    // filled by the launcher
 };
@@ -58,6 +59,7 @@ struct DenseUpdArgs {
     int nlayers, B, apply;
     UpdParams upd;
     const float *flat_grad;            // when set: use this instead of partials/B
+    float flat_div;                    // > 0: divide flat_grad by it (mean over workers after the all-reduce)
     float *grad_out;                   // flat gradient as handed to the updater (or nullptr)
     const int *skip;
 };
@@ -71,6 +73,9 @@ struct WideUpdArgs {
     const float *gbar;
     UpdParams upd;
     const int *skip;
+    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C
+    float *G, *C;                      // [rows] (+ G[2*rows] = bias gradient), contiguous G|C|bias
+    int nworkers;
 };
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st);
 

@@ -58,9 +58,14 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
     const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
     Vec<VEC> s = Vec<VEC>::zero();
     for (int64_t p = p0; p < p1; ++p) {
-        int64_t id = a.ids[p];
-        if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
-        const int64_t row = rb + id;
+        int64_t row;
+        if (a.slot) {
+            row = a.slot[p];                      // sharded worker: slot in the pulled-row cache
+        } else {
+            int64_t id = a.ids[p];
+            if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
+            row = rb + id;
+        }
         const Vec<VEC> r = Vec<VEC>::load(a.W + (size_t)row * a.D + part * VEC);
         if (p == p0) s = r;                       // rcopy of one row (EmbeddingField.java:73)
         else { VFOR(i) s.at(i) = r.get(i) + s.at(i); }  // sum pooling, in bag order
@@ -433,6 +438,7 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     if (a.flat_grad) {
         // multi-worker path: the (all-reduced) mean gradient was materialised flat
         g = a.flat_grad[t];
+        if (a.flat_div > 0.f) g = div_rn(g, a.flat_div);
     } else {
         float s = 0.f;
         for (int z = 0; z < L.nsplit; ++z) s += L.part[(size_t)z * L.part_stride + (size_t)k * L.ldp + n];
@@ -453,7 +459,20 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
 __global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
     if (a.skip && *a.skip) return;
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const float g = a.gbar[0];
+    if (a.mode == 1) {
+        // sharded worker, before the all-reduce: G[k] = touched[k] * gbar, C[k] = touched[k]
+        // (the PS averages a key over the workers that pushed it: net/PServer.java:164-214)
+        const float gb = a.gbar[0];
+        if (r < a.rows) { const float t = a.touched[r] ? 1.f : 0.f; a.G[r] = t * gb; a.C[r] = t; }
+        else if (r == a.rows) a.G[2 * a.rows] = gb;          // wide.bias: every worker pushes it
+        return;
+    }
+    float g = a.gbar ? a.gbar[0] : 0.f;
+    if (a.mode == 2) {
+        // after the all-reduce: mean over the workers that touched the key
+        if (r < a.rows) { const float c = a.C[r]; if (!(c > 0.f)) return; g = div_rn(a.G[r], c); }
+        else if (r == a.rows) g = div_rn(a.G[2 * a.rows], (float)a.nworkers);
+    }
     if (r == a.rows) {
         // "wide.bias": 1x1, same rowMeans(delta)  (layer/LRLayer.java:106-107)
         if (a.upd.kind == PS_UPD_FTRL) { if (g != 0.f) ftrl_elem(a.upd, g, a.bias[0], a.bias_state[0], a.bias_state[1]); }
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
     }
     if (r > a.rows) return;
     // compat (layer/LRLayer.java:110-117): every key ever touched gets the same gbar
-    if (!a.touched[r]) return;
+    if (a.mode == 0 && !a.touched[r]) return;
     float w = a.W[r], z = a.state[2 * r], n = a.state[2 * r + 1];
     if (a.upd.kind == PS_UPD_FTRL) { if (g == 0.f) return; ftrl_elem(a.upd, g, w, z, n); }
     else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, z, n);

@@ -155,7 +155,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
 // ---------------------------------------------------------------------------
 // batch staging
 // ---------------------------------------------------------------------------
-static int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
+int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
     const ps_model_config_t &c = m->cfg;
     if (!b || b->B <= 0 || b->B > m->Bcap) return ps_set_err(PS_E_BAD_ARG, "batch size %d out of (0,%d]", b ? b->B : 0, m->Bcap);
     if (!b->ids) return ps_set_err(PS_E_BAD_ARG, "batch.ids is NULL");
@@ -214,7 +214,7 @@ static int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // ---------------------------------------------------------------------------
 // the three phases, enqueued on the store's stream
 // ---------------------------------------------------------------------------
-static int enqueue_forward(ps_model *m, bool train) {
+int enqueue_forward(ps_model *m, bool train) {
     ps_store *s = m->s;
     const ps_model_config_t &c = m->cfg;
     hipStream_t st = s->stream;
@@ -228,8 +228,13 @@ static int enqueue_forward(ps_model *m, bool train) {
     e.key_out = train ? m->keys : nullptr;
     e.ent_bag = (train && m->cur_offsets) ? m->ent_bag : nullptr;
     e.err = s->err_dev;
+    if (m->sh.active) {
+        // sharded worker: rows come from the cache pulled from their owners (store/KVStore.java:96),
+        // keys and the sort were made by ps_shard_plan
+        e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr;
+    }
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
-    if (train) {
+    if (train && !m->sh.active) {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
         PSCHK(fork(m, st, ss));
@@ -268,11 +273,11 @@ static int enqueue_forward(ps_model *m, bool train) {
     h.P = m->P; h.wide_z = m->wide_z; h.terms = m->terms;
     h.dlast = m->fc[nfc - 1].dOut; h.ldd = m->fc[nfc - 1].ldD;
     h.err = s->err_dev;
-    { Prof pf(m, "head_loss"); PSCHK(launch_head(h, m->loss_dev, m->gbar_dev, m->skip_dev, 0, st)); }
+    { Prof pf(m, "head_loss"); PSCHK(launch_head(h, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, st)); }
     return PS_OK;
 }
 
-static int enqueue_backward(ps_model *m, bool apply) {
+int enqueue_backward(ps_model *m, bool apply) {
     ps_store *s = m->s;
     const ps_model_config_t &c = m->cfg;
     hipStream_t st = s->stream;
@@ -323,7 +328,7 @@ static int enqueue_backward(ps_model *m, bool apply) {
     d.nlayers = nfc; d.B = B; d.apply = apply ? 1 : 0; d.skip = skip;
     PSCHK(store_resolve_updater(s, "fc0.weights", &u));
     d.upd = make_upd_params(u);
-    d.grad_out = m->dense_grad_flat;
+    d.grad_out = m->sh.active ? m->sh.flat : m->dense_grad_flat;   // sharded: straight into the all-reduce buffer
     int64_t off = 0;
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
@@ -337,7 +342,7 @@ static int enqueue_backward(ps_model *m, bool apply) {
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
-    PSCHK(join(m, side_stream(m, 0), st));
+    if (!m->sh.active) PSCHK(join(m, side_stream(m, 0), st));
     m->side0_pending = false;
     EmbBwdArgs g;
     memset(&g, 0, sizeof g);
@@ -397,7 +402,7 @@ static int enqueue_update(ps_model *m) {
     return PS_OK;
 }
 
-static int finish_step(ps_model *m, float *loss) {
+int finish_step(ps_model *m, float *loss) {
     ps_store *s = m->s;
     if (!loss) return PS_OK;
     HIPCHK(hipMemcpyAsync(loss, m->loss_dev, sizeof(float), hipMemcpyDeviceToHost, s->stream));

@@ -1,0 +1,289 @@
+// ps_shard.hip -- the device-side halves of the parameter-server exchange when
+// the KVStore is sharded over N GPUs (one ps_store_t per GPU, rows routed by
+// id mod N exactly as net/PSRouterClient.java routes keys through net/Mod.java):
+//
+//   worker  PSRouterClient.getList  net/PSRouterClient.java:60-85   -> ps_shard_plan (unique keys grouped by owner)
+//   owner   PServer.getList         net/PServer.java:102-117        -> ps_shard_serve_pull (row gather)
+//   worker  KVStore cache + train   store/KVStore.java:96           -> ps_shard_forward_backward (rows read from the pulled cache)
+//   worker  PSClient.push per key   net/PSClient.java:154-174       -> ps_shard_grads (per-key gradients, already in send order)
+//   owner   PServer.push + psUpdate net/PServer.java:164-214        -> ps_shard_apply_push (mean over pushing workers, one updater step)
+//   dense   one RPC per tensor      net/PSClient.java:47-70,154-174 -> ps_shard_flat_grad / ps_shard_apply_flat (one all-reduce)
+//
+// The wire (RCCL all-to-all-v / all-reduce over xGMI) belongs to the host:
+// bench.py drives it through torch.distributed, a Java host through its own
+// binding; the buffers handed over here are plain device pointers.
+#include <string.h>
+
+#include "ps_store.h"
+
+namespace {
+
+int bits_for(int64_t n) {
+    int b = 1;
+    while (b < 32 && (1ll << b) < n) ++b;
+    return b;
+}
+
+// composite sort key of every entry: owner << sbits | owner-local row.  One thread per bag.
+__global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ ids, const int64_t *__restrict__ offsets,
+                                                    int64_t nbags, int F, int nshards, int sbits,
+                                                    const int64_t *__restrict__ lrb /*[nshards][F+1]*/,
+                                                    const int64_t *__restrict__ vocab /*[F]*/,
+                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ ent_bag, int *err) {
+    const int64_t bag = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (bag >= nbags) return;
+    const int f = (int)(bag % F);
+    const int64_t p0 = offsets ? offsets[bag] : bag, p1 = offsets ? offsets[bag + 1] : bag + 1;
+    for (int64_t p = p0; p < p1; ++p) {
+        int64_t id = ids[p];
+        if (id < 0 || id >= vocab[f]) { atomicAdd(err, 1); id = 0; }
+        const int o = (int)(id % nshards);
+        const int64_t local = lrb[(size_t)o * (F + 1) + f] + id / nshards;
+        keys[p] = ((uint32_t)o << sbits) | (uint32_t)local;
+        if (ent_bag) ent_bag[p] = (uint32_t)bag;
+    }
+}
+
+// per unique key: owner-local row to request, and where each owner's run starts
+__global__ __launch_bounds__(256) void k_shard_unique(const uint32_t *__restrict__ sorted_key, const uint32_t *__restrict__ seg_start,
+                                                      const uint32_t *__restrict__ nseg, int sbits, int nshards,
+                                                      uint32_t *__restrict__ send_rows, uint32_t *__restrict__ owner_start) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = *nseg;
+    if (u >= n) return;
+    const uint32_t key = sorted_key[seg_start[u]];
+    const uint32_t prev = u ? sorted_key[seg_start[u - 1]] : 0u;
+    send_rows[u] = key & ((1u << sbits) - 1u);
+    const int o = (int)(key >> sbits);
+    const int po = u ? (int)(prev >> sbits) : -1;
+    for (int oo = po + 1; oo <= o; ++oo) owner_start[oo] = u;     // owners without keys start where the next one does
+    if (u == n - 1)
+        for (int oo = o + 1; oo <= nshards; ++oo) owner_start[oo] = n;
+}
+
+__global__ __launch_bounds__(256) void k_slot_of_entry(const uint32_t *__restrict__ sorted_ent, const uint32_t *__restrict__ seg_id,
+                                                       int64_t n, uint32_t *__restrict__ slot) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) slot[sorted_ent[i]] = seg_id[i];
+}
+
+// rows_out[i][:] = W[rows[i]][:]   (PServer.getList: the rows for a key list)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, const uint32_t *__restrict__ rows, int64_t n,
+                                                     int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / LPR;
+    const int part = (int)(t % LPR);
+    if (i >= n) return;
+    int64_t r = rows[i];
+    if (r >= total_rows) { if (part == 0) atomicAdd(err, 1); r = 0; }
+    if (VEC == 4) *reinterpret_cast<float4 *>(out + (size_t)i * D + part * 4) = *reinterpret_cast<const float4 *>(W + (size_t)r * D + part * 4);
+    else out[(size_t)i * D + part] = W[(size_t)r * D + part];
+}
+
+int ensure_push_ws(ps_store *s, int64_t n) {
+    if (n <= s->push_cap) return PS_OK;
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    sort_ws_free(s->push_ws);
+    fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);
+    s->push_keys = s->push_ents = s->push_seg_start = s->push_seg_id = s->push_nseg = nullptr;
+    const int64_t cap = n + n / 4 + 1024;
+    PSCHK(sort_ws_alloc(s->push_ws, cap));
+    HIPCHK(hipMalloc((void **)&s->push_keys, sizeof(uint32_t) * (size_t)(cap + 1)));
+    HIPCHK(hipMalloc((void **)&s->push_ents, sizeof(uint32_t) * (size_t)(cap + 1)));
+    HIPCHK(hipMalloc((void **)&s->push_seg_start, sizeof(uint32_t) * (size_t)(cap + 2)));
+    HIPCHK(hipMalloc((void **)&s->push_seg_id, sizeof(uint32_t) * (size_t)(cap + 1)));
+    HIPCHK(hipMalloc((void **)&s->push_nseg, sizeof(uint32_t) * 4));
+    s->push_cap = cap;
+    return PS_OK;
+}
+
+int ensure_shard_state(ps_model *m, int nshards) {
+    ps_model::Shard &sh = m->sh;
+    ps_store *s = m->s;
+    if (sh.slot && sh.nshards == nshards) return PS_OK;
+    if (sh.slot) return ps_set_err(PS_E_STATE, "the shard count of a model cannot change (%d -> %d)", sh.nshards, nshards);
+    if (s->emb.nshards != nshards) return ps_set_err(PS_E_BAD_ARG, "store holds shard %d/%d, plan wants %d shards", s->emb.shard, s->emb.nshards, nshards);
+    const int F = s->emb.F;
+    sh.nshards = nshards;
+    std::vector<int64_t> lrb((size_t)nshards * (F + 1), 0);
+    int64_t maxrows = 1;
+    for (int o = 0; o < nshards; ++o) {
+        for (int f = 0; f < F; ++f) {
+            const int64_t cnt = s->emb.rows[f] > o ? (s->emb.rows[f] - o + nshards - 1) / nshards : 0;
+            lrb[(size_t)o * (F + 1) + f + 1] = lrb[(size_t)o * (F + 1) + f] + cnt;
+        }
+        if (lrb[(size_t)o * (F + 1) + F] > maxrows) maxrows = lrb[(size_t)o * (F + 1) + F];
+    }
+    sh.sbits = bits_for(maxrows);
+    if (sh.sbits + bits_for(nshards) > 32) return ps_set_err(PS_E_UNSUPPORTED, "owner and local row do not fit one 32-bit sort key");
+    const int64_t nc = m->nnz_cap;
+    PSCHK(store_dev_alloc(s, (void **)&sh.lrb_dev, sizeof(int64_t) * lrb.size() + sizeof(int64_t) * F, false));
+    HIPCHK(hipMemcpyAsync(sh.lrb_dev, lrb.data(), sizeof(int64_t) * lrb.size(), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(sh.lrb_dev + lrb.size(), s->emb.rows.data(), sizeof(int64_t) * F, hipMemcpyHostToDevice, s->stream));
+    PSCHK(store_dev_alloc(s, (void **)&sh.slot, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(store_dev_alloc(s, (void **)&sh.send_rows, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(store_dev_alloc(s, (void **)&sh.owner_start, sizeof(uint32_t) * (size_t)(nshards + 2), true));
+    sh.flat_elems = m->dense_elems + (m->cfg.kind == PS_MODEL_WIDEDEEP ? 2 * s->wide.rows + 1 : 0);
+    PSCHK(store_dev_alloc(s, (void **)&sh.flat, sizeof(float) * (size_t)sh.flat_elems, true));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PS_OK;
+}
+
+}  // namespace
+
+extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
+    // Adopt the host framework's stream (e.g. torch.cuda.current_stream().cuda_stream) so the
+    // kernels here and the RCCL collectives the host enqueues are ordered without host syncs.
+    if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->stream = (hipStream_t)hip_stream;      // the store's own stream is simply left idle
+    return PS_OK;
+}
+
+extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards, int64_t *counts_out,
+                             uint32_t **send_rows_dev, int64_t *n_unique) {
+    if (!m || !batch || !counts_out || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    ps_store *s = m->s;
+    HIPCHK(hipSetDevice(s->device));
+    PSCHK(ensure_shard_state(m, nshards));
+    PSCHK(stage_batch(m, batch, true));
+    ps_model::Shard &sh = m->sh;
+    hipStream_t st = s->stream;
+    const int F = m->cfg.F;
+    const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
+    hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, st, m->cur_ids, m->cur_offsets, nbags, F, nshards,
+                       sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), m->keys,
+                       m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev);
+    HIPCHK(hipGetLastError());
+    PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
+    PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
+    HIPCHK(hipMemsetAsync(sh.owner_start, 0, sizeof(uint32_t) * (nshards + 2), st));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_shard_unique, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_keys, m->seg_start, m->nseg_dev,
+                           sh.sbits, nshards, sh.send_rows, sh.owner_start);
+        hipLaunchKernelGGL(k_slot_of_entry, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_ents, m->seg_id, nnz, sh.slot);
+        HIPCHK(hipGetLastError());
+    }
+    std::vector<uint32_t> os(nshards + 1, 0);
+    HIPCHK(hipMemcpyAsync(os.data(), sh.owner_start, sizeof(uint32_t) * (nshards + 1), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int o = 0; o < nshards; ++o) counts_out[o] = (int64_t)os[o + 1] - (int64_t)os[o];
+    sh.U = os[nshards];
+    if (send_rows_dev) *send_rows_dev = sh.send_rows;
+    if (n_unique) *n_unique = sh.U;
+    return PS_OK;
+}
+
+extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int64_t n, float *rows_out_dev) {
+    if (!s || n < 0 || (n > 0 && (!rows_dev || !rows_out_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
+    if (n == 0) return PS_OK;
+    HIPCHK(hipSetDevice(s->device));
+    const int D = s->emb.D, vec = D % 4 == 0 ? 4 : 1, LPR = D / vec;
+    if (vec == 4)
+        hipLaunchKernelGGL(k_gather_rows<4>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev);
+    else
+        hipLaunchKernelGGL(k_gather_rows<1>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, float *loss) {
+    if (!m || (!cache_dev && m->sh.U > 0)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    if (!m->sh.slot) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
+    ps_store *s = m->s;
+    HIPCHK(hipSetDevice(s->device));
+    m->sh.active = true;
+    m->sh.cache = cache_dev;
+    int rc = enqueue_forward(m, true);
+    if (rc == PS_OK) rc = enqueue_backward(m, false);     // gradients only: the owners apply them
+    if (rc == PS_OK && m->cfg.kind == PS_MODEL_WIDEDEEP) {
+        WideUpdArgs w;
+        memset(&w, 0, sizeof w);
+        w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev; w.mode = 1;
+        w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
+        rc = launch_wide_update(w, s->stream);
+    }
+    m->sh.active = false;
+    PSCHK(rc);
+    m->fwd_done = true; m->bwd_done = true;
+    return finish_step(m, loss);
+}
+
+extern "C" int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_unique) {
+    if (!m || !grads_dev) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    if (!m->bwd_done) return ps_set_err(PS_E_STATE, "no gradients: ps_shard_forward_backward first");
+    *grads_dev = m->grads_out;          // [U][D], in the order of ps_shard_plan's send_rows
+    if (n_unique) *n_unique = m->sh.U;
+    return PS_OK;
+}
+
+extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n, int is_async) {
+    if (!s || n < 0 || (n > 0 && (!rows_dev || !grads_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    if (n > 0) {
+        PSCHK(ensure_push_ws(s, n));
+        // stable sort by row: within a key the pushes stay in arrival (= source worker) order
+        HIPCHK(hipMemcpyAsync(s->push_keys, rows_dev, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st));
+        uint32_t *sk = nullptr, *se = nullptr;
+        PSCHK(radix_sort_pairs(s->push_ws, s->push_keys, s->push_ents, n, bits_for(s->emb.total_rows), true, &sk, &se, st));
+        PSCHK(build_segments(s->push_ws, sk, n, s->push_seg_start, s->push_seg_id, s->push_nseg, st));
+        RowsApplyArgs r;
+        memset(&r, 0, sizeof r);
+        r.D = s->emb.D; r.is_async = is_async ? 1 : 0; r.identity = 0;
+        r.sorted_key = sk; r.sorted_ent = se; r.seg_start = s->push_seg_start; r.nseg = s->push_nseg;
+        r.grads = grads_dev; r.W = s->emb.W; r.state = s->emb.state;
+        ps_updater_t u;
+        PSCHK(store_resolve_updater(s, "emF", &u));
+        r.upd = make_upd_params(u);
+        PSCHK(launch_rows_apply(r, n, st));
+    }
+    s->global_step++;                    // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)
+    return PS_OK;
+}
+
+extern "C" int ps_shard_flat_grad(ps_model_t *m, float **flat_dev, int64_t *nfloats) {
+    if (!m || !flat_dev || !nfloats) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    if (!m->sh.flat) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
+    *flat_dev = m->sh.flat;
+    *nfloats = m->sh.flat_elems;
+    return PS_OK;
+}
+
+extern "C" int ps_shard_apply_flat(ps_model_t *m, int nworkers) {
+    if (!m || nworkers < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    if (!m->sh.flat) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
+    ps_store *s = m->s;
+    HIPCHK(hipSetDevice(s->device));
+    const int nfc = m->cfg.nfc;
+    ps_updater_t u;
+    DenseUpdArgs d;
+    memset(&d, 0, sizeof d);
+    d.nlayers = nfc; d.B = m->cur_B; d.apply = 1; d.flat_grad = m->sh.flat; d.flat_div = (float)nworkers;
+    PSCHK(store_resolve_updater(s, "fc0.weights", &u));
+    d.upd = make_upd_params(u);
+    int64_t off = 0;
+    for (int l = 0; l < nfc; ++l) {
+        FcParams &p = s->fc[l];
+        DenseLayer &L = d.L[l];
+        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+        L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
+        L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
+    }
+    PSCHK(launch_dense_update(d, s->stream));
+    if (m->cfg.kind == PS_MODEL_WIDEDEEP) {
+        WideUpdArgs w;
+        memset(&w, 0, sizeof w);
+        w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
+        w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.mode = 2; w.nworkers = nworkers;
+        w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
+        PSCHK(store_resolve_updater(s, "wide.weights", &u));
+        w.upd = make_upd_params(u);
+        PSCHK(launch_wide_update(w, s->stream));
+    }
+    return PS_OK;
+}

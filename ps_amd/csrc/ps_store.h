@@ -39,7 +39,8 @@ struct FcParams {
 struct ps_store {
     int device = 0;
     uint64_t seed = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream everything is enqueued on (own_stream, or one adopted from the host)
+    hipStream_t own_stream = nullptr;
     EmbTables emb;
     WideTable wide;
     std::vector<FcParams> fc;
@@ -97,6 +98,20 @@ struct ps_model {
     std::string prof_filter;    // when set: only this kernel group is bracketed
     std::vector<ProfEvent> prof_events;
     std::map<std::string, std::pair<long, double>> prof_acc;
+    // sharded (multi-GPU) step state: the worker half of PSRouterClient.getList / push
+    struct Shard {
+        bool active = false;          // forward reads rows from `cache` through `slot`
+        int nshards = 1;
+        const float *cache = nullptr; // [U][D] rows pulled from their owners, in send order
+        uint32_t *slot = nullptr;     // [nnz] unique slot of every entry
+        uint32_t *send_rows = nullptr;// [U] owner-local row of every unique key, grouped by owner
+        uint32_t *owner_start = nullptr; // [nshards+1] device
+        int64_t *lrb_dev = nullptr;   // [nshards][F+1] local row bases of every shard
+        float *flat = nullptr;        // [dense_elems | wideG | wideC | wide bias g] for the all-reduce
+        int64_t flat_elems = 0;
+        int sbits = 0;
+        int64_t U = 0;
+    } sh;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)
     hipStream_t side[2] = {nullptr, nullptr};
@@ -107,3 +122,9 @@ struct ps_model {
     struct GraphEntry { const void *sig[5]; int B; int64_t nnz; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
 };
+
+// shared between ps_model.hip and ps_shard.hip
+int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
+int enqueue_forward(ps_model *m, bool train);
+int enqueue_backward(ps_model *m, bool apply);
+int finish_step(ps_model *m, float *loss);

@@ -206,7 +206,8 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
     ps_store *s = new ps_store();
     s->device = device;
     s->seed = seed;
-    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
     PSCHK(store_dev_alloc(s, (void **)&s->err_dev, sizeof(int), true));
     ps_updater_t a;
     ps_updater_default_adam(&a);
@@ -226,7 +227,7 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     fr(s->err_dev); fr(s->idx_dev); fr(s->rowbuf_dev);
     sort_ws_free(s->push_ws);
     fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);
-    (void)hipStreamDestroy(s->stream);
+    (void)hipStreamDestroy(s->own_stream);    // an adopted stream belongs to the host
     delete s;
     return PS_OK;
 }

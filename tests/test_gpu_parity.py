@@ -281,3 +281,33 @@ def test_predict_matches_forward(orc):
     E, Xd, Y = data(rng, B, F, X, V)
     close(gm.predict({"E": E, "X": Xd}), om.predict(E.astype(f32), Xd), what="predict")
     gm.close(); kv.close()
+
+
+def test_sharded_path_n1_equals_fused_step(orc):
+    """The PS exchange with one shard (every collective the identity) is the fused step, bit for bit:
+    pull -> train on the cached rows -> push -> owner mean over 1 worker -> updater; dense/wide g/1."""
+    import ps_amd
+    from ps_amd.sharded import HipBackend, LocalComm, ShardedWorker
+    F, D, X, fc, V, B, WS = 5, 8, 3, [16, 8, 1], 40, 96, 31
+    res = []
+    for sharded in (False, True):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+        worker = ShardedWorker(HipBackend(gm), LocalComm())
+        rng = np.random.default_rng(4)
+        losses = []
+        for _ in range(4):
+            E, Xd, Y = data(rng, B, F, X, V, True)
+            b = ps_amd.Batch(E, Xd, Y, E % WS)
+            losses.append(worker.step(b) if sharded else gm.train(b))
+        res.append((losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get_rows(f, np.arange(V), 1) for f in range(F)],
+                    [kv.get("fc%d.weights" % i) for i in range(3)], [kv.get("fc%d.bias" % i) for i in range(3)],
+                    kv.get_wide(np.arange(WS)), kv.get("wide.bias")))
+        gm.close(); kv.close()
+    a, b = res
+    assert a[0] == b[0]
+    for i in (1, 2, 3, 4):
+        for x, y in zip(a[i], b[i]):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[5], b[5]); np.testing.assert_array_equal(a[6], b[6])
