@@ -1,0 +1,162 @@
+"""world_size-2 test of the sharded parameter-server orchestration (ps_amd/sharded.py) on CPU:
+gloo collectives + the oracle-backed stand-in backend.  Checks routing (id mod N), split sizes,
+buffer order, BSP averaging over the pushing workers, async arrival-order updates and the single
+dense/wide all-reduce against an independent single-process simulation of the PS semantics
+(net/PServer.java:164-214, net/PSRouterClient.java:60-151)."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+f32 = np.float32
+CFG = dict(F=3, V=23, D=4, X=2, fc=[6, 4, 1], wide=11, B=10)
+SEED, STEPS = 0x5EED, 3
+
+
+def make_batches(rank, steps):
+    rng = np.random.default_rng(100 + rank)
+    out = []
+    for _ in range(steps):
+        E = rng.integers(0, CFG["V"], size=(CFG["B"], CFG["F"])).astype(np.int64)
+        E[1] = E[0]; E[3, 0] = E[0, 0]
+        E[5] = [1, 2, 3]                 # a row every worker pushes: keys averaged over both workers
+        X = rng.standard_normal((CFG["B"], CFG["X"])).astype(f32)
+        Y = (rng.random(CFG["B"]) < 0.4).astype(f32)
+        out.append({"E": E, "X": X, "Y": Y, "W": E % CFG["wide"]})
+    return out
+
+
+def expected(world, is_async):
+    """Key-addressed single-process simulation: W workers, one global parameter dictionary."""
+    from oracle import oracle as orc
+    F, D = CFG["F"], CFG["D"]
+    dims = [F * D + CFG["X"]] + CFG["fc"]
+    xav = orc.xavier_scale(1, D)
+    emb = {}
+
+    def row(f, i):
+        if (f, i) not in emb:
+            emb[(f, i)] = [orc.init_rows(SEED, f, [i], D, xav)[0], np.zeros(D, f32), np.zeros(D, f32)]
+        return emb[(f, i)]
+
+    fcW = [orc.init_dense(SEED, orc.TABLE_FC(l), dims[l] * dims[l + 1], orc.xavier_scale(dims[l], dims[l + 1])) for l in range(3)]
+    fcb = [orc.init_dense(SEED, orc.TABLE_FC(l) + 1, dims[l + 1], orc.xavier_scale(dims[l], 1)) for l in range(3)]
+    fcS = [[np.zeros_like(w), np.zeros_like(w), np.zeros_like(b), np.zeros_like(b)] for w, b in zip(fcW, fcb)]
+    ws = CFG["wide"]
+    ww, wz, wn = np.zeros(ws, f32), np.zeros(ws, f32), np.zeros(ws, f32)
+    wb, wbz, wbn = np.zeros(1, f32), np.zeros(1, f32), np.zeros(1, f32)
+    models = []
+    for w in range(world):
+        st = orc.Store(SEED)
+        md = orc.Model(st, orc.WIDEDEEP, F, D, CFG["X"], CFG["fc"], wide_size=ws)
+        md.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 32)
+        models.append((st, md))
+    data = [make_batches(w, STEPS) for w in range(world)]
+    for step in range(STEPS):
+        pushes, dense, wide_g, wide_c, bias_g = {}, None, np.zeros(ws, f32), np.zeros(ws, f32), f32(0)
+        for w in range(world):
+            st, md = models[w]
+            b = data[w][step]
+            for f in range(F):
+                for i in np.unique(b["E"][:, f]):
+                    st.put(orc.emb_key(f, float(i)), row(f, int(i))[0], D, 1)
+            for l in range(3):
+                st.put("fc%d.weights" % l, fcW[l], dims[l + 1], dims[l]); st.put("fc%d.bias" % l, fcb[l], dims[l + 1], 1)
+            for k in np.unique(b["W"]):
+                st.put(orc.wide_key(float(k)), ww[k:k + 1], 1, 1)
+            st.put("wide.bias", wb, 1, 1)
+            md.train(b["E"].astype(f32), b["X"], b["Y"], b["W"].astype(f32), do_update=False)
+            d = np.concatenate([np.concatenate([md.grad("fc%d.weights" % l), md.grad("fc%d.bias" % l)]) for l in range(3)])
+            dense = d if dense is None else (dense + d).astype(f32)
+            gbar = md.grad("wide.bias")[0]
+            bias_g = f32(bias_g + gbar)
+            for k in md.grad_keys():
+                if k.startswith("emF"):
+                    f, i = k[3:].split(".")[0], k.split(".")[1]
+                    pushes.setdefault((int(f), int(i)), []).append(md.grad(k))
+                elif k.startswith("wide.weights."):
+                    i = int(float(k[len("wide.weights."):]))
+                    wide_g[i] = f32(wide_g[i] + gbar); wide_c[i] += 1
+        for (f, i), gs in pushes.items():
+            r = row(f, i)
+            if is_async:
+                for g in gs:
+                    r[0], r[1], r[2] = orc.adam_update(r[0], g, r[1], r[2])
+            else:
+                S = gs[0].copy()
+                for g in gs[1:]:
+                    S = (g + S).astype(f32)
+                r[0], r[1], r[2] = orc.adam_update(r[0], (S / f32(len(gs))).astype(f32), r[1], r[2])
+        off = 0
+        for l in range(3):
+            nw, nb = fcW[l].size, fcb[l].size
+            gw = (dense[off:off + nw] / f32(world)).astype(f32); off += nw
+            gb = (dense[off:off + nb] / f32(world)).astype(f32); off += nb
+            fcW[l], fcS[l][0], fcS[l][1] = orc.adam_update(fcW[l], gw, fcS[l][0], fcS[l][1])
+            fcb[l], fcS[l][2], fcS[l][3] = orc.adam_update(fcb[l], gb, fcS[l][2], fcS[l][3])
+        for k in np.nonzero(wide_c > 0)[0]:
+            w_, z_, n_, _ = orc.ftrl_update(ww[k:k + 1], [f32(wide_g[k] / wide_c[k])], wz[k:k + 1], wn[k:k + 1])
+            ww[k], wz[k], wn[k] = w_[0], z_[0], n_[0]
+        wb, wbz, wbn, _ = orc.ftrl_update(wb, [f32(bias_g / f32(world))], wbz, wbn)
+    return emb, fcW, fcb, ww, wb
+
+
+def worker_main(rank, world, port, is_async, q):
+    try:
+        sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+        import torch
+        import torch.distributed as dist
+        from oracle import oracle as orc
+        from oracle_backend import OracleBackend
+        from ps_amd.sharded import ShardedWorker, TorchComm
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        be = OracleBackend(torch, rank, world, CFG, SEED)
+        wk = ShardedWorker(be, TorchComm(dist, torch, torch.device("cpu")), is_async=is_async)
+        for b in make_batches(rank, STEPS):
+            wk.step(b)
+        emb, fcW, fcb, ww, wb = expected(world, is_async)
+        xav = orc.xavier_scale(1, CFG["D"])
+        checked = 0
+        for f in range(CFG["F"]):
+            for i in range(rank, CFG["V"], world):                 # every id this shard owns
+                want = emb[(f, i)][0] if (f, i) in emb else orc.init_rows(SEED, f, [i], CFG["D"], xav)[0]
+                got = be.W[be.lrb[rank, f] + i // world]
+                assert np.array_equal(got, want), "rank %d emF%d.%d: %r != %r" % (rank, f, i, got, want)
+                checked += (f, i) in emb
+        assert checked > 0
+        assert not any((f, i) in emb and i % world != rank and False for f, i in emb)
+        for l in range(3):
+            assert np.array_equal(be.fcW[l], fcW[l]) and np.array_equal(be.fcb[l], fcb[l]), "rank %d fc%d" % (rank, l)
+        assert np.array_equal(be.ww, ww) and np.array_equal(be.wb, wb), "rank %d wide" % rank
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", checked))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("is_async", [False, True])
+def test_sharded_orchestration_world2(is_async):
+    from oracle import oracle
+    oracle.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker_main, args=(r, 2, port, is_async, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, status, info in res:
+        assert status == "ok", "rank %d:\n%s" % (rank, info)
