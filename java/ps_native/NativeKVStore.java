@@ -1,0 +1,43 @@
+// NativeKVStore.java -- the reference-side binding of libps_amd.so (include/ps_native.h).
+// NOT compiled in this repository's image (no JDK / jni.h here); it is the stub a maintainer of
+// wudikua/ps adds next to store/KVStore.java.  One instance per GPU shard.
+package store;
+
+public final class NativeKVStore implements AutoCloseable {
+    static { System.loadLibrary("ps_amd_jni"); }       // ps_jni.cpp, linked against libps_amd.so
+
+    private long handle;                                // ps_store_t*
+
+    public NativeKVStore(int device, long seed) { handle = create(device, seed); }
+
+    // ---- store.KVStore (store/KVStore.java:129-166) ------------------------------------------
+    /** KVStore.get(key): null when absent (Resp 204). Keys: "emF3.28305.0", "fc0.weights", "wide.bias", ... */
+    public native float[] get(String key);
+    /** KVStore.put(key, val) */
+    public native void put(String key, float[] val);
+    /** PSClient.getList / updateList for one field (net/PSClient.java:72-98,128-151) */
+    public native float[] getRows(int field, long[] ids, int which);
+    public native void putRows(int field, long[] ids, int which, float[] rows);
+    /** Map<String,Updater>.put(key, updater) by Updater.getName() string (update/AdamUpdater.java:72-74) */
+    public native void setUpdater(String keyOrPrefix, String updaterName);
+    public native long globalStep();
+
+    // ---- tables -----------------------------------------------------------------------------------
+    public native void createEmbedding(long[] rowsPerField, int dim, int stateSlots, int shard, int nshards);
+    public native void createWide(long wideSize);
+    public native void createFc(int layer, int in, int out);
+
+    // ---- model/DNN.java, model/WideDeepNN.java -----------------------------------------------------
+    /** buildModel(...): returns a ps_model_t* handle */
+    public native long buildModel(int kind, int F, int D, int X, int[] fcDims, long wideSize, int maxBatch);
+    /** TrainerThread.call + KVStore.update + clear for thread = 1; E is the F x B id matrix as long[B*F]
+     *  (sample-major = the bytes of the column-major FloatMatrix), X [B*numberFieldNum], W wide ids, Y labels. */
+    public native float train(long model, long[] E, float[] X, long[] W, float[] Y, int B);
+    public native float[] predict(long model, long[] E, float[] X, long[] W, int B);
+    public native void destroyModel(long model);
+
+    private static native long create(int device, long seed);
+    private static native void destroy(long handle);
+    long handle() { return handle; }
+    @Override public void close() { if (handle != 0) { destroy(handle); handle = 0; } }
+}

@@ -30,8 +30,8 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------
 // counter-based row init: +-U(0, scale) as a pure function of
-// (seed, table, row, col).  Same definition as oracle/ps_oracle.c
-// orc_init_value (the oracle restates it; nothing is shared at link level).
+// (seed, table, row, col).  The test oracle restates this definition on the
+// CPU; nothing is shared with it at include or link level.
 // Replaces util/MatrixUtil.java:62-74 (unseeded RandomUtils).
 // ---------------------------------------------------------------------------
 #define PS_TABLE_WIDE (1ull << 20)

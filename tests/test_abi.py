@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol
+include/ps_native.h declares, the ctypes table covers exactly those, and the host logic that needs
+no GPU (Updater names, Router, error behaviour without a device) behaves like the reference."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ps_amd import build, native
+    build.build()
+    return native.lib()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ps_native.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from ps_amd import native
+    decl = declared_symbols()
+    assert len(decl) > 50
+    for name in decl:
+        assert hasattr(L, name), "libps_amd.so does not export %s" % name
+    assert decl == set(native.SIGNATURES), (sorted(decl - set(native.SIGNATURES)), sorted(set(native.SIGNATURES) - decl))
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under ps_amd/ may import, link or call it."""
+    for d, _, files in os.walk(os.path.join(ROOT, "ps_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                for pat in (r"#\s*include[^\n]*oracle", r"libps_oracle", r"^\s*from\s+oracle", r"^\s*import\s+oracle", r"\borc_[a-z_]+\s*\("):
+                    assert not re.search(pat, txt, flags=re.M), (os.path.join(d, f), pat)
+
+
+def test_updater_names_round_trip(L):
+    import ps_amd
+    # Updater.getName(): update/AdamUpdater.java:72-74, update/FtrlUpdater.java:78-80 (sic: "adam@"), SimpleUpdater.java:24-26
+    assert ps_amd.AdamUpdater(0.005, 0.9, 0.999, 1e-8).getName() == "adam@alfa:0.005@beta1:0.9@beta2:0.999@epsilon:1.0E-8@"
+    assert ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001).getName() == "adam@alfa:0.005@beta:1.0@l1:0.001@l2:0.001@"
+    assert ps_amd.SimpleUpdater(0.005).getName() == "simple@eta:0.005@"
+    for u in (ps_amd.AdamUpdater(0.01, 0.8, 0.99, 1e-6), ps_amd.FtrlUpdater(0.1, 2.0, 0.5, 0.25), ps_amd.SimpleUpdater(0.125)):
+        v = ps_amd.Updater.fromName(u.getName())
+        assert v.getName() == u.getName() and v.kind == u.kind
+    with pytest.raises(ps_amd.native.PsError) as e:            # PServer.push: "updater is null" -> Resp 500
+        ps_amd.Updater.fromName("rmsprop@lr:0.1@")
+    assert e.value.code == ps_amd.native.PS_NO_UPDATER
+
+
+def test_router_matches_oracle(orc, L):
+    import ps_amd
+    assert ps_amd.java_string_hash("hello") == 99162322 == orc.java_hashcode("hello")
+    m = ps_amd.Mod(8)
+    for f in range(5):
+        for i in range(0, 2000, 37):
+            k = orc.emb_key(f, float(i))
+            assert m.shard(k) == orc.mod_shard(k, 8, True) == orc.java_hashcode(k) % 8
+            assert L.ps_router_shard_id(1, f, i, 8) == m.shard(k)          # PS_ROUTE_JAVA_STRING
+            assert L.ps_router_shard_id(0, f, i, 8) == i % 8               # PS_ROUTE_ID_MOD
+
+
+def test_fails_loudly_without_a_gpu(L):
+    import ps_amd
+    n = C.c_int()
+    rc = L.ps_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ps_amd.native.PsError) as e:
+        ps_amd.KVStore(0)
+    assert e.value.code == ps_amd.native.PS_E_HIP and "HIP" in str(e.value)
+
+
+def test_struct_layouts_match_the_header(L):
+    """ctypes mirrors of ps_updater_t / ps_model_config_t / ps_batch_t have the C sizes."""
+    from ps_amd import native as N
+    assert C.sizeof(N.ps_updater_t) == 9 * 4
+    assert C.sizeof(N.ps_batch_t) == 8 + 5 * 8 + 8
+    assert C.sizeof(N.ps_model_config_t) == 5 * 4 + 8 * 4 + 4 + 8 + 4 + 4 + 8 + 4 * 3 + 4
+    u = N.ps_updater_t()
+    L.ps_updater_default_adam(C.byref(u))
+    assert (u.kind, np.float32(u.alfa), np.float32(u.beta1)) == (0, np.float32(0.005), np.float32(0.9))
