@@ -10,12 +10,21 @@ from collections import defaultdict
 
 
 def short(n):
-    n = re.sub(r"\(.*", "", n).replace("(anonymous namespace)::", "").replace("void ", "")
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    n = re.sub(r"\(.*", "", n)
     return n.strip()[:60]
 
 
 def main():
     out = sys.argv[1]
+    st = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        print("== rocprofv3 --kernel-trace --stats (whole bench run incl. warm-up and gather micro-bench) ==")
+        print("%-62s %7s %11s %9s %9s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+        for row in csv.DictReader(open(st[0])):
+            print("%-62s %7d %11.1f %9.2f %9.2f %9.2f %6.1f" % (short(row["Name"]), int(row["Calls"]), float(row["TotalDurationNs"]) / 1e3,
+                  float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3, float(row["Percentage"])))
+        print()
     tr = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
     if tr:
         per = defaultdict(list)
