@@ -30,7 +30,18 @@ struct NtArgs {
     int epi;
     const float *mask; int ldmask; int mask_cols;
     const int *skip;
+    int xcd_swizzle;
 };
+
+// XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
+// only), each XCD with its own 4 MiB L2.  The remap gives every XCD a CONTIGUOUS chunk of logical
+// tile ids, so the tiles that share an operand panel (all N tiles of one M tile; all tiles of one
+// batch split) run on one XCD and the panel is fetched from HBM once instead of once per XCD.
+// Bijective for any block count (guide section 5, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_chunked_id(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 
 __device__ __forceinline__ float sigmoid_clip_dev(float x) {
     // activations/Sigmoid.java:11 -- float constants, double exp, cast to float
@@ -50,11 +61,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int tn = (a.N + BN - 1) / BN;
+    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;     // consecutive ids: the N tiles of one M tile
     const int nk = (a.K + BKT - 1) / BKT;
 
-    float4 ra[A_F4], rb[B_F4];
-    auto gload = [&](int kt) {
+    // TWO register sets: slab t+2 is already in flight while slab t is multiplied and slab t+1
+    // waits in registers for its LDS slot -- one slab of prefetch does not cover the ~1.5 us a
+    // load takes under load when a slab is only ~0.4 us of MFMA work (measured: 50 % of peak).
+    // The sets are named (not indexed by t) so they stay in registers; the loop is unrolled by 2.
+    float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];
+    auto gload = [&](int kt, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
             rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
@@ -98,14 +115,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    swrite(0);
-    __syncthreads();
     const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
     const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < BKT / 8; ++q) {
             float4 fa[TM], fb[TN];
@@ -125,7 +137,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) swrite(buf ^ 1);
+    };
+    gload(0, ra0, rb0);
+    if (nk > 1) gload(1, ra1, rb1);
+    swrite(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even slab kt: in LDS buffer 0; set 1 holds slab kt+1; set 0 is free for slab kt+2
+        if (kt + 2 < nk) gload(kt + 2, ra0, rb0);
+        compute(0);
+        if (kt + 1 < nk) swrite(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd slab kt+1: in LDS buffer 1; set 0 holds slab kt+2; set 1 is free for slab kt+3
+        if (kt + 3 < nk) gload(kt + 3, ra1, rb1);
+        compute(1);
+        if (kt + 2 < nk) swrite(0, ra0, rb0);
         __syncthreads();
     }
 
@@ -165,6 +192,7 @@ struct TnArgs {
     float *Cpart; int ldc; long long part_stride;
     int Kout, N, M, mchunk;
     const int *skip;
+    int xcd_swizzle;
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
@@ -177,13 +205,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int m_begin = blockIdx.z * a.mchunk;
+    const int tk = (a.Kout + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int z = wg / (tk * tn), t = wg % (tk * tn);        // consecutive ids: all tiles of one batch split
+    const int k0 = (t / tn) * BM, n0 = (t % tn) * BN;
+    const int m_begin = z * a.mchunk;
     const int m_end = m_begin + a.mchunk < a.M ? m_begin + a.mchunk : a.M;
     const int nk = m_end > m_begin ? (m_end - m_begin + BKT - 1) / BKT : 0;
 
-    float4 ra[A_F4], rb[B_F4];
-    auto gload = [&](int kt) {
+    float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];     // two sets: see k_gemm_nt
+    auto gload = [&](int kt, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
         const int mb = m_begin + kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
             rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto swrite = [&](int buf) {
+    auto swrite = [&](int buf, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
@@ -225,17 +256,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) {
-        gload(0);
-        swrite(0);
-    }
-    __syncthreads();
     const int acol = wm * TM * 32 + (lane & 31);
     const int bcol = wn * TN * 32 + (lane & 31);
     const int kh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < BKT / 2; ++s) {
             float fa[TM], fb[TN];
@@ -249,10 +273,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) swrite(buf ^ 1);
+    };
+    if (nk > 0) {
+        gload(0, ra0, rb0);
+        if (nk > 1) gload(1, ra1, rb1);
+        swrite(0, ra0, rb0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) gload(kt + 2, ra0, rb0);
+        compute(0);
+        if (kt + 1 < nk) swrite(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) gload(kt + 3, ra1, rb1);
+        compute(1);
+        if (kt + 2 < nk) swrite(0, ra0, rb0);
         __syncthreads();
     }
-    float *Cz = a.Cpart + (size_t)blockIdx.z * a.part_stride;
+    float *Cz = a.Cpart + (size_t)z * a.part_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -271,10 +310,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
 
 // tuning knobs (ps_tune_set): 0 = automatic
 int g_gemm_nt_cfg = 0;   // 1 128x128/16, 2 64x128/16, 3 64x64/16, 4 128x32/16, 5 64x64/32, 6 64x128/32, 7 128x128/32, 8 128x32/32
+int g_gemm_xcd = 1;      // XCD-aware work-group order on/off (for A/B runs)
 int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5 128x32/32
 
 #define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
-    hipLaunchKernelGGL((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32), cdiv(N, WN * TN * 32)), \
+    hipLaunchKernelGGL((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), \
                        dim3(256), 0, st, a)
 
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
@@ -283,7 +323,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag};
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd};
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -319,7 +359,7 @@ int gemm_tn_choose_split(int Kout, int N, int M) {
 
 #define TN_LAUNCH(WM, WN, TM, TN, BKT)                                                                      \
     hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT>),                                                    \
-                       dim3(cdiv(Kout, WM * TM * 32), cdiv(N, WN * TN * 32), nsplit), dim3(256), 0, st, a)
+                       dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256), 0, st, a)
 
 int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
@@ -328,7 +368,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
         return ps_set_err(PS_E_BAD_ARG, "gemm_tn: leading dims / cols must be multiples of 4");
     if (Kout <= 0 || N <= 0 || nsplit <= 0) return PS_OK;
     const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), 32);
-    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag};
+    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd};
     int cfg = g_gemm_tn_cfg;
     if (cfg == 0) cfg = N <= 32 ? 5 : 2;
     switch (cfg) {

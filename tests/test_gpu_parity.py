@@ -311,3 +311,79 @@ def test_sharded_path_n1_equals_fused_step(orc):
         for x, y in zip(a[i], b[i]):
             np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[5], b[5]); np.testing.assert_array_equal(a[6], b[6])
+
+
+def test_multi_hot_bags(orc):
+    """Variable-length bags (config 5's shape: CSR offsets over (sample, field), sum pooling), incl. empty
+    bags and a key repeated inside one bag.  The reference is single-hot, so the oracle here is its arithmetic
+    applied to the bag semantics: forward = relu(sequential f32 sum of the bag's rows); every id of a bag
+    receives that bag's relu'-masked delta; per key the entries reduce in entry order with the reference's
+    double-backward factor; Adam as written.  All bit-exact."""
+    import ps_amd
+    F, D, X, fc, V, B = 3, 8, 2, [8, 1], 25, 48
+    rng = np.random.default_rng(21)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, max_nnz=B * F * 12)
+    for step in range(3):
+        lens = rng.integers(0, 9, size=B * F)
+        lens[0] = 0; lens[5] = 40                         # an empty bag and one longer than the 32-entry chunk
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = rng.integers(0, V, size=int(offsets[-1])).astype(np.int64)
+        ids[offsets[5]:offsets[5] + 40] = ids[offsets[5]]   # one key 40 times in one bag -> run > 32
+        Xd = rng.standard_normal((B, X)).astype(f32); Y = (rng.random(B) < 0.4).astype(f32)
+        tabs = [kv.get_rows(f, np.arange(V)) for f in range(F)]
+        m0 = [kv.get_rows(f, np.arange(V), 1) for f in range(F)]
+        v0 = [kv.get_rows(f, np.arange(V), 2) for f in range(F)]
+        gm.forward({"E": ids, "X": Xd, "Y": Y, "offsets": offsets})
+        A = gm.act(0)
+        for bag in range(B * F):
+            b, f = divmod(bag, F)
+            s = np.zeros(D, f32)
+            for k, p in enumerate(range(offsets[bag], offsets[bag + 1])):
+                s = tabs[f][ids[p]].copy() if k == 0 else (tabs[f][ids[p]] + s).astype(f32)
+            np.testing.assert_array_equal(A[b, f * D:(f + 1) * D], np.maximum(s, 0), err_msg="bag %d" % bag)
+        gm.backward()
+        dx = gm.delta(2)
+        field_of = np.repeat(np.arange(B * F) % F, lens)
+        samp_of = np.repeat(np.arange(B * F) // F, lens)
+        g_gpu = {}
+        for f in range(F):
+            gi, gg = gm.emb_grads(f)
+            sel = np.nonzero(field_of == f)[0]
+            np.testing.assert_array_equal(gi, np.unique(ids[sel]))
+            for i, idv in enumerate(gi):
+                ps = sel[ids[sel] == idv]                    # entries of this key, in entry (bag-major) order
+                gk = np.stack([dx[samp_of[p], f * D:(f + 1) * D] for p in ps])
+                np.testing.assert_array_equal(gg[i], orc.emb_geff(gk, orc.GRAD_COMPAT, 32), err_msg="emF%d.%d n=%d" % (f, idv, len(ps)))
+                g_gpu[(f, idv)] = gg[i]
+        gm.update()
+        for (f, idv), g in g_gpu.items():
+            we, me, ve = orc.adam_update(tabs[f][idv], g, m0[f][idv], v0[f][idv])
+            np.testing.assert_array_equal(kv.get_rows(f, [idv])[0], we)
+            np.testing.assert_array_equal(kv.get_rows(f, [idv], 1)[0], me)
+    # a bag of exactly one id per (sample, field) is the single-hot path, bit for bit
+    E = rng.integers(0, V, size=(B, F)).astype(np.int64)
+    Xd = rng.standard_normal((B, X)).astype(f32); Y = (rng.random(B) < 0.4).astype(f32)
+    l1 = gm.forward({"E": E, "X": Xd, "Y": Y}); a1 = gm.act(0).copy()
+    l2 = gm.forward({"E": E.ravel(), "X": Xd, "Y": Y, "offsets": np.arange(B * F + 1, dtype=np.int64)})
+    assert l1 == l2
+    np.testing.assert_array_equal(a1, gm.act(0))
+    gm.close(); kv.close()
+
+
+def test_out_of_range_id_is_reported(orc):
+    """An id outside its table is Resp 204 (PS_MISSING), reported after the step; nothing crashes."""
+    import ps_amd
+    F, D, X, fc, V, B = 2, 4, 1, [4, 1], 10, 8
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    E = np.zeros((B, F), np.int64); E[3, 1] = V + 7
+    with pytest.raises(ps_amd.native.PsError) as e:
+        gm.train({"E": E, "X": np.zeros((B, X), f32), "Y": np.ones(B, f32)})
+    assert e.value.code == ps_amd.native.PS_MISSING
+    assert kv.get("emF0.%d.0" % (V + 1)) is None
+    with pytest.raises(ps_amd.native.PsError):
+        gm.train({"E": np.zeros((B + 1, F), np.int64), "X": np.zeros((B + 1, X), f32), "Y": np.ones(B + 1, f32)})   # B > max_batch
+    gm.close(); kv.close()
