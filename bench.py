@@ -56,8 +56,8 @@ def group_algorithmic(cfg, name, nnz, uniq):
     dims = [F * D + cfg["X"]] + cfg["fc"]
     if name == "emb_fwd":
         return "hbm", nnz * (4.0 * D + 8.0)                       # row + int64 id (read roofline)
-    if name == "emb_bwd_update":
-        return "hbm", nnz * 4.0 * D + uniq * (3 * 4.0 * D * 2) + nnz * 8.0
+    # (emb_bwd_update, emb_sort, ... are groups of several kernels: reported in kernel_groups_us,
+    #  not candidates for the single-kernel roofline)
     for l in range(len(cfg["fc"])):
         if name == "fc_fwd%d" % l:
             return "mfma", 2.0 * B * dims[l] * dims[l + 1]
@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="run the sharded (multi-GPU) path even at N=1")
     ap.add_argument("--is-async", type=int, default=0, help="async push (-DisPsAsync=1): no averaging, arrival order")
+    ap.add_argument("--phases", type=int, default=0, help="sharded path: also report a per-phase stopwatch (serialised)")
     ap.add_argument("--gather", type=int, default=1)
     ap.add_argument("--gather-rows", type=int, default=64 * 1000 * 1000)   # 16.4 GB at D=64
     args = ap.parse_args()

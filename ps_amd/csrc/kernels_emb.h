@@ -29,7 +29,23 @@ struct HeadArgs {
     float *P, *wide_z, *terms;
     float *dlast; int ldd;             // delta at the last FcLayer's output
     int *err;
+    // when a_last is set the last FcLayer (out = 1) is computed here as a per-sample dot product
+    // (its GEMM would be a 4096 x 1 sliver): z = sum_k a_last[b][k] * w_last[k], bias via the ones column
+    const float *a_last; int lda_last; const float *w_last; int k_last; int last_sigmoid;
+    float *zout;                       // [B][ldz] column 0 receives the layer's activation
 };
+struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer (layer/FcLayer.java:93-110)
+    int B, K, Kp, chunk;               // K inputs (+1 ones column), rows per workgroup
+    const float *A; int lda;           // the layer's input [B][lda]
+    const float *dlast; int ldd;       // delta at its output, column 0
+    const float *W; int ldw;           // W' [K+1][ldw], column 0
+    float *dprev; int ldp;             // delta for the previous layer [B][ldp] (relu' of A fused); may be dx
+    int dprev_cols;                    // columns of dprev to write (K, or F*D for the first layer)
+    int mask_cols;                     // columns whose relu' mask applies
+    float *part; long long part_stride; int ldpart;   // dW partial slabs, one per workgroup
+    const int *skip;
+};
+int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);
 
 struct EmbBwdArgs {

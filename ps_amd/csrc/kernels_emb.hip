@@ -37,7 +37,13 @@ template <> struct Vec<1> {
 // ---------------------------------------------------------------------------
 // forward gather (+ bag sum, + relu, + dense concat, + sort keys)
 // ---------------------------------------------------------------------------
-template <int VEC>
+// GATHER_ILP independent row loads per lane group are in flight at once: single-hot groups take
+// GATHER_ILP consecutive bags (their outputs are contiguous), multi-hot groups walk their bag
+// GATHER_ILP entries at a time.  One row per group and launch kept too little memory in flight
+// to cover HBM latency (Little: ~8 MB chip-wide at 8 TB/s): measured 4.9 -> see profiles/.
+#define GATHER_ILP 4
+#define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
+template <int VEC, bool MULTI, bool SLOT>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x >= a.gather_blocks) {
@@ -49,32 +55,65 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
         }
         return;
     }
-    const int64_t bag = gt / a.LPR;
+    const int64_t grp = gt / a.LPR;
     const int part = (int)(gt % a.LPR);
-    if (bag >= (int64_t)a.B * a.F) return;
-    const int b = (int)(bag / a.F), f = (int)(bag % a.F);
-    const int64_t p0 = a.offsets ? a.offsets[bag] : bag;
-    const int64_t p1 = a.offsets ? a.offsets[bag + 1] : bag + 1;
-    const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
-    Vec<VEC> s = Vec<VEC>::zero();
-    for (int64_t p = p0; p < p1; ++p) {
-        int64_t row;
-        if (a.slot) {
-            row = a.slot[p];                      // sharded worker: slot in the pulled-row cache
-        } else {
-            int64_t id = a.ids[p];
-            if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
-            row = rb + id;
+    const int64_t nb = (int64_t)a.B * a.F;
+    // row of entry p of field f (clamped, counted in *err when out of range)
+    auto row_of = [&](int64_t p, int f) -> int64_t {
+        if (SLOT) return (int64_t)a.slot[p];              // sharded worker: slot in the pulled-row cache
+        const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
+        int64_t id = a.ids[p];
+        if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
+        return rb + id;
+    };
+    if (!MULTI) {
+        const int64_t bag0 = grp * GATHER_ILP;
+        if (bag0 >= nb) return;
+        int64_t rows[GATHER_ILP];
+#pragma unroll
+        for (int j = 0; j < GATHER_ILP; ++j) {
+            const int64_t bag = bag0 + j < nb ? bag0 + j : nb - 1;
+            rows[j] = row_of(bag, (int)(bag % a.F));
         }
-        const Vec<VEC> r = Vec<VEC>::load(a.W + (size_t)row * a.D + part * VEC);
-        if (p == p0) s = r;                       // rcopy of one row (EmbeddingField.java:73)
-        else { VFOR(i) s.at(i) = r.get(i) + s.at(i); }  // sum pooling, in bag order
-        if (part == 0 && a.key_out) {
-            a.key_out[p] = (uint32_t)row;
-            if (a.ent_bag) a.ent_bag[p] = (uint32_t)bag;
+        Vec<VEC> r[GATHER_ILP];
+#pragma unroll
+        for (int j = 0; j < GATHER_ILP; ++j) r[j] = Vec<VEC>::load(a.W + (size_t)rows[j] * a.D + part * VEC);   // rcopy (EmbeddingField.java:73)
+#pragma unroll
+        for (int j = 0; j < GATHER_ILP; ++j) {
+            const int64_t bag = bag0 + j;
+            if (bag < nb) {
+                if (a.act == PS_ACT_RELU) { VFOR(i) r[j].at(i) = r[j].get(i) > 0.f ? r[j].get(i) : 0.f; }   // Relu.java:7-12
+                r[j].store(a.out + (size_t)(bag / a.F) * a.ld + (size_t)(bag % a.F) * a.D + part * VEC);
+                if (part == 0 && a.key_out) a.key_out[bag] = (uint32_t)rows[j];
+            }
+        }
+        return;
+    }
+    const int64_t bag = grp;
+    if (bag >= nb) return;
+    const int b = (int)(bag / a.F), f = (int)(bag % a.F);
+    const int64_t p0 = a.offsets[bag], p1 = a.offsets[bag + 1];
+    Vec<VEC> s = Vec<VEC>::zero();
+    for (int64_t q = p0; q < p1; q += GATHER_ILP_MH) {
+        int64_t rows[GATHER_ILP_MH];
+#pragma unroll
+        for (int j = 0; j < GATHER_ILP_MH; ++j) rows[j] = row_of(q + j < p1 ? q + j : p1 - 1, f);
+        Vec<VEC> r[GATHER_ILP_MH];
+#pragma unroll
+        for (int j = 0; j < GATHER_ILP_MH; ++j) r[j] = Vec<VEC>::load(a.W + (size_t)rows[j] * a.D + part * VEC);
+#pragma unroll
+        for (int j = 0; j < GATHER_ILP_MH; ++j) {
+            if (q + j < p1) {
+                if (q + j == p0) s = r[j];
+                else { VFOR(i) s.at(i) = r[j].get(i) + s.at(i); }      // sum pooling, strictly in bag order
+                if (part == 0 && a.key_out) {
+                    a.key_out[q + j] = (uint32_t)rows[j];
+                    if (a.ent_bag) a.ent_bag[q + j] = (uint32_t)bag;
+                }
+            }
         }
     }
-    if (a.act == PS_ACT_RELU) { VFOR(i) s.at(i) = s.get(i) > 0.f ? s.get(i) : 0.f; }  // Relu.java:7-12
+    if (a.act == PS_ACT_RELU) { VFOR(i) s.at(i) = s.get(i) > 0.f ? s.get(i) : 0.f; }
     s.store(a.out + (size_t)b * a.ld + (size_t)f * a.D + part * VEC);
 }
 
@@ -92,6 +131,18 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= a.B) return;
+    float zl;                                               // the last FcLayer's activation for this sample
+    if (a.a_last) {
+        // FcLayer.forward with out = 1 (layer/FcLayer.java:76-77): lanes stride over k, butterfly sum
+        float acc = 0.f;
+        for (int k = lane; k < a.k_last; k += 64) acc += a.a_last[(size_t)b * a.lda_last + k] * a.w_last[k];
+#pragma unroll
+        for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+        zl = a.last_sigmoid ? sigmoid_clip_d(acc) : acc;
+        if (lane == 0) a.zout[(size_t)b * a.ldz] = zl;
+    } else {
+        zl = a.zlast[(size_t)b * a.ldz];
+    }
     float p;
     if (a.wide) {
         // LRLayer.forward (layer/LRLayer.java:73-84): sum over the F wide ids, sequential, then + bias
@@ -109,10 +160,10 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
         }
         sumW += a.wide_bias[0];
         if (lane == 0) a.wide_z[b] = sumW;
-        const float z = a.zlast[(size_t)b * a.ldz] + sumW;  // AddLayer.forward l.add(r)
+        const float z = zl + sumW;                          // AddLayer.forward l.add(r)
         p = sigmoid_clip_d(z);
     } else {
-        p = a.zlast[(size_t)b * a.ldz];                     // last FcLayer already applied the sigmoid
+        p = zl;                                             // last FcLayer already applied the sigmoid
     }
     if (lane != 0) return;
     a.P[b] = p;
@@ -123,6 +174,44 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     float d = (p - l) / (p * (1 - p));                      // loss/CrossEntropy.java:25
     d *= p * (1 - p);                                       // Sigmoid.backward (activations/Sigmoid.java:18)
     a.dlast[(size_t)b * a.ldd] = d;
+}
+
+// FcLayer.backward of the out = 1 layer in one pass over its input: delta_prev = W^T delta (* relu'),
+// dW/db partial sums over this workgroup's rows (reduced by k_dense_update like the split-K slabs).
+__global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a) {
+    if (a.skip && *a.skip) return;
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * a.chunk;
+    const int r1 = r0 + a.chunk < a.B ? r0 + a.chunk : a.B;
+    const float *__restrict__ A = a.A;
+    const float *__restrict__ dl = a.dlast;
+    float *__restrict__ dp = a.dprev;
+    for (int k = tid; k < a.Kp; k += 256) {
+        const bool in = k <= a.K;                               // k == K is the ones column (bias)
+        const float w = (k < a.K) ? a.W[(size_t)k * a.ldw] : 0.f;
+        float acc = 0.f;
+        for (int b0 = r0; b0 < r1; b0 += 16) {
+            float x[16], d[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {                      // 32 independent loads in flight
+                const int b = b0 + j < r1 ? b0 + j : r1 - 1;
+                x[j] = A[(size_t)b * a.lda + k];
+                d[j] = dl[(size_t)b * a.ldd];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (b0 + j < r1) {
+                    acc += x[j] * d[j];                         // rows in order: the sequential batch sum
+                    if (k < a.dprev_cols) {
+                        float v = w * d[j];                     // weights.transpose().mmul(delta) with one output
+                        if (k < a.mask_cols) v *= x[j] > 0.f ? 1.f : 0.f;   // the previous layer's relu'
+                        dp[(size_t)(b0 + j) * a.ldp + k] = v;
+                    }
+                }
+            }
+        }
+        if (in) a.part[(size_t)blockIdx.x * a.part_stride + (size_t)k * a.ldpart] = acc;
+    }
 }
 
 // loss = sum(terms)/B, gbar = rowMeans(delta) ; sets the skip flag (model/DNN.java:58-63)
@@ -211,7 +300,7 @@ __device__ __forceinline__ Vec<VEC> load_g(const EmbBwdArgs &a, uint32_t p, int 
 // order), but the loads are not: entries are fetched PS_EMB_ILP at a time -- 16 independent
 // index loads, then 16 independent row loads -- so a run costs ~2 memory latencies per 16
 // entries instead of 2 per entry (measured 30 us -> the latency chain was the whole kernel).
-#define PS_EMB_ILP 16
+#define PS_EMB_ILP 32
 template <int VEC, bool BAG>
 __device__ __forceinline__ void run_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part, Vec<VEC> &acc, bool have) {
     for (uint32_t k = s; k < e; k += PS_EMB_ILP) {
@@ -236,6 +325,31 @@ __device__ __forceinline__ Vec<VEC> chunk_sum(const EmbBwdArgs &a, uint32_t s, u
     Vec<VEC> acc = Vec<VEC>::zero();
     run_sum<VEC, BAG>(a, s, e, part, acc, false);     // first touch: put :91; then addi :94
     return acc;
+}
+
+// A key seen n <= NL times: exactly NL index loads and NL row loads (clamped duplicates beyond n),
+// all independent, then both passes from registers.  NL is sized to n (1 / 4 / 16): issuing 16
+// clamped loads for the typical n = 1 key made the kernel TA-bound on redundant requests.
+template <int VEC, bool BAG, int NL>
+__device__ __forceinline__ Vec<VEC> small_key(const EmbBwdArgs &a, uint32_t s0, uint32_t n, int part) {
+    uint32_t ent[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) ent[j] = a.sorted_ent[s0 + ((uint32_t)j < n ? j : n - 1)];
+    Vec<VEC> g[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) g[j] = load_g<VEC, BAG>(a, ent[j], part);
+    Vec<VEC> S = g[0];                                              // put :91
+#pragma unroll
+    for (int j = 1; j < NL; ++j)
+        if ((uint32_t)j < n) { VFOR(i) S.at(i) = g[j].get(i) + S.at(i); }       // addi :94, batch order
+    VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);                   // divi(N) :100  (pass 1)
+    if (a.grad_mode == PS_GRAD_COMPAT) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j)                                // pass 2: every g_k again
+            if ((uint32_t)j < n) { VFOR(i) S.at(i) = g[j].get(i) + S.at(i); }
+        VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));         // divi(2n); then x2 (sum.addi self), /2 (cnt) exact
+    }
+    return S;
 }
 
 template <int VEC, bool BAG>
@@ -290,26 +404,17 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     const uint32_t n = e0 - s0;
     const uint32_t row = a.sorted_key[s0];
     Vec<VEC> S;
-    if (n <= PS_EMB_ILP) {
-        // the common case (most keys occur a handful of times): one batch of independent loads
-        // serves both passes from registers
-        uint32_t ent[PS_EMB_ILP];
-#pragma unroll
-        for (int j = 0; j < PS_EMB_ILP; ++j) ent[j] = a.sorted_ent[s0 + ((uint32_t)j < n ? j : n - 1)];
-        Vec<VEC> g[PS_EMB_ILP];
-#pragma unroll
-        for (int j = 0; j < PS_EMB_ILP; ++j) g[j] = load_g<VEC, BAG>(a, ent[j], part);
-        S = g[0];                                                   // put :91
-#pragma unroll
-        for (int j = 1; j < PS_EMB_ILP; ++j)
-            if ((uint32_t)j < n) { VFOR(i) S.at(i) = g[j].get(i) + S.at(i); }   // addi :94, batch order
-        VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);               // divi(N) :100  (pass 1)
-        if (a.grad_mode == PS_GRAD_COMPAT) {
-#pragma unroll
-            for (int j = 0; j < PS_EMB_ILP; ++j)                    // pass 2: every g_k again
-                if ((uint32_t)j < n) { VFOR(i) S.at(i) = g[j].get(i) + S.at(i); }
-            VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));     // divi(2n); then x2 (sum.addi self), /2 (cnt) exact
-        }
+    if (n == 1) {
+        // by far the most common key: one index, one row; g_eff = g exactly (App. A.6, n = 1)
+        S = small_key<VEC, BAG, 1>(a, s0, n, part);
+    } else if (n <= 4) {
+        S = small_key<VEC, BAG, 4>(a, s0, n, part);
+    } else if (n <= 16) {
+        S = small_key<VEC, BAG, 16>(a, s0, n, part);
+    } else if (n <= PS_EMB_ILP) {
+        // up to a whole chunk in registers: the kernel's duration is its slowest lane group, and a
+        // 17..32-entry key walked in two batches per pass was that group (8 dependent round trips)
+        S = small_key<VEC, BAG, PS_EMB_ILP>(a, s0, n, part);
     } else if (n <= CH) {
         S = chunk_sum<VEC, BAG>(a, s0, e0, part);
         VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
@@ -441,7 +546,14 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
         if (a.flat_div > 0.f) g = div_rn(g, a.flat_div);
     } else {
         float s = 0.f;
-        for (int z = 0; z < L.nsplit; ++z) s += L.part[(size_t)z * L.part_stride + (size_t)k * L.ldp + n];
+        const float *__restrict__ pp = L.part + (size_t)k * L.ldp + n;
+        for (int z0 = 0; z0 < L.nsplit; z0 += 8) {        // fixed slab order, 8 loads in flight
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pp[(size_t)(z0 + j < L.nsplit ? z0 + j : L.nsplit - 1) * L.part_stride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (z0 + j < L.nsplit) s += v[j];
+        }
         g = div_rn(s, (float)a.B);                       // divi(delta.columns) FcLayer.java:105 / rowMeans :103
     }
     if (a.grad_out) a.grad_out[t] = g;
@@ -540,13 +652,22 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
     const int vec = (a.D % 4 == 0) ? 4 : 1;
     a.LPR = a.D / vec;
-    const int64_t threads = (int64_t)a.B * a.F * a.LPR;
-    a.gather_blocks = cdiv(threads, 256);
+    const bool multi = a.offsets != nullptr, slot = a.slot != nullptr;
+    const int64_t nb = (int64_t)a.B * a.F;
+    const int64_t groups = multi ? nb : (nb + GATHER_ILP - 1) / GATHER_ILP;
+    a.gather_blocks = cdiv(groups * a.LPR, 256);
     const int dense_blocks = a.dense ? cdiv((int64_t)a.B * a.X, 256) : 0;
     const int grid = a.gather_blocks + dense_blocks;
     if (grid == 0) return PS_OK;
-    if (vec == 4) hipLaunchKernelGGL(k_emb_fwd<4>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_emb_fwd<1>, dim3(grid), dim3(256), 0, st, a);
+#define EMB_FWD_LAUNCH(V)                                                                                          \
+    do {                                                                                                           \
+        if (multi) { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, true, true>), dim3(grid), dim3(256), 0, st, a);     \
+                     else hipLaunchKernelGGL((k_emb_fwd<V, true, false>), dim3(grid), dim3(256), 0, st, a); }        \
+        else { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, false, true>), dim3(grid), dim3(256), 0, st, a);          \
+               else hipLaunchKernelGGL((k_emb_fwd<V, false, false>), dim3(grid), dim3(256), 0, st, a); }             \
+    } while (0)
+    if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
+#undef EMB_FWD_LAUNCH
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -645,6 +766,13 @@ int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st) {
         if (a.identity) hipLaunchKernelGGL((k_rows_apply<1, true>), dim3(g), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_rows_apply<1, false>), dim3(g), dim3(256), 0, st, a);
     }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st) {
+    if (a.B <= 0 || nsplit <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_last_bwd, dim3(nsplit), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

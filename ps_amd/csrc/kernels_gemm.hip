@@ -31,6 +31,7 @@ struct NtArgs {
     const float *mask; int ldmask; int mask_cols;
     const int *skip;
     int xcd_swizzle;
+    int ablate;      // measurement only: 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barriers
 };
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
@@ -142,18 +143,19 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     if (nk > 1) gload(1, ra1, rb1);
     swrite(0, ra0, rb0);
     __syncthreads();
+    const bool do_ld = !(a.ablate & 1), do_st = !(a.ablate & 2), do_bar = !(a.ablate & 4);
     for (int kt = 0; kt < nk; kt += 2) {
         // even slab kt: in LDS buffer 0; set 1 holds slab kt+1; set 0 is free for slab kt+2
-        if (kt + 2 < nk) gload(kt + 2, ra0, rb0);
+        if (kt + 2 < nk && do_ld) gload(kt + 2, ra0, rb0);
         compute(0);
-        if (kt + 1 < nk) swrite(1, ra1, rb1);
-        __syncthreads();
+        if (kt + 1 < nk && do_st) swrite(1, ra1, rb1);
+        if (do_bar) __syncthreads();
         if (kt + 1 >= nk) break;
         // odd slab kt+1: in LDS buffer 1; set 0 holds slab kt+2; set 1 is free for slab kt+3
-        if (kt + 3 < nk) gload(kt + 3, ra1, rb1);
+        if (kt + 3 < nk && do_ld) gload(kt + 3, ra1, rb1);
         compute(1);
-        if (kt + 2 < nk) swrite(0, ra0, rb0);
-        __syncthreads();
+        if (kt + 2 < nk && do_st) swrite(0, ra0, rb0);
+        if (do_bar) __syncthreads();
     }
 
     // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
 
 // tuning knobs (ps_tune_set): 0 = automatic
 int g_gemm_nt_cfg = 0;   // 1 128x128/16, 2 64x128/16, 3 64x64/16, 4 128x32/16, 5 64x64/32, 6 64x128/32, 7 128x128/32, 8 128x32/32
+int g_gemm_ablate = 0;  // measurement-only ablation bits for k_gemm_nt (results are garbage when set)
 int g_gemm_xcd = 1;      // XCD-aware work-group order on/off (for A/B runs)
 int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5 128x32/32
 
@@ -323,7 +326,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd};
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate};
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -341,6 +344,10 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 5: NT_LAUNCH(2, 2, 1, 1, 32); break;
     case 6: NT_LAUNCH(2, 2, 1, 2, 32); break;
     case 7: NT_LAUNCH(2, 2, 2, 2, 32); break;
+    case 9: NT_LAUNCH(2, 2, 2, 1, 32); break;
+    case 10: NT_LAUNCH(2, 2, 1, 1, 64); break;
+    case 11: NT_LAUNCH(4, 1, 1, 2, 32); break;
+    case 12: NT_LAUNCH(1, 4, 2, 1, 32); break;
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());

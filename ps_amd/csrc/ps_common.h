@@ -103,4 +103,4 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
                    const int *skip_flag, hipStream_t st);
 int gemm_tn_choose_split(int Kout, int N, int M);
-extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd;
+extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate;

@@ -93,6 +93,10 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
         b.ldD = p.ldw;
         PSCHK(model_alloc(m, (void **)&b.dOut, sizeof(float) * (size_t)B * b.ldD, true));
         b.nsplit = gemm_tn_choose_split(p.K + 1, p.N, B);
+        if (l == nfc - 1 && p.N == 1) {              // k_last_bwd: one partial slab per 32 batch rows
+            b.nsplit = cdiv(B, 32);
+            if (b.nsplit > 256) b.nsplit = 256;
+        }
         b.ldp = p.ldw;
         b.part_stride = (int64_t)p.Kpad * b.ldp;
         PSCHK(model_alloc(m, (void **)&b.part, sizeof(float) * (size_t)b.nsplit * b.part_stride, true));
@@ -258,6 +262,7 @@ int enqueue_forward(ps_model *m, bool train) {
         int epi = EPI_RELU;
         if (l == nfc - 1) epi = c.kind == PS_MODEL_WIDEDEEP ? EPI_NONE : EPI_SIGMOID;   // FcLayer.java:58-62, WideDeepNN.java:128
         static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
+        if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
         Prof pf(m, names[l]);
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st));
@@ -273,6 +278,12 @@ int enqueue_forward(ps_model *m, bool train) {
     h.P = m->P; h.wide_z = m->wide_z; h.terms = m->terms;
     h.dlast = m->fc[nfc - 1].dOut; h.ldd = m->fc[nfc - 1].ldD;
     h.err = s->err_dev;
+    if (s->fc[nfc - 1].N == 1) {
+        const FcParams &pl = s->fc[nfc - 1];
+        h.a_last = m->fc[nfc - 1].A; h.lda_last = m->fc[nfc - 1].ldA; h.w_last = pl.Wt; h.k_last = pl.Kpad;
+        h.last_sigmoid = c.kind == PS_MODEL_WIDEDEEP ? 0 : 1;    // FcLayer.java:58-62, WideDeepNN.java:128
+        h.zout = m->out_last;
+    }
     { Prof pf(m, "head_loss"); PSCHK(launch_head(h, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, st)); }
     return PS_OK;
 }
@@ -304,6 +315,21 @@ int enqueue_backward(ps_model *m, bool apply) {
     for (int l = nfc - 1; l >= 0; --l) {
         FcParams &p = s->fc[l];
         FcBuf &b = m->fc[l];
+        if (l == nfc - 1 && p.N == 1) {
+            // out = 1: delta_prev = W^T delta (outer product) and dW/db (column sums over the batch)
+            // in one pass over the layer's input instead of two sliver GEMMs
+            LastBwdArgs q;
+            memset(&q, 0, sizeof q);
+            q.B = B; q.K = p.K; q.Kp = p.Kpad; q.chunk = cdiv(B, b.nsplit);
+            q.A = b.A; q.lda = b.ldA; q.dlast = b.dOut; q.ldd = b.ldD; q.W = p.W; q.ldw = p.ldw;
+            if (l > 0) { q.dprev = m->fc[l - 1].dOut; q.ldp = m->fc[l - 1].ldD; q.dprev_cols = p.K; q.mask_cols = p.K; }
+            else { q.dprev = m->dx; q.ldp = m->ldx; q.dprev_cols = c.F * c.D; q.mask_cols = c.F * c.D; }
+            q.part = b.part; q.part_stride = b.part_stride; q.ldpart = b.ldp; q.skip = skip;
+            Prof pf(m, "fc_bwd_last");
+            PSCHK(launch_last_bwd(q, b.nsplit, st));
+            if (nfc == 1) PSCHK(fork(m, st, sw));   // otherwise the next layer's fork orders the dense update behind this
+            continue;
+        }
         if (l < nfc - 1) PSCHK(fork(m, st, sw));     // delta_l was just produced on the main chain
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};

@@ -86,6 +86,30 @@ class ShardedWorker:
     def __init__(self, backend, comm, is_async=False):
         self.be, self.comm, self.is_async = backend, comm, is_async
 
+    def step_timed(self, batch, sync, acc):
+        """The same step with a host-side stopwatch around every phase (sync() between phases):
+        measurement only -- it serialises what the real step overlaps."""
+        be, comm = self.be, self.comm
+        t = [time.perf_counter()]
+
+        def lap(name):
+            sync()
+            t.append(time.perf_counter())
+            acc[name] = acc.get(name, 0.0) + (t[-1] - t[-2])
+
+        counts, send_rows = be.plan(batch, comm.world); lap("plan")
+        rcounts = comm.exchange_counts(counts); lap("a2a_counts")
+        recv_rows = comm.all_to_all_v(send_rows, counts, rcounts, 1, "u32"); lap("a2a_ids")
+        rows_out = be.serve_pull(recv_rows, int(sum(rcounts))); lap("serve_pull")
+        cache = comm.all_to_all_v(rows_out, rcounts, counts, be.D, "f32"); lap("a2a_rows")
+        be.forward_backward(cache, False); lap("forward_backward")
+        grads = be.grads()
+        recv_grads = comm.all_to_all_v(grads, counts, rcounts, be.D, "f32"); lap("a2a_grads")
+        be.apply_push(recv_rows, recv_grads, int(sum(rcounts)), self.is_async); lap("apply_push")
+        flat = be.flat_grad()
+        comm.all_reduce_sum(flat); lap("allreduce_flat")
+        be.apply_flat(comm.world); lap("apply_flat")
+
     def step(self, batch, want_loss=True):
         be, comm = self.be, self.comm
         counts, send_rows = be.plan(batch, comm.world)                     # PSRouterClient.getList fan-out
@@ -225,6 +249,11 @@ def run_bench(args, cfg, synth_batch):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     loss = worker.step(batches[0], want_loss=True)
+    phases = {}
+    if getattr(args, "phases", 0):
+        for i in range(50):
+            worker.step_timed(batches[i % nb], torch.cuda.synchronize, phases)
+        phases = {k: round(1e6 * v / 50, 1) for k, v in phases.items()}
     out = None
     if rank == 0:
         out = {
@@ -236,6 +265,8 @@ def run_bench(args, cfg, synth_batch):
                        "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True},
             "final_loss": loss,
         }
+        if phases:
+            out["phase_us_serialised"] = phases
     for b in batches:
         b.close()
     dist.barrier()

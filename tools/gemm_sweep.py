@@ -9,12 +9,12 @@ from ps_amd import native as N
 
 kv = ps_amd.KVStore(0, 1)
 L = N.lib()
-NT = {3: "64x64/16", 5: "64x64/32", 6: "64x128/32", 7: "128x128/32", 8: "128x32/32"}
+NT = {5: "64x64/32", 6: "64x128/32", 9: "128x64/32", 10: "64x64/64", 11: "128x64w41", 12: "64x128w14", 8: "128x32/32"}
 TN = {1: "64x64/16", 2: "64x64/32", 3: "128x128/16"}
 shapes = [("fwd0", 4096, 512, 432), ("fwd1", 4096, 256, 528), ("bwd_data0", 4096, 416, 512),
           ("bwd_data1", 4096, 512, 256), ("big", 4096, 4096, 4096)]
 quick = "--quick" in sys.argv
-for xcd in (0, 1):
+for xcd in (1,):
     L.ps_tune_set(b"gemm_xcd", xcd)
     for name, M, Nn, K in shapes:
         for cfg in ([5] if quick else NT):
