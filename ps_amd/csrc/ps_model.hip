@@ -130,7 +130,11 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->grads_out, sizeof(float) * (size_t)(nc + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->dense_grad_flat, sizeof(float) * (size_t)m->dense_elems, true));
-    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+    {   // the side chains (sort, dW + dense update) yield to the main FC chain, which is the critical path
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent (numerically largest)
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&m->side[i], hipStreamNonBlocking, lo));
+    }
     m->events.resize(64);
     for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));

@@ -206,7 +206,11 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
     ps_store *s = new ps_store();
     s->device = device;
     s->seed = seed;
-    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&s->own_stream, hipStreamNonBlocking, hi));   // main chain: most urgent
+    }
     s->stream = s->own_stream;
     PSCHK(store_dev_alloc(s, (void **)&s->err_dev, sizeof(int), true));
     ps_updater_t a;

@@ -387,3 +387,55 @@ def test_out_of_range_id_is_reported(orc):
     with pytest.raises(ps_amd.native.PsError):
         gm.train({"E": np.zeros((B + 1, F), np.int64), "X": np.zeros((B + 1, X), f32), "Y": np.ones(B + 1, f32)})   # B > max_batch
     gm.close(); kv.close()
+
+
+@pytest.mark.parametrize("name", ["dnn.npz", "widedeep.npz"])
+def test_against_committed_golden(name):
+    """HIP path against tests/golden/*.npz (fixed numbers; the oracle is not executed here).
+    Copies / init are bit-exact; GEMM-fed values within 1e-5 relative of the stored ones."""
+    import os
+    import ps_amd
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    m = [int(x) for x in z["meta"]]
+    F, D, X, B, V, WS, wide, fc = m[0], m[1], m[2], m[3], m[4], m[5], bool(m[6]), m[7:]
+    kv = ps_amd.KVStore(0, int(z["seed"][0]))
+    kv.create_embedding([V] * F, D)
+    gm = (ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B) if wide
+          else ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B))
+    for f in range(F):
+        np.testing.assert_array_equal(kv.get_rows(f, np.arange(V)), z["init_emb"][f])
+    for l in range(len(fc)):
+        np.testing.assert_array_equal(kv.get("fc%d.weights" % l), z["init_fc%d_w" % l])
+        np.testing.assert_array_equal(kv.get("fc%d.bias" % l), z["init_fc%d_b" % l])
+    for s in range(2):
+        p = "s%d_" % s
+        E = z[p + "E"]
+        loss = gm.forward({"E": E, "X": z[p + "X"], "Y": z[p + "Y"], "W": (E % WS) if wide else None})
+        if s == 0:
+            np.testing.assert_array_equal(gm.act(0), z[p + "embA"])
+            np.testing.assert_array_equal(gm.act(1), z[p + "concatA"])
+        for l in range(len(fc)):
+            close(gm.act(2 + l), z[p + "fc%d_A" % l], what="fc%d A" % l)
+        close(gm.p(B), z[p + "P"], what="P")
+        close(loss, z[p + "loss"][0], what="loss")
+        gm.backward()
+        for l in range(len(fc)):
+            close(gm.fc_grad(l), z[p + "fc%d_dW" % l], rtol=E2E, what="dW%d" % l)
+            close(gm.fc_grad(l, True), z[p + "fc%d_db" % l], rtol=E2E, what="db%d" % l)
+        dscale = np.abs(gm.delta(2)).max()
+        for f in range(F):
+            ids, g = gm.emb_grads(f)
+            np.testing.assert_array_equal(ids, np.nonzero(z[p + "emb_touched"][f])[0])
+            close(g, z[p + "emb_grad"][f][ids], scale=dscale, rtol=E2E, what="emb grad f%d" % f)
+        gm.update()
+        tol = 2e-5 * (s + 1)
+        for f in range(F):
+            have = np.nonzero(z[p + "emb_have"][f])[0]
+            assert np.abs(kv.get_rows(f, have) - z[p + "emb_W"][f][have]).max() <= tol
+        for l in range(len(fc)):
+            assert np.abs(kv.get("fc%d.weights" % l) - z[p + "fc%d_w" % l]).max() <= tol
+            assert np.abs(kv.get("fc%d.bias" % l) - z[p + "fc%d_b" % l]).max() <= tol
+        if wide:
+            assert np.abs(kv.get_wide(np.arange(WS)) - z[p + "wide_w"]).max() <= tol
+            assert abs(kv.get("wide.bias")[0] - z[p + "wide_bias"][0]) <= tol
+    gm.close(); kv.close()
