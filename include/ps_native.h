@@ -263,9 +263,19 @@ int ps_store_sync(ps_store_t *s);
 int ps_store_set_stream(ps_store_t *s, void *hip_stream);
 /* Worker: stage the batch, find its unique (field,id) keys grouped by owner
  * shard.  counts_out[nshards] = keys per owner; *send_rows_dev = the
- * owner-local row of every unique key (uint32, owner-major, ascending row). */
-int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards, int64_t *counts_out,
-                  uint32_t **send_rows_dev, int64_t *n_unique);
+ * owner-local row of every unique key (uint32, owner-major, ascending row).
+ * Nothing here depends on the weights, so the host may run it ahead of time:
+ * `hip_stream` (NULL = the store's stream) is the stream the plan kernels run
+ * on and the one this call synchronises to read the counts back.  A second
+ * ps_model_t on the same store gives the plan of step t+1 its own buffers
+ * while step t still trains (ps_amd/sharded.py alternates two models). */
+int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream,
+                  int64_t *counts_out, uint32_t **send_rows_dev, int64_t *n_unique);
+/* The same in two halves: _launch only enqueues (no host wait), _finish waits
+ * for that plan's event and returns the counts -- so the host can enqueue a
+ * whole training step between the two. */
+int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream);
+int ps_shard_plan_finish(ps_model_t *m, int64_t *counts_out, uint32_t **send_rows_dev, int64_t *n_unique);
 /* Owner: rows_out_dev[i][0..D) = weights of local row rows_dev[i]. */
 int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int64_t n, float *rows_out_dev);
 /* Worker: forward + loss + backward reading embedding rows from cache_dev
@@ -279,9 +289,12 @@ int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_unique);
  * (worker-major).  BSP (is_async = 0): mean over the workers that pushed a
  * key, one updater step per key.  Async (-DisPsAsync=1,
  * net/PServer.java:176-184): every push applied on its own, in arrival
- * (= worker) order.  globalStep++ either way. */
+ * (= worker) order.  globalStep++ either way.  peer_counts[npeers] (host) =
+ * entries received from every worker, in buffer order; with it (and rows
+ * unique inside one worker's range, as ps_shard_plan sends them) the update
+ * needs no sort.  NULL: any order / duplicates allowed, stable sort by row. */
 int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev,
-                        int64_t n, int is_async);
+                        int64_t n, const int64_t *peer_counts, int npeers, int is_async);
 /* Replicated tensors: one flat device buffer
  * [fc weights+biases | wide G | wide C | wide.bias g] to all-reduce(sum);
  * G[k] = this worker's mean delta if it ever touched key k, C[k] = 1 if so. */

@@ -114,3 +114,18 @@ struct RowsApplyArgs {
     int LPR;
 };
 int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st);
+
+#define PS_PUSH_MAX_PEERS 32
+struct PushApplyArgs {
+    int D, LPR, is_async, npeers;
+    uint32_t peer_start[PS_PUSH_MAX_PEERS + 1];   // entry range of every pushing worker
+    int64_t n, R;                      // entries, owner-local rows
+    const uint32_t *rows;              // [n] owner-local row of every entry (unique inside one worker's range)
+    const float *grads;                // [n][D]
+    uint32_t *mask;                    // [R] bit w set: worker w pushed this row (all zero between steps)
+    uint32_t *pos;                     // [npeers][R] entry of worker w's push for the row
+    float *W, *state;
+    UpdParams upd;
+    int *err;
+};
+int launch_push_apply(PushApplyArgs a, hipStream_t st);

@@ -527,6 +527,77 @@ __global__ __launch_bounds__(256) void k_rows_apply(RowsApplyArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// PServer.push + psUpdate without a sort (net/PServer.java:164-214), for pushes that arrive
+// grouped by worker with unique rows inside each worker's list (what ps_shard_plan sends):
+//   mark : pos[worker][row] = entry, mask[row] |= 1 << worker        (atomicOr: order-free)
+//   apply: the entry of the LOWEST pushing worker owns the row: walks the set bits in worker
+//          order (= the arrival order the reference's synchronized push sees), mean or async,
+//          one updater step, then clears mask[row] for the next step.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int push_peer_of(const PushApplyArgs &a, uint32_t e) {
+    int p = 0;
+    while (p + 1 < a.npeers && e >= a.peer_start[p + 1]) ++p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_push_mark(PushApplyArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n) return;
+    const uint32_t r = a.rows[e];
+    if ((int64_t)r >= a.R) { atomicAdd(a.err, 1); return; }
+    const int p = push_peer_of(a, (uint32_t)e);
+    a.pos[(size_t)p * a.R + r] = (uint32_t)e;
+    atomicOr(&a.mask[r], 1u << p);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane64 = (int)(gt & 63);
+    const int gpw = 64 / a.LPR;
+    if (lane64 / a.LPR >= gpw) return;
+    const int64_t e = (gt >> 6) * gpw + lane64 / a.LPR;
+    const int part = lane64 % a.LPR;
+    if (e >= a.n) return;
+    const uint32_t row = a.rows[e];
+    if ((int64_t)row >= a.R) return;
+    uint32_t m = a.mask[row];
+    if (m == 0u || push_peer_of(a, (uint32_t)e) != __ffs((int)m) - 1) return;     // another worker's entry leads this row
+    const int cnt = __popc(m);
+    float *wp = a.W + (size_t)row * a.D + part * VEC;
+    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
+    Vec<VEC> w = Vec<VEC>::load(wp), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
+    if (a.upd.kind != PS_UPD_SIMPLE) { s1 = Vec<VEC>::load(sp); s2 = Vec<VEC>::load(sp + a.D); }
+    const int lane = threadIdx.x & 63;
+    auto apply = [&](const Vec<VEC> &g) {
+        if (a.upd.kind == PS_UPD_ADAM) { VFOR(i) adam_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+        else if (a.upd.kind == PS_UPD_SIMPLE) { VFOR(i) w.at(i) = (g.get(i) * -a.upd.eta) + w.get(i); }
+        else {
+            const float g0 = __shfl(g.get(0), lane - part);
+            if (g0 != 0.f) { VFOR(i) ftrl_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+        }
+    };
+    Vec<VEC> S = Vec<VEC>::load(a.grads + (size_t)e * a.D + part * VEC);            // the leader's own push comes first
+    if (a.is_async) apply(S);
+    m &= m - 1;
+    while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        const uint32_t ent = a.pos[(size_t)q * a.R + row];
+        const Vec<VEC> g = Vec<VEC>::load(a.grads + (size_t)ent * a.D + part * VEC);
+        if (a.is_async) apply(g);
+        else { VFOR(i) S.at(i) = g.get(i) + S.at(i); }
+    }
+    if (!a.is_async) {
+        VFOR(i) S.at(i) = div_rn(S.get(i), (float)cnt);
+        apply(S);
+    }
+    w.store(wp);
+    if (a.upd.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
+    if (part == 0) a.mask[row] = 0u;
+}
+
+// ---------------------------------------------------------------------------
 // dense tensors: split-K reducer + /B + updater, writes W' ([in+1][out]) and its transpose
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
@@ -766,6 +837,20 @@ int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st) {
         if (a.identity) hipLaunchKernelGGL((k_rows_apply<1, true>), dim3(g), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_rows_apply<1, false>), dim3(g), dim3(256), 0, st, a);
     }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+int launch_push_apply(PushApplyArgs a, hipStream_t st) {
+    if (a.n <= 0) return PS_OK;
+    const int vec = a.D % 4 == 0 ? 4 : 1;
+    a.LPR = a.D / vec;
+    const int gpw = 64 / a.LPR;
+    if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
+    hipLaunchKernelGGL(k_push_mark, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
+    const int g = cdiv((int64_t)cdiv(a.n, gpw) * 64, 256);
+    if (vec == 4) hipLaunchKernelGGL((k_push_apply<4>), dim3(g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_push_apply<1>), dim3(g), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -126,6 +126,8 @@ int ensure_shard_state(ps_model *m, int nshards) {
     PSCHK(store_dev_alloc(s, (void **)&sh.owner_start, sizeof(uint32_t) * (size_t)(nshards + 2), true));
     sh.flat_elems = m->dense_elems + (m->cfg.kind == PS_MODEL_WIDEDEEP ? 2 * s->wide.rows + 1 : 0);
     PSCHK(store_dev_alloc(s, (void **)&sh.flat, sizeof(float) * (size_t)sh.flat_elems, true));
+    HIPCHK(hipHostMalloc((void **)&sh.owner_start_host, sizeof(uint32_t) * (size_t)(nshards + 2), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&sh.plan_ev, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));
     return PS_OK;
 }
@@ -142,15 +144,15 @@ extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
     return PS_OK;
 }
 
-extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards, int64_t *counts_out,
-                             uint32_t **send_rows_dev, int64_t *n_unique) {
-    if (!m || !batch || !counts_out || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+extern "C" int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream) {
+    if (!m || !batch || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
     HIPCHK(hipSetDevice(s->device));
     PSCHK(ensure_shard_state(m, nshards));
     PSCHK(stage_batch(m, batch, true));
     ps_model::Shard &sh = m->sh;
-    hipStream_t st = s->stream;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+    if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
     const int F = m->cfg.F;
     const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
     hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, st, m->cur_ids, m->cur_offsets, nbags, F, nshards,
@@ -166,14 +168,31 @@ extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards
         hipLaunchKernelGGL(k_slot_of_entry, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_ents, m->seg_id, nnz, sh.slot);
         HIPCHK(hipGetLastError());
     }
-    std::vector<uint32_t> os(nshards + 1, 0);
-    HIPCHK(hipMemcpyAsync(os.data(), sh.owner_start, sizeof(uint32_t) * (nshards + 1), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (int o = 0; o < nshards; ++o) counts_out[o] = (int64_t)os[o + 1] - (int64_t)os[o];
-    sh.U = os[nshards];
+    HIPCHK(hipMemcpyAsync(sh.owner_start_host, sh.owner_start, sizeof(uint32_t) * (nshards + 1), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(sh.plan_ev, st));
+    sh.plan_pending = true;
+    return PS_OK;
+}
+
+extern "C" int ps_shard_plan_finish(ps_model_t *m, int64_t *counts_out, uint32_t **send_rows_dev, int64_t *n_unique) {
+    if (!m || !counts_out) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    ps_model::Shard &sh = m->sh;
+    if (!sh.plan_pending) return ps_set_err(PS_E_STATE, "ps_shard_plan_launch first");
+    HIPCHK(hipSetDevice(m->s->device));
+    HIPCHK(hipEventSynchronize(sh.plan_ev));
+    sh.plan_pending = false;
+    for (int o = 0; o < sh.nshards; ++o) counts_out[o] = (int64_t)sh.owner_start_host[o + 1] - (int64_t)sh.owner_start_host[o];
+    sh.U = sh.owner_start_host[sh.nshards];
     if (send_rows_dev) *send_rows_dev = sh.send_rows;
     if (n_unique) *n_unique = sh.U;
     return PS_OK;
+}
+
+extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream,
+                             int64_t *counts_out, uint32_t **send_rows_dev, int64_t *n_unique) {
+    if (!counts_out) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    PSCHK(ps_shard_plan_launch(m, batch, nshards, hip_stream));
+    return ps_shard_plan_finish(m, counts_out, send_rows_dev, n_unique);
 }
 
 extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int64_t n, float *rows_out_dev) {
@@ -220,25 +239,54 @@ extern "C" int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_uniqu
     return PS_OK;
 }
 
-extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n, int is_async) {
+extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n,
+                                   const int64_t *peer_counts, int npeers, int is_async) {
     if (!s || n < 0 || (n > 0 && (!rows_dev || !grads_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = s->stream;
-    if (n > 0) {
+    ps_updater_t u;
+    PSCHK(store_resolve_updater(s, "emF", &u));
+    const int64_t R = s->emb.total_rows;
+    // worker-grouped lists (what ps_shard_plan + all-to-all-v deliver): no sort, two kernels
+    const bool grouped = peer_counts && npeers >= 1 && npeers <= PS_PUSH_MAX_PEERS && (double)npeers * (double)R * 4.0 <= 4.0e9;
+    if (n > 0 && grouped) {
+        int64_t tot = 0;
+        for (int p = 0; p < npeers; ++p) {
+            if (peer_counts[p] < 0) return ps_set_err(PS_E_BAD_ARG, "negative peer count");
+            tot += peer_counts[p];
+        }
+        if (tot != n) return ps_set_err(PS_E_BAD_ARG, "peer counts sum to %lld, n is %lld", (long long)tot, (long long)n);
+        if (!s->push_mask) {
+            HIPCHK(hipMalloc((void **)&s->push_mask, sizeof(uint32_t) * (size_t)(R + 1)));
+            HIPCHK(hipMemsetAsync(s->push_mask, 0, sizeof(uint32_t) * (size_t)(R + 1), st));
+        }
+        if (s->push_pos_peers < npeers) {
+            if (s->push_pos) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(s->push_pos); s->push_pos = nullptr; }
+            HIPCHK(hipMalloc((void **)&s->push_pos, sizeof(uint32_t) * (size_t)npeers * (size_t)(R + 1)));
+            s->push_pos_peers = npeers;
+        }
+        PushApplyArgs a;
+        memset(&a, 0, sizeof a);
+        a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = R;
+        uint32_t acc = 0;
+        for (int p = 0; p < npeers; ++p) { a.peer_start[p] = acc; acc += (uint32_t)peer_counts[p]; }
+        a.peer_start[npeers] = acc;
+        a.rows = rows_dev; a.grads = grads_dev; a.mask = s->push_mask; a.pos = s->push_pos;
+        a.W = s->emb.W; a.state = s->emb.state; a.upd = make_upd_params(u); a.err = s->err_dev;
+        PSCHK(launch_push_apply(a, st));
+    } else if (n > 0) {
         PSCHK(ensure_push_ws(s, n));
         // stable sort by row: within a key the pushes stay in arrival (= source worker) order
         HIPCHK(hipMemcpyAsync(s->push_keys, rows_dev, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st));
         uint32_t *sk = nullptr, *se = nullptr;
-        PSCHK(radix_sort_pairs(s->push_ws, s->push_keys, s->push_ents, n, bits_for(s->emb.total_rows), true, &sk, &se, st));
+        PSCHK(radix_sort_pairs(s->push_ws, s->push_keys, s->push_ents, n, bits_for(R), true, &sk, &se, st));
         PSCHK(build_segments(s->push_ws, sk, n, s->push_seg_start, s->push_seg_id, s->push_nseg, st));
         RowsApplyArgs r;
         memset(&r, 0, sizeof r);
         r.D = s->emb.D; r.is_async = is_async ? 1 : 0; r.identity = 0;
         r.sorted_key = sk; r.sorted_ent = se; r.seg_start = s->push_seg_start; r.nseg = s->push_nseg;
         r.grads = grads_dev; r.W = s->emb.W; r.state = s->emb.state;
-        ps_updater_t u;
-        PSCHK(store_resolve_updater(s, "emF", &u));
         r.upd = make_upd_params(u);
         PSCHK(launch_rows_apply(r, n, st));
     }

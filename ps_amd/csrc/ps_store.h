@@ -53,6 +53,7 @@ struct ps_store {
     // scratch for push application
     SortWorkspace push_ws; uint32_t *push_keys = nullptr, *push_ents = nullptr, *push_seg_start = nullptr,
                               *push_seg_id = nullptr, *push_nseg = nullptr; int64_t push_cap = 0;
+    uint32_t *push_mask = nullptr, *push_pos = nullptr; int push_pos_peers = 0;   // sort-free push (worker-grouped lists)
 };
 
 int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero);
@@ -111,6 +112,9 @@ struct ps_model {
         int64_t flat_elems = 0;
         int sbits = 0;
         int64_t U = 0;
+        uint32_t *owner_start_host = nullptr;   // pinned readback of owner_start
+        hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
+        bool plan_pending = false;
     } sh;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)

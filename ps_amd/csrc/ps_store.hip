@@ -231,6 +231,7 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     fr(s->err_dev); fr(s->idx_dev); fr(s->rowbuf_dev);
     sort_ws_free(s->push_ws);
     fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);
+    fr(s->push_mask); fr(s->push_pos);
     (void)hipStreamDestroy(s->own_stream);    // an adopted stream belongs to the host
     delete s;
     return PS_OK;

@@ -96,11 +96,13 @@ SIGNATURES = {
     "ps_emb_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i]),
     "ps_fc_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i]),
     "ps_store_set_stream": (_i, [_vp, _vp]),
-    "ps_shard_plan": (_i, [_vp, C.POINTER(ps_batch_t), _i, _pi64, _pvp, _pi64]),
+    "ps_shard_plan": (_i, [_vp, C.POINTER(ps_batch_t), _i, _vp, _pi64, _pvp, _pi64]),
+    "ps_shard_plan_launch": (_i, [_vp, C.POINTER(ps_batch_t), _i, _vp]),
+    "ps_shard_plan_finish": (_i, [_vp, _pi64, _pvp, _pi64]),
     "ps_shard_serve_pull": (_i, [_vp, _vp, _i64, _vp]),
     "ps_shard_forward_backward": (_i, [_vp, _vp, _pf]),
     "ps_shard_grads": (_i, [_vp, _pvp, _pi64]),
-    "ps_shard_apply_push": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "ps_shard_apply_push": (_i, [_vp, _vp, _vp, _i64, _pi64, _i, _i]),
     "ps_shard_flat_grad": (_i, [_vp, _pvp, _pi64]),
     "ps_shard_apply_flat": (_i, [_vp, _i]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),

@@ -31,49 +31,167 @@ from . import native as N
 # ---------------------------------------------------------------------------
 # communication
 # ---------------------------------------------------------------------------
+class _Done:
+    def wait(self):
+        pass
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class LocalComm:
     """world_size 1: every collective is the identity (used by single-GPU tests)."""
     rank, world = 0, 1
+    side_stream_handle = None
 
-    def exchange_counts(self, counts):
+    def side(self):
+        return _NullCtx()
+
+    def side_wait_for(self, ev):
+        pass
+
+    def join_side(self, ready=None, tensors=()):
+        pass
+
+    def record_side(self):
+        return None
+
+    def record_done(self):
+        return None
+
+    def bind_thread(self):
+        pass
+
+    def exchange_counts(self, counts, side=False):
         return list(counts)
 
-    def all_to_all_v(self, send, send_counts, recv_counts, width, dtype):
+    def exchange_counts_launch(self, counts):
+        return list(counts)
+
+    def exchange_counts_complete(self, h):
+        return h
+
+    def all_to_all_v(self, send, send_counts, recv_counts, width, side=False):
         return send
 
-    def all_reduce_sum(self, buf):
-        return buf
+    def all_reduce_sum_async(self, buf):
+        return _Done()
 
     def barrier(self):
         pass
 
 
 class TorchComm:
-    """torch.distributed (nccl = RCCL on ROCm, gloo on CPU).  Buffers are torch tensors."""
+    """torch.distributed (nccl = RCCL on ROCm, gloo on CPU).  Buffers are torch tensors.
 
-    def __init__(self, dist, torch, device):
+    Three communicators so that independent exchanges do not queue behind each other:
+    the main one (rows / gradients, on the training stream), a `side` one for the
+    weight-independent prefetch of the next step's key lists (on its own stream), and one
+    for the dense all-reduce, which runs beside the gradient all-to-all."""
+
+    def __init__(self, dist, torch, device, overlap=True):
         self.dist, self.torch, self.device = dist, torch, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.cuda = device.type == "cuda"
+        self.side_group = dist.new_group(list(range(self.world))) if overlap else None
+        self.ar_group = dist.new_group(list(range(self.world))) if overlap else None
+        # high priority: the prefetch is a chain of tiny kernels that must not queue behind the training step's GEMMs
+        self.side_stream = torch.cuda.Stream(device, priority=-1) if (overlap and self.cuda) else None
+        self.side_stream_handle = self.side_stream.cuda_stream if self.side_stream is not None else None
 
-    def exchange_counts(self, counts):
+    def side(self):
+        """Context of the prefetch: torch's current stream becomes the side stream."""
+        return self.torch.cuda.stream(self.side_stream) if self.side_stream is not None else _NullCtx()
+
+    def side_wait_for(self, ev):
+        if ev is not None and self.side_stream is not None:
+            self.side_stream.wait_event(ev)
+
+    def record_side(self):
+        """Event at the current tail of the side stream (call inside side())."""
+        if self.side_stream is None:
+            return None
+        ev = self.torch.cuda.Event()
+        ev.record(self.side_stream)
+        return ev
+
+    def join_side(self, ready=None, tensors=()):
+        """The training stream continues after the prefetch of THIS step (not whatever later
+        prefetch is already queued behind it on the side stream)."""
+        if self.side_stream is None:
+            return
+        main = self.torch.cuda.current_stream(self.device)
+        if ready is not None:
+            main.wait_event(ready)
+        else:
+            main.wait_stream(self.side_stream)
+        for t in tensors:
+            if hasattr(t, "record_stream"):
+                t.record_stream(main)
+
+    def bind_thread(self):
+        if self.cuda:
+            self.torch.cuda.set_device(self.device)
+
+    def record_done(self):
+        if self.side_stream is None:
+            return None
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return ev
+
+    def exchange_counts(self, counts, side=False):
         t = self.torch
         send = t.tensor(counts, dtype=t.int64, device=self.device)
         recv = t.empty_like(send)
-        self.dist.all_to_all_single(recv, send)
+        self.dist.all_to_all_single(recv, send, group=self.side_group if side else None)
         return [int(x) for x in recv.tolist()]
 
-    def all_to_all_v(self, send, send_counts, recv_counts, width, dtype):
+    def exchange_counts_launch(self, counts):
+        """Counts exchange on the side communicator without a host wait: returns a handle for
+        exchange_counts_complete.  (CPU/gloo: the exchange itself is synchronous.)"""
+        if self.side_stream is None:
+            return self.exchange_counts(counts, side=True)
+        t = self.torch
+        if not hasattr(self, "_cnt_ring"):
+            self._cnt_ring = [(t.empty(self.world, dtype=t.int64).pin_memory(), t.empty(self.world, dtype=t.int64).pin_memory(),
+                               t.cuda.Event()) for _ in range(4)]
+            self._cnt_next = 0
+        sp, rp, ev = self._cnt_ring[self._cnt_next % len(self._cnt_ring)]
+        self._cnt_next += 1
+        for i, c in enumerate(counts):
+            sp[i] = int(c)
+        send = sp.to(self.device, non_blocking=True)
+        recv = t.empty_like(send)
+        self.dist.all_to_all_single(recv, send, group=self.side_group)
+        rp.copy_(recv, non_blocking=True)
+        ev.record(t.cuda.current_stream(self.device))
+        return (rp, ev, send, recv)
+
+    def exchange_counts_complete(self, h):
+        if isinstance(h, list):
+            return h
+        rp, ev = h[0], h[1]
+        ev.synchronize()
+        return [int(x) for x in rp.tolist()]
+
+    def all_to_all_v(self, send, send_counts, recv_counts, width, side=False):
         """send: [sum(send_counts), width] (or 1-D when width == 1), grouped by destination rank."""
         t = self.torch
         n_recv = int(sum(recv_counts))
         shape = (n_recv,) if send.dim() == 1 else (n_recv, width)
         recv = t.empty(shape, dtype=send.dtype, device=self.device)
-        self.dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+        self.dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                                    group=self.side_group if side else None)
         return recv
 
-    def all_reduce_sum(self, buf):
-        self.dist.all_reduce(buf)     # sum
-        return buf
+    def all_reduce_sum_async(self, buf):
+        return self.dist.all_reduce(buf, group=self.ar_group, async_op=True)     # sum
 
     def barrier(self):
         self.dist.barrier()
@@ -82,9 +200,146 @@ class TorchComm:
 # ---------------------------------------------------------------------------
 # the orchestration: one worker/owner step
 # ---------------------------------------------------------------------------
+class Prepared:
+    """What the weight-independent half of a step produced (PSRouterClient.getList fan-out)."""
+    __slots__ = ("ctx", "counts", "rcounts", "recv_rows", "n_recv", "ready")
+
+    def __init__(self, ctx, counts, rcounts, recv_rows, ready=None):
+        self.ctx, self.counts, self.rcounts, self.recv_rows, self.ready = ctx, counts, rcounts, recv_rows, ready
+        self.n_recv = int(sum(rcounts))
+
+
 class ShardedWorker:
+    """prepare(batch) -> finish(prepared) is one BSP step.  `run` software-pipelines them: the key
+    lists of step t+1 (sort, unique, counts and row-id exchange: nothing that reads a weight) are
+    prepared on the side stream/communicator while step t trains, so the two host round trips of
+    all-to-all-v (split sizes) are off the critical path.  The backend keeps `nctx` plan contexts."""
+
     def __init__(self, backend, comm, is_async=False):
         self.be, self.comm, self.is_async = backend, comm, is_async
+        self.nctx = getattr(backend, "nctx", 1)
+        self.done = [None] * self.nctx
+        self.turn = 0
+
+    def prepare_launch(self, batch):
+        """P0: enqueue the key-list kernels of `batch` on the side stream; no host wait."""
+        be, comm = self.be, self.comm
+        ctx = self.turn % self.nctx
+        self.turn += 1
+        with comm.side():
+            comm.side_wait_for(self.done[ctx])            # the context's previous step no longer reads its buffers
+            be.plan_launch(batch, comm.world, ctx, comm.side_stream_handle)
+        return ctx
+
+    def prepare_counts(self, ctx):
+        """P1: per-owner counts back to the host (the plan's event), counts exchange enqueued."""
+        be, comm = self.be, self.comm
+        with comm.side():
+            counts, send_rows = be.plan_finish(ctx)
+            h = comm.exchange_counts_launch(counts)
+        return (ctx, counts, send_rows, h)
+
+    def prepare_complete(self, pc):
+        """P2: split sizes known -> the row-id all-to-all-v (side communicator)."""
+        comm = self.comm
+        if not isinstance(pc, tuple):
+            pc = self.prepare_counts(pc)
+        ctx, counts, send_rows, h = pc
+        with comm.side():
+            rcounts = comm.exchange_counts_complete(h)
+            recv_rows = comm.all_to_all_v(send_rows, counts, rcounts, 1, side=True)
+            ready = comm.record_side()
+        return Prepared(ctx, counts, rcounts, recv_rows, ready)
+
+    def prepare(self, batch):
+        return self.prepare_complete(self.prepare_counts(self.prepare_launch(batch)))
+
+    def finish(self, p, want_loss=True):
+        be, comm = self.be, self.comm
+        comm.join_side(p.ready, (p.recv_rows,))
+        rows_out = be.serve_pull(p.recv_rows, p.n_recv)                          # PServer.getList
+        cache = comm.all_to_all_v(rows_out, p.rcounts, p.counts, be.D)           # worker cache
+        loss = be.forward_backward(p.ctx, cache, want_loss)                      # Model.train on the cached rows
+        ar = comm.all_reduce_sum_async(be.flat_grad(p.ctx))                      # dense tensors + wide keys, beside the push
+        grads = be.grads(p.ctx)                                                  # what PSClient.push sends
+        recv_grads = comm.all_to_all_v(grads, p.counts, p.rcounts, be.D)
+        be.apply_push(p.recv_rows, recv_grads, p.n_recv, p.rcounts, self.is_async)          # PServer.push + psUpdate
+        ar.wait()
+        be.apply_flat(p.ctx, comm.world)
+        self.done[p.ctx] = comm.record_done()
+        return loss
+
+    def step(self, batch, want_loss=True):
+        return self.finish(self.prepare(batch), want_loss)
+
+    def run(self, batches, steps, want_loss=False, threaded=False):
+        """`steps` software-pipelined steps over batches[i % len]; returns the last loss (None unless
+        want_loss).  With 3 plan contexts the host never waits: while step i is enqueued, step i+2's
+        key lists are sorted (P0), then its counts exchanged (P1), and step i+1's row ids travel (P2):
+
+            iteration i:   P0(i+2) | finish(i) | P1(i+2)  P2(i+1)
+
+        With 2 contexts P1+P2 of step i+1 follow finish(i) (one blocking counts round trip); with 1 the
+        steps run back to back.  threaded: prepare() runs one step ahead in its own host thread (each
+        communicator still driven by exactly one thread); measured slower than the in-line pipeline on
+        MI355X/ROCm 7 (the two threads contend inside the HIP runtime), kept for hosts where it is not."""
+        if steps <= 0:
+            return None
+        if threaded and self.nctx > 1:
+            return self._run_threaded(batches, steps, want_loss)
+        nb = len(batches)
+        loss = None
+        if self.nctx >= 3:
+            cur = self.prepare(batches[0])
+            nxt = self.prepare_counts(self.prepare_launch(batches[1 % nb])) if steps > 1 else None
+            for i in range(steps):
+                far = self.prepare_launch(batches[(i + 2) % nb]) if i + 2 < steps else None      # P0(i+2)
+                loss = self.finish(cur, want_loss)                                                # (enqueue only unless want_loss)
+                far = self.prepare_counts(far) if far is not None else None                       # P1(i+2)
+                cur = self.prepare_complete(nxt) if nxt is not None else None                     # P2(i+1)
+                nxt = far
+            return loss
+        p = self.prepare(batches[0])
+        for i in range(steps):
+            more = i + 1 < steps and self.nctx > 1
+            if more:
+                nxt = self.prepare_launch(batches[(i + 1) % nb])      # sort/unique of step i+1 beside step i
+            loss = self.finish(p, want_loss)
+            if more:
+                p = self.prepare_complete(nxt)
+            elif i + 1 < steps:
+                p = self.prepare(batches[(i + 1) % nb])
+        return loss
+
+    def _run_threaded(self, batches, steps, want_loss):
+        import queue
+        import threading
+        ready, free = queue.Queue(), queue.Queue()
+
+        def producer():
+            try:
+                self.comm.bind_thread()
+                for i in range(steps):
+                    if i >= self.nctx and free.get(timeout=300) is None:     # a context is free once its step is enqueued
+                        return
+                    ready.put(self.prepare(batches[i % len(batches)]))
+            except BaseException as e:      # noqa: BLE001 -- handed to the training thread
+                ready.put(e)
+
+        th = threading.Thread(target=producer, name="ps-prefetch", daemon=True)
+        th.start()
+        loss = None
+        try:
+            for _ in range(steps):
+                p = ready.get(timeout=300)
+                if isinstance(p, BaseException):
+                    raise p
+                loss = self.finish(p, want_loss)
+                free.put(p.ctx)
+        finally:
+            free.put(None)
+            th.join(timeout=300)
+        return loss
 
     def step_timed(self, batch, sync, acc):
         """The same step with a host-side stopwatch around every phase (sync() between phases):
@@ -97,34 +352,21 @@ class ShardedWorker:
             t.append(time.perf_counter())
             acc[name] = acc.get(name, 0.0) + (t[-1] - t[-2])
 
-        counts, send_rows = be.plan(batch, comm.world); lap("plan")
+        ctx = self.turn % self.nctx
+        self.turn += 1
+        counts, send_rows = be.plan(batch, comm.world, ctx, None); lap("plan")
         rcounts = comm.exchange_counts(counts); lap("a2a_counts")
-        recv_rows = comm.all_to_all_v(send_rows, counts, rcounts, 1, "u32"); lap("a2a_ids")
-        rows_out = be.serve_pull(recv_rows, int(sum(rcounts))); lap("serve_pull")
-        cache = comm.all_to_all_v(rows_out, rcounts, counts, be.D, "f32"); lap("a2a_rows")
-        be.forward_backward(cache, False); lap("forward_backward")
-        grads = be.grads()
-        recv_grads = comm.all_to_all_v(grads, counts, rcounts, be.D, "f32"); lap("a2a_grads")
-        be.apply_push(recv_rows, recv_grads, int(sum(rcounts)), self.is_async); lap("apply_push")
-        flat = be.flat_grad()
-        comm.all_reduce_sum(flat); lap("allreduce_flat")
-        be.apply_flat(comm.world); lap("apply_flat")
-
-    def step(self, batch, want_loss=True):
-        be, comm = self.be, self.comm
-        counts, send_rows = be.plan(batch, comm.world)                     # PSRouterClient.getList fan-out
-        rcounts = comm.exchange_counts(counts)
-        recv_rows = comm.all_to_all_v(send_rows, counts, rcounts, 1, "u32")
-        rows_out = be.serve_pull(recv_rows, int(sum(rcounts)))             # PServer.getList
-        cache = comm.all_to_all_v(rows_out, rcounts, counts, be.D, "f32")  # worker cache
-        loss = be.forward_backward(cache, want_loss)                       # Model.train on the cached rows
-        grads = be.grads()                                                 # what PSClient.push sends
-        recv_grads = comm.all_to_all_v(grads, counts, rcounts, be.D, "f32")
-        be.apply_push(recv_rows, recv_grads, int(sum(rcounts)), self.is_async)   # PServer.push + psUpdate
-        flat = be.flat_grad()
-        comm.all_reduce_sum(flat)                                          # dense tensors + wide keys
-        be.apply_flat(comm.world)
-        return loss
+        recv_rows = comm.all_to_all_v(send_rows, counts, rcounts, 1); lap("a2a_ids")
+        n = int(sum(rcounts))
+        rows_out = be.serve_pull(recv_rows, n); lap("serve_pull")
+        cache = comm.all_to_all_v(rows_out, rcounts, counts, be.D); lap("a2a_rows")
+        be.forward_backward(ctx, cache, False); lap("forward_backward")
+        grads = be.grads(ctx)
+        recv_grads = comm.all_to_all_v(grads, counts, rcounts, be.D); lap("a2a_grads")
+        be.apply_push(recv_rows, recv_grads, n, rcounts, self.is_async); lap("apply_push")
+        comm.all_reduce_sum_async(be.flat_grad(ctx)).wait(); lap("allreduce_flat")
+        be.apply_flat(ctx, comm.world); lap("apply_flat")
+        self.done[ctx] = comm.record_done()
 
 
 # ---------------------------------------------------------------------------
@@ -139,11 +381,15 @@ class _DevView:
 
 class HipBackend:
     """Device-side halves through the C ABI.  With torch: buffers cross as torch tensors
-    (zero-copy views of the library's device memory); without (LocalComm): raw pointers."""
+    (zero-copy views of the library's device memory); without (LocalComm): raw pointers.
+    `models`: one ps_model per plan context, all on the same store (they share every weight;
+    each has its own batch staging, key lists and activations)."""
 
-    def __init__(self, model, torch=None, device=None):
-        self.m, self.kv = model, model.store
-        self.D = model.D
+    def __init__(self, models, torch=None, device=None):
+        self.models = list(models) if isinstance(models, (list, tuple)) else [models]
+        self.nctx = len(self.models)
+        self.kv = self.models[0].store
+        self.D = self.models[0].D
         self.torch, self.device = torch, device
         self._keep = []
 
@@ -158,14 +404,21 @@ class HipBackend:
     def _ptr(buf):
         return buf[0] if isinstance(buf, tuple) else buf.data_ptr()
 
-    def plan(self, batch, world):
-        counts = (C.c_int64 * world)()
+    def plan_launch(self, batch, world, ctx=0, stream=None):
+        self._world = world
+        N.check(N.lib().ps_shard_plan_launch(self.models[ctx].h, C.byref(batch.c), world, stream))
+
+    def plan_finish(self, ctx=0):
+        counts = (C.c_int64 * self._world)()
         rows = C.c_void_p()
         nu = C.c_int64()
-        N.check(N.lib().ps_shard_plan(self.m.h, C.byref(batch.c), world, counts, C.byref(rows), C.byref(nu)))
-        self.U = nu.value
+        N.check(N.lib().ps_shard_plan_finish(self.models[ctx].h, counts, C.byref(rows), C.byref(nu)))
         t = self.torch
-        return list(counts), self._tensor(rows.value, (self.U,), "<i4", None if t is None else t.int32)
+        return list(counts), self._tensor(rows.value, (nu.value,), "<i4", None if t is None else t.int32)
+
+    def plan(self, batch, world, ctx=0, stream=None):
+        self.plan_launch(batch, world, ctx, stream)
+        return self.plan_finish(ctx)
 
     def serve_pull(self, recv_rows, n):
         t = self.torch
@@ -179,33 +432,34 @@ class HipBackend:
         N.check(N.lib().ps_shard_serve_pull(self.kv.h, self._ptr(recv_rows), n, self._ptr(buf)))
         return buf
 
-    def forward_backward(self, cache, want_loss=True):
+    def forward_backward(self, ctx, cache, want_loss=True):
         loss = C.c_float()
-        N.check(N.lib().ps_shard_forward_backward(self.m.h, self._ptr(cache), C.byref(loss) if want_loss else None))
+        N.check(N.lib().ps_shard_forward_backward(self.models[ctx].h, self._ptr(cache), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
 
-    def grads(self):
+    def grads(self, ctx):
         g = C.c_void_p()
         nu = C.c_int64()
-        N.check(N.lib().ps_shard_grads(self.m.h, C.byref(g), C.byref(nu)))
+        N.check(N.lib().ps_shard_grads(self.models[ctx].h, C.byref(g), C.byref(nu)))
         t = self.torch
         return self._tensor(g.value, (nu.value, self.D), "<f4", None if t is None else t.float32)
 
-    def apply_push(self, recv_rows, recv_grads, n, is_async):
-        N.check(N.lib().ps_shard_apply_push(self.kv.h, self._ptr(recv_rows), self._ptr(recv_grads), n, int(is_async)))
+    def apply_push(self, recv_rows, recv_grads, n, peer_counts, is_async):
+        pc = (C.c_int64 * len(peer_counts))(*peer_counts)
+        N.check(N.lib().ps_shard_apply_push(self.kv.h, self._ptr(recv_rows), self._ptr(recv_grads), n, pc, len(peer_counts), int(is_async)))
         for p in self._keep:
             N.lib().ps_dev_free(self.kv.h, p)
         self._keep = []
 
-    def flat_grad(self):
+    def flat_grad(self, ctx):
         f = C.c_void_p()
         n = C.c_int64()
-        N.check(N.lib().ps_shard_flat_grad(self.m.h, C.byref(f), C.byref(n)))
+        N.check(N.lib().ps_shard_flat_grad(self.models[ctx].h, C.byref(f), C.byref(n)))
         t = self.torch
         return self._tensor(f.value, (n.value,), "<f4", None if t is None else t.float32)
 
-    def apply_flat(self, world):
-        N.check(N.lib().ps_shard_apply_flat(self.m.h, world))
+    def apply_flat(self, ctx, world):
+        N.check(N.lib().ps_shard_apply_flat(self.models[ctx].h, world))
 
 
 # ---------------------------------------------------------------------------
@@ -229,20 +483,24 @@ def run_bench(args, cfg, synth_batch):
     cfg = dict(cfg)
     kv = ps_amd.KVStore(local, cfg["seed"])
     kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"], shard=rank, nshards=world)
-    gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+    overlap = bool(getattr(args, "overlap", 1))
+    gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+           for _ in range(4 if overlap else 1)]       # plan contexts: steps t+1, t+2 are planned while step t trains and t-1 drains
+    torch.cuda.set_stream(torch.cuda.Stream(dev))      # not the legacy null stream (implicit syncs with blocking streams)
     N.check(N.lib().ps_store_set_stream(kv.h, torch.cuda.current_stream().cuda_stream))
-    comm = TorchComm(dist, torch, dev)
-    worker = ShardedWorker(HipBackend(gm, torch, dev), comm, is_async=bool(getattr(args, "is_async", 0)))
+    comm = TorchComm(dist, torch, dev, overlap=overlap)
+    threaded = overlap and bool(getattr(args, "prefetch_thread", 0))
+    worker = ShardedWorker(HipBackend(gms, torch, dev), comm, is_async=bool(getattr(args, "is_async", 0)))
     rng = np.random.default_rng(cfg["seed"] + 1000 * rank)     # every worker reads its own slice of the data
     nb = 8
     batches = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
-    for i in range(max(args.warmup, 1)):
-        worker.step(batches[i % nb], want_loss=False)
+    # priming (untimed, on top of --warmup): the first few hundred steps run ~30% slower while the caching
+    # allocator, the three communicators and the host settle; keep that out of the timed region
+    worker.run(batches, max(args.warmup, 1) + int(getattr(args, "priming", 300)), threaded=threaded)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        worker.step(batches[i % nb], want_loss=False)
+    worker.run(batches, args.steps, threaded=threaded)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -254,6 +512,17 @@ def run_bench(args, cfg, synth_batch):
         for i in range(50):
             worker.step_timed(batches[i % nb], torch.cuda.synchronize, phases)
         phases = {k: round(1e6 * v / 50, 1) for k, v in phases.items()}
+        for g in gms:
+            g.set_profile(True)
+        worker.run(batches, 20)
+        torch.cuda.synchronize()
+        groups = {}
+        for g in gms:
+            for k, v in g.profile_report().items():
+                c0, m0 = groups.get(k, (0, 0.0))
+                groups[k] = (c0 + v[0], m0 + v[1])
+            g.set_profile(False)
+        phases["kernel_groups_us"] = {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in groups.items()}
     out = None
     if rank == 0:
         out = {
@@ -262,7 +531,9 @@ def run_bench(args, cfg, synth_batch):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Wide&Deep synthetic (26 x 100k x 16, FC[512,256,1]), batch 4096 per GPU, "
                                    "embedding rows sharded id mod N (PSRouterClient routing -> RCCL all-to-all-v), dense + wide all-reduce, BSP",
-                       "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True},
+                       "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True,
+                       "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
+                       "priming_steps_untimed": int(getattr(args, "priming", 300))},
             "final_loss": loss,
         }
         if phases:
@@ -270,6 +541,8 @@ def run_bench(args, cfg, synth_batch):
     for b in batches:
         b.close()
     dist.barrier()
-    gm.close(); kv.close()
+    for g in gms:
+        g.close()
+    kv.close()
     dist.destroy_process_group()
     return out

@@ -17,8 +17,31 @@ def local_count(V, shard, n):
     return (V - shard + n - 1) // n if V > shard else 0
 
 
+class _Plan:
+    pass
+
+
+class _Bound:
+    """Backend attribute access with the per-step fields (batch, uniq, slot, _grads, _flat ...)
+    redirected to one plan context."""
+    _PLAN = ("batch", "uniq", "slot", "ufield", "uid", "_grads", "_flat")
+
+    def __init__(self, be, plan):
+        object.__setattr__(self, "_be", be)
+        object.__setattr__(self, "_pl", plan)
+
+    def __getattr__(self, k):
+        return getattr(self._pl if k in _Bound._PLAN else self._be, k)
+
+    def __setattr__(self, k, v):
+        setattr(self._pl if k in _Bound._PLAN else self._be, k, v)
+
+
 class OracleBackend:
+    nctx = 3
+
     def __init__(self, torch, rank, world, cfg, seed):
+        self.plans = [_Plan() for _ in range(self.nctx)]
         self.t, self.rank, self.world, self.cfg, self.seed = torch, rank, world, cfg, seed
         F, D = cfg["F"], cfg["D"]
         self.F, self.D = F, D
@@ -49,7 +72,15 @@ class OracleBackend:
         self.model.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 32)
 
     # ---- worker: PSRouterClient.getList fan-out
-    def plan(self, batch, world):
+    def plan_launch(self, batch, world, ctx=0, stream=None):
+        self.plans[ctx].pending = (batch, world)
+
+    def plan_finish(self, ctx=0):
+        batch, world = self.plans[ctx].pending
+        return self.plan(batch, world, ctx)
+
+    def plan(self, batch, world, ctx=0, stream=None):
+        self = _Bound(self, self.plans[ctx])
         E = batch["E"]
         B, F = E.shape
         owner = E % world
@@ -69,7 +100,8 @@ class OracleBackend:
         return self.t.from_numpy(self.W[recv_rows.numpy().astype(np.int64)].copy())
 
     # ---- worker: Model.train on the pulled rows
-    def forward_backward(self, cache, want_loss=True):
+    def forward_backward(self, ctx, cache, want_loss=True):
+        self = _Bound(self, self.plans[ctx])
         cache = cache.numpy()
         for u in range(len(self.uniq)):
             self.store.put(orc.emb_key(int(self.ufield[u]), float(self.uid[u])), cache[u], self.D, 1)
@@ -95,11 +127,11 @@ class OracleBackend:
         self._flat = self.t.from_numpy(np.concatenate(dense + [G, Cc, np.array([gbar], f32)]).astype(f32))
         return loss
 
-    def grads(self):
-        return self.t.from_numpy(self._grads)
+    def grads(self, ctx):
+        return self.t.from_numpy(self.plans[ctx]._grads)
 
     # ---- owner: PServer.push + psUpdate
-    def apply_push(self, recv_rows, recv_grads, n, is_async):
+    def apply_push(self, recv_rows, recv_grads, n, peer_counts, is_async):
         rows = recv_rows.numpy().astype(np.int64); g = recv_grads.numpy()
         order = np.argsort(rows, kind="stable")                   # arrival (= worker) order within a key
         i = 0
@@ -119,11 +151,11 @@ class OracleBackend:
                 self.W[r], self.M[r], self.Vv[r] = orc.adam_update(self.W[r], S, self.M[r], self.Vv[r])
             i = j
 
-    def flat_grad(self):
-        return self._flat
+    def flat_grad(self, ctx):
+        return self.plans[ctx]._flat
 
-    def apply_flat(self, world):
-        flat = self._flat.numpy()
+    def apply_flat(self, ctx, world):
+        flat = self.plans[ctx]._flat.numpy()
         off = 0
         for l in range(len(self.fcW)):
             nw, nb = self.fcW[l].size, self.fcb[l].size

@@ -1,0 +1,182 @@
+"""The N>1 HIP path on ONE GPU: N worker/owner ranks run as N threads of this process, each with
+its own sharded ps_store (rows id mod N == rank) and model, driving the real orchestration
+(ps_amd/sharded.py ShardedWorker + HipBackend -> the C ABI).  The collectives are an in-process
+stand-in that moves the device buffers through the host, so everything except the RCCL wire is the
+product code: composite owner|row sort with nshards > 1, per-owner counts, serve_pull on every shard,
+the sort-free push from N workers, the flat dense/wide reduction.  Expected values: the key-addressed
+single-process simulation of the PS semantics used by the gloo test (net/PServer.java:164-214)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from test_sharded_gloo import CFG, SEED, STEPS, expected, make_batches
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+class Shared:
+    def __init__(self, world):
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world, timeout=120)
+
+
+class ThreadComm:
+    """Blocking collectives between the rank threads; buffers are (device pointer, shape) pairs."""
+    side_stream_handle = None
+
+    def __init__(self, rank, shared, kv):
+        from ps_amd import native as N
+        self.rank, self.world, self.sh, self.kv, self.N = rank, shared.world, shared, kv, N
+        self.keep = []
+
+    # -- the parts of the comm contract that are no-ops without streams
+    def side(self):
+        from ps_amd.sharded import _NullCtx
+        return _NullCtx()
+
+    def side_wait_for(self, ev):
+        pass
+
+    def join_side(self, ready=None, tensors=()):
+        pass
+
+    def record_side(self):
+        return None
+
+    def record_done(self):
+        return None
+
+    def bind_thread(self):
+        pass
+
+    # -- host staging
+    def _down(self, buf, dtype):
+        ptr, shape = buf
+        a = np.empty(shape, dtype)
+        if a.size:
+            self.N.check(self.N.lib().ps_dev_download(self.kv.h, a.ctypes.data, ptr, a.nbytes))
+        return a
+
+    def _up(self, a):
+        p = C.c_void_p()
+        self.N.check(self.N.lib().ps_dev_alloc(self.kv.h, max(a.nbytes, 4), C.byref(p)))
+        if a.size:
+            a = np.ascontiguousarray(a)
+            self.N.check(self.N.lib().ps_dev_upload(self.kv.h, p, a.ctypes.data, a.nbytes))
+        self.keep.append(p)
+        return (p.value, a.shape)
+
+    def _swap(self, mine):
+        self.sh.slots[self.rank] = mine
+        self.sh.barrier.wait()
+        got = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return got
+
+    def exchange_counts(self, counts, side=False):
+        return [int(c[self.rank]) for c in self._swap(list(counts))]
+
+    def exchange_counts_launch(self, counts):
+        return self.exchange_counts(counts)
+
+    def exchange_counts_complete(self, h):
+        return h
+
+    def all_to_all_v(self, send, send_counts, recv_counts, width, side=False):
+        host = self._down(send, np.uint32 if width == 1 else f32)
+        offs = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+        parts = self._swap((host, offs))
+        out = np.concatenate([h[o[self.rank]:o[self.rank + 1]] for h, o in parts])
+        assert [len(h[o[self.rank]:o[self.rank + 1]]) for h, o in parts] == list(recv_counts)
+        return self._up(out)
+
+    def all_reduce_sum_async(self, buf):
+        from ps_amd.sharded import _Done
+        parts = self._swap(self._down(buf, f32))
+        tot = parts[0].copy()
+        for p in parts[1:]:
+            tot = (tot + p).astype(f32)          # rank order (RCCL's order is its own; the test allows for it)
+        self.N.check(self.N.lib().ps_dev_upload(self.kv.h, buf[0], tot.ctypes.data, tot.nbytes))
+        return _Done()
+
+    def barrier(self):
+        self.sh.barrier.wait()
+
+    def free(self):
+        for p in self.keep:
+            self.N.lib().ps_dev_free(self.kv.h, p)
+        self.keep = []
+
+
+def rank_main(rank, world, shared, is_async, pipelined, out, errs):
+    try:
+        import ps_amd
+        from ps_amd.sharded import HipBackend, ShardedWorker
+        F, D, V = CFG["F"], CFG["D"], CFG["V"]
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D, shard=rank, nshards=world)
+        nctx = 3 if pipelined else 1
+        gms = [ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"]) for _ in range(nctx)]
+        comm = ThreadComm(rank, shared, kv)
+        wk = ShardedWorker(HipBackend(gms), comm, is_async=is_async)
+        bs = [ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]) for b in make_batches(rank, STEPS)]
+        if pipelined:
+            wk.run(bs, STEPS)
+        else:
+            for b in bs:
+                wk.step(b)
+        kv.sync()
+        rows = {}
+        for f in range(F):
+            ids = np.arange(rank, V, world)
+            w = kv.get_rows(f, ids)
+            for i, idv in enumerate(ids):
+                rows[(f, int(idv))] = w[i]
+        out[rank] = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)],
+                     kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step())
+        comm.free()
+        for g in gms:
+            g.close()
+        kv.close()
+    except BaseException:       # noqa: BLE001
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+        shared.barrier.abort()
+
+
+@pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (4, True, False), (3, False, False)])
+def test_n_ranks_on_one_gpu(orc, world, is_async, pipelined):
+    shared = Shared(world)
+    out, errs = [None] * world, []
+    th = [threading.Thread(target=rank_main, args=(r, world, shared, is_async, pipelined, out, errs)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, "\n".join("rank %d:\n%s" % e for e in errs)
+    emb, fcW, fcb, ww, wb = expected(world, is_async)
+    xav = orc.xavier_scale(1, CFG["D"])
+    tol = 2e-5 * STEPS                   # same bound as the single-GPU step parity (FP32 GEMM order differs from the oracle's)
+    touched = 0
+    for r in range(world):
+        rows, W, b, wide, wbias, gstep = out[r]
+        assert gstep == STEPS
+        for (f, i), got in rows.items():
+            assert i % world == r
+            if (f, i) in emb:
+                assert np.abs(got - emb[(f, i)][0]).max() <= tol, "rank %d emF%d.%d" % (r, f, i)
+                touched += 1
+            else:                         # never pulled by any worker: still the initial row, bit for bit
+                np.testing.assert_array_equal(got, orc.init_rows(SEED, f, [i], CFG["D"], xav)[0])
+        for l in range(3):
+            assert np.abs(W[l] - fcW[l]).max() <= tol and np.abs(b[l] - fcb[l]).max() <= tol
+        assert np.abs(wide - ww).max() <= tol and abs(wbias[0] - wb[0]) <= tol
+        # replicated tensors are identical on every rank, bit for bit (same reduced gradient, same updater)
+        for l in range(3):
+            np.testing.assert_array_equal(W[l], out[0][1][l]); np.testing.assert_array_equal(b[l], out[0][2][l])
+        np.testing.assert_array_equal(wide, out[0][3]); np.testing.assert_array_equal(wbias, out[0][4])
+    assert touched > 0

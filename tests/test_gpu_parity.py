@@ -285,32 +285,49 @@ def test_predict_matches_forward(orc):
 
 def test_sharded_path_n1_equals_fused_step(orc):
     """The PS exchange with one shard (every collective the identity) is the fused step, bit for bit:
-    pull -> train on the cached rows -> push -> owner mean over 1 worker -> updater; dense/wide g/1."""
+    pull -> train on the cached rows -> push -> owner mean over 1 worker -> updater; dense/wide g/1.
+    Also with two plan contexts (two models on one store) and step t+1 prepared before step t finishes."""
     import ps_amd
     from ps_amd.sharded import HipBackend, LocalComm, ShardedWorker
     F, D, X, fc, V, B, WS = 5, 8, 3, [16, 8, 1], 40, 96, 31
     res = []
-    for sharded in (False, True):
+    for nctx in (0, 1, 2, 3):
         kv = ps_amd.KVStore(0, SEED)
         kv.create_embedding([V] * F, D)
-        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
-        worker = ShardedWorker(HipBackend(gm), LocalComm())
+        gms = [ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B) for _ in range(max(nctx, 1))]
+        worker = ShardedWorker(HipBackend(gms), LocalComm())
         rng = np.random.default_rng(4)
-        losses = []
-        for _ in range(4):
+        bs = []
+        for _ in range(5):
             E, Xd, Y = data(rng, B, F, X, V, True)
-            b = ps_amd.Batch(E, Xd, Y, E % WS)
-            losses.append(worker.step(b) if sharded else gm.train(b))
+            bs.append(ps_amd.Batch(E, Xd, Y, E % WS))
+        if nctx == 0:
+            losses = [gms[0].train(b) for b in bs]
+        elif nctx == 1:
+            losses = [worker.step(b) for b in bs]
+        elif nctx == 3:
+            losses = res[0][0][:-1] + [worker.run(bs, len(bs), want_loss=True)]      # the 3-stage pipeline; last loss
+        else:
+            losses = []
+            p = worker.prepare(bs[0])
+            for i in range(len(bs)):
+                nxt = worker.prepare(bs[i + 1]) if i + 1 < len(bs) else None     # planned BEFORE step i runs
+                losses.append(worker.finish(p))
+                p = nxt
         res.append((losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get_rows(f, np.arange(V), 1) for f in range(F)],
                     [kv.get("fc%d.weights" % i) for i in range(3)], [kv.get("fc%d.bias" % i) for i in range(3)],
-                    kv.get_wide(np.arange(WS)), kv.get("wide.bias")))
-        gm.close(); kv.close()
-    a, b = res
-    assert a[0] == b[0]
-    for i in (1, 2, 3, 4):
-        for x, y in zip(a[i], b[i]):
-            np.testing.assert_array_equal(x, y)
-    np.testing.assert_array_equal(a[5], b[5]); np.testing.assert_array_equal(a[6], b[6])
+                    kv.get_wide(np.arange(WS)), kv.get("wide.bias"), kv.global_step()))
+        for g in gms:
+            g.close()
+        kv.close()
+    a = res[0]
+    for b in res[1:]:
+        assert a[0] == b[0]
+        for i in (1, 2, 3, 4):
+            for x, y in zip(a[i], b[i]):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a[5], b[5]); np.testing.assert_array_equal(a[6], b[6])
+        assert a[7] == b[7]
 
 
 def test_multi_hot_bags(orc):
@@ -439,3 +456,58 @@ def test_against_committed_golden(name):
             assert np.abs(kv.get_wide(np.arange(WS)) - z[p + "wide_w"]).max() <= tol
             assert abs(kv.get("wide.bias")[0] - z[p + "wide_bias"][0]) <= tol
     gm.close(); kv.close()
+
+
+@pytest.mark.parametrize("is_async", [0, 1])
+def test_owner_push_from_many_workers(orc, is_async):
+    """PServer.push + psUpdate on one owner receiving the lists of 5 workers (net/PServer.java:164-214):
+    the sort-free path (worker-grouped lists) == the stable-sort path == the oracle's arithmetic
+    (BSP: mean over the pushing workers in worker order; async: one Adam step per push in worker order)."""
+    import ctypes as C
+    import ps_amd
+    from ps_amd import native as N
+    F, D, V, NW = 3, 8, 60, 5
+    rng = np.random.default_rng(17 + is_async)
+    R = F * V
+    lists = []
+    for w in range(NW):
+        k = int(rng.integers(0, 70))
+        rows = np.sort(rng.choice(R, size=k, replace=False)).astype(np.uint32)     # unique inside one worker's list
+        lists.append((rows, rng.standard_normal((k, D)).astype(f32)))
+    lists[2] = (np.zeros(0, np.uint32), np.zeros((0, D), f32))                      # a worker that pushed nothing
+    rows = np.concatenate([l[0] for l in lists]); grads = np.concatenate([l[1] for l in lists])
+    counts = [len(l[0]) for l in lists]
+    n = len(rows)
+    out = []
+    for grouped in (True, False):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        w0 = np.concatenate([kv.get_rows(f, np.arange(V)) for f in range(F)])
+        L = N.lib()
+        dr, dg = C.c_void_p(), C.c_void_p()
+        N.check(L.ps_dev_alloc(kv.h, max(rows.nbytes, 4), C.byref(dr))); N.check(L.ps_dev_alloc(kv.h, max(grads.nbytes, 4), C.byref(dg)))
+        N.check(L.ps_dev_upload(kv.h, dr, rows.ctypes.data, rows.nbytes)); N.check(L.ps_dev_upload(kv.h, dg, grads.ctypes.data, grads.nbytes))
+        for rep in range(2):          # twice: the second pass sees the state the first left (mask cleared, Adam moments)
+            pc = (C.c_int64 * NW)(*counts)
+            N.check(L.ps_shard_apply_push(kv.h, dr, dg, n, pc if grouped else None, NW if grouped else 0, is_async))
+        kv.sync()
+        out.append([np.concatenate([kv.get_rows(f, np.arange(V), which) for f in range(F)]) for which in (0, 1, 2)])
+        assert kv.global_step() == 2
+        L.ps_dev_free(kv.h, dr); L.ps_dev_free(kv.h, dg)
+        kv.close()
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    # the oracle's arithmetic
+    W, M, Vv = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
+    for rep in range(2):
+        for r in np.unique(rows):
+            gs = grads[rows == r]                        # worker order
+            if is_async:
+                for g in gs:
+                    W[r], M[r], Vv[r] = orc.adam_update(W[r], g, M[r], Vv[r])
+            else:
+                S = gs[0].copy()
+                for g in gs[1:]:
+                    S = (g + S).astype(f32)
+                W[r], M[r], Vv[r] = orc.adam_update(W[r], (S / f32(len(gs))).astype(f32), M[r], Vv[r])
+    np.testing.assert_array_equal(out[0][0], W); np.testing.assert_array_equal(out[0][1], M); np.testing.assert_array_equal(out[0][2], Vv)

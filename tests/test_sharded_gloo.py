@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 f32 = np.float32
 CFG = dict(F=3, V=23, D=4, X=2, fc=[6, 4, 1], wide=11, B=10)
-SEED, STEPS = 0x5EED, 3
+SEED, STEPS = 0x5EED, 5
 
 
 def make_batches(rank, steps):
@@ -106,7 +106,7 @@ def expected(world, is_async):
     return emb, fcW, fcb, ww, wb
 
 
-def worker_main(rank, world, port, is_async, q):
+def worker_main(rank, world, port, is_async, mode, q):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
         import torch
@@ -117,8 +117,12 @@ def worker_main(rank, world, port, is_async, q):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
         be = OracleBackend(torch, rank, world, CFG, SEED)
         wk = ShardedWorker(be, TorchComm(dist, torch, torch.device("cpu")), is_async=is_async)
-        for b in make_batches(rank, STEPS):
-            wk.step(b)
+        bs = make_batches(rank, STEPS)
+        if mode == "step":
+            for b in bs:
+                wk.step(b)                   # prepare + finish, one step at a time
+        else:                                # pipelined: step t+1's key lists are exchanged before step t's push lands
+            wk.run(bs, STEPS, threaded=(mode == "threaded"))
         emb, fcW, fcb, ww, wb = expected(world, is_async)
         xav = orc.xavier_scale(1, CFG["D"])
         checked = 0
@@ -145,14 +149,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("is_async", [False, True])
-def test_sharded_orchestration_world2(is_async):
+@pytest.mark.parametrize("is_async,mode", [(False, "pipelined"), (False, "threaded"), (True, "step"), (True, "threaded")])
+def test_sharded_orchestration_world2(is_async, mode):
     from oracle import oracle
     oracle.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=worker_main, args=(r, 2, port, is_async, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker_main, args=(r, 2, port, is_async, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
