@@ -141,6 +141,15 @@ def run_single(args):
         roof = {"kernel": dom, "bound": "hbm", "achieved": work / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "traffic": None}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # HBM bytes per launch of that kernel from the committed PMC passes (tools/profile_round.sh +
+    # tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950 corrections applied)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        roof["traffic"] = pmc["groups"][dom]["hbm_bytes_per_launch"]
+        roof["traffic_unit"] = "bytes/launch"
+        roof["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + ")"
+    except (OSError, KeyError, ValueError):
+        pass
     roof["avg_launch_us"] = avg_s * 1e6
     groups = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in prof.items()}
     out = {
@@ -165,13 +174,18 @@ def run_single(args):
 
 
 def gather_roofline(kv, args):
-    """BASELINE config 4 shape: one table >> 256 MiB Infinity Cache, D=64, 2^22 random ids / launch."""
+    """BASELINE configs[3] shape: ONE 1e9-row x 64-dim f32 table (256 GB of the 288 GB HBM), uniformly random
+    ids: 2^22 single-hot lookups / launch, and 2^17 bags of 32 ids (configs[4]'s multi-hot shape)."""
     import ctypes as C
     from ps_amd import native as N
     res = []
     for rows, D, n, bag in ((args.gather_rows, 64, 1 << 22, 1), (args.gather_rows, 64, 1 << 17, 32)):
         ms, br, bw = C.c_double(), C.c_double(), C.c_double()
-        N.check(N.lib().ps_bench_gather(kv.h, rows, D, n, bag, 20, 0x5EED, C.byref(ms), C.byref(br), C.byref(bw)))
+        rc = N.lib().ps_bench_gather(kv.h, rows, D, n, bag, 20, 0x5EED, C.byref(ms), C.byref(br), C.byref(bw))
+        if rc != 0 and rows > 64 * 1000 * 1000:          # the 256 GB table did not fit beside what else is resident
+            rows = 64 * 1000 * 1000
+            rc = N.lib().ps_bench_gather(kv.h, rows, D, n, bag, 20, 0x5EED, C.byref(ms), C.byref(br), C.byref(bw))
+        N.check(rc)
         res.append({"rows": rows, "D": D, "lookups": n * bag, "bag": bag, "table_GB": rows * D * 4 / 1e9,
                     "avg_launch_us": ms.value * 1e3, "read_GBs": br.value / ms.value / 1e6,
                     "read_plus_write_GBs": (br.value + bw.value) / ms.value / 1e6,
@@ -195,7 +209,7 @@ def main():
     ap.add_argument("--prefetch-thread", type=int, default=0, help="sharded path: run that prefetch in its own host thread")
     ap.add_argument("--phases", type=int, default=0, help="sharded path: also report a per-phase stopwatch (serialised)")
     ap.add_argument("--gather", type=int, default=1)
-    ap.add_argument("--gather-rows", type=int, default=64 * 1000 * 1000)   # 16.4 GB at D=64
+    ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.sharded:

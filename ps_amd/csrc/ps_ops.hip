@@ -114,7 +114,10 @@ extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, in
     const int64_t nnz = n * bag;
     const size_t wbytes = sizeof(float) * (size_t)rows * D;
     hipError_t e = hipMalloc((void **)&W, wbytes);
-    if (e != hipSuccess) return ps_set_err(PS_E_HIP, "hipMalloc of the %.1f GB table failed: %s", wbytes / 1e9, hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // clear: the caller may retry with a smaller table
+        return ps_set_err(PS_E_HIP, "hipMalloc of the %.1f GB table failed: %s", wbytes / 1e9, hipGetErrorString(e));
+    }
     int rc = PS_OK;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(st);
