@@ -237,6 +237,47 @@ int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx
                   int B, float *y_dev, int ldy);
 int ps_store_sync(ps_store_t *s);
 
+/* ---- data.LibsvmParser + CTR.parseFeature + DataSource/DataSet -----------
+ * The step in FRONT of the hot path: libsvm text -> the
+ * arrays Model.train consumes.  One sample per line:
+ *   "<label> <idx>:<v> ... "   data/LibsvmParser.java:13-25
+ * columns 1..F give the sparse ids (the idx; CTR.java:55-57), columns
+ * F+1..F+X the dense values (CTR.java:58-60), W = E mod wideSize
+ * (MatrixUtil.hash, util/MatrixUtil.java:27-33).  ids_via_float = 1 keeps the
+ * reference's long -> float -> id path (exact below 2^24); 0 keeps int64.
+ * offset/step: this reader takes the non-blank lines offset, offset+step, ...
+ * (data/DataSource.java:25-46 worker sharding).  Blank lines are skipped
+ * (LibsvmParser returns an empty list); runs of spaces are tolerated. */
+typedef struct ps_ingest_config {
+    int F, X;            /* sparse fields, dense features                     */
+    int batch;           /* samples per batch (CTR.java:84: 1000)             */
+    int threads;         /* host parser threads                               */
+    int offset, step;    /* DataSource offset / step                          */
+    int ids_via_float;   /* 1 = reference compat                              */
+    int64_t wide_size;   /* 0: no W                                           */
+} ps_ingest_config_t;
+typedef struct ps_ingest ps_ingest_t;
+/* Host-only (no GPU): number of lines of this reader; parse lines
+ * [first_line, first_line+max_lines) of this reader into caller arrays
+ * ids[n][F] (int64), dense[n][X], labels[n], wide_ids[n][F] (may be NULL). */
+int ps_libsvm_count(const char *text, size_t len, int offset, int step, int64_t *n_lines);
+int ps_libsvm_parse(const char *text, size_t len, const ps_ingest_config_t *cfg, int64_t first_line,
+                    int64_t max_lines, int64_t *ids, float *dense, float *labels, int64_t *wide_ids,
+                    int64_t *n_parsed);
+/* The pipeline (= DataSet's reader threads + queue): batch k+1 is parsed by
+ * the host pool into pinned memory and copied to HBM on its own stream while
+ * batch k trains.  ps_ingest_next returns device pointers (on_device = 1),
+ * valid until the call after the next one; PS_MISSING at the end of the data
+ * (FileSource returns null); ps_ingest_reset rewinds (DataSource.reset). */
+int ps_ingest_create(ps_store_t *s, const ps_ingest_config_t *cfg, ps_ingest_t **out);
+int ps_ingest_destroy(ps_ingest_t *g);
+int ps_ingest_open_file(ps_ingest_t *g, const char *path);
+int ps_ingest_open_memory(ps_ingest_t *g, const char *text, size_t len);
+int ps_ingest_lines(ps_ingest_t *g, int64_t *n_lines);
+int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out);
+int ps_ingest_reset(ps_ingest_t *g);
+int ps_ingest_stats(ps_ingest_t *g, double *parse_seconds, int64_t *lines, int64_t *bytes);
+
 /* ---- net.PSClient / PSRouterClient / PServer over a sharded store ------
  * One ps_store_t per GPU holds the embedding rows with id mod N == shard
  * (net/Mod.java routing, PS_ROUTE_ID_MOD); dense FC tensors and the wide

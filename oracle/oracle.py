@@ -315,3 +315,26 @@ class PS:
 
     def global_step(self):
         return lib().orc_ps_global_step(self.h)
+
+
+# ---------------------------------------------------------------------------
+# data/LibsvmParser.java:13-25 + CTR.parseFeature (CTR.java:47-68) + DataSource.readLine
+# (data/DataSource.java:25-46), restated in plain Python (test infrastructure only).
+# ---------------------------------------------------------------------------
+def parse_libsvm(text, F, X, wide_size=0, offset=0, step=1):
+    """Returns E [n][F] float32 (ids AS FLOATS, as the reference keeps them), X [n][X], Y [n], W [n][F] float32."""
+    import numpy as _np
+    lines = [ln for ln in text.split("\n") if ln.strip() != ""]           # StringUtils.isBlank -> skipped
+    lines = lines[offset::step]                                             # offset, offset+step, ...
+    n = len(lines)
+    E = _np.zeros((n, F), _np.float32); Xd = _np.zeros((n, X), _np.float32); Y = _np.zeros(n, _np.float32)
+    for i, ln in enumerate(lines):
+        cols = ln.rstrip("\r ").split(" ")
+        cols = [c for c in cols if c != ""]
+        Y[i] = _np.float32(cols[0])                                         # Float.parseFloat: nearest float
+        for j in range(1, 1 + F):
+            E[i, j - 1] = _np.float32(int(cols[j].split(":")[0]))          # long -> float (CTR.java:57)
+        for j in range(1 + F, 1 + F + X):
+            Xd[i, j - 1 - F] = _np.float32(cols[j].split(":")[1])
+    W = _np.fmod(E, _np.float32(wide_size)).astype(_np.float32) if wide_size > 0 else None   # MatrixUtil.hash
+    return E, Xd, Y, W

@@ -292,7 +292,7 @@ class _Model:
 
     @staticmethod
     def _batch(datas):
-        if isinstance(datas, (Batch, DeviceBatch)):
+        if isinstance(datas, (Batch, DeviceBatch)) or hasattr(datas, "c"):      # incl. DataSet's device batches
             return datas
         return Batch(datas["E"], datas.get("X"), datas.get("Y"), datas.get("W"), datas.get("offsets"))
 
@@ -432,3 +432,102 @@ class Trainer:
 
     def getTrainResult(self):
         return self.models[0]
+
+
+# ---------------------------------------------------------------------------
+# data.LibsvmParser / data.FileSource / CTR (DataSet): libsvm text -> batches in HBM
+# ---------------------------------------------------------------------------
+def _ingest_cfg(F, X, batch, wide_size, threads, offset, step, ids_via_float):
+    c = N.ps_ingest_config_t()
+    c.F, c.X, c.batch, c.threads, c.offset, c.step = int(F), int(X), int(batch), int(threads), int(offset), int(step)
+    c.ids_via_float, c.wide_size = int(bool(ids_via_float)), int(wide_size)
+    return c
+
+
+class LibsvmParser:
+    """data/LibsvmParser.java + CTR.parseFeature (CTR.java:47-68) on the host: text -> {"E","X","Y","W"}.
+    E/W come back as int64 [n][F] (the bytes of the reference's F x n float matrices for ids < 2^24)."""
+
+    def __init__(self, F, X, wide_size=0, threads=1, ids_via_float=True):
+        self.F, self.X, self.wide_size, self.threads, self.ids_via_float = F, X, wide_size, threads, ids_via_float
+
+    def parse(self, text, offset=0, step=1, first_line=0, max_lines=None):
+        if isinstance(text, str):
+            text = text.encode()
+        n = C.c_int64()
+        N.check(N.lib().ps_libsvm_count(text, len(text), offset, step, C.byref(n)))
+        n = max(n.value - first_line, 0)
+        if max_lines is not None:
+            n = min(n, max_lines)
+        cfg = _ingest_cfg(self.F, self.X, max(n, 1), self.wide_size, self.threads, offset, step, self.ids_via_float)
+        E = np.zeros((n, self.F), np.int64); W = np.zeros((n, self.F), np.int64)
+        X = np.zeros((n, self.X), np.float32); Y = np.zeros(n, np.float32)
+        got = C.c_int64()
+        N.check(N.lib().ps_libsvm_parse(text, len(text), C.byref(cfg), first_line, n, _ip(E), _fp(X), _fp(Y), _ip(W), C.byref(got)))
+        assert got.value == n
+        out = {"E": E, "X": X, "Y": Y}
+        if self.wide_size > 0:
+            out["W"] = W
+        return out
+
+
+class _IngestBatch:
+    def __init__(self, c):
+        self.c = c
+        self.B = c.B
+
+
+class DataSet:
+    """The reader side of data/DataSet.java for CTR-shaped libsvm: host threads parse batch k+1 into pinned
+    memory and copy it to HBM while batch k trains.  `source`: a file path (FileSource) or bytes."""
+
+    def __init__(self, store, source, F, X, batch, wide_size=0, threads=4, offset=0, step=1, ids_via_float=True):
+        self.store = store
+        self.h = C.c_void_p()
+        cfg = _ingest_cfg(F, X, batch, wide_size, threads, offset, step, ids_via_float)
+        N.check(N.lib().ps_ingest_create(store.h, C.byref(cfg), C.byref(self.h)))
+        if isinstance(source, (bytes, bytearray)):
+            N.check(N.lib().ps_ingest_open_memory(self.h, bytes(source), len(source)))
+        else:
+            N.check(N.lib().ps_ingest_open_file(self.h, str(source).encode()))
+
+    def lines(self):
+        n = C.c_int64()
+        N.check(N.lib().ps_ingest_lines(self.h, C.byref(n)))
+        return n.value
+
+    def next(self):
+        """The next batch (device-resident), or None at the end of the data."""
+        b = N.ps_batch_t()
+        rc = N.lib().ps_ingest_next(self.h, C.byref(b))
+        if rc == N.PS_MISSING:
+            return None
+        N.check(rc)
+        return _IngestBatch(b)
+
+    def __iter__(self):
+        while True:
+            b = self.next()
+            if b is None:
+                return
+            yield b
+
+    def reset(self):
+        N.check(N.lib().ps_ingest_reset(self.h))
+
+    def stats(self):
+        s, l, b = C.c_double(), C.c_int64(), C.c_int64()
+        N.check(N.lib().ps_ingest_stats(self.h, C.byref(s), C.byref(l), C.byref(b)))
+        return {"parse_seconds": s.value, "lines": l.value, "bytes": b.value}
+
+    def close(self):
+        if self.h:
+            N.lib().ps_ingest_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if getattr(self.store, "h", None):
+                self.close()
+        except Exception:
+            pass

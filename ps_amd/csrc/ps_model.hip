@@ -370,6 +370,10 @@ int enqueue_backward(ps_model *m, bool apply) {
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }
+    // The dense update overwrites W / Wt of EVERY layer: it must not start before the main chain's last
+    // delta GEMM (which reads W_0; the earlier ones read W_l before it, in order) has finished.  Without this
+    // edge the update raced with fc_bwd_data0 whenever the dW GEMMs finished first (rare, shape dependent).
+    if (apply) PSCHK(fork(m, st, sw));
     { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }   // in order behind the dW GEMMs
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater

@@ -48,6 +48,11 @@ _pi, _pi64, _pf, _pd = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_f
 _pvp = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes): one entry per function declared in include/ps_native.h
+class ps_ingest_config_t(C.Structure):
+    _fields_ = [("F", C.c_int), ("X", C.c_int), ("batch", C.c_int), ("threads", C.c_int), ("offset", C.c_int),
+                ("step", C.c_int), ("ids_via_float", C.c_int), ("wide_size", C.c_int64)]
+
+
 SIGNATURES = {
     "ps_last_error": (_cp, []),
     "ps_version": (_cp, []),
@@ -105,6 +110,16 @@ SIGNATURES = {
     "ps_shard_apply_push": (_i, [_vp, _vp, _vp, _i64, _pi64, _i, _i]),
     "ps_shard_flat_grad": (_i, [_vp, _pvp, _pi64]),
     "ps_shard_apply_flat": (_i, [_vp, _i]),
+    "ps_libsvm_count": (_i, [_cp, C.c_size_t, _i, _i, _pi64]),
+    "ps_libsvm_parse": (_i, [_cp, C.c_size_t, C.POINTER(ps_ingest_config_t), _i64, _i64, _pi64, _pf, _pf, _pi64, _pi64]),
+    "ps_ingest_create": (_i, [_vp, C.POINTER(ps_ingest_config_t), _pvp]),
+    "ps_ingest_destroy": (_i, [_vp]),
+    "ps_ingest_open_file": (_i, [_vp, _cp]),
+    "ps_ingest_open_memory": (_i, [_vp, _cp, C.c_size_t]),
+    "ps_ingest_lines": (_i, [_vp, _pi64]),
+    "ps_ingest_next": (_i, [_vp, C.POINTER(ps_batch_t)]),
+    "ps_ingest_reset": (_i, [_vp]),
+    "ps_ingest_stats": (_i, [_vp, _pd, _pi64, _pi64]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),
     "ps_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _pd]),
     "ps_tune_set": (_i, [_cp, _i]),

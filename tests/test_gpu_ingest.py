@@ -1,0 +1,96 @@
+"""The ingest pipeline on the GPU (ps_ingest_*: host threads parse batch k+1 into pinned memory and copy it to
+HBM while batch k trains): the device batches are the parser's arrays bit for bit, and training from the
+pipeline == training from the same arrays handed over as host batches (CTR.java's C1 shape)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_ingest_cpu import make_text
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+SEED = 0x5EED
+
+
+def _down(kv, ptr, shape, dtype):
+    from ps_amd import native as N
+    a = np.empty(shape, dtype)
+    if a.size:
+        N.check(N.lib().ps_dev_download(kv.h, a.ctypes.data, ptr, a.nbytes))
+    return a
+
+
+def test_device_batches_are_the_parsed_arrays(orc):
+    import ps_amd
+    rng = np.random.default_rng(3)
+    F, X, WS, B = 23, 45, 1000, 64
+    text = make_text(rng, 300, F, X)
+    E, Xd, Y, W = orc.parse_libsvm(text, F, X, WS)
+    kv = ps_amd.KVStore(0, SEED)
+    ds = ps_amd.DataSet(kv, text.encode(), F, X, B, wide_size=WS, threads=3)
+    assert ds.lines() == 300
+    for epoch in range(2):
+        seen = 0
+        for b in ds:
+            n = b.B
+            assert n == min(B, 300 - seen)
+            kv.sync()
+            np.testing.assert_array_equal(_down(kv, b.c.ids, (n, F), np.int64), E[seen:seen + n].astype(np.int64))
+            np.testing.assert_array_equal(_down(kv, b.c.wide_ids, (n, F), np.int64), W[seen:seen + n].astype(np.int64))
+            np.testing.assert_array_equal(_down(kv, b.c.dense, (n, X), f32), Xd[seen:seen + n])
+            np.testing.assert_array_equal(_down(kv, b.c.labels, (n,), f32), Y[seen:seen + n])
+            seen += n
+        assert seen == 300
+        assert ds.next() is None                     # FileSource returns null at the end
+        ds.reset()
+    ds.close(); kv.close()
+
+
+def test_training_from_the_pipeline_equals_host_batches():
+    import ps_amd
+    rng = np.random.default_rng(4)
+    F, D, X, fc, V, B = 23, 10, 45, [150, 10, 1], 50, 100          # DNN.buildModel(23, 10, 45, {150,10,1}) (CTR.java:91)
+    lines = []
+    for i in range(730):
+        cols = [str(int(rng.random() < 0.4))] + ["%d:1" % int(rng.integers(0, V)) for _ in range(F)]
+        cols += ["%d:%.5f" % (F + 1 + j, rng.standard_normal()) for j in range(X)]
+        lines.append(" ".join(cols))
+    text = "\n".join(lines).encode()
+    parsed = ps_amd.LibsvmParser(F, X).parse(text)
+    res = []
+    for mode in ("host", "pipeline"):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+        losses = []
+        if mode == "host":
+            for s in range(0, 730, B):
+                losses.append(gm.train(ps_amd.Batch(parsed["E"][s:s + B], parsed["X"][s:s + B], parsed["Y"][s:s + B])))
+        else:
+            ds = ps_amd.DataSet(kv, text, F, X, B, threads=4)
+            for b in ds:
+                losses.append(gm.train(b))
+            ds.close()
+        res.append((losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)]))
+        gm.close(); kv.close()
+    assert len(res[0][0]) == 8 and res[0][0] == res[1][0]
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_two_readers_split_the_file_like_datasource_offset_step(orc):
+    import ps_amd
+    rng = np.random.default_rng(6)
+    text = make_text(rng, 41, 4, 3)
+    kv = ps_amd.KVStore(0, SEED)
+    for offset in (0, 1):
+        E, Xd, Y, _ = orc.parse_libsvm(text, 4, 3, 0, offset, 2)
+        ds = ps_amd.DataSet(kv, text.encode(), 4, 3, 8, offset=offset, step=2, threads=2)
+        got = []
+        for b in ds:
+            kv.sync()
+            got.append(_down(kv, b.c.ids, (b.B, 4), np.int64))
+        np.testing.assert_array_equal(np.concatenate(got), E.astype(np.int64))
+        ds.close()
+    kv.close()

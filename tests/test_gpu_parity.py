@@ -199,10 +199,13 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
     gm.close(); kv.close()
 
 
-def test_fused_train_equals_split_form(orc):
-    """ps_model_train (fused updaters) == forward/backward/update (split form), bit for bit."""
+@pytest.mark.parametrize("F,D,X,fc,V,B", [(4, 8, 3, [16, 8, 1], 30, 64), (23, 10, 45, [150, 10, 1], 50, 100),
+                                          (26, 16, 13, [512, 256, 1], 2000, 1024)])
+def test_fused_train_equals_split_form(orc, F, D, X, fc, V, B):
+    """ps_model_train (fused updaters, three streams) == forward/backward/update (split form), bit for bit.
+    Also the regression test of a stream-ordering bug: the fused dense update (side stream) once could overwrite
+    W while the main chain's last delta GEMM was still reading it -- shape/timing dependent, hence several shapes."""
     import ps_amd
-    F, D, X, fc, V, B = 4, 8, 3, [16, 8, 1], 30, 64
     rng = np.random.default_rng(3)
     res = []
     for fused in (True, False):
@@ -210,7 +213,7 @@ def test_fused_train_equals_split_form(orc):
         kv.create_embedding([V] * F, D)
         gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, 50, store=kv, max_batch=B)
         r2 = np.random.default_rng(3)
-        for _ in range(4):
+        for _ in range(6):
             E, Xd, Y = data(r2, B, F, X, V, True)
             d = {"E": E, "X": Xd, "Y": Y, "W": E % 50}
             if fused:
@@ -226,7 +229,7 @@ def test_fused_train_equals_split_form(orc):
     for x, y in zip(a[1], b[1]):
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
-    assert a[4] == b[4] == 4
+    assert a[4] == b[4] == 6
 
 
 def test_ftrl_rows_bit_exact(orc):
