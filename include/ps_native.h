@@ -278,6 +278,18 @@ int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out);
 int ps_ingest_reset(ps_ingest_t *g);
 int ps_ingest_stats(ps_ingest_t *g, double *parse_seconds, int64_t *lines, int64_t *bytes);
 
+/* ---- evaluate.AUC (evaluate/AUC.java:32-82; train/Trainer.java:44-68) ------
+ * AUC of predictions p[n] against labels y[n] (y > 0 = positive) exactly as
+ * AUC.calculate() defines it: stable ascending sort by p, walk from the top,
+ * add (x - prev) * y at every negative -- i.e. the fraction of (positive,
+ * negative) pairs ranked correctly, ties resolved by input order.  The pair
+ * count is computed exactly on the device (stable radix sort + prefix
+ * counts) and divided once in double.  on_device: p, y are device pointers.
+ * No negatives -> 0.0, no positives -> NaN (what the reference's arithmetic
+ * yields). */
+int ps_auc_compute(ps_store_t *s, const float *p, const float *y, int64_t n, int on_device,
+                   double *auc, int64_t *pos_num, int64_t *neg_num);
+
 /* ---- net.PSClient / PSRouterClient / PServer over a sharded store ------
  * One ps_store_t per GPU holds the embedding rows with id mod N == shard
  * (net/Mod.java routing, PS_ROUTE_ID_MOD); dense FC tensors and the wide

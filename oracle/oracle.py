@@ -338,3 +338,34 @@ def parse_libsvm(text, F, X, wide_size=0, offset=0, step=1):
             Xd[i, j - 1 - F] = _np.float32(cols[j].split(":")[1])
     W = _np.fmod(E, _np.float32(wide_size)).astype(_np.float32) if wide_size > 0 else None   # MatrixUtil.hash
     return E, Xd, Y, W
+
+
+# ---------------------------------------------------------------------------
+# evaluate/AUC.java:32-82, op for op in double (test infrastructure only)
+# ---------------------------------------------------------------------------
+def auc(p, y):
+    import numpy as _np
+    pd = _np.asarray(p, _np.float32).astype(_np.float64)            # new MutablePair((double) p[i], (double) y[i])
+    yd = _np.asarray(y, _np.float32).astype(_np.float64)
+    # Arrays.sort(Object[], Comparator) is a stable merge sort; the comparator is Double.compareTo: a TOTAL order
+    # (-0.0 < 0.0, every NaN equal and above +Infinity), i.e. the order of these keys
+    bits = pd.view(_np.int64)
+    key = _np.where(bits < 0, ~bits.view(_np.uint64), bits.view(_np.uint64) | _np.uint64(1 << 63))
+    key = _np.where(_np.isnan(pd), _np.uint64(0xFFFFFFFFFFFFFFFF), key)
+    order = _np.argsort(key, kind="stable")
+    pos = float((yd > 0.0).sum()); neg = float(len(yd)) - pos        # sampleCount
+    tp = fp = 0.0
+    prev = 0.0
+    total = 0.0
+    with _np.errstate(divide="ignore", invalid="ignore"):
+        for i in order[::-1]:                                        # getCoordinatePoint: from the highest p down
+            if yd[i] > 0.0:
+                fp += 1.0
+            else:
+                tp += 1.0
+            x = _np.float64(tp) / _np.float64(pos)                   # (tp / posNum, fp / negNum)
+            yy = _np.float64(fp) / _np.float64(neg)
+            if x != prev:                                            # calculate()
+                total = total + (x - prev) * yy
+                prev = x
+    return float(total)

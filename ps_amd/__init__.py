@@ -6,8 +6,8 @@ include/ps_native.h, implemented by hand-written HIP kernels for gfx950
 use does, and fails loudly if it was not built (`python -m ps_amd.build`).
 """
 from . import native  # noqa: F401
-from .api import (AdamUpdater, Batch, DataSet, DeviceBatch, DNN, FtrlUpdater, KVStore, LibsvmParser, Mod,  # noqa: F401
+from .api import (AUC, AdamUpdater, Batch, DataSet, DeviceBatch, DNN, FtrlUpdater, KVStore, LibsvmParser, Mod,  # noqa: F401
                   SimpleUpdater, Trainer, Updater, WideDeepNN, java_string_hash)
 
-__all__ = ["AdamUpdater", "Batch", "DataSet", "DeviceBatch", "DNN", "LibsvmParser", "FtrlUpdater", "KVStore", "Mod", "SimpleUpdater", "Trainer",
+__all__ = ["AUC", "AdamUpdater", "Batch", "DataSet", "DeviceBatch", "DNN", "LibsvmParser", "FtrlUpdater", "KVStore", "Mod", "SimpleUpdater", "Trainer",
            "Updater", "WideDeepNN", "java_string_hash", "native"]

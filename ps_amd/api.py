@@ -531,3 +531,30 @@ class DataSet:
                 self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------
+# evaluate.AUC
+# ---------------------------------------------------------------------------
+class AUC:
+    """evaluate/AUC.java: AUC(p, y).calculate().  p, y: host arrays (or device pointers with n and on_device)."""
+
+    def __init__(self, p, y, store=None, n=None, on_device=False):
+        self.store = store if store is not None else KVStore.ins()
+        self.on_device = bool(on_device)
+        if self.on_device:
+            self.p, self.y, self.n = p, y, int(n)
+        else:
+            self.p = np.ascontiguousarray(p, np.float32).ravel()
+            self.y = np.ascontiguousarray(y, np.float32).ravel()
+            self.n = int(self.p.size)
+            assert self.y.size == self.n
+        self.posNum = self.negNum = None
+
+    def calculate(self):
+        auc, pos, neg = C.c_double(), C.c_int64(), C.c_int64()
+        pp = self.p if self.on_device else self.p.ctypes.data
+        yy = self.y if self.on_device else self.y.ctypes.data
+        N.check(N.lib().ps_auc_compute(self.store.h, pp, yy, self.n, int(self.on_device), C.byref(auc), C.byref(pos), C.byref(neg)))
+        self.posNum, self.negNum = pos.value, neg.value
+        return auc.value
