@@ -325,6 +325,15 @@ class _Model:
         N.check(N.lib().ps_model_predict(self.h, C.byref(b.c), _fp(out)))
         return out
 
+    def labels(self, datas):
+        """The labels "Y" of a batch as a host array (device batches: copied back)."""
+        b = self._batch(datas)
+        if not b.c.on_device:
+            return b.Y
+        out = np.empty(b.c.B, np.float32)
+        N.check(N.lib().ps_dev_download(self.store.h, out.ctypes.data, b.c.labels, out.nbytes))
+        return out
+
     def sync(self):
         N.check(N.lib().ps_model_sync(self.h))
 
