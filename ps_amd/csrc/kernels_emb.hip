@@ -43,7 +43,7 @@ template <> struct Vec<1> {
 // to cover HBM latency (Little: ~8 MB chip-wide at 8 TB/s): measured 4.9 -> see profiles/.
 #define GATHER_ILP 4
 #define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
-template <int VEC, bool MULTI, bool SLOT>
+template <int VEC, bool MULTI, bool SLOT, int MHI>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x >= a.gather_blocks) {
@@ -94,6 +94,40 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
     const int b = (int)(bag / a.F), f = (int)(bag % a.F);
     const int64_t p0 = a.offsets[bag], p1 = a.offsets[bag + 1];
     Vec<VEC> s = Vec<VEC>::zero();
+    constexpr int MH = MHI > 0 ? MHI : 1;
+    if (MHI > 0) {
+        // The lane group (LPR lanes, inside one wave) fetches LPR consecutive ids of its bag with ONE coalesced
+        // load, turns them into rows, and hands them round by shuffle: the id -> row -> data chain is paid once
+        // per LPR entries, MHI row loads are in flight per group, and the sort keys go out LPR at a time.
+        const int lane = threadIdx.x & 63, gbase = lane - part;
+        for (int64_t q = p0; q < p1; q += a.LPR) {
+            const int64_t qi = q + part;
+            const uint32_t myrow = (uint32_t)row_of(qi < p1 ? qi : p1 - 1, f);
+            if (qi < p1 && a.key_out) {
+                a.key_out[qi] = myrow;
+                if (a.ent_bag) a.ent_bag[qi] = (uint32_t)bag;
+            }
+            const int cnt = (int)(p1 - q < a.LPR ? p1 - q : a.LPR);
+            for (int j0 = 0; j0 < cnt; j0 += MH) {
+                uint32_t rows[MH];
+#pragma unroll
+                for (int j = 0; j < MH; ++j) rows[j] = (uint32_t)__shfl((int)myrow, gbase + (j0 + j < cnt ? j0 + j : cnt - 1));
+                Vec<VEC> r[MH];
+#pragma unroll
+                for (int j = 0; j < MH; ++j) r[j] = Vec<VEC>::load(a.W + (size_t)rows[j] * a.D + part * VEC);
+#pragma unroll
+                for (int j = 0; j < MH; ++j) {
+                    if (j0 + j < cnt) {
+                        if (q + j0 + j == p0) s = r[j];
+                        else { VFOR(i) s.at(i) = r[j].get(i) + s.at(i); }      // sum pooling, strictly in bag order
+                    }
+                }
+            }
+        }
+        if (a.act == PS_ACT_RELU) { VFOR(i) s.at(i) = s.get(i) > 0.f ? s.get(i) : 0.f; }
+        s.store(a.out + (size_t)b * a.ld + (size_t)f * a.D + part * VEC);
+        return;
+    }
     for (int64_t q = p0; q < p1; q += GATHER_ILP_MH) {
         int64_t rows[GATHER_ILP_MH];
 #pragma unroll
@@ -720,6 +754,8 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+int g_mh_ilp16 = 0;
+
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
     const int vec = (a.D % 4 == 0) ? 4 : 1;
     a.LPR = a.D / vec;
@@ -730,15 +766,24 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
     const int dense_blocks = a.dense ? cdiv((int64_t)a.B * a.X, 256) : 0;
     const int grid = a.gather_blocks + dense_blocks;
     if (grid == 0) return PS_OK;
+    // multi-hot: ids handed round a lane group by shuffle when the group sits inside one wave
+    const int mhi = (multi && 64 % a.LPR == 0) ? (a.LPR <= 4 ? a.LPR : a.LPR == 8 ? 2 : (g_mh_ilp16 > 0 ? g_mh_ilp16 : 1)) : 0;
+#define EMB_FWD_MH(V, S)                                                                                           \
+    do {                                                                                                           \
+        if (mhi == 4) hipLaunchKernelGGL((k_emb_fwd<V, true, S, 4>), dim3(grid), dim3(256), 0, st, a);             \
+        else if (mhi == 2) hipLaunchKernelGGL((k_emb_fwd<V, true, S, 2>), dim3(grid), dim3(256), 0, st, a);        \
+        else if (mhi == 1) hipLaunchKernelGGL((k_emb_fwd<V, true, S, 1>), dim3(grid), dim3(256), 0, st, a);        \
+        else hipLaunchKernelGGL((k_emb_fwd<V, true, S, 0>), dim3(grid), dim3(256), 0, st, a);                      \
+    } while (0)
 #define EMB_FWD_LAUNCH(V)                                                                                          \
     do {                                                                                                           \
-        if (multi) { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, true, true>), dim3(grid), dim3(256), 0, st, a);     \
-                     else hipLaunchKernelGGL((k_emb_fwd<V, true, false>), dim3(grid), dim3(256), 0, st, a); }        \
-        else { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, false, true>), dim3(grid), dim3(256), 0, st, a);          \
-               else hipLaunchKernelGGL((k_emb_fwd<V, false, false>), dim3(grid), dim3(256), 0, st, a); }             \
+        if (multi) { if (slot) EMB_FWD_MH(V, true); else EMB_FWD_MH(V, false); }                                   \
+        else { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, a);       \
+               else hipLaunchKernelGGL((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, a); }          \
     } while (0)
     if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
 #undef EMB_FWD_LAUNCH
+#undef EMB_FWD_MH
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
