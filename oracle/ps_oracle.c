@@ -186,23 +186,46 @@ int orc_ftrl_update(float *w, const float *g, float *z, float *nn, int n,
     return 1;
 }
 
+/* Sum of the chunk partials [j0, j1) of a run, folded in chunk order (p_j0, then p + acc). */
+static void fold_chunks(const float *gk, int n, int D, int chunk, int j0, int j1, float *acc) {
+    for (int j = j0; j < j1; ++j) {
+        int c0 = j * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+        for (int d = 0; d < D; ++d) {
+            float p = gk[(size_t)c0 * D + d];
+            for (int k = c0 + 1; k < c1; ++k) p = gk[(size_t)k * D + d] + p;
+            acc[d] = (j == j0) ? p : p + acc[d];
+        }
+    }
+}
+
+/* Order of the f32 adds over a run of n per-sample gradients (SURVEY App. A.6 keeps the reference's strictly
+ * sequential order only for n <= chunk -- a hot key's run cannot be summed by one thread at speed):
+ *   n <= chunk                 : g_1, then g_k + acc, in batch order (the reference's order)
+ *   chunk < n <= 128 * chunk   : chunk partials (each in batch order), folded in chunk order
+ *   n > 128 * chunk            : chunk partials folded 32 at a time into super partials, those folded in order
+ * The same folding is used for pass 1 (S) and for pass 2 (S/n + ...). */
+#define ORC_SUPER 32
+#define ORC_SUPER_MIN_CHUNKS 128
+static void run_fold(const float *gk, int n, int D, int chunk, float *S, int have) {
+    float *t = (float *)calloc((size_t)D, sizeof(float));
+    if (chunk <= 0 || n <= chunk) {
+        for (int k = 0; k < n; ++k)
+            for (int d = 0; d < D; ++d) S[d] = (!have && k == 0) ? gk[d] : gk[(size_t)k * D + d] + S[d];   /* put :91 / addi :94 */
+    } else {
+        int nch = (n + chunk - 1) / chunk;
+        int step = nch > ORC_SUPER_MIN_CHUNKS ? ORC_SUPER : 1;
+        for (int j = 0; j < nch; j += step) {
+            fold_chunks(gk, n, D, chunk, j, j + step < nch ? j + step : nch, t);
+            for (int d = 0; d < D; ++d) S[d] = (!have && j == 0) ? t[d] : t[d] + S[d];
+        }
+    }
+    free(t);
+}
+
 void orc_emb_geff(const float *gk, int n, int D, float *out, int mode, int chunk) {
     /* SURVEY App. A.6.  S = sum of the n per-sample gradients. */
     float *S = (float *)calloc((size_t)D, sizeof(float));
-    if (chunk <= 0 || n <= chunk) {
-        for (int d = 0; d < D; ++d) S[d] = gk[d];                 /* first touch: put :91 */
-        for (int k = 1; k < n; ++k)
-            for (int d = 0; d < D; ++d) S[d] = gk[(size_t)k * D + d] + S[d]; /* addi :94 */
-    } else {
-        for (int c0 = 0, first = 1; c0 < n; c0 += chunk, first = 0) {
-            int c1 = c0 + chunk < n ? c0 + chunk : n;
-            for (int d = 0; d < D; ++d) {
-                float p = gk[(size_t)c0 * D + d];
-                for (int k = c0 + 1; k < c1; ++k) p = gk[(size_t)k * D + d] + p;
-                S[d] = first ? p : p + S[d];
-            }
-        }
-    }
+    run_fold(gk, n, D, chunk, S, 0);
     if (mode == ORC_GRAD_INTENDED) {
         for (int d = 0; d < D; ++d) out[d] = S[d] / (float)n;
         free(S);
@@ -211,20 +234,7 @@ void orc_emb_geff(const float *gk, int n, int D, float *out, int mode, int chunk
     /* pass 1 end: G = S / n (divi :100); sum.put(key, G) by reference, cnt=1 */
     for (int d = 0; d < D; ++d) S[d] = S[d] / (float)n;
     /* pass 2: G += g_k for every k again (:94), N = 2n */
-    if (chunk <= 0 || n <= chunk) {
-        for (int k = 0; k < n; ++k)
-            for (int d = 0; d < D; ++d) S[d] = gk[(size_t)k * D + d] + S[d];
-    } else {
-        /* chunked order: the partial sums are formed as above, then folded in */
-        for (int c0 = 0; c0 < n; c0 += chunk) {
-            int c1 = c0 + chunk < n ? c0 + chunk : n;
-            for (int d = 0; d < D; ++d) {
-                float p = gk[(size_t)c0 * D + d];
-                for (int k = c0 + 1; k < c1; ++k) p = gk[(size_t)k * D + d] + p;
-                S[d] = p + S[d];
-            }
-        }
-    }
+    run_fold(gk, n, D, chunk, S, 1);
     /* G /= 2n (:100); sum[key].addi(G) on itself = 2G, cnt=2 (KVStore.java:197);
      * update divides by cnt (KVStore.java:253): (2G)/2 == G exactly. */
     for (int d = 0; d < D; ++d) {

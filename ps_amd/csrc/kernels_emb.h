@@ -3,6 +3,8 @@
 #include "ps_common.h"
 
 #define PS_EMB_CHUNK 32  // per-key runs longer than this are summed as CH-chunks (oracle: orc_emb_geff chunk=32)
+#define PS_EMB_SUPER 32        // runs above PS_EMB_SUPER_MIN chunks: chunk partials are first folded 32 at a time
+#define PS_EMB_SUPER_MIN 128   // (oracle: ORC_SUPER / ORC_SUPER_MIN_CHUNKS)
 
 struct EmbFwdArgs {
     const float *W;            // [rows_total][D] all fields' tables back to back
@@ -55,6 +57,8 @@ struct EmbBwdArgs {
     const uint32_t *ent_bag;           // nullptr => bag = entry
     const float *delta; int ldd;       // [B][ldd], embedding columns already relu'-masked
     float *partials;                   // [2*ceil(nnz/CH)][D]
+    float *partials2;                  // same indexing: super partials of runs above PS_EMB_SUPER_MIN chunks
+    int long_runs;                     // a run above PS_EMB_SUPER_MIN chunks is possible (launch k_emb_super)
     float *W, *state;                  // [rows][D], [rows][2][D]
     UpdParams upd;
     float *grads_out; uint32_t *uniq_row; uint32_t *uniq_cnt;   // [nseg][D], [nseg], [nseg]

@@ -420,6 +420,52 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
     }
 }
 
+// Second level for very long runs (> PS_EMB_SUPER_MIN chunks): the lane group whose tile holds the start of
+// chunk j with j % PS_EMB_SUPER == 0 folds the chunk partials j .. j+31 (in chunk order) into one super partial,
+// stored under the same slot index in partials2.  Same tile walk as k_emb_partials; almost every group exits.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_super(EmbBwdArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane64 = (int)(gt & 63);
+    const int gpw = 64 / a.LPR;
+    if (lane64 / a.LPR >= gpw) return;
+    const int64_t c = (gt >> 6) * gpw + lane64 / a.LPR;
+    const int part = lane64 % a.LPR;
+    const uint32_t CH = PS_EMB_CHUNK;
+    const uint32_t t0 = (uint32_t)(c * CH);
+    if ((int64_t)t0 >= a.nnz) return;
+    const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
+    auto fold = [&](uint32_t s0, uint32_t e0, uint32_t j, size_t out_slot) {
+        const uint32_t nch = (e0 - s0 + CH - 1) / CH;
+        const uint32_t j1 = j + PS_EMB_SUPER < nch ? j + PS_EMB_SUPER : nch;
+        Vec<VEC> p[PS_EMB_SUPER];
+#pragma unroll
+        for (int k = 0; k < PS_EMB_SUPER; ++k) {
+            const uint32_t jj = j + k < j1 ? j + k : j1 - 1;
+            const uint32_t s = s0 + jj * CH;
+            p[k] = Vec<VEC>::load(a.partials + ((size_t)2 * (s / CH) + (jj == 0 ? 1 : 0)) * a.D + part * VEC);
+        }
+        Vec<VEC> acc = p[0];
+#pragma unroll
+        for (int k = 1; k < PS_EMB_SUPER; ++k)
+            if (j + k < j1) { VFOR(i) acc.at(i) = p[k].get(i) + acc.at(i); }
+        acc.store(a.partials2 + out_slot * a.D + part * VEC);
+    };
+    const uint32_t u0 = a.seg_id[t0];
+    const uint32_t s0 = a.seg_start[u0], e0 = a.seg_start[u0 + 1];
+    if ((e0 - s0 + CH - 1) / CH > PS_EMB_SUPER_MIN) {
+        const uint32_t j = (t0 - s0 + CH - 1) / CH;
+        const uint32_t s = s0 + j * CH;
+        if (s <= t1 && s < e0 && j % PS_EMB_SUPER == 0) fold(s0, e0, j, (size_t)2 * c + (j == 0 ? 1 : 0));
+    }
+    const uint32_t u1 = a.seg_id[t1];
+    if (u1 != u0) {
+        const uint32_t s1 = a.seg_start[u1], e1 = a.seg_start[u1 + 1];
+        if ((e1 - s1 + CH - 1) / CH > PS_EMB_SUPER_MIN) fold(s1, e1, 0, (size_t)2 * c + 1);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // per-key reduce (+ double-backward factor) (+ fused updater)
 // ---------------------------------------------------------------------------
@@ -458,19 +504,25 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         }
     } else {
         const uint32_t nch = (n + CH - 1) / CH;
+        // runs above 128 chunks were pre-folded 32 chunks at a time by k_emb_super (one lane group walking the
+        // 1968 partials of a 63k-entry key WAS the kernel: ~250 us); their super partials sit in partials2
+        const bool two = nch > PS_EMB_SUPER_MIN;
+        const uint32_t step = two ? PS_EMB_SUPER : 1u;
+        const float *src = two ? a.partials2 : a.partials;
+        const uint32_t cnt = (nch + step - 1) / step;
         auto slot_of = [&](uint32_t j) -> size_t {
             const uint32_t s = s0 + j * CH;
             return (size_t)2 * (s / CH) + (j == 0 ? 1 : 0);
         };
-        auto add_partials = [&](bool have) {                        // chunk partials in chunk order, 8 loads in flight
-            for (uint32_t j0 = 0; j0 < nch; j0 += PS_EMB_ILP) {
+        auto add_partials = [&](bool have) {                        // partials in order, 32 loads in flight
+            for (uint32_t j0 = 0; j0 < cnt; j0 += PS_EMB_ILP) {
                 Vec<VEC> p[PS_EMB_ILP];
 #pragma unroll
                 for (int j = 0; j < PS_EMB_ILP; ++j)
-                    p[j] = Vec<VEC>::load(a.partials + slot_of(j0 + j < nch ? j0 + j : nch - 1) * a.D + part * VEC);
+                    p[j] = Vec<VEC>::load(src + slot_of((j0 + j < cnt ? j0 + j : cnt - 1) * step) * a.D + part * VEC);
 #pragma unroll
                 for (int j = 0; j < PS_EMB_ILP; ++j) {
-                    if (j0 + j < nch) {
+                    if (j0 + j < cnt) {
                         if (have) { VFOR(i) S.at(i) = p[j].get(i) + S.at(i); }
                         else { S = p[j]; have = true; }
                     }
@@ -809,6 +861,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
         hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gp), dim3(256), 0, st, a);            \
+        if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gp), dim3(256), 0, st, a);  \
         hipLaunchKernelGGL((k_emb_reduce_update<V, BG>), dim3(gr), dim3(256), 0, st, a);       \
     } while (0)
     if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }

@@ -40,38 +40,41 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restric
     counts[(size_t)tid * nblk + blockIdx.x] = h[tid];
 }
 
-// in-place exclusive scan of `total` u32 by ONE workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t *__restrict__ a, int total) {
-    __shared__ uint32_t wsum[16];
+// counts is digit-major [256][nblk].  Workgroup d turns row d into its exclusive prefix (positions of digit d's
+// keys of block b among all keys with digit d) and leaves the row total in totals[d].  One workgroup per digit:
+// the scan scales with the key count (a single-workgroup scan of 256*nblk counters was THE cost at 3e6 keys).
+__global__ __launch_bounds__(RS_TPB) void k_scan_rows(uint32_t *__restrict__ counts, int nblk, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    uint32_t *row = counts + (size_t)blockIdx.x * nblk;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int per = (total + 1023) / 1024;
-    const int lo = tid * per;
-    const int hi = lo + per < total ? lo + per : total;
-    uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += a[i];
-    // wave-level inclusive scan with shuffles, then across the 16 waves
-    uint32_t inc = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off);
-        if (lane >= off) inc += v;
-    }
-    if (lane == 63) wsum[w] = inc;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int i = 0; i < w; ++i) wbase += wsum[i];
-    uint32_t run = wbase + inc - s;  // exclusive prefix of this thread's chunk
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t v = a[i];
-        a[i] = run;
-        run += v;
+    for (int base = 0; base < nblk; base += RS_TPB) {
+        const int i = base + tid;
+        const uint32_t v = i < nblk ? row[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wb = carry_s;
+        for (int ww = 0; ww < w; ++ww) wb += wsum[ww];
+        if (i < nblk) row[i] = wb + inc - v;
+        __syncthreads();
+        if (tid == RS_TPB - 1) carry_s = wb + inc;
+        __syncthreads();
     }
+    if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
-// stable scatter: wave w of the block owns keys [blk*4096 + w*1024, +1024) and
-// walks them in 16 batches of 64 in index order, ranking equal digits inside
-// a batch with ballots (lanes in increasing order) and across batches with a
-// running per-(wave,digit) cursor in LDS.
+// Stable scatter through LDS.  Wave w of the block owns keys [blk*4096 + w*1024, +1024) and ranks them in index
+// order (equal digits inside a batch of 64 by ballots, across batches and waves by per-(wave,digit) cursors);
+// the ranked pairs are first placed at their position INSIDE THE BLOCK's sorted order in LDS, then written out
+// by consecutive threads, so one store instruction covers runs of one digit instead of 64 scattered words.
 template <bool IOTA>
 __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__restrict__ kin,
                                                           const uint32_t *__restrict__ vin,
@@ -79,11 +82,16 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
                                                           uint32_t *__restrict__ vout, int64_t n,
                                                           int shift,
                                                           const uint32_t *__restrict__ offs,
+                                                          const uint32_t *__restrict__ totals,
                                                           int nblk) {
     __shared__ uint32_t cur[4][256];
+    __shared__ uint32_t gdelta[256];       // global position - block-local position, per digit
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t sk[RS_TILE], sv[RS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 1024; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
-    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_SPAN;
+    const int64_t bbase = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t wbase = bbase + (int64_t)w * RS_WAVE_SPAN;
     uint32_t k[RS_IPT], v[RS_IPT];
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
@@ -92,23 +100,40 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
         k[j] = kin[ci];
         v[j] = IOTA ? (uint32_t)idx : vin[ci];
     }
-    const uint32_t goff = offs[(size_t)tid * nblk + blockIdx.x];   // digit tid's global cursor for this block
+    const uint32_t in_digit = offs[(size_t)tid * nblk + blockIdx.x];   // keys of digit tid in earlier blocks
+    const uint32_t dtot = totals[tid];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = wbase + j * 64 + lane;
         if (idx < n) atomicAdd(&cur[w][(k[j] >> shift) & 255u], 1u);
     }
-    __syncthreads();
-    {   // thread tid owns digit tid: turn per-wave counts into per-wave global cursors
-        uint32_t g = goff;
+    // exclusive scan of the 256 digit totals (global digit bases) and of this block's digit counts (local bases)
+    uint32_t ginc = dtot;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const uint32_t c = cur[ww][tid];
-            cur[ww][tid] = g;
-            g += c;
-        }
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(ginc, off);
+        if (lane >= off) ginc += t;
     }
+    if (lane == 63) wtot[w] = ginc;
+    __syncthreads();
+    uint32_t gbase = ginc - dtot;
+    for (int ww = 0; ww < w; ++ww) gbase += wtot[ww];
+    const uint32_t c0 = cur[0][tid], c1 = cur[1][tid], c2 = cur[2][tid], c3 = cur[3][tid];
+    const uint32_t btot = c0 + c1 + c2 + c3;
+    uint32_t linc = btot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(linc, off);
+        if (lane >= off) linc += t;
+    }
+    __syncthreads();                       // wtot is re-used
+    if (lane == 63) wtot[w] = linc;
+    __syncthreads();
+    uint32_t lbase = linc - btot;
+    for (int ww = 0; ww < w; ++ww) lbase += wtot[ww];
+    cur[0][tid] = lbase; cur[1][tid] = lbase + c0; cur[2][tid] = lbase + c0 + c1; cur[3][tid] = lbase + c0 + c1 + c2;
+    gdelta[tid] = gbase + in_digit - lbase;
     __syncthreads();
     const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -128,10 +153,23 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
             rank = (uint32_t)__popcll(same & below);
             cnt = (uint32_t)__popcll(same);
             const uint32_t pos = cur[w][d] + rank;
-            kout[pos] = k[j];
-            vout[pos] = v[j];
+            sk[pos] = k[j];
+            sv[pos] = v[j];
         }
         if (valid && rank + 1 == cnt) cur[w][d] += cnt;  // last lane of the group advances the cursor
+    }
+    __syncthreads();
+    const int64_t rem = n - bbase;
+    const int cnt_blk = rem < RS_TILE ? (int)rem : RS_TILE;
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const int lp = j * RS_TPB + tid;
+        if (lp < cnt_blk) {
+            const uint32_t key = sk[lp];
+            const uint32_t gp = lp + gdelta[(key >> shift) & 255u];
+            kout[gp] = key;
+            vout[gp] = sv[lp];
+        }
     }
 }
 
@@ -226,6 +264,7 @@ int sort_ws_alloc(SortWorkspace &ws, int64_t cap) {
     HIPCHK(hipMalloc(&ws.vals_alt, sizeof(uint32_t) * (size_t)(cap + 1)));
     HIPCHK(hipMalloc(&ws.counts, sizeof(uint32_t) * 256 * (size_t)ws.nblk));
     HIPCHK(hipMalloc(&ws.blk_heads, sizeof(uint32_t) * (size_t)ws.nblk));
+    HIPCHK(hipMalloc(&ws.totals, sizeof(uint32_t) * 256));
     return PS_OK;
 }
 
@@ -234,6 +273,7 @@ void sort_ws_free(SortWorkspace &ws) {
     if (ws.vals_alt) (void)hipFree(ws.vals_alt);
     if (ws.counts) (void)hipFree(ws.counts);
     if (ws.blk_heads) (void)hipFree(ws.blk_heads);
+    if (ws.totals) (void)hipFree(ws.totals);
     ws = SortWorkspace();
 }
 
@@ -249,11 +289,11 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, ws.counts, 256 * nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
         if (p == 0 && iota_vals)
-            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, nblk);
+            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk);
         else
-            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, nblk);
+            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk);
         uint32_t *t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

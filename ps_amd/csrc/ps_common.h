@@ -73,6 +73,7 @@ struct SortWorkspace {
     uint32_t *keys_alt = nullptr, *vals_alt = nullptr;  // ping-pong buffers [cap]
     uint32_t *counts = nullptr;                         // [256 * nblk]
     uint32_t *blk_heads = nullptr;                      // [nblk]
+    uint32_t *totals = nullptr;                         // [256] keys per digit of the current pass
     int64_t cap = 0;
     int nblk = 0;
 };

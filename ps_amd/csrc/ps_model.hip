@@ -128,6 +128,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
+    PSCHK(model_alloc(m, (void **)&m->partials2, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->grads_out, sizeof(float) * (size_t)(nc + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->dense_grad_flat, sizeof(float) * (size_t)m->dense_elems, true));
     {   // the side chains (sort, dW + dense update) yield to the main FC chain, which is the critical path
@@ -157,7 +158,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
     sort_ws_free(m->ws);
     fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
-    fr(m->partials); fr(m->grads_out); fr(m->dense_grad_flat);
+    fr(m->partials); fr(m->partials2); fr(m->grads_out); fr(m->dense_grad_flat);
     delete m;
     return PS_OK;
 }
@@ -251,8 +252,16 @@ int enqueue_forward(ps_model *m, bool train) {
         const int64_t nnz = m->cur_nnz;
         {
             Prof pf(m, "emb_sort");
-            PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
-                                   &m->sorted_ents, ss));
+            // payload of the sort = the BAG of every entry (single-hot: entry == bag, an iota).  The backward only
+            // needs each entry's delta row (its bag's) in entry order, which the stable sort keeps: carrying the bag
+            // through the sort saves the entry -> bag indirection (a random 4-byte load per entry) in both backward
+            // kernels.  ent_bag is consumed as ping-pong storage here.
+            if (m->cur_offsets)
+                PSCHK(radix_sort_pairs(m->ws, m->keys, m->ent_bag, nnz, bits_for(s->emb.total_rows), false, &m->sorted_keys,
+                                       &m->sorted_ents, ss));
+            else
+                PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
+                                       &m->sorted_ents, ss));
         }
         {
             Prof pf(m, "emb_segments");
@@ -384,8 +393,11 @@ int enqueue_backward(ps_model *m, bool apply) {
     memset(&g, 0, sizeof g);
     g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = (apply && s->emb.state) ? 1 : 0;
     g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
-    g.nseg = m->nseg_dev; g.ent_bag = m->cur_offsets ? m->ent_bag : nullptr;
-    g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.W = s->emb.W; g.state = s->emb.state;
+    g.nseg = m->nseg_dev;
+    g.ent_bag = (m->cur_offsets && m->sh.active) ? m->ent_bag : nullptr;     // fused path: sorted_ent already holds bags
+    g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.partials2 = m->partials2; g.W = s->emb.W; g.state = s->emb.state;
+    // a key's run is at most B entries when single-hot: no second level (and no extra launch) up to 128 chunks
+    g.long_runs = (m->cur_offsets != nullptr || (int64_t)B > (int64_t)PS_EMB_CHUNK * PS_EMB_SUPER_MIN) ? 1 : 0;
     PSCHK(store_resolve_updater(s, "emF", &u));
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;

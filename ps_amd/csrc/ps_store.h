@@ -91,7 +91,7 @@ struct ps_model {
     uint32_t *keys = nullptr, *ents = nullptr, *ent_bag = nullptr, *seg_start = nullptr, *seg_id = nullptr,
              *nseg_dev = nullptr, *uniq_row = nullptr, *uniq_cnt = nullptr;
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
-    float *partials = nullptr, *grads_out = nullptr;
+    float *partials = nullptr, *partials2 = nullptr, *grads_out = nullptr;
     float *dense_grad_flat = nullptr; int64_t dense_elems = 0;
     // per-kernel-group event timing (ps_model_set_profile)
     struct ProfEvent { const char *name; hipEvent_t a, b; };

@@ -514,3 +514,43 @@ def test_owner_push_from_many_workers(orc, is_async):
                     S = (g + S).astype(f32)
                 W[r], M[r], Vv[r] = orc.adam_update(W[r], (S / f32(len(gs))).astype(f32), M[r], Vv[r])
     np.testing.assert_array_equal(out[0][0], W); np.testing.assert_array_equal(out[0][1], M); np.testing.assert_array_equal(out[0][2], Vv)
+
+
+def test_very_long_runs_two_level_order(orc):
+    """A hot key with a run above 128 chunks (here 4500 and 9000 entries, multi-hot) is folded in two levels
+    (32-entry chunks, then 32 chunks at a time): bit-exact against the oracle's same order, including the
+    double-backward pass; shorter runs in the same batch keep the one-level / sequential order."""
+    import ps_amd
+    F, D, X, fc, V, B = 2, 8, 1, [8, 1], 12, 64
+    rng = np.random.default_rng(33)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, max_nnz=B * F * 200)
+    for step in range(2):
+        lens = rng.integers(1, 6, size=B * F)
+        lens[0::2] += 70                                   # field 0: every bag carries 70 copies of the hot key
+        lens[1::2] += 141 * (np.arange(B) < 64)            # field 1: 141 copies -> 9024 entries of one key
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = rng.integers(0, V, size=int(offsets[-1])).astype(np.int64)
+        for bag in range(B * F):
+            hot = 70 if bag % 2 == 0 else 141
+            ids[offsets[bag]:offsets[bag] + hot] = 3 if bag % 2 == 0 else 7
+        Xd = rng.standard_normal((B, X)).astype(f32); Y = (rng.random(B) < 0.4).astype(f32)
+        gm.forward({"E": ids, "X": Xd, "Y": Y, "offsets": offsets})
+        gm.backward()
+        dx = gm.delta(2)
+        field_of = np.repeat(np.arange(B * F) % F, lens)
+        samp_of = np.repeat(np.arange(B * F) // F, lens)
+        longest = 0
+        for f in range(F):
+            gi, gg = gm.emb_grads(f)
+            sel = np.nonzero(field_of == f)[0]
+            np.testing.assert_array_equal(gi, np.unique(ids[sel]))
+            for i, idv in enumerate(gi):
+                ps = sel[ids[sel] == idv]
+                gk = dx[samp_of[ps], f * D:(f + 1) * D]
+                longest = max(longest, len(ps))
+                np.testing.assert_array_equal(gg[i], orc.emb_geff(gk, orc.GRAD_COMPAT, 32), err_msg="emF%d.%d n=%d" % (f, idv, len(ps)))
+        assert longest > 128 * 32
+        gm.update()
+    gm.close(); kv.close()

@@ -16,7 +16,8 @@ for _ in range(4):
     lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     nnz = int(offsets[-1]); nnz_tot += nnz
-    ids = np.minimum(rng.zipf(1.05, size=nnz) - 1, V - 1).astype(np.int64)
+    ids = (rng.integers(0, V, size=nnz) if 'uniform' in sys.argv else np.minimum(rng.zipf(1.05, size=nnz) - 1, V - 1)).astype(np.int64)
+    uniq = len(np.unique(ids + V * (np.repeat(np.arange(B * F), lens) % F)))
     X = rng.standard_normal((B, cfg["X"])).astype(np.float32); Y = (rng.random(B) < 0.25).astype(np.float32)
     W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)
     batches.append(ps_amd.DeviceBatch(kv, ids, X, Y, W, offsets))
@@ -30,6 +31,7 @@ gm.sync(); prof = gm.profile_report(); gm.set_profile(False)
 t0 = time.perf_counter(); n = 100
 for i in range(n): gm.train_async(batches[i % 4])
 gm.sync(); dt = (time.perf_counter() - t0) / n
+print("unique keys in the last batch: %d" % uniq)
 print("nnz/step %d: %.3f ms/step, %.2f M examples/s, %.1f M ids/s" % (nnz, 1e3 * dt, B / dt / 1e6, nnz / dt / 1e6))
 for k, v in sorted(prof.items(), key=lambda kv_: -kv_[1][1]):
     print("  %-16s %8.1f us" % (k, 1e3 * v[1] / max(v[0], 1)))
