@@ -278,6 +278,14 @@ int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out);
 int ps_ingest_reset(ps_ingest_t *g);
 int ps_ingest_stats(ps_ingest_t *g, double *parse_seconds, int64_t *lines, int64_t *bytes);
 
+/* ---- shard checkpoint / resume (absent in the reference) --
+ * One file per shard: the store's arrays raw (embedding rows + updater state
+ * of THIS shard, the wide table, every FC tensor + state, the registered
+ * updaters, globalStep).  ps_store_load needs a store of the same geometry
+ * (create the tables / the model first); resuming is exact. */
+int ps_store_save(ps_store_t *s, const char *path);
+int ps_store_load(ps_store_t *s, const char *path);
+
 /* ---- evaluate.AUC (evaluate/AUC.java:32-82; train/Trainer.java:44-68) ------
  * AUC of predictions p[n] against labels y[n] (y > 0 = positive) exactly as
  * AUC.calculate() defines it: stable ascending sort by p, walk from the top,

@@ -177,6 +177,13 @@ class KVStore:
         val = np.ascontiguousarray(val, np.float32)
         N.check(N.lib().ps_store_put_wide(self.h, _ip(ids), len(ids), which, _fp(val)))
 
+    def save(self, path):
+        """Checkpoint of this shard (tables, updater state, FC tensors, updaters, globalStep)."""
+        N.check(N.lib().ps_store_save(self.h, str(path).encode()))
+
+    def load(self, path):
+        N.check(N.lib().ps_store_load(self.h, str(path).encode()))
+
     def global_step(self):
         return N.lib().ps_store_global_step(self.h)
 

@@ -959,3 +959,19 @@ int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
+
+// Wt[n][k] = W'[k][n] for k <= K (rows of W' incl. the bias row), n < N  (rebuild of the transposed copy after a load)
+namespace {
+__global__ __launch_bounds__(256) void k_transpose_w(const float *__restrict__ W, float *__restrict__ Wt, int Kpad, int ldw, int N) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)Kpad * N) return;
+    const int k = (int)(t / N), n = (int)(t % N);
+    Wt[(size_t)n * Kpad + k] = W[(size_t)k * ldw + n];
+}
+}  // namespace
+
+int launch_transpose_w(const float *W, float *Wt, int Kpad, int ldw, int N, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv((int64_t)Kpad * N, 256)), dim3(256), 0, st, W, Wt, Kpad, ldw, N);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}

@@ -120,6 +120,8 @@ SIGNATURES = {
     "ps_ingest_next": (_i, [_vp, C.POINTER(ps_batch_t)]),
     "ps_ingest_reset": (_i, [_vp]),
     "ps_ingest_stats": (_i, [_vp, _pd, _pi64, _pi64]),
+    "ps_store_save": (_i, [_vp, _cp]),
+    "ps_store_load": (_i, [_vp, _cp]),
     "ps_auc_compute": (_i, [_vp, _vp, _vp, _i64, _i, _pd, _pi64, _pi64]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),
     "ps_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _pd]),
