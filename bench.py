@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="run the sharded (multi-GPU) path even at N=1")
     ap.add_argument("--is-async", type=int, default=0, help="async push (-DisPsAsync=1): no averaging, arrival order")
     ap.add_argument("--overlap", type=int, default=0, help="sharded path: plan step t+1 (key lists) while step t trains")
+    ap.add_argument("--native", type=int, default=1, help="sharded path: 1 = ps_shard_step (the library drives RCCL), 0 = torch.distributed wire")
     ap.add_argument("--priming", type=int, default=300, help="sharded path: extra untimed steps before the timed region")
     ap.add_argument("--prefetch-thread", type=int, default=0, help="sharded path: run that prefetch in its own host thread")
     ap.add_argument("--phases", type=int, default=0, help="sharded path: also report a per-phase stopwatch (serialised)")

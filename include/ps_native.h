@@ -356,6 +356,30 @@ int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_unique);
  * needs no sort.  NULL: any order / duplicates allowed, stable sort by row. */
 int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev,
                         int64_t n, const int64_t *peer_counts, int npeers, int is_async);
+/* ---- the same exchange driven by the library: ONE call per step ------------
+ * ps_shard_step = plan, all-gather of the per-owner key counts (the step's
+ * only host wait), all-to-all-v ids / rows / gradients, the dense + wide
+ * all-reduce, owner push + updater, replicated update -- everything above,
+ * enqueued from C.  The collectives are reached through a table of callbacks:
+ * ps_comm_rccl_create fills it with RCCL (ncclSend/ncclRecv groups,
+ * ncclAllGather, ncclAllReduce over xGMI; librccl is dlopen'ed on first use;
+ * rank 0 makes the 128-byte id with ps_comm_rccl_unique_id and the host
+ * hands it to every rank); a host may plug in its own.  All pointers are
+ * device pointers; every callback enqueues on `stream` (hipStream_t).
+ * counts are in elements of elem_bytes, ordered by peer rank. */
+typedef struct ps_comm_ops {
+    void *ctx;
+    int nranks, rank;
+    int (*all_gather)(void *ctx, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+    int (*all_to_all_v)(void *ctx, const void *send, const int64_t *send_counts, void *recv,
+                        const int64_t *recv_counts, size_t elem_bytes, void *stream);
+    int (*all_reduce_sum_f32)(void *ctx, float *buf, int64_t n, void *stream);
+} ps_comm_ops_t;
+int ps_comm_rccl_unique_id(char *out128);
+int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id128, ps_comm_ops_t *out);
+int ps_comm_rccl_destroy(ps_comm_ops_t *ops);
+int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);
+
 /* Replicated tensors: one flat device buffer
  * [fc weights+biases | wide G | wide C | wide.bias g] to all-reduce(sum);
  * G[k] = this worker's mean delta if it ever touched key k, C[k] = 1 if so. */

@@ -1,0 +1,218 @@
+// ps_comm.hip -- the parameter-server exchange driven from inside the library: ONE C call per step.
+//
+// ps_amd/sharded.py drives the same device-side halves through torch.distributed; measured on MI355X that
+// wire is host-bound (five Python-level collectives, two host round trips for split sizes, ~45 ctypes
+// launches: ~0.5 ms per step for ~0.3 ms of GPU work).  Here the whole step of net/PSRouterClient.java:60-151
+// + net/PServer.java:102-283 is enqueued by ps_shard_step with ONE host wait (the N x N matrix of key counts):
+//
+//   plan (sort/unique by owner)            ps_shard_plan_launch
+//   all-gather of the per-owner counts     -> every rank learns what it sends AND what it receives
+//   all-to-all-v row ids                   PSRouterClient.getList fan-out
+//   owner gather + all-to-all-v rows back  PServer.getList -> worker cache
+//   forward / backward on the cache        Model.train
+//   all-reduce of [fc | wide G | wide C | wide.bias]
+//   all-to-all-v per-key gradients         PSClient.push
+//   owner: mean over pushing workers (or async) + updater; replicated tensors: identical update
+//
+// The collectives go through a small table of callbacks (ps_comm_ops_t): the product implementation is RCCL
+// (ncclSend/ncclRecv groups, ncclAllGather, ncclAllReduce over xGMI), loaded with dlopen so that single-GPU
+// use never maps the 570 MB library; tests plug in an in-process implementation to run N ranks on one GPU.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ps_store.h"
+
+// ---------------------------------------------------------------------------
+// RCCL, bound at run time (the soname torch also ships: one copy per process)
+// ---------------------------------------------------------------------------
+namespace {
+
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void *rcclComm_t;
+enum { RCCL_CHAR = 0, RCCL_FLOAT = 7, RCCL_SUM = 0 };     // ncclInt8 / ncclFloat32 / ncclSum (rccl.h)
+
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(rcclUniqueId *) = nullptr;
+    int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+} g_rccl;
+
+int rccl_load() {
+    if (g_rccl.h) return PS_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return ps_set_err(PS_MISSING, "librccl.so.1 not found: %s", dlerror());
+#define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return ps_set_err(PS_MISSING, "RCCL symbol %s missing", name); } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+    SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return PS_OK;
+}
+
+#define RCCLCHK(x) do { int r__ = (x); if (r__ != 0) return ps_set_err(PS_E_HIP, "%s -> %s", #x, g_rccl.GetErrorString(r__)); } while (0)
+
+struct RcclCtx { rcclComm_t comm = nullptr; int nranks = 1, rank = 0; };
+
+int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void *stream) {
+    RcclCtx *c = (RcclCtx *)ctx;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->nranks == 1) {
+        HIPCHK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
+        return PS_OK;
+    }
+    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, c->comm, st));
+    return PS_OK;
+}
+
+int rccl_all_to_all_v(void *ctx, const void *send, const int64_t *sc, void *recv, const int64_t *rc, size_t eb, void *stream) {
+    RcclCtx *c = (RcclCtx *)ctx;
+    hipStream_t st = (hipStream_t)stream;
+    size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
+    const bool wire = c->nranks > 1;
+    if (wire) RCCLCHK(g_rccl.GroupStart());
+    for (int p = 0; p < c->nranks; ++p) {
+        if (p == c->rank) { self_so = so; self_ro = ro; }
+        else {
+            if (sc[p] > 0) RCCLCHK(g_rccl.Send((const char *)send + so * eb, (size_t)sc[p] * eb, RCCL_CHAR, p, c->comm, st));
+            if (rc[p] > 0) RCCLCHK(g_rccl.Recv((char *)recv + ro * eb, (size_t)rc[p] * eb, RCCL_CHAR, p, c->comm, st));
+        }
+        so += (size_t)sc[p]; ro += (size_t)rc[p];
+    }
+    if (wire) RCCLCHK(g_rccl.GroupEnd());
+    if (sc[c->rank] != rc[c->rank]) return ps_set_err(PS_E_STATE, "all-to-all-v: self counts differ");
+    if (sc[c->rank] > 0)       // this rank's own keys never touch the wire
+        HIPCHK(hipMemcpyAsync((char *)recv + self_ro * eb, (const char *)send + self_so * eb, (size_t)sc[c->rank] * eb, hipMemcpyDeviceToDevice, st));
+    return PS_OK;
+}
+
+int rccl_all_reduce(void *ctx, float *buf, int64_t n, void *stream) {
+    RcclCtx *c = (RcclCtx *)ctx;
+    if (c->nranks == 1 || n <= 0) return PS_OK;
+    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, c->comm, (hipStream_t)stream));
+    return PS_OK;
+}
+
+__global__ void k_owner_counts(const uint32_t *__restrict__ owner_start, int nsh, int64_t *__restrict__ counts) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < nsh) counts[o] = (int64_t)owner_start[o + 1] - (int64_t)owner_start[o];
+}
+
+template <typename T>
+int grow(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
+    if (need <= *cap) return PS_OK;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    const int64_t c = need + need / 4 + 1024;
+    HIPCHK(hipMalloc((void **)p, elem * (size_t)c));
+    *cap = c;
+    return PS_OK;
+}
+
+}  // namespace
+
+extern "C" int ps_comm_rccl_unique_id(char *out128) {
+    if (!out128) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    PSCHK(rccl_load());
+    rcclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(out128, id.internal, 128);
+    return PS_OK;
+}
+
+extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id128, ps_comm_ops_t *out) {
+    if (!s || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id128)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    RcclCtx *c = new RcclCtx();
+    c->nranks = nranks; c->rank = rank;
+    if (nranks > 1) {
+        int rc = rccl_load();
+        if (rc != PS_OK) { delete c; return rc; }
+        rcclUniqueId id;
+        memcpy(id.internal, id128, 128);
+        const int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+        if (r != 0) { delete c; return ps_set_err(PS_E_HIP, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r)); }
+    }
+    memset(out, 0, sizeof *out);
+    out->ctx = c; out->nranks = nranks; out->rank = rank;
+    out->all_gather = rccl_all_gather; out->all_to_all_v = rccl_all_to_all_v; out->all_reduce_sum_f32 = rccl_all_reduce;
+    return PS_OK;
+}
+
+extern "C" int ps_comm_rccl_destroy(ps_comm_ops_t *ops) {
+    if (!ops || !ops->ctx) return PS_OK;
+    RcclCtx *c = (RcclCtx *)ops->ctx;
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    ops->ctx = nullptr;
+    return PS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one BSP (or async) step of worker + owner
+// ---------------------------------------------------------------------------
+extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss) {
+    if (!m || !batch || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32)
+        return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    ps_store *s = m->s;
+    const int nsh = comm->nranks, rank = comm->rank;
+    if (nsh < 1 || rank < 0 || rank >= nsh) return ps_set_err(PS_E_BAD_ARG, "bad communicator");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    PSCHK(ps_shard_plan_launch(m, batch, nsh, nullptr));
+    ps_model::Shard &sh = m->sh;
+    const int D = m->cfg.D;
+    if (!sh.counts_dev) {
+        HIPCHK(hipMalloc((void **)&sh.counts_dev, sizeof(int64_t) * (size_t)nsh));
+        HIPCHK(hipMalloc((void **)&sh.matrix_dev, sizeof(int64_t) * (size_t)nsh * nsh));
+        HIPCHK(hipHostMalloc((void **)&sh.matrix_host, sizeof(int64_t) * (size_t)nsh * nsh, hipHostMallocDefault));
+    }
+    hipLaunchKernelGGL(k_owner_counts, dim3(cdiv(nsh, 64)), dim3(64), 0, st, sh.owner_start, nsh, sh.counts_dev);
+    HIPCHK(hipGetLastError());
+    PSCHK(comm->all_gather(comm->ctx, sh.counts_dev, sh.matrix_dev, sizeof(int64_t) * (size_t)nsh, st));
+    HIPCHK(hipMemcpyAsync(sh.matrix_host, sh.matrix_dev, sizeof(int64_t) * (size_t)nsh * nsh, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));                  // the step's one host wait: split sizes of every exchange
+    sh.plan_pending = false;
+    std::vector<int64_t> sc((size_t)nsh), rc((size_t)nsh);
+    int64_t U = 0, nrecv = 0;
+    for (int o = 0; o < nsh; ++o) {
+        sc[o] = sh.matrix_host[(size_t)rank * nsh + o];     // what I request from / push to owner o
+        rc[o] = sh.matrix_host[(size_t)o * nsh + rank];     // what worker o requests from / pushes to me
+        if (sc[o] < 0 || rc[o] < 0) return ps_set_err(PS_E_STATE, "negative key count in the exchange matrix");
+        U += sc[o]; nrecv += rc[o];
+    }
+    sh.U = U;
+    PSCHK(grow(s, &sh.x_recv_rows, &sh.x_recv_cap, nrecv, sizeof(uint32_t)));
+    PSCHK(grow(s, &sh.x_rows_out, &sh.x_rows_cap, nrecv * D, sizeof(float)));
+    PSCHK(grow(s, &sh.x_recv_grads, &sh.x_grads_cap, nrecv * D, sizeof(float)));
+    PSCHK(grow(s, &sh.x_cache, &sh.x_cache_cap, U * D, sizeof(float)));
+    // getList: ids out, rows back
+    PSCHK(comm->all_to_all_v(comm->ctx, sh.send_rows, sc.data(), sh.x_recv_rows, rc.data(), sizeof(uint32_t), st));
+    PSCHK(ps_shard_serve_pull(s, sh.x_recv_rows, nrecv, sh.x_rows_out));
+    PSCHK(comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st));
+    // train on the cache
+    PSCHK(ps_shard_forward_backward(m, sh.x_cache, nullptr));
+    // push: dense + wide in one reduction, per-key gradients to their owners
+    PSCHK(comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, st));
+    PSCHK(comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st));
+    PSCHK(ps_shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, rc.data(), nsh, is_async));
+    PSCHK(ps_shard_apply_flat(m, nsh));
+    if (loss) {
+        HIPCHK(hipMemcpyAsync(loss, m->loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return PS_OK;
+}

@@ -153,6 +153,8 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     for (auto &e : m->events) (void)hipEventDestroy(e);
     if (m->sh.plan_ev) (void)hipEventDestroy(m->sh.plan_ev);
     if (m->sh.owner_start_host) (void)hipHostFree(m->sh.owner_start_host);
+    if (m->sh.matrix_host) (void)hipHostFree(m->sh.matrix_host);
+    fr(m->sh.counts_dev); fr(m->sh.matrix_dev); fr(m->sh.x_recv_rows); fr(m->sh.x_rows_out); fr(m->sh.x_recv_grads); fr(m->sh.x_cache);
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);

@@ -115,6 +115,12 @@ struct ps_model {
         uint32_t *owner_start_host = nullptr;   // pinned readback of owner_start
         hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
         bool plan_pending = false;
+        // ps_shard_step (library-driven exchange): counts, the N x N count matrix, exchange buffers
+        int64_t *counts_dev = nullptr, *matrix_dev = nullptr, *matrix_host = nullptr;
+        uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;
+        float *x_rows_out = nullptr; int64_t x_rows_cap = 0;
+        float *x_recv_grads = nullptr; int64_t x_grads_cap = 0;
+        float *x_cache = nullptr; int64_t x_cache_cap = 0;
     } sh;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)

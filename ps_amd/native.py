@@ -53,6 +53,16 @@ class ps_ingest_config_t(C.Structure):
                 ("step", C.c_int), ("ids_via_float", C.c_int), ("wide_size", C.c_int64)]
 
 
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_TO_ALL_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_size_t, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class ps_comm_ops_t(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("nranks", C.c_int), ("rank", C.c_int), ("all_gather", ALL_GATHER_FN),
+                ("all_to_all_v", ALL_TO_ALL_V_FN), ("all_reduce_sum_f32", ALL_REDUCE_FN)]
+
+
 SIGNATURES = {
     "ps_last_error": (_cp, []),
     "ps_version": (_cp, []),
@@ -122,6 +132,10 @@ SIGNATURES = {
     "ps_ingest_stats": (_i, [_vp, _pd, _pi64, _pi64]),
     "ps_store_save": (_i, [_vp, _cp]),
     "ps_store_load": (_i, [_vp, _cp]),
+    "ps_comm_rccl_unique_id": (_i, [C.c_char_p]),
+    "ps_comm_rccl_create": (_i, [_vp, _i, _i, C.c_char_p, C.POINTER(ps_comm_ops_t)]),
+    "ps_comm_rccl_destroy": (_i, [C.POINTER(ps_comm_ops_t)]),
+    "ps_shard_step": (_i, [_vp, C.POINTER(ps_batch_t), C.POINTER(ps_comm_ops_t), _i, _pf]),
     "ps_auc_compute": (_i, [_vp, _vp, _vp, _i64, _i, _pd, _pi64, _pi64]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),
     "ps_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _pd]),

@@ -463,6 +463,44 @@ class HipBackend:
 
 
 # ---------------------------------------------------------------------------
+# the library-driven step: ONE C call (ps_shard_step) per step, RCCL bound inside libps_amd.so
+# ---------------------------------------------------------------------------
+class NativeWorker:
+    """ps_shard_step over a ps_comm_ops_t.  `ops` None: an RCCL communicator is created from `id128`
+    (made by rank 0 with NativeWorker.unique_id() and handed to every rank by the host)."""
+
+    def __init__(self, model, nranks, rank, id128=None, ops=None, is_async=False):
+        self.m, self.kv, self.is_async = model, model.store, is_async
+        self._own = ops is None
+        if ops is None:
+            ops = N.ps_comm_ops_t()
+            N.check(N.lib().ps_comm_rccl_create(self.kv.h, nranks, rank, id128, C.byref(ops)))
+        self.ops = ops
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        N.check(N.lib().ps_comm_rccl_unique_id(buf))
+        return buf.raw
+
+    def step(self, batch, want_loss=True):
+        loss = C.c_float()
+        N.check(N.lib().ps_shard_step(self.m.h, C.byref(batch.c), C.byref(self.ops), int(self.is_async), C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def run(self, batches, steps, want_loss=False):
+        loss = None
+        for i in range(steps):
+            loss = self.step(batches[i % len(batches)], want_loss)
+        return loss
+
+    def close(self):
+        if self._own and self.ops is not None:
+            N.lib().ps_comm_rccl_destroy(C.byref(self.ops))
+        self.ops = None
+
+
+# ---------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): BASELINE configs[2]
 # ---------------------------------------------------------------------------
 def run_bench(args, cfg, synth_batch):
@@ -484,31 +522,59 @@ def run_bench(args, cfg, synth_batch):
     kv = ps_amd.KVStore(local, cfg["seed"])
     kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"], shard=rank, nshards=world)
     overlap = bool(getattr(args, "overlap", 1))
-    gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
-           for _ in range(4 if overlap else 1)]       # plan contexts: steps t+1, t+2 are planned while step t trains and t-1 drains
-    torch.cuda.set_stream(torch.cuda.Stream(dev))      # not the legacy null stream (implicit syncs with blocking streams)
-    N.check(N.lib().ps_store_set_stream(kv.h, torch.cuda.current_stream().cuda_stream))
-    comm = TorchComm(dist, torch, dev, overlap=overlap)
-    threaded = overlap and bool(getattr(args, "prefetch_thread", 0))
-    worker = ShardedWorker(HipBackend(gms, torch, dev), comm, is_async=bool(getattr(args, "is_async", 0)))
+    native = bool(getattr(args, "native", 1))
+    threaded = False
+    if native:
+        # the library drives the exchange (ps_shard_step: one C call per step, RCCL bound inside libps_amd.so);
+        # torch.distributed only hands the 128-byte RCCL id round and keeps the bench's barriers
+        gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])]
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(NativeWorker.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            worker = NativeWorker(gms[0], world, rank, id128=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
+        except Exception as e:      # noqa: BLE001 -- decided collectively below
+            worker = None
+            ok.zero_()
+            print("rank %d: RCCL communicator inside libps_amd failed (%s); falling back to the torch.distributed wire" % (rank, e), flush=True)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if int(ok.item()) == 0:
+            if worker is not None:
+                worker.close()
+            for g in gms:
+                g.close()
+            native = False
+        else:
+            worker_run = lambda n: worker.run(batches, n)                              # noqa: E731
+    if not native:
+        gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+               for _ in range(4 if overlap else 1)]       # plan contexts: steps t+1, t+2 are planned while step t trains and t-1 drains
+        torch.cuda.set_stream(torch.cuda.Stream(dev))      # not the legacy null stream (implicit syncs with blocking streams)
+        N.check(N.lib().ps_store_set_stream(kv.h, torch.cuda.current_stream().cuda_stream))
+        comm = TorchComm(dist, torch, dev, overlap=overlap)
+        threaded = overlap and bool(getattr(args, "prefetch_thread", 0))
+        worker = ShardedWorker(HipBackend(gms, torch, dev), comm, is_async=bool(getattr(args, "is_async", 0)))
+        worker_run = lambda n: worker.run(batches, n, threaded=threaded)               # noqa: E731
     rng = np.random.default_rng(cfg["seed"] + 1000 * rank)     # every worker reads its own slice of the data
     nb = 8
     batches = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
     # priming (untimed, on top of --warmup): the first few hundred steps run ~30% slower while the caching
     # allocator, the three communicators and the host settle; keep that out of the timed region
-    worker.run(batches, max(args.warmup, 1) + int(getattr(args, "priming", 300)), threaded=threaded)
-    torch.cuda.synchronize()
+    worker_run(max(args.warmup, 1) + int(getattr(args, "priming", 300)))
+    kv.sync(); torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    worker.run(batches, args.steps, threaded=threaded)
-    torch.cuda.synchronize()
+    worker_run(args.steps)
+    kv.sync(); torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     loss = worker.step(batches[0], want_loss=True)
     phases = {}
-    if getattr(args, "phases", 0):
+    if getattr(args, "phases", 0) and not native:
         for i in range(50):
             worker.step_timed(batches[i % nb], torch.cuda.synchronize, phases)
         phases = {k: round(1e6 * v / 50, 1) for k, v in phases.items()}
@@ -532,7 +598,8 @@ def run_bench(args, cfg, synth_batch):
             "config": {"workload": "BASELINE configs[2]: Wide&Deep synthetic (26 x 100k x 16, FC[512,256,1]), batch 4096 per GPU, "
                                    "embedding rows sharded id mod N (PSRouterClient routing -> RCCL all-to-all-v), dense + wide all-reduce, BSP",
                        "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True,
-                       "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
+                       "exchange_driver": "libps_amd (ps_shard_step, RCCL via dlopen)" if native else "torch.distributed",
+                       "prefetch_next_key_lists": overlap and not native, "prefetch_thread": threaded,
                        "priming_steps_untimed": int(getattr(args, "priming", 300))},
             "final_loss": loss,
         }
@@ -541,6 +608,8 @@ def run_bench(args, cfg, synth_batch):
     for b in batches:
         b.close()
     dist.barrier()
+    if native:
+        worker.close()
     for g in gms:
         g.close()
     kv.close()

@@ -180,3 +180,160 @@ def test_n_ranks_on_one_gpu(orc, world, is_async, pipelined):
             np.testing.assert_array_equal(W[l], out[0][1][l]); np.testing.assert_array_equal(b[l], out[0][2][l])
         np.testing.assert_array_equal(wide, out[0][3]); np.testing.assert_array_equal(wbias, out[0][4])
     assert touched > 0
+
+
+# ---------------------------------------------------------------------------
+# the library-driven step (ps_shard_step): same ranks-as-threads set-up, the collectives plugged into the
+# C callback table (ps_comm_ops_t) -- so the C++ orchestration (count matrix, split sizes, buffer order) is
+# exercised at N > 1 on one GPU; only the RCCL calls themselves are replaced.
+# ---------------------------------------------------------------------------
+class CallbackComm:
+    def __init__(self, rank, shared, kv):
+        from ps_amd import native as N
+        self.rank, self.world, self.sh, self.kv, self.N = rank, shared.world, shared, kv, N
+        self.ops = N.ps_comm_ops_t()
+        self.ops.ctx, self.ops.nranks, self.ops.rank = None, self.world, rank
+        self._ag = N.ALL_GATHER_FN(self.all_gather); self._a2a = N.ALL_TO_ALL_V_FN(self.all_to_all_v); self._ar = N.ALL_REDUCE_FN(self.all_reduce)
+        self.ops.all_gather, self.ops.all_to_all_v, self.ops.all_reduce_sum_f32 = self._ag, self._a2a, self._ar
+        self.err = None
+
+    def _down(self, ptr, nbytes):
+        a = np.empty(nbytes, np.uint8)
+        if nbytes:
+            self.N.check(self.N.lib().ps_dev_download(self.kv.h, a.ctypes.data, ptr, nbytes))
+        return a
+
+    def _up(self, ptr, a):
+        if a.size:
+            a = np.ascontiguousarray(a)
+            self.N.check(self.N.lib().ps_dev_upload(self.kv.h, ptr, a.ctypes.data, a.nbytes))
+
+    def _swap(self, mine):
+        self.sh.slots[self.rank] = mine
+        self.sh.barrier.wait()
+        got = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return got
+
+    def _guard(self, fn):
+        try:
+            self.kv.sync()                      # the callbacks are "enqueue on stream": here simply drained first
+            fn()
+            return 0
+        except BaseException as e:             # noqa: BLE001 -- reported through the status code
+            self.err = e
+            self.sh.barrier.abort()
+            return 500
+
+    def all_gather(self, ctx, send, recv, nbytes, stream):
+        def f():
+            parts = self._swap(self._down(send, nbytes))
+            self._up(recv, np.concatenate(parts))
+        return self._guard(f)
+
+    def all_to_all_v(self, ctx, send, sc, recv, rc, eb, stream):
+        def f():
+            scl = [int(sc[i]) for i in range(self.world)]; rcl = [int(rc[i]) for i in range(self.world)]
+            host = self._down(send, sum(scl) * eb)
+            offs = np.concatenate([[0], np.cumsum(scl)]).astype(np.int64) * eb
+            parts = self._swap((host, offs))
+            pieces = [h[o[self.rank]:o[self.rank + 1]] for h, o in parts]
+            assert [len(x) // eb for x in pieces] == rcl
+            self._up(recv, np.concatenate(pieces) if pieces else np.zeros(0, np.uint8))
+        return self._guard(f)
+
+    def all_reduce(self, ctx, buf, n, stream):
+        def f():
+            parts = self._swap(self._down(buf, n * 4).view(f32))
+            tot = parts[0].copy()
+            for p in parts[1:]:
+                tot = (tot + p).astype(f32)
+            self._up(buf, tot)
+        return self._guard(f)
+
+
+def native_rank_main(rank, world, shared, is_async, out, errs):
+    try:
+        import ps_amd
+        from ps_amd.sharded import NativeWorker
+        F, D, V = CFG["F"], CFG["D"], CFG["V"]
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D, shard=rank, nshards=world)
+        gm = ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"])
+        comm = CallbackComm(rank, shared, kv)
+        wk = NativeWorker(gm, world, rank, ops=comm.ops, is_async=is_async)
+        for b in make_batches(rank, STEPS):
+            wk.step(ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]))
+        kv.sync()
+        if comm.err is not None:
+            raise comm.err
+        rows = {}
+        for f in range(F):
+            ids = np.arange(rank, V, world)
+            w = kv.get_rows(f, ids)
+            for i, idv in enumerate(ids):
+                rows[(f, int(idv))] = w[i]
+        out[rank] = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)],
+                     kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step())
+        gm.close(); kv.close()
+    except BaseException:       # noqa: BLE001
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+        shared.barrier.abort()
+
+
+@pytest.mark.parametrize("world,is_async", [(2, False), (4, False), (3, True)])
+def test_library_driven_step_n_ranks_on_one_gpu(orc, world, is_async):
+    shared = Shared(world)
+    out, errs = [None] * world, []
+    th = [threading.Thread(target=native_rank_main, args=(r, world, shared, is_async, out, errs)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, "\\n".join("rank %d:\\n%s" % e for e in errs)
+    emb, fcW, fcb, ww, wb = expected(world, is_async)
+    xav = orc.xavier_scale(1, CFG["D"])
+    tol = 2e-5 * STEPS
+    touched = 0
+    for r in range(world):
+        rows, W, b, wide, wbias, gstep = out[r]
+        assert gstep == STEPS
+        for (f, i), got in rows.items():
+            if (f, i) in emb:
+                assert np.abs(got - emb[(f, i)][0]).max() <= tol, "rank %d emF%d.%d" % (r, f, i)
+                touched += 1
+            else:
+                np.testing.assert_array_equal(got, orc.init_rows(SEED, f, [i], CFG["D"], xav)[0])
+        for l in range(3):
+            assert np.abs(W[l] - fcW[l]).max() <= tol and np.abs(b[l] - fcb[l]).max() <= tol
+            np.testing.assert_array_equal(W[l], out[0][1][l]); np.testing.assert_array_equal(b[l], out[0][2][l])
+        assert np.abs(wide - ww).max() <= tol and abs(wbias[0] - wb[0]) <= tol
+        np.testing.assert_array_equal(wide, out[0][3])
+    assert touched > 0
+
+
+def test_library_driven_step_equals_python_driven_step():
+    """N = 2 ranks on one GPU: ps_shard_step (C++ orchestration) == ShardedWorker (Python orchestration), bit for bit."""
+    world = 2
+    res = []
+    for native in (False, True):
+        shared = Shared(world)
+        out, errs = [None] * world, []
+        tgt = native_rank_main if native else rank_main
+        args = (lambda r: (r, world, shared, False, out, errs)) if native else (lambda r: (r, world, shared, False, False, out, errs))
+        th = [threading.Thread(target=tgt, args=args(r)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        assert not errs, "\\n".join("rank %d:\\n%s" % e for e in errs)
+        res.append(out)
+    for r in range(world):
+        a, b = res[0][r], res[1][r]
+        for k in a[0]:
+            np.testing.assert_array_equal(a[0][k], b[0][k])
+        for i in (1, 2):
+            for x, y in zip(a[i], b[i]):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
