@@ -375,10 +375,15 @@ typedef struct ps_comm_ops {
                         const int64_t *recv_counts, size_t elem_bytes, void *stream);
     int (*all_reduce_sum_f32)(void *ctx, float *buf, int64_t n, void *stream);
 } ps_comm_ops_t;
-int ps_comm_rccl_unique_id(char *out128);
-int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id128, ps_comm_ops_t *out);
+int ps_comm_rccl_unique_id(char *out256);   /* two 128-byte ids: main + prefetch communicator */
+int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id256, ps_comm_ops_t *out);
 int ps_comm_rccl_destroy(ps_comm_ops_t *ops);
 int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);
+/* The step in two halves.  _begin enqueues what reads no weight (plan, counts all-gather) without a host
+ * wait; use_side = 1 runs it on the store's prefetch stream so that step t+1 can begin -- on another model of
+ * the same store -- before step t finishes.  _finish waits for the counts and enqueues the rest. */
+int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side);
+int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss);
 
 /* Replicated tensors: one flat device buffer
  * [fc weights+biases | wide G | wide C | wide.bias g] to all-reduce(sum);

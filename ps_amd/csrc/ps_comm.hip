@@ -64,7 +64,9 @@ int rccl_load() {
 
 #define RCCLCHK(x) do { int r__ = (x); if (r__ != 0) return ps_set_err(PS_E_HIP, "%s -> %s", #x, g_rccl.GetErrorString(r__)); } while (0)
 
-struct RcclCtx { rcclComm_t comm = nullptr; int nranks = 1, rank = 0; };
+// `side` carries the counts all-gather of the NEXT step's prefetch (its own communicator: operations on one
+// communicator are ordered, so sharing it would chain the running step behind the prefetch)
+struct RcclCtx { rcclComm_t comm = nullptr, side = nullptr; int nranks = 1, rank = 0; };
 
 int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
@@ -73,7 +75,7 @@ int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void 
         HIPCHK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
         return PS_OK;
     }
-    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, c->comm, st));
+    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, c->side ? c->side : c->comm, st));
     return PS_OK;
 }
 
@@ -124,17 +126,19 @@ int grow(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
 
 }  // namespace
 
-extern "C" int ps_comm_rccl_unique_id(char *out128) {
-    if (!out128) return ps_set_err(PS_E_BAD_ARG, "null argument");
+extern "C" int ps_comm_rccl_unique_id(char *out256) {
+    if (!out256) return ps_set_err(PS_E_BAD_ARG, "null argument");
     PSCHK(rccl_load());
-    rcclUniqueId id;
-    RCCLCHK(g_rccl.GetUniqueId(&id));
-    memcpy(out128, id.internal, 128);
+    for (int k = 0; k < 2; ++k) {          // two ids: the main communicator and the prefetch one
+        rcclUniqueId id;
+        RCCLCHK(g_rccl.GetUniqueId(&id));
+        memcpy(out256 + 128 * k, id.internal, 128);
+    }
     return PS_OK;
 }
 
-extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id128, ps_comm_ops_t *out) {
-    if (!s || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id128)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id256, ps_comm_ops_t *out) {
+    if (!s || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id256)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(s->device));
     RcclCtx *c = new RcclCtx();
     c->nranks = nranks; c->rank = rank;
@@ -142,9 +146,17 @@ extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const ch
         int rc = rccl_load();
         if (rc != PS_OK) { delete c; return rc; }
         rcclUniqueId id;
-        memcpy(id.internal, id128, 128);
-        const int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
-        if (r != 0) { delete c; return ps_set_err(PS_E_HIP, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r)); }
+        memcpy(id.internal, id256, 128);
+        int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+        if (r == 0) {
+            memcpy(id.internal, id256 + 128, 128);
+            r = g_rccl.CommInitRank(&c->side, nranks, id, rank);
+        }
+        if (r != 0) {
+            if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+            delete c;
+            return ps_set_err(PS_E_HIP, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r));
+        }
     }
     memset(out, 0, sizeof *out);
     out->ctx = c; out->nranks = nranks; out->rank = rank;
@@ -155,6 +167,7 @@ extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const ch
 extern "C" int ps_comm_rccl_destroy(ps_comm_ops_t *ops) {
     if (!ops || !ops->ctx) return PS_OK;
     RcclCtx *c = (RcclCtx *)ops->ctx;
+    if (c->side) (void)g_rccl.CommDestroy(c->side);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     delete c;
     ops->ctx = nullptr;
@@ -164,17 +177,35 @@ extern "C" int ps_comm_rccl_destroy(ps_comm_ops_t *ops) {
 // ---------------------------------------------------------------------------
 // one BSP (or async) step of worker + owner
 // ---------------------------------------------------------------------------
-extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss) {
+// Measured on MI355X at N = 1: beginning step t+1 on the prefetch stream while step t trains is SLOWER (0.40 vs
+// 0.33 ms per step) -- the plan is a chain of ~15 tiny kernels, and interleaving them with the training chain
+// delays every launch of the critical path more than the overlap saves; bench.py therefore runs the halves back
+// to back (--overlap 0).  The split stays: it is what a host with longer steps (bigger batches) would use.
+// begin: everything of a step that reads no weight -- plan, per-owner counts, the all-gather of the counts and
+// their copy to pinned memory -- enqueued without a host wait.  use_side != 0 runs it on the store's prefetch
+// stream (and the prefetch communicator) so it can run beside the previous step's training: call begin for
+// step t+1 (on ANOTHER model of the same store: its own key lists and activations) before finish of step t.
+extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side) {
     if (!m || !batch || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32)
         return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
     const int nsh = comm->nranks, rank = comm->rank;
     if (nsh < 1 || rank < 0 || rank >= nsh) return ps_set_err(PS_E_BAD_ARG, "bad communicator");
     HIPCHK(hipSetDevice(s->device));
-    hipStream_t st = s->stream;
-    PSCHK(ps_shard_plan_launch(m, batch, nsh, nullptr));
+    if (use_side && !s->prefetch_stream) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&s->prefetch_stream, hipStreamNonBlocking, hi));
+    }
+    hipStream_t st = use_side ? s->prefetch_stream : s->stream;
     ps_model::Shard &sh = m->sh;
-    const int D = m->cfg.D;
+    if (!sh.x_ev) {
+        HIPCHK(hipEventCreateWithFlags(&sh.x_ev, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sh.done_ev, hipEventDisableTiming));
+    }
+    // this model's previous step still reads its key lists until its finish has run on the training stream
+    if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
+    PSCHK(ps_shard_plan_launch(m, batch, nsh, use_side ? (void *)st : nullptr));
     if (!sh.counts_dev) {
         HIPCHK(hipMalloc((void **)&sh.counts_dev, sizeof(int64_t) * (size_t)nsh));
         HIPCHK(hipMalloc((void **)&sh.matrix_dev, sizeof(int64_t) * (size_t)nsh * nsh));
@@ -184,8 +215,23 @@ extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_co
     HIPCHK(hipGetLastError());
     PSCHK(comm->all_gather(comm->ctx, sh.counts_dev, sh.matrix_dev, sizeof(int64_t) * (size_t)nsh, st));
     HIPCHK(hipMemcpyAsync(sh.matrix_host, sh.matrix_dev, sizeof(int64_t) * (size_t)nsh * nsh, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));                  // the step's one host wait: split sizes of every exchange
-    sh.plan_pending = false;
+    HIPCHK(hipEventRecord(sh.x_ev, st));
+    sh.x_begun = true; sh.x_side = use_side != 0;
+    return PS_OK;
+}
+
+extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss) {
+    if (!m || !comm) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    ps_store *s = m->s;
+    ps_model::Shard &sh = m->sh;
+    if (!sh.x_begun) return ps_set_err(PS_E_STATE, "ps_shard_step_begin first");
+    const int nsh = comm->nranks, rank = comm->rank;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    HIPCHK(hipEventSynchronize(sh.x_ev));              // the step's one host wait: split sizes of every exchange
+    if (sh.x_side) HIPCHK(hipStreamWaitEvent(st, sh.x_ev, 0));
+    sh.x_begun = false; sh.plan_pending = false;
+    const int D = m->cfg.D;
     std::vector<int64_t> sc((size_t)nsh), rc((size_t)nsh);
     int64_t U = 0, nrecv = 0;
     for (int o = 0; o < nsh; ++o) {
@@ -210,9 +256,16 @@ extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_co
     PSCHK(comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st));
     PSCHK(ps_shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, rc.data(), nsh, is_async));
     PSCHK(ps_shard_apply_flat(m, nsh));
+    HIPCHK(hipEventRecord(sh.done_ev, st));
+    sh.done_recorded = true;
     if (loss) {
         HIPCHK(hipMemcpyAsync(loss, m->loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     return PS_OK;
+}
+
+extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss) {
+    PSCHK(ps_shard_step_begin(m, batch, comm, 0));
+    return ps_shard_step_finish(m, comm, is_async, loss);
 }

@@ -41,6 +41,7 @@ struct ps_store {
     uint64_t seed = 0;
     hipStream_t stream = nullptr;      // the stream everything is enqueued on (own_stream, or one adopted from the host)
     hipStream_t own_stream = nullptr;
+    hipStream_t prefetch_stream = nullptr;   // ps_shard_step_begin(use_side): the next step's key lists, beside training
     EmbTables emb;
     WideTable wide;
     std::vector<FcParams> fc;
@@ -121,6 +122,8 @@ struct ps_model {
         float *x_rows_out = nullptr; int64_t x_rows_cap = 0;
         float *x_recv_grads = nullptr; int64_t x_grads_cap = 0;
         float *x_cache = nullptr; int64_t x_cache_cap = 0;
+        hipEvent_t x_ev = nullptr, done_ev = nullptr;   // begin's work is done | finish's work was enqueued
+        bool x_begun = false, x_side = false, done_recorded = false;
     } sh;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)

@@ -233,6 +233,7 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);
     fr(s->push_mask); fr(s->push_pos);
     (void)hipStreamDestroy(s->own_stream);    // an adopted stream belongs to the host
+    if (s->prefetch_stream) (void)hipStreamDestroy(s->prefetch_stream);
     delete s;
     return PS_OK;
 }

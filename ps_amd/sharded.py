@@ -466,32 +466,52 @@ class HipBackend:
 # the library-driven step: ONE C call (ps_shard_step) per step, RCCL bound inside libps_amd.so
 # ---------------------------------------------------------------------------
 class NativeWorker:
-    """ps_shard_step over a ps_comm_ops_t.  `ops` None: an RCCL communicator is created from `id128`
-    (made by rank 0 with NativeWorker.unique_id() and handed to every rank by the host)."""
+    """ps_shard_step over a ps_comm_ops_t.  `ops` None: an RCCL communicator pair is created from `id256`
+    (made by rank 0 with NativeWorker.unique_id() and handed to every rank by the host).
+    `models`: one ps_model, or two on the same store -- then `run` begins step t+1 (its key lists and the
+    counts all-gather, on the prefetch stream) before it finishes step t."""
 
-    def __init__(self, model, nranks, rank, id128=None, ops=None, is_async=False):
-        self.m, self.kv, self.is_async = model, model.store, is_async
+    def __init__(self, models, nranks, rank, id256=None, ops=None, is_async=False):
+        self.models = list(models) if isinstance(models, (list, tuple)) else [models]
+        self.kv, self.is_async = self.models[0].store, is_async
         self._own = ops is None
         if ops is None:
             ops = N.ps_comm_ops_t()
-            N.check(N.lib().ps_comm_rccl_create(self.kv.h, nranks, rank, id128, C.byref(ops)))
+            N.check(N.lib().ps_comm_rccl_create(self.kv.h, nranks, rank, id256, C.byref(ops)))
         self.ops = ops
 
     @staticmethod
     def unique_id():
-        buf = C.create_string_buffer(128)
+        buf = C.create_string_buffer(256)
         N.check(N.lib().ps_comm_rccl_unique_id(buf))
         return buf.raw
 
     def step(self, batch, want_loss=True):
         loss = C.c_float()
-        N.check(N.lib().ps_shard_step(self.m.h, C.byref(batch.c), C.byref(self.ops), int(self.is_async), C.byref(loss) if want_loss else None))
+        N.check(N.lib().ps_shard_step(self.models[0].h, C.byref(batch.c), C.byref(self.ops), int(self.is_async), C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
+    def begin(self, k, batch, side=True):
+        N.check(N.lib().ps_shard_step_begin(self.models[k].h, C.byref(batch.c), C.byref(self.ops), int(side)))
+
+    def finish(self, k, want_loss=False):
+        loss = C.c_float()
+        N.check(N.lib().ps_shard_step_finish(self.models[k].h, C.byref(self.ops), int(self.is_async), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
 
     def run(self, batches, steps, want_loss=False):
+        nb, nm = len(batches), len(self.models)
         loss = None
+        if nm < 2:
+            for i in range(steps):
+                loss = self.step(batches[i % nb], want_loss)
+            return loss
+        if steps > 0:
+            self.begin(0, batches[0])
         for i in range(steps):
-            loss = self.step(batches[i % len(batches)], want_loss)
+            if i + 1 < steps:
+                self.begin((i + 1) % 2, batches[(i + 1) % nb])      # step i+1's key lists beside step i's training
+            loss = self.finish(i % 2, want_loss)
         return loss
 
     def close(self):
@@ -527,14 +547,15 @@ def run_bench(args, cfg, synth_batch):
     if native:
         # the library drives the exchange (ps_shard_step: one C call per step, RCCL bound inside libps_amd.so);
         # torch.distributed only hands the 128-byte RCCL id round and keeps the bench's barriers
-        gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])]
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+               for _ in range(2 if overlap else 1)]      # two plan contexts: step t+1 begins before step t finishes
+        idt = torch.zeros(256, dtype=torch.uint8, device=dev)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(NativeWorker.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         ok = torch.ones(1, dtype=torch.int32, device=dev)
         try:
-            worker = NativeWorker(gms[0], world, rank, id128=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
+            worker = NativeWorker(gms, world, rank, id256=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
         except Exception as e:      # noqa: BLE001 -- decided collectively below
             worker = None
             ok.zero_()
@@ -549,6 +570,7 @@ def run_bench(args, cfg, synth_batch):
         else:
             worker_run = lambda n: worker.run(batches, n)                              # noqa: E731
     if not native:
+        overlap = bool(getattr(args, "overlap_torch", 0))     # measured: no gain on this wire (host-bound), keep it simple
         gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
                for _ in range(4 if overlap else 1)]       # plan contexts: steps t+1, t+2 are planned while step t trains and t-1 drains
         torch.cuda.set_stream(torch.cuda.Stream(dev))      # not the legacy null stream (implicit syncs with blocking streams)
@@ -599,7 +621,7 @@ def run_bench(args, cfg, synth_batch):
                                    "embedding rows sharded id mod N (PSRouterClient routing -> RCCL all-to-all-v), dense + wide all-reduce, BSP",
                        "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True,
                        "exchange_driver": "libps_amd (ps_shard_step, RCCL via dlopen)" if native else "torch.distributed",
-                       "prefetch_next_key_lists": overlap and not native, "prefetch_thread": threaded,
+                       "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
                        "priming_steps_untimed": int(getattr(args, "priming", 300))},
             "final_loss": loss,
         }

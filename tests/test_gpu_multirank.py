@@ -252,18 +252,23 @@ class CallbackComm:
         return self._guard(f)
 
 
-def native_rank_main(rank, world, shared, is_async, out, errs):
+def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
     try:
         import ps_amd
         from ps_amd.sharded import NativeWorker
         F, D, V = CFG["F"], CFG["D"], CFG["V"]
         kv = ps_amd.KVStore(0, SEED)
         kv.create_embedding([V] * F, D, shard=rank, nshards=world)
-        gm = ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"])
+        gms = [ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"]) for _ in range(2 if pipelined else 1)]
+        gm = gms[0]
         comm = CallbackComm(rank, shared, kv)
-        wk = NativeWorker(gm, world, rank, ops=comm.ops, is_async=is_async)
-        for b in make_batches(rank, STEPS):
-            wk.step(ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]))
+        wk = NativeWorker(gms, world, rank, ops=comm.ops, is_async=is_async)
+        bs = [ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]) for b in make_batches(rank, STEPS)]
+        if pipelined:
+            wk.run(bs, STEPS)                   # begin(t+1) on the prefetch stream before finish(t)
+        else:
+            for b in bs:
+                wk.step(b)
         kv.sync()
         if comm.err is not None:
             raise comm.err
@@ -275,18 +280,20 @@ def native_rank_main(rank, world, shared, is_async, out, errs):
                 rows[(f, int(idv))] = w[i]
         out[rank] = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)],
                      kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step())
-        gm.close(); kv.close()
+        for g in gms:
+            g.close()
+        kv.close()
     except BaseException:       # noqa: BLE001
         import traceback
         errs.append((rank, traceback.format_exc()))
         shared.barrier.abort()
 
 
-@pytest.mark.parametrize("world,is_async", [(2, False), (4, False), (3, True)])
-def test_library_driven_step_n_ranks_on_one_gpu(orc, world, is_async):
+@pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (3, True, False), (2, True, True)])
+def test_library_driven_step_n_ranks_on_one_gpu(orc, world, is_async, pipelined):
     shared = Shared(world)
     out, errs = [None] * world, []
-    th = [threading.Thread(target=native_rank_main, args=(r, world, shared, is_async, out, errs)) for r in range(world)]
+    th = [threading.Thread(target=native_rank_main, args=(r, world, shared, is_async, out, errs, pipelined)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:

@@ -562,25 +562,32 @@ def test_library_driven_step_n1_equals_fused_step():
     from ps_amd.sharded import NativeWorker
     F, D, X, fc, V, B, WS = 5, 8, 3, [16, 8, 1], 40, 96, 31
     res = []
-    for native in (False, True):
+    for native in (0, 1, 2):                   # fused | one call per step | begin(t+1) before finish(t), two models
         kv = ps_amd.KVStore(0, SEED)
         kv.create_embedding([V] * F, D)
-        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
-        wk = NativeWorker(gm, 1, 0) if native else None
+        gms = [ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B) for _ in range(max(native, 1))]
+        gm = gms[0]
+        wk = NativeWorker(gms, 1, 0) if native else None
         rng = np.random.default_rng(4)
-        losses = []
+        bs = []
         for _ in range(5):
             E, Xd, Y = data(rng, B, F, X, V, True)
-            b = ps_amd.Batch(E, Xd, Y, E % WS)
-            losses.append(wk.step(b) if native else gm.train(b))
+            bs.append(ps_amd.Batch(E, Xd, Y, E % WS))
+        if native == 2:
+            losses = res[0][0][:-1] + [wk.run(bs, len(bs), want_loss=True)]
+        else:
+            losses = [wk.step(b) if native else gm.train(b) for b in bs]
         res.append((losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)],
                     kv.get_wide(np.arange(WS)), kv.get("wide.bias"), kv.global_step()))
         if wk:
             wk.close()
-        gm.close(); kv.close()
-    a, b = res
-    assert a[0] == b[0] and a[5] == b[5]
-    for i in (1, 2):
-        for x, y in zip(a[i], b[i]):
-            np.testing.assert_array_equal(x, y)
-    np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+        for g in gms:
+            g.close()
+        kv.close()
+    a = res[0]
+    for b in res[1:]:
+        assert a[0] == b[0] and a[5] == b[5]
+        for i in (1, 2):
+            for x, y in zip(a[i], b[i]):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
