@@ -36,6 +36,16 @@ public final class NativeKVStore implements AutoCloseable {
     public native float[] predict(long model, long[] E, float[] X, long[] W, int B);
     public native void destroyModel(long model);
 
+    // -Dmode=dist: one process per GPU is worker and owner (net/PSRouterClient.java:60-151, net/PServer.java:102-283)
+    public static native byte[] commUniqueId();                                   // rank 0; hand the 256 bytes to every rank
+    public native long commCreate(int nranks, int rank, byte[] id);               // RCCL inside libps_amd (ps_comm_rccl_create)
+    public native float shardStep(long model, long comm, long[] E, float[] X, long[] W, float[] Y, int B, boolean isPsAsync);
+
+    // the rows either side of the path
+    public native double auc(float[] p, float[] y);                               // evaluate/AUC.java
+    public native void save(String path);                                         // shard checkpoint
+    public native void load(String path);
+
     private static native long create(int device, long seed);
     private static native void destroy(long handle);
     long handle() { return handle; }

@@ -64,6 +64,23 @@ JNIEXPORT jfloat JNICALL Java_store_NativeKVStore_train(JNIEnv *env, jobject, jl
     fail(env, rc);
     return loss;
 }
+JNIEXPORT jfloat JNICALL Java_store_NativeKVStore_shardStep(JNIEnv *env, jobject, jlong model, jlong comm, jlongArray E, jfloatArray X,
+                                                            jlongArray W, jfloatArray Y, jint B, jboolean isPsAsync) {
+    ps_batch_t b = {};
+    b.B = B;
+    jlong *e = env->GetLongArrayElements(E, nullptr);
+    jfloat *x = env->GetFloatArrayElements(X, nullptr), *y = env->GetFloatArrayElements(Y, nullptr);
+    jlong *w = W ? env->GetLongArrayElements(W, nullptr) : nullptr;
+    b.ids = reinterpret_cast<const int64_t *>(e); b.dense = x; b.labels = y; b.wide_ids = reinterpret_cast<const int64_t *>(w);
+    float loss = 0.f;       // pull + train + push + psUpdate + barrier of one minibatch, all ranks in step
+    const int rc = ps_shard_step(reinterpret_cast<ps_model_t *>(model), &b, reinterpret_cast<const ps_comm_ops_t *>(comm), isPsAsync ? 1 : 0, &loss);
+    env->ReleaseLongArrayElements(E, e, JNI_ABORT); env->ReleaseFloatArrayElements(X, x, JNI_ABORT);
+    env->ReleaseFloatArrayElements(Y, y, JNI_ABORT); if (w) env->ReleaseLongArrayElements(W, w, JNI_ABORT);
+    fail(env, rc);
+    return loss;
+}
+// commUniqueId / commCreate: ps_comm_rccl_unique_id into a byte[256]; a heap ps_comm_ops_t filled by ps_comm_rccl_create.
+// auc / save / load: ps_auc_compute(on_device = 0), ps_store_save, ps_store_load.
 // getRows / putRows / createEmbedding / createWide / createFc / buildModel / predict / destroyModel / globalStep:
 // the same pattern over ps_store_get_rows, ps_store_put_rows, ps_store_create_*, ps_model_create, ps_model_predict,
 // ps_model_destroy, ps_store_global_step.
