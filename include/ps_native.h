@@ -236,6 +236,8 @@ int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets
 int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx,
                   int B, float *y_dev, int ldy);
 int ps_store_sync(ps_store_t *s);
+/* Host wait for one HIP stream (NULL = the store's): for ps_comm_ops_t callbacks that stage through the host. */
+int ps_stream_sync(ps_store_t *s, void *hip_stream);
 
 /* ---- data.LibsvmParser + CTR.parseFeature + DataSource/DataSet -----------
  * The step in FRONT of the hot path: libsvm text -> the

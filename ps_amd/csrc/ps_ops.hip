@@ -168,6 +168,15 @@ extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, in
 // ---------------------------------------------------------------------------
 // tuning knobs and the GEMM micro-benchmark (measurement only)
 // ---------------------------------------------------------------------------
+// Host wait for one stream (NULL: the store's) -- for hosts that plug their own collectives into ps_comm_ops_t
+// and stage through the host: the callbacks' `stream` argument is the stream their inputs were produced on.
+extern "C" int ps_stream_sync(ps_store_t *s, void *hip_stream) {
+    if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : s->stream));
+    return PS_OK;
+}
+
 extern "C" int ps_tune_set(const char *knob, int value) {
     if (!knob) return ps_set_err(PS_E_BAD_ARG, "null knob");
     if (strcmp(knob, "gemm_nt_cfg") == 0) { g_gemm_nt_cfg = value; return PS_OK; }

@@ -90,6 +90,7 @@ SIGNATURES = {
     "ps_store_global_step": (_i64, [_vp]),
     "ps_store_bytes": (_i64, [_vp]),
     "ps_store_sync": (_i, [_vp]),
+    "ps_stream_sync": (_i, [_vp, _vp]),
     "ps_model_create": (_i, [_vp, C.POINTER(ps_model_config_t), _pvp]),
     "ps_model_destroy": (_i, [_vp]),
     "ps_model_train": (_i, [_vp, C.POINTER(ps_batch_t), _pf]),

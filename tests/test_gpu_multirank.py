@@ -215,9 +215,9 @@ class CallbackComm:
         self.sh.barrier.wait()
         return got
 
-    def _guard(self, fn):
+    def _guard(self, fn, stream):
         try:
-            self.kv.sync()                      # the callbacks are "enqueue on stream": here simply drained first
+            self.N.check(self.N.lib().ps_stream_sync(self.kv.h, stream))    # "enqueue on stream": here the stream is drained first
             fn()
             return 0
         except BaseException as e:             # noqa: BLE001 -- reported through the status code
@@ -229,7 +229,7 @@ class CallbackComm:
         def f():
             parts = self._swap(self._down(send, nbytes))
             self._up(recv, np.concatenate(parts))
-        return self._guard(f)
+        return self._guard(f, stream)
 
     def all_to_all_v(self, ctx, send, sc, recv, rc, eb, stream):
         def f():
@@ -240,7 +240,7 @@ class CallbackComm:
             pieces = [h[o[self.rank]:o[self.rank + 1]] for h, o in parts]
             assert [len(x) // eb for x in pieces] == rcl
             self._up(recv, np.concatenate(pieces) if pieces else np.zeros(0, np.uint8))
-        return self._guard(f)
+        return self._guard(f, stream)
 
     def all_reduce(self, ctx, buf, n, stream):
         def f():
@@ -249,7 +249,7 @@ class CallbackComm:
             for p in parts[1:]:
                 tot = (tot + p).astype(f32)
             self._up(buf, tot)
-        return self._guard(f)
+        return self._guard(f, stream)
 
 
 def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
@@ -344,3 +344,129 @@ def test_library_driven_step_equals_python_driven_step():
             for x, y in zip(a[i], b[i]):
                 np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs[4] semantics at small scale: multi-hot bags (incl. empty ones), FTRL on every embedding
+# row, async push, N ranks -- through ps_shard_step.  Expected: the PS semantics re-played on the host with the
+# single-GPU split form as each worker's gradient engine (forward + backward(apply = false) on a full-table
+# store loaded with the step's global weights), then mean / per-push updates with the oracle's updaters.
+# ---------------------------------------------------------------------------
+BF, BV, BD, BX, BFC, BB = 3, 23, 4, 2, [6, 4, 1], 10
+
+
+def bag_batches(rank, steps):
+    rng = np.random.default_rng(500 + rank)
+    out = []
+    for _ in range(steps):
+        lens = rng.integers(0, 5, size=BB * BF)
+        lens[2] = 0
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = rng.integers(0, BV, size=int(offsets[-1])).astype(np.int64)
+        ids[:3] = [1, 2, 3][:len(ids[:3])]                       # keys several workers push in the same step
+        out.append({"E": ids, "offsets": offsets, "X": rng.standard_normal((BB, BX)).astype(f32), "Y": (rng.random(BB) < 0.4).astype(f32)})
+    return out
+
+
+def bag_rank_main(rank, world, shared, is_async, out, errs):
+    try:
+        import ps_amd
+        from ps_amd.sharded import NativeWorker
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([BV] * BF, BD, shard=rank, nshards=world)
+        kv.set_updater("emF", ps_amd.FtrlUpdater())
+        gm = ps_amd.DNN.buildModel(BF, BD, BX, BFC, store=kv, max_batch=BB, max_nnz=BB * BF * 5)
+        comm = CallbackComm(rank, shared, kv)
+        wk = NativeWorker(gm, world, rank, ops=comm.ops, is_async=is_async)
+        for b in bag_batches(rank, STEPS):
+            wk.step(ps_amd.Batch(b["E"], b["X"], b["Y"], None, b["offsets"]))
+        kv.sync()
+        if comm.err is not None:
+            raise comm.err
+        rows = {}
+        for f in range(BF):
+            ids = np.arange(rank, BV, world)
+            w, z, n = kv.get_rows(f, ids), kv.get_rows(f, ids, 1), kv.get_rows(f, ids, 2)
+            for i, idv in enumerate(ids):
+                rows[(f, int(idv))] = (w[i], z[i], n[i])
+        out[rank] = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)])
+        gm.close(); kv.close()
+    except BaseException:       # noqa: BLE001
+        import traceback
+        errs.append((rank, traceback.format_exc()))
+        shared.barrier.abort()
+
+
+def bag_expected(orc, world, is_async):
+    import ps_amd
+    engines = []
+    for w in range(world):                      # one full-table store + model per worker: its gradient engine
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([BV] * BF, BD)
+        engines.append((kv, ps_amd.DNN.buildModel(BF, BD, BX, BFC, store=kv, max_batch=BB, max_nnz=BB * BF * 5)))
+    kv0 = engines[0][0]
+    allid = np.arange(BV)
+    W = [kv0.get_rows(f, allid) for f in range(BF)]
+    Z = [np.zeros_like(x) for x in W]; Nn = [np.zeros_like(x) for x in W]
+    fcW = [kv0.get("fc%d.weights" % l) for l in range(3)]; fcb = [kv0.get("fc%d.bias" % l) for l in range(3)]
+    fcS = [[np.zeros_like(w), np.zeros_like(w), np.zeros_like(b), np.zeros_like(b)] for w, b in zip(fcW, fcb)]
+    data = [bag_batches(w, STEPS) for w in range(world)]
+    for step in range(STEPS):
+        pushes, dense = {}, None
+        for w, (kv, gm) in enumerate(engines):
+            for f in range(BF):
+                kv.put_rows(f, allid, W[f])
+            for l in range(3):
+                kv.put("fc%d.weights" % l, fcW[l]); kv.put("fc%d.bias" % l, fcb[l])
+            b = data[w][step]
+            gm.forward({"E": b["E"], "X": b["X"], "Y": b["Y"], "offsets": b["offsets"]})
+            gm.backward()
+            for f in range(BF):
+                ids, g = gm.emb_grads(f)
+                for i, idv in enumerate(ids):
+                    pushes.setdefault((f, int(idv)), []).append(g[i])           # worker order
+            d = np.concatenate([np.concatenate([gm.fc_grad(l), gm.fc_grad(l, True)]) for l in range(3)])
+            dense = d if dense is None else (dense + d).astype(f32)
+        for (f, i), gs in pushes.items():
+            if is_async:
+                for g in gs:
+                    W[f][i], Z[f][i], Nn[f][i], _ = orc.ftrl_update(W[f][i], g, Z[f][i], Nn[f][i])
+            else:
+                S = gs[0].copy()
+                for g in gs[1:]:
+                    S = (g + S).astype(f32)
+                W[f][i], Z[f][i], Nn[f][i], _ = orc.ftrl_update(W[f][i], (S / f32(len(gs))).astype(f32), Z[f][i], Nn[f][i])
+        off = 0
+        for l in range(3):
+            nw, nb = fcW[l].size, fcb[l].size
+            gw = (dense[off:off + nw] / f32(world)).astype(f32); off += nw
+            gb = (dense[off:off + nb] / f32(world)).astype(f32); off += nb
+            fcW[l], fcS[l][0], fcS[l][1] = orc.adam_update(fcW[l], gw, fcS[l][0], fcS[l][1])
+            fcb[l], fcS[l][2], fcS[l][3] = orc.adam_update(fcb[l], gb, fcS[l][2], fcS[l][3])
+    for kv, gm in engines:
+        gm.close(); kv.close()
+    return W, Z, Nn, fcW, fcb
+
+
+@pytest.mark.parametrize("world,is_async", [(3, True), (2, False)])
+def test_multi_hot_ftrl_ranks(orc, world, is_async):
+    shared = Shared(world)
+    out, errs = [None] * world, []
+    th = [threading.Thread(target=bag_rank_main, args=(r, world, shared, is_async, out, errs)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, "\n".join("rank %d:\n%s" % e for e in errs)
+    W, Z, Nn, fcW, fcb = bag_expected(orc, world, is_async)
+    moved = 0
+    for r in range(world):
+        rows, gW, gb = out[r]
+        for (f, i), (w, z, n) in rows.items():
+            assert i % world == r
+            np.testing.assert_array_equal(w, W[f][i], err_msg="rank %d emF%d.%d w" % (r, f, i))
+            np.testing.assert_array_equal(z, Z[f][i]); np.testing.assert_array_equal(n, Nn[f][i])
+            moved += int(np.any(n != 0))
+        for l in range(3):
+            np.testing.assert_array_equal(gW[l], fcW[l]); np.testing.assert_array_equal(gb[l], fcb[l])
+    assert moved > 10
