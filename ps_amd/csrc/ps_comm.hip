@@ -103,13 +103,10 @@ int rccl_all_to_all_v(void *ctx, const void *send, const int64_t *sc, void *recv
 int rccl_all_reduce(void *ctx, float *buf, int64_t n, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
     if (c->nranks == 1 || n <= 0) return PS_OK;
-    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, c->comm, (hipStream_t)stream));
+    // on the side communicator: it runs beside the gradient all-to-all-v of the main one (per step the side
+    // communicator sees all-gather, all-reduce -- the same order on every rank)
+    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, c->side ? c->side : c->comm, (hipStream_t)stream));
     return PS_OK;
-}
-
-__global__ void k_owner_counts(const uint32_t *__restrict__ owner_start, int nsh, int64_t *__restrict__ counts) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < nsh) counts[o] = (int64_t)owner_start[o + 1] - (int64_t)owner_start[o];
 }
 
 template <typename T>
@@ -205,16 +202,14 @@ extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const
     }
     // this model's previous step still reads its key lists until its finish has run on the training stream
     if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
-    PSCHK(ps_shard_plan_launch(m, batch, nsh, use_side ? (void *)st : nullptr));
-    if (!sh.counts_dev) {
-        HIPCHK(hipMalloc((void **)&sh.counts_dev, sizeof(int64_t) * (size_t)nsh));
-        HIPCHK(hipMalloc((void **)&sh.matrix_dev, sizeof(int64_t) * (size_t)nsh * nsh));
-        HIPCHK(hipHostMalloc((void **)&sh.matrix_host, sizeof(int64_t) * (size_t)nsh * nsh, hipHostMallocDefault));
+    PSCHK(shard_plan_enqueue(m, batch, nsh, st, false));
+    const size_t row = sizeof(uint32_t) * (size_t)(nsh + 1);        // every rank's owner_start[0..nranks]: the host takes the differences
+    if (!sh.matrix_dev) {
+        HIPCHK(hipMalloc((void **)&sh.matrix_dev, row * (size_t)nsh));
+        HIPCHK(hipHostMalloc((void **)&sh.matrix_host, row * (size_t)nsh, hipHostMallocDefault));
     }
-    hipLaunchKernelGGL(k_owner_counts, dim3(cdiv(nsh, 64)), dim3(64), 0, st, sh.owner_start, nsh, sh.counts_dev);
-    HIPCHK(hipGetLastError());
-    PSCHK(comm->all_gather(comm->ctx, sh.counts_dev, sh.matrix_dev, sizeof(int64_t) * (size_t)nsh, st));
-    HIPCHK(hipMemcpyAsync(sh.matrix_host, sh.matrix_dev, sizeof(int64_t) * (size_t)nsh * nsh, hipMemcpyDeviceToHost, st));
+    PSCHK(comm->all_gather(comm->ctx, sh.owner_start, sh.matrix_dev, row, st));
+    HIPCHK(hipMemcpyAsync(sh.matrix_host, sh.matrix_dev, row * (size_t)nsh, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(sh.x_ev, st));
     sh.x_begun = true; sh.x_side = use_side != 0;
     return PS_OK;
@@ -235,8 +230,9 @@ extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, in
     std::vector<int64_t> sc((size_t)nsh), rc((size_t)nsh);
     int64_t U = 0, nrecv = 0;
     for (int o = 0; o < nsh; ++o) {
-        sc[o] = sh.matrix_host[(size_t)rank * nsh + o];     // what I request from / push to owner o
-        rc[o] = sh.matrix_host[(size_t)o * nsh + rank];     // what worker o requests from / pushes to me
+        const uint32_t *mine = sh.matrix_host + (size_t)rank * (nsh + 1), *theirs = sh.matrix_host + (size_t)o * (nsh + 1);
+        sc[o] = (int64_t)mine[o + 1] - (int64_t)mine[o];              // what I request from / push to owner o
+        rc[o] = (int64_t)theirs[rank + 1] - (int64_t)theirs[rank];    // what worker o requests from / pushes to me
         if (sc[o] < 0 || rc[o] < 0) return ps_set_err(PS_E_STATE, "negative key count in the exchange matrix");
         U += sc[o]; nrecv += rc[o];
     }
@@ -251,10 +247,26 @@ extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, in
     PSCHK(comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st));
     // train on the cache
     PSCHK(ps_shard_forward_backward(m, sh.x_cache, nullptr));
-    // push: dense + wide in one reduction, per-key gradients to their owners
-    PSCHK(comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, st));
+    // push: the dense + wide reduction runs on the prefetch stream (its own communicator) beside the per-key
+    // gradient exchange and the owner update; the replicated update waits for it
+    if (nsh > 1) {
+        if (!s->prefetch_stream) {
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&s->prefetch_stream, hipStreamNonBlocking, hi));
+        }
+        if (!sh.ar_ev) {
+            HIPCHK(hipEventCreateWithFlags(&sh.ar_ev, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sh.ar_done_ev, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(sh.ar_ev, st));
+        HIPCHK(hipStreamWaitEvent(s->prefetch_stream, sh.ar_ev, 0));
+        PSCHK(comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, s->prefetch_stream));
+        HIPCHK(hipEventRecord(sh.ar_done_ev, s->prefetch_stream));
+    }
     PSCHK(comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st));
     PSCHK(ps_shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, rc.data(), nsh, is_async));
+    if (nsh > 1) HIPCHK(hipStreamWaitEvent(st, sh.ar_done_ev, 0));
     PSCHK(ps_shard_apply_flat(m, nsh));
     HIPCHK(hipEventRecord(sh.done_ev, st));
     sh.done_recorded = true;

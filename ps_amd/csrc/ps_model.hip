@@ -156,7 +156,9 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     if (m->sh.matrix_host) (void)hipHostFree(m->sh.matrix_host);
     if (m->sh.x_ev) (void)hipEventDestroy(m->sh.x_ev);
     if (m->sh.done_ev) (void)hipEventDestroy(m->sh.done_ev);
-    fr(m->sh.counts_dev); fr(m->sh.matrix_dev); fr(m->sh.x_recv_rows); fr(m->sh.x_rows_out); fr(m->sh.x_recv_grads); fr(m->sh.x_cache);
+    if (m->sh.ar_ev) (void)hipEventDestroy(m->sh.ar_ev);
+    if (m->sh.ar_done_ev) (void)hipEventDestroy(m->sh.ar_done_ev);
+    fr(m->sh.matrix_dev); fr(m->sh.x_recv_rows); fr(m->sh.x_rows_out); fr(m->sh.x_recv_grads); fr(m->sh.x_cache);
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);

@@ -44,12 +44,18 @@ __global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ 
     }
 }
 
-// per unique key: owner-local row to request, and where each owner's run starts
-__global__ __launch_bounds__(256) void k_shard_unique(const uint32_t *__restrict__ sorted_key, const uint32_t *__restrict__ seg_start,
-                                                      const uint32_t *__restrict__ nseg, int sbits, int nshards,
-                                                      uint32_t *__restrict__ send_rows, uint32_t *__restrict__ owner_start) {
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t n = *nseg;
+// One launch for the tail of the plan (it is a chain of tiny kernels: every launch is ~5 us of serial time):
+// thread i stores entry i's slot (its unique key's index) and, when i < nseg, handles unique key i: the
+// owner-local row to request, and where each owner's run starts.  Writes every owner_start entry.
+__global__ __launch_bounds__(256) void k_shard_finish(const uint32_t *__restrict__ sorted_key, const uint32_t *__restrict__ sorted_ent,
+                                                      const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_id,
+                                                      const uint32_t *__restrict__ nseg, int64_t nnz, int sbits, int nshards,
+                                                      uint32_t *__restrict__ send_rows, uint32_t *__restrict__ owner_start,
+                                                      uint32_t *__restrict__ slot) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz) return;
+    slot[sorted_ent[i]] = seg_id[i];
+    const uint32_t n = *nseg, u = (uint32_t)i;
     if (u >= n) return;
     const uint32_t key = sorted_key[seg_start[u]];
     const uint32_t prev = u ? sorted_key[seg_start[u - 1]] : 0u;
@@ -59,12 +65,6 @@ __global__ __launch_bounds__(256) void k_shard_unique(const uint32_t *__restrict
     for (int oo = po + 1; oo <= o; ++oo) owner_start[oo] = u;     // owners without keys start where the next one does
     if (u == n - 1)
         for (int oo = o + 1; oo <= nshards; ++oo) owner_start[oo] = n;
-}
-
-__global__ __launch_bounds__(256) void k_slot_of_entry(const uint32_t *__restrict__ sorted_ent, const uint32_t *__restrict__ seg_id,
-                                                       int64_t n, uint32_t *__restrict__ slot) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) slot[sorted_ent[i]] = seg_id[i];
 }
 
 // rows_out[i][:] = W[rows[i]][:]   (PServer.getList: the rows for a key list)
@@ -144,14 +144,12 @@ extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
     return PS_OK;
 }
 
-extern "C" int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream) {
-    if (!m || !batch || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+// the plan's kernels; readback: also copy owner_start to pinned memory and record plan_ev (ps_shard_plan_finish)
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback) {
     ps_store *s = m->s;
-    HIPCHK(hipSetDevice(s->device));
     PSCHK(ensure_shard_state(m, nshards));
     PSCHK(stage_batch(m, batch, true));
     ps_model::Shard &sh = m->sh;
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
     if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
     const int F = m->cfg.F;
     const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
@@ -161,17 +159,25 @@ extern "C" int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int 
     HIPCHK(hipGetLastError());
     PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
     PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
-    HIPCHK(hipMemsetAsync(sh.owner_start, 0, sizeof(uint32_t) * (nshards + 2), st));
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_shard_unique, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_keys, m->seg_start, m->nseg_dev,
-                           sh.sbits, nshards, sh.send_rows, sh.owner_start);
-        hipLaunchKernelGGL(k_slot_of_entry, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_ents, m->seg_id, nnz, sh.slot);
+        hipLaunchKernelGGL(k_shard_finish, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_keys, m->sorted_ents, m->seg_start, m->seg_id,
+                           m->nseg_dev, nnz, sh.sbits, nshards, sh.send_rows, sh.owner_start, sh.slot);
         HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemsetAsync(sh.owner_start, 0, sizeof(uint32_t) * (nshards + 2), st));
     }
-    HIPCHK(hipMemcpyAsync(sh.owner_start_host, sh.owner_start, sizeof(uint32_t) * (nshards + 1), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(sh.plan_ev, st));
-    sh.plan_pending = true;
+    if (readback) {
+        HIPCHK(hipMemcpyAsync(sh.owner_start_host, sh.owner_start, sizeof(uint32_t) * (nshards + 1), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(sh.plan_ev, st));
+        sh.plan_pending = true;
+    }
     return PS_OK;
+}
+
+extern "C" int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream) {
+    if (!m || !batch || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(m->s->device));
+    return shard_plan_enqueue(m, batch, nshards, hip_stream ? (hipStream_t)hip_stream : m->s->stream, true);
 }
 
 extern "C" int ps_shard_plan_finish(ps_model_t *m, int64_t *counts_out, uint32_t **send_rows_dev, int64_t *n_unique) {

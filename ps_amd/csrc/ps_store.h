@@ -117,12 +117,13 @@ struct ps_model {
         hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
         bool plan_pending = false;
         // ps_shard_step (library-driven exchange): counts, the N x N count matrix, exchange buffers
-        int64_t *counts_dev = nullptr, *matrix_dev = nullptr, *matrix_host = nullptr;
+        uint32_t *matrix_dev = nullptr, *matrix_host = nullptr;      // [nranks][nranks+1]: every rank's owner_start
         uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;
         float *x_rows_out = nullptr; int64_t x_rows_cap = 0;
         float *x_recv_grads = nullptr; int64_t x_grads_cap = 0;
         float *x_cache = nullptr; int64_t x_cache_cap = 0;
         hipEvent_t x_ev = nullptr, done_ev = nullptr;   // begin's work is done | finish's work was enqueued
+        hipEvent_t ar_ev = nullptr, ar_done_ev = nullptr;   // flat gradient ready | reduced
         bool x_begun = false, x_side = false, done_recorded = false;
     } sh;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
@@ -138,6 +139,7 @@ struct ps_model {
 
 // shared between ps_model.hip and ps_shard.hip
 int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback);   // ps_shard.hip
 int enqueue_forward(ps_model *m, bool train);
 int enqueue_backward(ps_model *m, bool apply);
 int finish_step(ps_model *m, float *loss);
