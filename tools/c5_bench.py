@@ -23,6 +23,16 @@ for _ in range(4):
     batches.append(ps_amd.DeviceBatch(kv, ids, X, Y, W, offsets))
 nnz = nnz_tot // 4
 gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=B, max_nnz=int(nnz * 1.1))
+if "sharded" in sys.argv:          # the same batches through ps_shard_step with a 1-rank communicator
+    from ps_amd.sharded import NativeWorker
+    wk = NativeWorker(gm, 1, 0, is_async="async" in sys.argv)
+    wk.run(batches, 20); kv.sync()
+    t0 = time.perf_counter(); wk.run(batches, 100); kv.sync(); dt = (time.perf_counter() - t0) / 100
+    print("sharded (N=1, ps_shard_step): nnz/step %d: %.3f ms/step, %.1f M ids/s" % (nnz, 1e3 * dt, nnz / dt / 1e6))
+    gm.set_profile(True); wk.run(batches, 8); kv.sync(); prof = gm.profile_report(); gm.set_profile(False)
+    for k, v in sorted(prof.items(), key=lambda kv_: -kv_[1][1])[:6]:
+        print("  %-16s %8.1f us" % (k, 1e3 * v[1] / max(v[0], 1)))
+    sys.exit(0)
 for i in range(10): gm.train_async(batches[i % 4])
 gm.sync()
 gm.set_profile(True)
