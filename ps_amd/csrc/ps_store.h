@@ -126,6 +126,15 @@ struct ps_model {
         hipEvent_t ar_ev = nullptr, ar_done_ev = nullptr;   // flat gradient ready | reduced
         bool x_begun = false, x_side = false, done_recorded = false;
     } sh;
+    // host batches: pinned staging + two device slots on a copy stream (stage_batch)
+    struct HostStage {
+        hipStream_t copy_stream = nullptr;
+        char *pin[2] = {nullptr, nullptr}, *dev[2] = {nullptr, nullptr};
+        hipEvent_t copied[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+        bool done_rec[2] = {false, false};
+        size_t off[5] = {0, 0, 0, 0, 0}, bytes = 0;
+        uint64_t turn = 0;
+    } hstage;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)
     hipStream_t side[2] = {nullptr, nullptr};
