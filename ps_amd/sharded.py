@@ -555,6 +555,8 @@ def run_bench(args, cfg, synth_batch):
         dist.broadcast(idt, 0)
         ok = torch.ones(1, dtype=torch.int32, device=dev)
         try:
+            if os.environ.get("PS_AMD_FORCE_TORCH_WIRE"):       # exercise the fallback
+                raise RuntimeError("PS_AMD_FORCE_TORCH_WIRE is set")
             worker = NativeWorker(gms, world, rank, id256=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
         except Exception as e:      # noqa: BLE001 -- decided collectively below
             worker = None
