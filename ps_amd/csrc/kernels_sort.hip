@@ -75,7 +75,7 @@ __global__ __launch_bounds__(RS_TPB) void k_scan_rows(uint32_t *__restrict__ cou
 // order (equal digits inside a batch of 64 by ballots, across batches and waves by per-(wave,digit) cursors);
 // the ranked pairs are first placed at their position INSIDE THE BLOCK's sorted order in LDS, then written out
 // by consecutive threads, so one store instruction covers runs of one digit instead of 64 scattered words.
-template <bool IOTA>
+template <bool IOTA, bool STAGED>
 __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__restrict__ kin,
                                                           const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout,
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
     __shared__ uint32_t cur[4][256];
     __shared__ uint32_t gdelta[256];       // global position - block-local position, per digit
     __shared__ uint32_t wtot[4];
-    __shared__ uint32_t sk[RS_TILE], sv[RS_TILE];
+    __shared__ uint32_t sk[STAGED ? RS_TILE : 1], sv[STAGED ? RS_TILE : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 1024; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
     const int64_t bbase = (int64_t)blockIdx.x * RS_TILE;
@@ -153,11 +153,12 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
             rank = (uint32_t)__popcll(same & below);
             cnt = (uint32_t)__popcll(same);
             const uint32_t pos = cur[w][d] + rank;
-            sk[pos] = k[j];
-            sv[pos] = v[j];
+            if (STAGED) { sk[pos] = k[j]; sv[pos] = v[j]; }
+            else { const uint32_t gp = pos + gdelta[d]; kout[gp] = k[j]; vout[gp] = v[j]; }     // small inputs: latency, not bandwidth
         }
         if (valid && rank + 1 == cnt) cur[w][d] += cnt;  // last lane of the group advances the cursor
     }
+    if (!STAGED) return;
     __syncthreads();
     const int64_t rem = n - bbase;
     const int cnt_blk = rem < RS_TILE ? (int)rem : RS_TILE;
@@ -290,10 +291,13 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
-        if (p == 0 && iota_vals)
-            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk);
-        else
-            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk);
+        // LDS staging pays once the scatter is bandwidth-bound (measured: 3.2 M pairs 3x faster, 1e5 pairs 25 % slower)
+        const bool staged = n >= (1 << 19);
+        const bool iota = p == 0 && iota_vals;
+#define RS_SCATTER(I, S) hipLaunchKernelGGL((k_radix_scatter<I, S>), dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk)
+        if (iota) { if (staged) RS_SCATTER(true, true); else RS_SCATTER(true, false); }
+        else { if (staged) RS_SCATTER(false, true); else RS_SCATTER(false, false); }
+#undef RS_SCATTER
         uint32_t *t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
