@@ -871,7 +871,43 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     return PS_OK;
 }
 
-int launch_dense_update(const DenseUpdArgs &a, hipStream_t st) {
+// A tensor whose gradient arrives in MANY slabs (the out = 1 layer: one slab per 32 batch rows, 128 of them at
+// B = 4096, for 257 elements) would make k_dense_update's one-thread-per-element slab walk the longest chain of
+// the whole launch (16 batches of 8 dependent-on-nothing loads, ~19 us for 257 threads).  One WAVE per element
+// folds the slabs first: lane j takes slabs j, j+64, ..., then a butterfly (a fixed order), result in slab 0.
+namespace {
+__global__ __launch_bounds__(256) void k_dense_prereduce(float *__restrict__ part, int64_t part_stride, int ldp, int N, int64_t elems, int nsplit) {
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= elems) return;
+    const int k = (int)(e / N), n = (int)(e % N);
+    float *pp = part + (size_t)k * ldp + n;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int z = lane + 64 * j;
+        v[j] = pp[(size_t)(z < nsplit ? z : nsplit - 1) * part_stride];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (lane + 64 * j < nsplit) s += v[j];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) pp[0] = s;
+}
+}  // namespace
+
+int launch_dense_update(const DenseUpdArgs &a0, hipStream_t st) {
+    DenseUpdArgs a = a0;
+    if (!a.flat_grad)
+        for (int l = 0; l < a.nlayers; ++l) {
+            DenseLayer &L = a.L[l];
+            if (L.nsplit > 32 && L.nsplit <= 256) {
+                const int64_t elems = L.elem_end - L.elem_begin;
+                hipLaunchKernelGGL(k_dense_prereduce, dim3(cdiv(elems, 4)), dim3(256), 0, st, const_cast<float *>(L.part), L.part_stride, L.ldp, L.N, elems, L.nsplit);
+                L.nsplit = 1;
+            }
+        }
     const int64_t total = a.L[a.nlayers - 1].elem_end;
     hipLaunchKernelGGL(k_dense_update, dim3(cdiv(total, 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
