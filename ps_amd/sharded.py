@@ -582,7 +582,7 @@ def run_bench(args, cfg, synth_batch):
         worker = ShardedWorker(HipBackend(gms, torch, dev), comm, is_async=bool(getattr(args, "is_async", 0)))
         worker_run = lambda n: worker.run(batches, n, threaded=threaded)               # noqa: E731
     rng = np.random.default_rng(cfg["seed"] + 1000 * rank)     # every worker reads its own slice of the data
-    nb = 8
+    nb = 32        # enough distinct samples that the model cannot memorise them within the run (see bench.py)
     batches = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
     # priming (untimed, on top of --warmup): the first few hundred steps run ~30% slower while the caching
     # allocator, the three communicators and the host settle; keep that out of the timed region
