@@ -101,7 +101,7 @@ def run_single(args):
     # 64 resident batches (262 144 samples): the labels are independent of the features, so the model can only memorise;
     # with a handful of batches it does within ~1500 steps, the loss falls under the reference's stop threshold
     # (model/DNN.java:58-63: loss <= 0.01 -> no backward) and the step would silently get cheaper
-    nb = 64
+    nb = min(4096, max(64, (args.steps + args.warmup + 20) // 8))   # a batch is seen at most ~8 times
     batches = []
     for _ in range(nb):
         E, X, Y, W = synth_batch(cfg, rng)
