@@ -173,10 +173,51 @@ def run_single(args):
         out["cpu_baseline"] = cpu_baseline(cfg)
     if args.gather:
         out["gather_hbm"] = gather_roofline(kv, args)
+    if args.multi_hot:
+        for b in batches:
+            b.close()
+        batches = []
+        out["multi_hot"] = multi_hot_step(cfg)
     for b in batches:
         b.close()
     gm.close(); kv.close()
     return out
+
+
+def multi_hot_step(cfg, steps=60):
+    """BASELINE configs[4]'s shape on this GPU (reported beside the headline, not part of `value`): the same model with
+    Poisson(30) ids per (sample, field) -- ~3.2 M ids per step -- Zipf(1.05), sum pooling, FTRL on the embedding rows."""
+    import ps_amd
+    rng = np.random.default_rng(cfg["seed"] + 5)
+    B, F, V = cfg["B"], cfg["F"], cfg["V"]
+    kv = ps_amd.KVStore(0, cfg["seed"])
+    kv.create_embedding([V] * F, cfg["D"])
+    kv.set_updater("emF", ps_amd.FtrlUpdater())
+    bs, nnz_max, nnz_sum = [], 0, 0
+    for _ in range(16):
+        lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nnz = int(offsets[-1]); nnz_max = max(nnz_max, nnz); nnz_sum += nnz
+        ids = np.minimum(rng.zipf(1.05, size=nnz) - 1, V - 1).astype(np.int64)
+        W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)
+        bs.append(ps_amd.DeviceBatch(kv, ids, rng.standard_normal((B, cfg["X"])).astype(np.float32),
+                                     (rng.random(B) < 0.25).astype(np.float32), W, offsets))
+    gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=B, max_nnz=nnz_max)
+    for i in range(16):
+        gm.train_async(bs[i])
+    gm.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        gm.train_async(bs[i % 16])
+    gm.sync()
+    dt = (time.perf_counter() - t0) / steps
+    loss = gm.train(bs[0])
+    for b in bs:
+        b.close()
+    gm.close(); kv.close()
+    return {"workload": "configs[4] shape on 1 GPU: bags of Poisson(30) ids per (sample, field), Zipf(1.05), FTRL rows, batch 4096",
+            "ids_per_step": nnz_sum // 16, "ms_per_step": 1e3 * dt, "examples_per_s": B / dt, "ids_per_s": nnz_sum / 16 / dt,
+            "final_loss": loss}
 
 
 def gather_roofline(kv, args):
@@ -216,6 +257,7 @@ def main():
     ap.add_argument("--prefetch-thread", type=int, default=0, help="sharded path: run that prefetch in its own host thread")
     ap.add_argument("--phases", type=int, default=0, help="sharded path: also report a per-phase stopwatch (serialised)")
     ap.add_argument("--gather", type=int, default=1)
+    ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
