@@ -118,6 +118,8 @@ CASES = [
     (True, 3, 4, 2, [5, 3, 1], 5, 6, False),
     (False, 23, 10, 45, [150, 10, 1], 40, 100, False), # CTR.java shape (C1): D=10 -> scalar lanes
     (True, 26, 16, 13, [64, 32, 1], 300, 256, True),   # Criteo-like, zipf duplicates, runs > 32 (chunked order)
+    (False, 2, 64, 3, [32, 1], 50, 96, True),          # configs[3]'s row width: 16 lanes per row
+    (True, 3, 32, 0, [16, 8, 1], 20, 40, False),       # no dense features at all (X = 0), 8 lanes per row
 ]
 
 
@@ -591,3 +593,33 @@ def test_library_driven_step_n1_equals_fused_step():
             for x, y in zip(a[i], b[i]):
                 np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+def test_simple_updater_rows_and_dense():
+    """update/SimpleUpdater.java:20-22 (w += g * -eta) on embedding rows and FC tensors: bit-exact given the gradients."""
+    import ps_amd
+    F, D, X, fc, V, B = 3, 8, 2, [8, 1], 20, 32
+    rng = np.random.default_rng(12)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    upd = ps_amd.SimpleUpdater(0.05)
+    kv.set_updater("default", upd)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    eta = f32(0.05)
+    for _ in range(2):
+        E, Xd, Y = data(rng, B, F, X, V)
+        w0 = [kv.get_rows(f, np.arange(V)) for f in range(F)]
+        fw0 = [kv.get("fc%d.weights" % l) for l in range(2)]; fb0 = [kv.get("fc%d.bias" % l) for l in range(2)]
+        gm.forward({"E": E, "X": Xd, "Y": Y}); gm.backward()
+        grads = [gm.emb_grads(f) for f in range(F)]
+        fg = [(gm.fc_grad(l), gm.fc_grad(l, True)) for l in range(2)]
+        gm.update()
+        for f in range(F):
+            ids, g = grads[f]
+            want = w0[f].copy()
+            want[ids] = ((g * -eta).astype(f32) + w0[f][ids]).astype(f32)
+            np.testing.assert_array_equal(kv.get_rows(f, np.arange(V)), want)
+        for l in range(2):
+            np.testing.assert_array_equal(kv.get("fc%d.weights" % l), ((fg[l][0] * -eta).astype(f32) + fw0[l]).astype(f32))
+            np.testing.assert_array_equal(kv.get("fc%d.bias" % l), ((fg[l][1] * -eta).astype(f32) + fb0[l]).astype(f32))
+    gm.close(); kv.close()
