@@ -623,3 +623,27 @@ def test_simple_updater_rows_and_dense():
             np.testing.assert_array_equal(kv.get("fc%d.weights" % l), ((fg[l][0] * -eta).astype(f32) + fw0[l]).astype(f32))
             np.testing.assert_array_equal(kv.get("fc%d.bias" % l), ((fg[l][1] * -eta).astype(f32) + fb0[l]).astype(f32))
     gm.close(); kv.close()
+
+
+def test_intended_embedding_gradient_mode(orc):
+    """emb_grad_mode = PS_GRAD_INTENDED (the evident intent, the mean S/n instead of the double-
+    backward factor (n+1)/(2n^2)): per-key gradients bit-exact against the oracle's intended mode, incl. runs > 32."""
+    import ps_amd
+    from ps_amd import native as N
+    F, D, X, fc, V, B = 3, 8, 2, [8, 1], 6, 128
+    rng = np.random.default_rng(31)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, emb_grad_mode=N.PS_GRAD_INTENDED)
+    E, Xd, Y = data(rng, B, F, X, V, True)                       # V = 6: every key has a run of ~20, some above 32
+    gm.forward({"E": E, "X": Xd, "Y": Y}); gm.backward()
+    dx = gm.delta(2)
+    longest = 0
+    for f in range(F):
+        ids, g = gm.emb_grads(f)
+        for i, idv in enumerate(ids):
+            ks = np.nonzero(E[:, f] == idv)[0]
+            longest = max(longest, len(ks))
+            np.testing.assert_array_equal(g[i], orc.emb_geff(dx[ks, f * D:(f + 1) * D], orc.GRAD_INTENDED, 32), err_msg="emF%d.%d n=%d" % (f, idv, len(ks)))
+    assert longest > 32
+    gm.close(); kv.close()
