@@ -112,6 +112,7 @@ int rccl_all_reduce(void *ctx, float *buf, int64_t n, void *stream) {
 template <typename T>
 int grow(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
     if (need <= *cap) return PS_OK;
+    RtGuard rt_guard;
     HIPCHK(hipStreamSynchronize(s->stream));
     if (*p) (void)hipFree(*p);
     *p = nullptr;

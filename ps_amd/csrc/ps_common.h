@@ -12,6 +12,17 @@
 
 int ps_set_err(int code, const char *fmt, ...);
 
+// Creation / destruction of HIP runtime objects (streams, events, device and pinned allocations) is serialised
+// process-wide: several host threads may each drive their own store (tests run N ranks as N threads on one GPU),
+// and concurrent hipStreamCreate / hipMalloc / hipFree from many threads is the one place where the threads meet
+// inside the runtime.  Never held across a kernel launch chain, a collective or a callback.
+#include <mutex>
+std::recursive_mutex &ps_rt_mutex();
+struct RtGuard {
+    std::lock_guard<std::recursive_mutex> g;
+    RtGuard() : g(ps_rt_mutex()) {}
+};
+
 #define HIPCHK(x)                                                                       \
     do {                                                                                \
         hipError_t e__ = (x);                                                           \

@@ -57,6 +57,7 @@ int bits_for(int64_t n) {
 }  // namespace
 
 extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_model_t **out) {
+    RtGuard rt_guard;
     if (!s || !cfg || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     *out = nullptr;
     if (cfg->F <= 0 || cfg->D <= 0 || cfg->X < 0 || cfg->nfc <= 0 || cfg->nfc > 8 || cfg->max_batch <= 0)
@@ -144,6 +145,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
 }
 
 extern "C" int ps_model_destroy(ps_model_t *m) {
+    RtGuard rt_guard;
     if (!m) return PS_OK;
     (void)hipSetDevice(m->s->device);
     (void)hipStreamSynchronize(m->s->stream);
@@ -351,10 +353,13 @@ int enqueue_backward(ps_model *m, bool apply) {
     hipStream_t st = s->stream;
     const int B = m->cur_B, nfc = c.nfc;
     const int *skip = m->skip_dev;
+    ps_updater_t u;
+    PSCHK(store_resolve_updater(s, "emF", &u));
+    if (apply && !s->emb.state && u.kind != PS_UPD_SIMPLE)       // before anything is enqueued
+        return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
     // side chain 1: wide update, then every dW GEMM as soon as its delta exists, then the dense update
     hipStream_t sw = side_stream(m, 1);
     PSCHK(fork(m, st, sw));
-    ps_updater_t u;
     // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
     if (c.kind == PS_MODEL_WIDEDEEP && apply) {
         if (c.wide_grad_mode != PS_GRAD_COMPAT)
@@ -433,7 +438,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     m->side0_pending = false;
     EmbBwdArgs g;
     memset(&g, 0, sizeof g);
-    g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = (apply && s->emb.state) ? 1 : 0;
+    g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = apply ? 1 : 0;
     g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
     g.nseg = m->nseg_dev;
     g.ent_bag = (m->cur_offsets && m->sh.active) ? m->ent_bag : nullptr;     // fused path: sorted_ent already holds bags
@@ -455,6 +460,9 @@ static int enqueue_update(ps_model *m) {
     hipStream_t st = s->stream;
     const int nfc = c.nfc;
     ps_updater_t u;
+    PSCHK(store_resolve_updater(s, "emF", &u));
+    if (!s->emb.state && u.kind != PS_UPD_SIMPLE)                 // before anything is enqueued
+        return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
     DenseUpdArgs d;
     memset(&d, 0, sizeof d);
     d.nlayers = nfc; d.B = m->cur_B; d.apply = 1; d.skip = m->skip_dev; d.flat_grad = m->dense_grad_flat;
@@ -478,7 +486,7 @@ static int enqueue_update(ps_model *m) {
         w.upd = make_upd_params(u);
         PSCHK(launch_wide_update(w, st));
     }
-    if (s->emb.state) {
+    {
         // the per-key gradients are unique already: one "push" per key
         RowsApplyArgs r;
         memset(&r, 0, sizeof r);
@@ -497,13 +505,7 @@ int finish_step(ps_model *m, float *loss) {
     if (!loss) return PS_OK;
     HIPCHK(hipMemcpyAsync(loss, m->loss_dev, sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, s->err_dev, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) {
-        HIPCHK(hipMemset(s->err_dev, 0, sizeof(int)));
-        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err);
-    }
-    return PS_OK;
+    return store_check_bad_ids(s);
 }
 
 // One training step as a replayed hipGraph: the kernel arguments bake in the batch pointers,
@@ -583,7 +585,7 @@ extern "C" int ps_model_update(ps_model_t *m) {
 }
 
 extern "C" int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p_out) {
-    if (!m || !p_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    if (!m || !p_out || !batch) return ps_set_err(PS_E_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(m->s->device));
     ps_batch_t b = *batch;
     b.labels = nullptr;
@@ -599,7 +601,7 @@ extern "C" int ps_model_sync(ps_model_t *m) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     HIPCHK(hipSetDevice(m->s->device));
     HIPCHK(hipStreamSynchronize(m->s->stream));
-    return PS_OK;
+    return store_check_bad_ids(m->s);       // ps_model_train(loss = NULL) never waits: out-of-range ids surface here
 }
 
 extern "C" int ps_model_last_loss(ps_model_t *m, float *loss) {
@@ -661,9 +663,13 @@ extern "C" int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     uint32_t nseg = 0;
-    HIPCHK(hipMemcpy(&nseg, m->nseg_dev, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&nseg, m->nseg_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<uint32_t> rows(nseg);
-    if (nseg) HIPCHK(hipMemcpy(rows.data(), m->uniq_row, sizeof(uint32_t) * nseg, hipMemcpyDeviceToHost));
+    if (nseg) {
+        HIPCHK(hipMemcpyAsync(rows.data(), m->uniq_row, sizeof(uint32_t) * nseg, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     const EmbTables &e = s->emb;
     if (field < 0 || field >= e.F) return ps_set_err(PS_E_BAD_ARG, "no field %d", field);
     int64_t lo = 0, hi = 0;
@@ -676,7 +682,10 @@ extern "C" int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out
     if (!ids_out || !grads_out) return PS_OK;
     if (cap_rows < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
     for (int64_t i = 0; i < n; ++i) ids_out[i] = e.shard + ((int64_t)rows[lo + i] - e.row_base[field]) * e.nshards;
-    if (n) HIPCHK(hipMemcpy(grads_out, m->grads_out + (size_t)lo * e.D, sizeof(float) * n * e.D, hipMemcpyDeviceToHost));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(grads_out, m->grads_out + (size_t)lo * e.D, sizeof(float) * n * e.D, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     return PS_OK;
 }
 
@@ -692,7 +701,8 @@ extern "C" int ps_model_get_fc_grad(ps_model_t *m, int layer, int bias, float *o
     const int n = bias ? p.N : p.K * p.N;
     if (cap < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
     if (bias) off += (int64_t)p.K * p.N;
-    HIPCHK(hipMemcpy(out, m->dense_grad_flat + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(out, m->dense_grad_flat + off, sizeof(float) * n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
     return PS_OK;
 }
 
@@ -767,5 +777,5 @@ extern "C" int ps_model_time_steps(ps_model_t *m, const ps_batch_t *batch, int s
     HIPCHK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *ms_out = ms;
-    return finish_step(m, nullptr);
+    return store_check_bad_ids(s);
 }

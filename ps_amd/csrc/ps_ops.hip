@@ -7,6 +7,7 @@
 #include "ps_store.h"
 
 extern "C" int ps_dev_alloc(ps_store_t *s, size_t bytes, void **out_dev) {
+    RtGuard rt_guard;
     if (!s || !out_dev) return ps_set_err(PS_E_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMalloc(out_dev, bytes ? bytes : 16));
@@ -15,6 +16,7 @@ extern "C" int ps_dev_alloc(ps_store_t *s, size_t bytes, void **out_dev) {
     return PS_OK;
 }
 extern "C" int ps_dev_free(ps_store_t *s, void *p) {
+    RtGuard rt_guard;
     if (!s) return ps_set_err(PS_E_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -39,13 +41,7 @@ extern "C" int ps_store_sync(ps_store_t *s) {
     if (!s) return ps_set_err(PS_E_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, s->err_dev, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) {
-        HIPCHK(hipMemset(s->err_dev, 0, sizeof(int)));
-        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err);
-    }
-    return PS_OK;
+    return store_check_bad_ids(s);
 }
 
 extern "C" int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets_dev, int B,

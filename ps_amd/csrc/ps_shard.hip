@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W
 }
 
 int ensure_push_ws(ps_store *s, int64_t n) {
+    RtGuard rt_guard;
     if (n <= s->push_cap) return PS_OK;
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     sort_ws_free(s->push_ws);
@@ -99,6 +100,7 @@ int ensure_push_ws(ps_store *s, int64_t n) {
 }
 
 int ensure_shard_state(ps_model *m, int nshards) {
+    RtGuard rt_guard;
     ps_model::Shard &sh = m->sh;
     ps_store *s = m->s;
     if (sh.slot && sh.nshards == nshards) return PS_OK;

@@ -63,6 +63,8 @@ int store_resolve_updater(const ps_store *s, const char *key, ps_updater_t *out)
 // local global row of (field, id) on this shard, or -1 when not held here
 int64_t store_local_row(const ps_store *s, int field, int64_t id);
 int store_ensure_scratch(ps_store *s, int64_t rows, int D);
+// after a host wait on the store's stream: report (and clear) the device-side count of ids that were outside their table
+int store_check_bad_ids(ps_store *s);
 
 struct FcBuf {
     float *A = nullptr;  int ldA = 0;     // input activations of layer l: [Bcap][ldA]

@@ -13,6 +13,11 @@
 // ---------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
 
+std::recursive_mutex &ps_rt_mutex() {
+    static std::recursive_mutex mu;
+    return mu;
+}
+
 int ps_set_err(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -186,6 +191,7 @@ extern "C" int ps_router_shard_id(int route_mode, int field, int64_t id, int nsh
 // store
 // ---------------------------------------------------------------------------
 int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero) {
+    RtGuard rt_guard;
     if (bytes == 0) bytes = 16;
     HIPCHK(hipMalloc(p, bytes));
     if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, s->stream));
@@ -194,6 +200,7 @@ int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero) {
 }
 
 extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
+    RtGuard rt_guard;
     if (!out) return ps_set_err(PS_E_BAD_ARG, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -221,6 +228,7 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
 }
 
 extern "C" int ps_store_destroy(ps_store_t *s) {
+    RtGuard rt_guard;
     if (!s) return PS_OK;
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
@@ -235,6 +243,17 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     (void)hipStreamDestroy(s->own_stream);    // an adopted stream belongs to the host
     if (s->prefetch_stream) (void)hipStreamDestroy(s->prefetch_stream);
     delete s;
+    return PS_OK;
+}
+
+int store_check_bad_ids(ps_store *s) {
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, s->err_dev, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (err) {
+        HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof(int), s->stream));
+        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err);
+    }
     return PS_OK;
 }
 
@@ -356,6 +375,7 @@ int64_t store_local_row(const ps_store *s, int field, int64_t id) {
 }
 
 int store_ensure_scratch(ps_store *s, int64_t rows, int D) {
+    RtGuard rt_guard;
     if (rows <= s->scratch_rows && D <= s->scratch_D) return PS_OK;
     if (s->idx_dev) (void)hipFree(s->idx_dev);
     if (s->rowbuf_dev) (void)hipFree(s->rowbuf_dev);
