@@ -156,7 +156,19 @@ typedef struct ps_model_config {
     int emb_grad_mode;   /* PS_GRAD_*                                         */
     int wide_grad_mode;  /* PS_GRAD_*                                         */
     int use_graph;       /* 1: replay the step as a hipGraph                  */
+    int emb_sum_order;   /* PS_SUM_*: order in which a key's per-sample
+                            gradients are added (layer/EmbeddingField.java:86-104) */
 } ps_model_config_t;
+/* EmbeddingField.backward adds a key's per-sample gradients strictly in
+ * sample order.  PS_SUM_SEQUENTIAL reproduces that order for every key
+ * (bit-exact with the oracle's orc_emb_geff(chunk = 0)); a key seen n times
+ * costs a chain of n (compat mode: 2n) dependent f32 adds on one wave.
+ * PS_SUM_CHUNKED adds runs above 32 entries as 32-entry chunks folded in two
+ * levels (orc_emb_geff(chunk = 32)): same sum, different rounding, no long
+ * chain.  PS_SUM_AUTO: sequential for single-hot batches (everything the
+ * reference can express: n <= B), chunked for multi-hot bags, where one key
+ * can occur tens of thousands of times per step. */
+enum { PS_SUM_AUTO = 0, PS_SUM_SEQUENTIAL = 1, PS_SUM_CHUNKED = 2 };
 
 /* One minibatch.  Single-hot (the reference): offsets == NULL and ids is
  * [B][F] (the bytes of the F x B matrix "E", CTR.java:47-68).  Multi-hot:
@@ -405,6 +417,15 @@ int ps_shard_apply_flat(ps_model_t *m, int nworkers);
 int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, int iters,
                     uint64_t seed, double *avg_ms_out, double *bytes_read_out,
                     double *bytes_written_out);
+/* The same table and lookups (same rows, D, n, bag, seed), ONE launch, then
+ * n_sample of the n output rows spread over the launch are copied back with
+ * their bag index and ids, so a test can check full-size outputs against
+ * the table's definition: float4 i of the table is the k_fill_table hash of
+ * (seed, i) (ps_ops.hip), id j is splitmix64((seed ^ 0xABCDEF) + j*golden)
+ * mod rows; out = relu(sum of the bag's rows in order).
+ * bag_index_out[n_sample], ids_out[n_sample][bag], out_rows[n_sample][D]. */
+int ps_bench_gather_check(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, uint64_t seed,
+                          int64_t n_sample, int64_t *bag_index_out, int64_t *ids_out, float *out_rows);
 /* GEMM micro-benchmark: kind 0 = C[M][N] = A[M][K] * Bt[N][K]^T (FcLayer forward / delta),
  * kind 1 = split-K dW[K][N] = A[M][K]^T * D[M][N].  Average ms per launch (HIP events). */
 int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int nsplit, int iters, double *avg_ms_out);

@@ -107,6 +107,11 @@ class KVStore:
         N.check(N.lib().ps_store_create(device, seed, C.byref(h)))
         self.h = h
         self.device = device
+        self._dependents = []      # weak references to models / datasets built on this store: closed before it is
+
+    def _adopt(self, obj):
+        import weakref
+        self._dependents.append(weakref.ref(obj))
 
     @classmethod
     def ins(cls, device=0, seed=0):
@@ -116,6 +121,11 @@ class KVStore:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in getattr(self, "_dependents", []):       # a model keeps pointers into the store
+                obj = ref()
+                if obj is not None:
+                    obj.close()
+            self._dependents = []
             N.lib().ps_store_destroy(self.h)
             self.h = None
 
@@ -245,6 +255,7 @@ class DeviceBatch:
         b.on_device = 1
         self.c = b
         self.nnz = int(host.E.size)
+        store._adopt(self)
 
     def close(self):
         for p in self._bufs:
@@ -263,7 +274,7 @@ class _Model:
     KIND = N.PS_MODEL_DNN
 
     def __init__(self, store, F, D, X, fc_dims, wide_size=0, max_batch=4096, max_nnz=0,
-                 emb_grad_mode=N.PS_GRAD_COMPAT, wide_grad_mode=N.PS_GRAD_COMPAT, use_graph=0):
+                 emb_grad_mode=N.PS_GRAD_COMPAT, wide_grad_mode=N.PS_GRAD_COMPAT, use_graph=0, emb_sum_order=N.PS_SUM_AUTO):
         self.store = store
         cfg = N.ps_model_config_t()
         cfg.kind = self.KIND
@@ -273,11 +284,13 @@ class _Model:
         cfg.wide_size = wide_size
         cfg.max_batch, cfg.max_nnz = max_batch, max_nnz
         cfg.emb_grad_mode, cfg.wide_grad_mode, cfg.use_graph = emb_grad_mode, wide_grad_mode, use_graph
+        cfg.emb_sum_order = emb_sum_order
         self.cfg = cfg
         self.F, self.D, self.X, self.fc_dims = F, D, X, list(fc_dims)
         h = C.c_void_p()
         N.check(N.lib().ps_model_create(store.h, C.byref(cfg), C.byref(h)))
         self.h = h
+        store._adopt(self)
         self._updater = {"default": AdamUpdater()}
 
     def close(self):
@@ -502,6 +515,7 @@ class DataSet:
         self.h = C.c_void_p()
         cfg = _ingest_cfg(F, X, batch, wide_size, threads, offset, step, ids_via_float)
         N.check(N.lib().ps_ingest_create(store.h, C.byref(cfg), C.byref(self.h)))
+        store._adopt(self)
         if isinstance(source, (bytes, bytearray)):
             N.check(N.lib().ps_ingest_open_memory(self.h, bytes(source), len(source)))
         else:

@@ -469,10 +469,118 @@ __global__ __launch_bounds__(256) void k_emb_super(EmbBwdArgs a) {
 // ---------------------------------------------------------------------------
 // per-key reduce (+ double-backward factor) (+ fused updater)
 // ---------------------------------------------------------------------------
+// what KVStore.sum + KVStore.update(Map) do with one key's effective gradient S (store/KVStore.java:192-268):
+// hand it out (split form / sharded push) and/or run the updater on the row in place.  Called by the LPR lanes
+// of the key's lane group (all of them: the Ftrl skip test shuffles element 0 from part 0).
+template <int VEC>
+__device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint32_t row, uint32_t n, Vec<VEC> &S, int part) {
+    if (a.grads_out) {
+        S.store(a.grads_out + (size_t)u * a.D + part * VEC);
+        if (part == 0) { a.uniq_row[u] = row; if (a.uniq_cnt) a.uniq_cnt[u] = n; }
+    }
+    if (!a.apply) return;
+    float *wp = a.W + (size_t)row * a.D + part * VEC;
+    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
+    Vec<VEC> w = Vec<VEC>::load(wp);
+    if (a.upd.kind == PS_UPD_SIMPLE) {
+        VFOR(i) w.at(i) = (S.get(i) * -a.upd.eta) + w.get(i);      // update/SimpleUpdater.java:20-22
+        w.store(wp);
+        return;
+    }
+    Vec<VEC> s1 = Vec<VEC>::load(sp), s2 = Vec<VEC>::load(sp + a.D);
+    if (a.upd.kind == PS_UPD_ADAM) {
+        VFOR(i) adam_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+    } else {
+        // FtrlUpdater.java:52: skip the whole key when dw[0] == 0; element 0 lives in part 0
+        const int lane = threadIdx.x & 63;
+        const float g0 = __shfl(S.get(0), lane - part);
+        if (g0 == 0.f) return;
+        VFOR(i) ftrl_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+    }
+    w.store(wp); s1.store(sp); s2.store(sp + a.D);
+}
+
+// The REFERENCE order for a key seen n > PS_EMB_CHUNK times (layer/EmbeddingField.java:86-104: one addi per sample,
+// strictly in batch order; then the second pass of App. A.6): a strict f32 chain of n (or 2n) dependent adds cannot
+// be split over lanes, but its LOADS can.  One wave owns the key: all its lane groups fetch the key's entries
+// SEQ_ILP x groups at a time (index load -> delta row, all independent, the next batch already in flight while the
+// current one is consumed), park them in LDS in batch order, and lane group 0 folds them one by one.  The wave of the
+// 32-entry tile in which the key's run STARTS owns it (at most one such run can start in a tile).
+#define SEQ_ILP 4
 template <int VEC, bool BAG>
+__device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *lds /* [64 * VEC * SEQ_ILP] of this wave */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t CH = PS_EMB_CHUNK;
+    if (c * CH >= a.nnz) return;
+    const uint32_t t0 = (uint32_t)(c * CH);
+    const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
+    const uint32_t u = a.seg_id[t1];
+    const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
+    const uint32_t n = e0 - s0;
+    if (s0 < t0 || n <= CH) return;                            // the run starts in an earlier tile, or is a short key
+    const int G = 64 / a.LPR, grp = lane / a.LPR, part = lane % a.LPR;
+    const bool loader = grp < G;                                // D = 10: lanes 60..63 idle
+    const uint32_t NB = (uint32_t)G * SEQ_ILP;                  // entries per batch
+    const uint32_t row = a.sorted_key[s0];
+    Vec<VEC> S = Vec<VEC>::zero();
+    const int npass = a.grad_mode == PS_GRAD_COMPAT ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        bool have = pass > 0;                                   // pass 2 adds every g_k to S/n (App. A.6)
+        Vec<VEC> r[SEQ_ILP];
+        auto fetch = [&](uint32_t base) {
+            uint32_t ent[SEQ_ILP];
+#pragma unroll
+            for (int i = 0; i < SEQ_ILP; ++i) {
+                const uint32_t p = base + (uint32_t)i * G + (loader ? grp : 0);
+                ent[i] = a.sorted_ent[p < e0 ? p : e0 - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < SEQ_ILP; ++i) r[i] = load_g<VEC, BAG>(a, ent[i], loader ? part : 0);
+        };
+        fetch(s0);
+        for (uint32_t base = s0; base < e0; base += NB) {
+            if (loader) {
+#pragma unroll
+                for (int i = 0; i < SEQ_ILP; ++i) r[i].store(lds + ((size_t)(i * G + grp) * a.LPR + part) * VEC);
+            }
+            if (base + NB < e0) fetch(base + NB);               // in flight while this batch is folded
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (grp == 0) {
+                const uint32_t cnt = e0 - base < NB ? e0 - base : NB;
+                for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
+                    Vec<VEC> v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = Vec<VEC>::load(lds + ((size_t)(j0 + j < cnt ? j0 + j : cnt - 1) * a.LPR + part) * VEC);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (j0 + j < cnt) {
+                            if (have) { VFOR(i) S.at(i) = v[j].get(i) + S.at(i); }      // addi :94, batch order
+                            else { S = v[j]; have = true; }                             // put :91
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                    // LDS is overwritten by the next batch
+        }
+        if (grp == 0) { VFOR(i) S.at(i) = div_rn(S.get(i), (float)((pass + 1) * n)); }   // divi(n) :100 ; then divi(2n)
+    }
+    if (grp == 0) finish_key<VEC>(a, u, row, n, S, part);
+}
+
+// SEQ: the reference's summation order for every key.  Blocks [0, a.long_blocks) are the long-key waves above,
+// the rest handle one key per lane group as before and leave keys above PS_EMB_CHUNK to them.
+template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 4 * 64 * VEC * SEQ_ILP : 4];
     if (a.skip && *a.skip) return;
-    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (SEQ && (int)blockIdx.x < a.long_blocks) {
+        long_key_sequential<VEC, BAG>(a, seq_lds + (threadIdx.x >> 6) * 64 * VEC * SEQ_ILP);
+        return;
+    }
+    const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
     const int gpw = 64 / a.LPR;
     if (lane64 / a.LPR >= gpw) return;
@@ -495,6 +603,8 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         // up to a whole chunk in registers: the kernel's duration is its slowest lane group, and a
         // 17..32-entry key walked in two batches per pass was that group (8 dependent round trips)
         S = small_key<VEC, BAG, PS_EMB_ILP>(a, s0, n, part);
+    } else if (SEQ) {
+        return;                                                 // n > PS_EMB_CHUNK: a long-key wave owns this key
     } else if (n <= CH) {
         S = chunk_sum<VEC, BAG>(a, s0, e0, part);
         VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
@@ -536,30 +646,7 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
             VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));
         }
     }
-    if (a.grads_out) {
-        S.store(a.grads_out + (size_t)u * a.D + part * VEC);
-        if (part == 0) { a.uniq_row[u] = row; if (a.uniq_cnt) a.uniq_cnt[u] = n; }
-    }
-    if (!a.apply) return;
-    float *wp = a.W + (size_t)row * a.D + part * VEC;
-    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
-    Vec<VEC> w = Vec<VEC>::load(wp);
-    if (a.upd.kind == PS_UPD_SIMPLE) {
-        VFOR(i) w.at(i) = (S.get(i) * -a.upd.eta) + w.get(i);      // update/SimpleUpdater.java:20-22
-        w.store(wp);
-        return;
-    }
-    Vec<VEC> s1 = Vec<VEC>::load(sp), s2 = Vec<VEC>::load(sp + a.D);
-    if (a.upd.kind == PS_UPD_ADAM) {
-        VFOR(i) adam_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
-    } else {
-        // FtrlUpdater.java:52: skip the whole key when dw[0] == 0; element 0 lives in part 0
-        const int lane = threadIdx.x & 63;
-        const float g0 = __shfl(S.get(0), lane - part);
-        if (g0 == 0.f) return;
-        VFOR(i) ftrl_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
-    }
-    w.store(wp); s1.store(sp); s2.store(sp + a.D);
+    finish_key<VEC>(a, (uint32_t)u, row, n, S, part);
 }
 
 // ---------------------------------------------------------------------------
@@ -762,12 +849,15 @@ __global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
 // ---------------------------------------------------------------------------
 // init / row access
 // ---------------------------------------------------------------------------
+// Grid-stride: a HIP launch carries at most 2^32 - 1 threads, and a configs[3]-sized table (320 M rows x 64 =
+// 2e10 elements) is far beyond that -- one thread per element silently initialised only the first 2^32 of them.
 __global__ void k_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
                            int64_t id_first, int64_t id_stride) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= rows * D) return;
-    const int64_t r = t / D; const int d = (int)(t % D);
-    W[t] = ps_init_value(seed, table, (uint64_t)(id_first + r * id_stride), (uint64_t)d, scale);
+    const int64_t total = rows * D, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t r = t / D; const int d = (int)(t % D);
+        W[t] = ps_init_value(seed, table, (uint64_t)(id_first + r * id_stride), (uint64_t)d, scale);
+    }
 }
 
 __global__ void k_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldwt, uint64_t seed,
@@ -783,8 +873,8 @@ __global__ void k_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldw
 }
 
 __global__ void k_fill(float *p, int64_t n, float v) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) p[t] = v;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) p[t] = v;
 }
 __global__ void k_fill_col(float *p, int rows, int ld, int col, float v) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -858,11 +948,16 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const int gp = cdiv((int64_t)cdiv(tiles, gpw) * 64, 256);
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
+    a.long_blocks = a.seq_order ? cdiv(tiles, 4) : 0;      // one wave per 32-entry tile looks for a long run starting in it
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
+        if (a.seq_order) {                                                                     \
+            hipLaunchKernelGGL((k_emb_reduce_update<V, BG, true>), dim3(a.long_blocks + gr), dim3(256), 0, st, a); \
+            break;                                                                             \
+        }                                                                                      \
         hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gp), dim3(256), 0, st, a);            \
         if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gp), dim3(256), 0, st, a);  \
-        hipLaunchKernelGGL((k_emb_reduce_update<V, BG>), dim3(gr), dim3(256), 0, st, a);       \
+        hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(gr), dim3(256), 0, st, a); \
     } while (0)
     if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }
     else { if (bag) EMB_BWD_LAUNCH(1, true); else EMB_BWD_LAUNCH(1, false); }
@@ -923,7 +1018,8 @@ int launch_wide_update(const WideUpdArgs &a, hipStream_t st) {
 int launch_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
                     int64_t id_first, int64_t id_stride, hipStream_t st) {
     if (rows * D == 0) return PS_OK;
-    hipLaunchKernelGGL(k_init_emb, dim3(cdiv(rows * D, 256)), dim3(256), 0, st, W, rows, D, seed, table, scale, id_first, id_stride);
+    const int64_t blocks = (rows * D + 255) / 256;
+    hipLaunchKernelGGL(k_init_emb, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, W, rows, D, seed, table, scale, id_first, id_stride);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -937,7 +1033,8 @@ int launch_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldwt, uint
 
 int launch_fill(float *p, int64_t n, float v, hipStream_t st) {
     if (n <= 0) return PS_OK;
-    hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, v);
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, p, n, v);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -62,6 +62,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     *out = nullptr;
     if (cfg->F <= 0 || cfg->D <= 0 || cfg->X < 0 || cfg->nfc <= 0 || cfg->nfc > 8 || cfg->max_batch <= 0)
         return ps_set_err(PS_E_BAD_ARG, "bad model config");
+    if (cfg->emb_sum_order < PS_SUM_AUTO || cfg->emb_sum_order > PS_SUM_CHUNKED) return ps_set_err(PS_E_BAD_ARG, "bad emb_sum_order %d", cfg->emb_sum_order);
     if (cfg->fc_dims[cfg->nfc - 1] != 1) return ps_set_err(PS_E_UNSUPPORTED, "the last FcLayer must have 1 output (CrossEntropy is binary)");
     if (!s->emb.W) return ps_set_err(PS_E_STATE, "create the embedding tables first (ps_store_create_embedding)");
     if (s->emb.F != cfg->F || s->emb.D != cfg->D) return ps_set_err(PS_E_BAD_ARG, "store embedding is %dx%d, model wants %dx%d", s->emb.F, s->emb.D, cfg->F, cfg->D);
@@ -445,6 +446,8 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.partials2 = m->partials2; g.W = s->emb.W; g.state = s->emb.state;
     // a key's run is at most B entries when single-hot: no second level (and no extra launch) up to 128 chunks
     g.long_runs = (m->cur_offsets != nullptr || (int64_t)B > (int64_t)PS_EMB_CHUNK * PS_EMB_SUPER_MIN) ? 1 : 0;
+    // the reference's own summation order wherever the reference's input domain reaches (single-hot: n <= B)
+    g.seq_order = (c.emb_sum_order == PS_SUM_SEQUENTIAL || (c.emb_sum_order == PS_SUM_AUTO && m->cur_offsets == nullptr)) ? 1 : 0;
     PSCHK(store_resolve_updater(s, "emF", &u));
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;

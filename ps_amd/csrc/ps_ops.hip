@@ -98,66 +98,100 @@ __global__ void k_iota_offsets(int64_t *off, int64_t nbags, int bag) {
 }
 }  // namespace
 
-extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, int iters, uint64_t seed,
-                               double *avg_ms_out, double *bytes_read_out, double *bytes_written_out) {
-    if (!s || rows <= 0 || D <= 0 || (D & 3) || n <= 0 || bag <= 0 || iters <= 0 || !avg_ms_out)
-        return ps_set_err(PS_E_BAD_ARG, "bad argument (D must be a multiple of 4)");
-    HIPCHK(hipSetDevice(s->device));
-    hipStream_t st = s->stream;
+namespace {
+// the synthetic table + lookups of BASELINE configs[3]: everything a pure function of (rows, D, n, bag, seed)
+struct GatherRun {
     float *W = nullptr, *out = nullptr;
     int64_t *ids = nullptr, *off = nullptr, *rb = nullptr;
     int *err = nullptr;
-    const int64_t nnz = n * bag;
-    const size_t wbytes = sizeof(float) * (size_t)rows * D;
-    hipError_t e = hipMalloc((void **)&W, wbytes);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();      // clear: the caller may retry with a smaller table
-        return ps_set_err(PS_E_HIP, "hipMalloc of the %.1f GB table failed: %s", wbytes / 1e9, hipGetErrorString(e));
-    }
-    int rc = PS_OK;
-    auto cleanup = [&]() {
+    hipStream_t st = nullptr;
+    EmbFwdArgs a;
+    ~GatherRun() {
+        RtGuard rt_guard;
         (void)hipStreamSynchronize(st);
         if (W) (void)hipFree(W); if (out) (void)hipFree(out); if (ids) (void)hipFree(ids);
         if (off) (void)hipFree(off); if (rb) (void)hipFree(rb); if (err) (void)hipFree(err);
-    };
-#define BG(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rc = ps_set_err(PS_E_HIP, "%s -> %s", #x, hipGetErrorString(e__)); cleanup(); return rc; } } while (0)
-    BG(hipMalloc((void **)&out, sizeof(float) * (size_t)n * D));
-    BG(hipMalloc((void **)&ids, sizeof(int64_t) * (size_t)nnz));
-    BG(hipMalloc((void **)&off, sizeof(int64_t) * (size_t)(n + 1)));
-    BG(hipMalloc((void **)&rb, sizeof(int64_t) * 2));
-    BG(hipMalloc((void **)&err, sizeof(int)));
-    BG(hipMemsetAsync(err, 0, sizeof(int), st));
-    const int64_t base[2] = {0, rows};
-    BG(hipMemcpyAsync(rb, base, sizeof base, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_fill_table, dim3(256 * 32), dim3(256), 0, st, W, (int64_t)(rows * (int64_t)D / 4), seed);
-    hipLaunchKernelGGL(k_rand_ids, dim3(cdiv(nnz, 256)), dim3(256), 0, st, ids, nnz, rows, seed ^ 0xABCDEFull);
-    hipLaunchKernelGGL(k_iota_offsets, dim3(cdiv(n + 1, 256)), dim3(256), 0, st, off, n, bag);
-    BG(hipGetLastError());
-    EmbFwdArgs a;
-    memset(&a, 0, sizeof a);
-    a.W = W; a.row_base = rb; a.ids = ids; a.offsets = bag > 1 ? off : nullptr;
-    a.B = (int)n; a.F = 1; a.D = D; a.X = 0; a.act = PS_ACT_RELU; a.out = out; a.ld = D; a.err = err;
-    if (n > 0x7fffffff) { cleanup(); return ps_set_err(PS_E_BAD_ARG, "n too large"); }
-    rc = launch_emb_fwd(a, st);   // warm-up
-    if (rc != PS_OK) { cleanup(); return rc; }
-    hipEvent_t ea, eb;
-    BG(hipEventCreate(&ea)); BG(hipEventCreate(&eb));
-    BG(hipStreamSynchronize(st));
-    BG(hipEventRecord(ea, st));
-    for (int i = 0; i < iters; ++i) {
-        rc = launch_emb_fwd(a, st);
-        if (rc != PS_OK) { cleanup(); return rc; }
     }
-    BG(hipEventRecord(eb, st));
-    BG(hipEventSynchronize(eb));
+    int setup(ps_store *s, int64_t rows, int D, int64_t n, int bag, uint64_t seed) {
+        RtGuard rt_guard;
+        st = s->stream;
+        const int64_t nnz = n * bag;
+        const size_t wbytes = sizeof(float) * (size_t)rows * D;
+        hipError_t e = hipMalloc((void **)&W, wbytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();      // clear: the caller may retry with a smaller table
+            W = nullptr;
+            return ps_set_err(PS_E_HIP, "hipMalloc of the %.1f GB table failed: %s", wbytes / 1e9, hipGetErrorString(e));
+        }
+        HIPCHK(hipMalloc((void **)&out, sizeof(float) * (size_t)n * D));
+        HIPCHK(hipMalloc((void **)&ids, sizeof(int64_t) * (size_t)nnz));
+        HIPCHK(hipMalloc((void **)&off, sizeof(int64_t) * (size_t)(n + 1)));
+        HIPCHK(hipMalloc((void **)&rb, sizeof(int64_t) * 2));
+        HIPCHK(hipMalloc((void **)&err, sizeof(int)));
+        HIPCHK(hipMemsetAsync(err, 0, sizeof(int), st));
+        const int64_t base[2] = {0, rows};
+        HIPCHK(hipMemcpyAsync(rb, base, sizeof base, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));          // `base` is a stack array
+        hipLaunchKernelGGL(k_fill_table, dim3(256 * 32), dim3(256), 0, st, W, (int64_t)(rows * (int64_t)D / 4), seed);
+        hipLaunchKernelGGL(k_rand_ids, dim3(cdiv(nnz, 256)), dim3(256), 0, st, ids, nnz, rows, seed ^ 0xABCDEFull);
+        hipLaunchKernelGGL(k_iota_offsets, dim3(cdiv(n + 1, 256)), dim3(256), 0, st, off, n, bag);
+        HIPCHK(hipGetLastError());
+        memset(&a, 0, sizeof a);
+        a.W = W; a.row_base = rb; a.ids = ids; a.offsets = bag > 1 ? off : nullptr;
+        a.B = (int)n; a.F = 1; a.D = D; a.X = 0; a.act = PS_ACT_RELU; a.out = out; a.ld = D; a.err = err;
+        return PS_OK;
+    }
+};
+}  // namespace
+
+extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, int iters, uint64_t seed,
+                               double *avg_ms_out, double *bytes_read_out, double *bytes_written_out) {
+    if (!s || rows <= 0 || D <= 0 || (D & 3) || n <= 0 || n > 0x7fffffff || bag <= 0 || iters <= 0 || !avg_ms_out)
+        return ps_set_err(PS_E_BAD_ARG, "bad argument (D must be a multiple of 4)");
+    HIPCHK(hipSetDevice(s->device));
+    GatherRun g;
+    PSCHK(g.setup(s, rows, D, n, bag, seed));
+    hipStream_t st = g.st;
+    PSCHK(launch_emb_fwd(g.a, st));   // warm-up
+    hipEvent_t ea, eb;
+    HIPCHK(hipEventCreate(&ea)); HIPCHK(hipEventCreate(&eb));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventRecord(ea, st));
+    for (int i = 0; i < iters; ++i) PSCHK(launch_emb_fwd(g.a, st));
+    HIPCHK(hipEventRecord(eb, st));
+    HIPCHK(hipEventSynchronize(eb));
     float ms = 0.f;
-    BG(hipEventElapsedTime(&ms, ea, eb));
+    HIPCHK(hipEventElapsedTime(&ms, ea, eb));
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    const int64_t nnz = n * bag;
     *avg_ms_out = (double)ms / iters;
     if (bytes_read_out) *bytes_read_out = (double)nnz * (4.0 * D + 8.0) + (bag > 1 ? 8.0 * (double)(n + 1) : 0.0);
     if (bytes_written_out) *bytes_written_out = 4.0 * (double)n * D;
-    cleanup();
-#undef BG
+    return PS_OK;
+}
+
+extern "C" int ps_bench_gather_check(ps_store_t *s, int64_t rows, int D, int64_t n, int bag, uint64_t seed,
+                                     int64_t n_sample, int64_t *bag_index_out, int64_t *ids_out, float *out_rows) {
+    if (!s || rows <= 0 || D <= 0 || (D & 3) || n <= 0 || n > 0x7fffffff || bag <= 0 || n_sample <= 0 || n_sample > n ||
+        !bag_index_out || !ids_out || !out_rows)
+        return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    GatherRun g;
+    PSCHK(g.setup(s, rows, D, n, bag, seed));
+    hipStream_t st = g.st;
+    PSCHK(launch_emb_fwd(g.a, st));
+    const int64_t stride = n / n_sample;
+    for (int64_t i = 0; i < n_sample; ++i) {
+        const int64_t b = i * stride + (i * 7919) % stride;       // spread over the launch, not only tile starts
+        bag_index_out[i] = b;
+        HIPCHK(hipMemcpyAsync(ids_out + i * bag, g.ids + b * bag, sizeof(int64_t) * (size_t)bag, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out_rows + i * D, g.out + b * D, sizeof(float) * (size_t)D, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, g.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (err) return ps_set_err(PS_E_STATE, "%d generated ids were out of range", err);
     return PS_OK;
 }
 

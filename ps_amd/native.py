@@ -17,6 +17,7 @@ PS_ROUTE_ID_MOD, PS_ROUTE_JAVA_STRING = 0, 1
 PS_MODEL_DNN, PS_MODEL_WIDEDEEP = 0, 1
 PS_GRAD_COMPAT, PS_GRAD_INTENDED = 0, 1
 PS_ACT_NONE, PS_ACT_RELU, PS_ACT_SIGMOID = 0, 1, 2
+PS_SUM_AUTO, PS_SUM_SEQUENTIAL, PS_SUM_CHUNKED = 0, 1, 2
 
 
 class PsError(RuntimeError):
@@ -35,7 +36,7 @@ class ps_model_config_t(C.Structure):
     _fields_ = [("kind", C.c_int), ("F", C.c_int), ("D", C.c_int), ("X", C.c_int), ("nfc", C.c_int),
                 ("fc_dims", C.c_int * 8), ("wide_size", C.c_int64), ("max_batch", C.c_int),
                 ("max_nnz", C.c_int64), ("emb_grad_mode", C.c_int), ("wide_grad_mode", C.c_int),
-                ("use_graph", C.c_int)]
+                ("use_graph", C.c_int), ("emb_sum_order", C.c_int)]
 
 
 class ps_batch_t(C.Structure):
@@ -141,6 +142,7 @@ SIGNATURES = {
     "ps_shard_step_finish": (_i, [_vp, C.POINTER(ps_comm_ops_t), _i, _pf]),
     "ps_auc_compute": (_i, [_vp, _vp, _vp, _i64, _i, _pd, _pi64, _pi64]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),
+    "ps_bench_gather_check": (_i, [_vp, _i64, _i, _i64, _i, C.c_uint64, _i64, _pi64, _pi64, _pf]),
     "ps_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _pd]),
     "ps_tune_set": (_i, [_cp, _i]),
     "ps_model_time_steps": (_i, [_vp, C.POINTER(ps_batch_t), _i, _pd]),

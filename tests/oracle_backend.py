@@ -69,7 +69,7 @@ class OracleBackend:
         self.wb = np.zeros(1, f32); self.wbz = np.zeros(1, f32); self.wbn = np.zeros(1, f32)
         self.store = orc.Store(seed)
         self.model = orc.Model(self.store, orc.WIDEDEEP, F, D, cfg["X"], cfg["fc"], wide_size=ws)
-        self.model.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 32)
+        self.model.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 0)     # single-hot batches: the reference order
 
     # ---- worker: PSRouterClient.getList fan-out
     def plan_launch(self, batch, world, ctx=0, stream=None):

@@ -117,7 +117,7 @@ CASES = [
     (False, 3, 4, 2, [5, 3, 1], 5, 6, False),          # tiny, heavy duplicates
     (True, 3, 4, 2, [5, 3, 1], 5, 6, False),
     (False, 23, 10, 45, [150, 10, 1], 40, 100, False), # CTR.java shape (C1): D=10 -> scalar lanes
-    (True, 26, 16, 13, [64, 32, 1], 300, 256, True),   # Criteo-like, zipf duplicates, runs > 32 (chunked order)
+    (True, 26, 16, 13, [64, 32, 1], 300, 256, True),   # Criteo-like, zipf duplicates, runs > 32 (long-key waves)
     (False, 2, 64, 3, [32, 1], 50, 96, True),          # configs[3]'s row width: 16 lanes per row
     (True, 3, 32, 0, [16, 8, 1], 20, 40, False),       # no dense features at all (X = 0), 8 lanes per row
 ]
@@ -127,7 +127,7 @@ CASES = [
 def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
     rng = np.random.default_rng(7)
     st, om, kv, gm = make_pair(orc, wide, F, D, X, fc, V, B, wide_size=97)
-    om.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 32)      # runs > 32 use the chunked order on both sides
+    om.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 0)       # single-hot: the reference's sequential order on both sides
     nfc = len(fc)
     for step in range(3):
         E, Xd, Y = data(rng, B, F, X, V, zipf)
@@ -172,7 +172,7 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
             for i, idv in enumerate(ids):
                 ks = np.nonzero(E[:, f] == idv)[0]
                 gk = dx[ks, f * D:(f + 1) * D]
-                np.testing.assert_array_equal(g[i], orc.emb_geff(gk, orc.GRAD_COMPAT, 32), err_msg="emF%d.%d" % (f, idv))
+                np.testing.assert_array_equal(g[i], orc.emb_geff(gk, orc.GRAD_COMPAT, 0), err_msg="emF%d.%d" % (f, idv))
                 close(g[i], om.grad(orc.emb_key(f, float(idv))), scale=np.abs(dx).max(), rtol=E2E, what="g emF%d.%d" % (f, idv))
             g_gpu.append(g)
         gm.update()
@@ -644,6 +644,6 @@ def test_intended_embedding_gradient_mode(orc):
         for i, idv in enumerate(ids):
             ks = np.nonzero(E[:, f] == idv)[0]
             longest = max(longest, len(ks))
-            np.testing.assert_array_equal(g[i], orc.emb_geff(dx[ks, f * D:(f + 1) * D], orc.GRAD_INTENDED, 32), err_msg="emF%d.%d n=%d" % (f, idv, len(ks)))
+            np.testing.assert_array_equal(g[i], orc.emb_geff(dx[ks, f * D:(f + 1) * D], orc.GRAD_INTENDED, 0), err_msg="emF%d.%d n=%d" % (f, idv, len(ks)))
     assert longest > 32
     gm.close(); kv.close()

@@ -54,7 +54,7 @@ def expected(world, is_async):
     for w in range(world):
         st = orc.Store(SEED)
         md = orc.Model(st, orc.WIDEDEEP, F, D, CFG["X"], CFG["fc"], wide_size=ws)
-        md.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 32)
+        md.set_grad_mode(orc.GRAD_COMPAT, orc.GRAD_COMPAT, 0)
         models.append((st, md))
     data = [make_batches(w, STEPS) for w in range(world)]
     for step in range(STEPS):
