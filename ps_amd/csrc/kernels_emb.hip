@@ -501,83 +501,161 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
 }
 
 // The REFERENCE order for a key seen n > PS_EMB_CHUNK times (layer/EmbeddingField.java:86-104: one addi per sample,
-// strictly in batch order; then the second pass of App. A.6): a strict f32 chain of n (or 2n) dependent adds cannot
-// be split over lanes, but its LOADS can.  One wave owns the key: all its lane groups fetch the key's entries
-// SEQ_ILP x groups at a time (index load -> delta row, all independent, the next batch already in flight while the
-// current one is consumed), park them in LDS in batch order, and lane group 0 folds them one by one.  The wave of the
-// 32-entry tile in which the key's run STARTS owns it (at most one such run can start in a tile).
+// strictly in batch order; then the second pass of App. A.6).  A strict f32 chain of n (compat: 2n) dependent adds
+// cannot be split over lanes -- but everything around it can:
+//   * the WORKGROUP of the 32-entry tile in which the key's run starts owns the key (at most one run above 32
+//     entries can start in a tile); every other workgroup of the long-key range exits after three loads;
+//   * waves 1..3 are loaders: index load -> delta row, SEQ_ILP entries per lane group in flight, one batch ahead of
+//     the fold, rows parked in LDS TRANSPOSED ([component][entry]);
+//   * wave 0 folds: lane d owns component d and walks its LDS row four entries per ds_read_b128 -- five
+//     instructions per four entries on the only serial path of the kernel.
+// One barrier per batch, two LDS buffers.  (A first version with one wave doing both, fetching rows as float4 and
+// folding [entry][part], spent ~60 cycles per entry in its own instruction stream: 114 us for the 2240-entry keys of
+// configs[1]; this one ~5.)
 #define SEQ_ILP 4
+#define SEQ_LDS_FLOATS 4096       // per buffer: D * (3 * (64 / LPR) * SEQ_ILP + 4) <= 768 * VEC + 4 * D
+__device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magic, uint32_t &rem) {
+    uint32_t q = __umulhi(x, magic);            // magic = floor(2^32 / d): q is the quotient or one less
+    uint32_t r = x - q * d;
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
 template <int VEC, bool BAG>
-__device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *lds /* [64 * VEC * SEQ_ILP] of this wave */) {
-    const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *lds /* [2][SEQ_LDS_FLOATS] */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t CH = PS_EMB_CHUNK;
+    const int64_t c = blockIdx.x;
     if (c * CH >= a.nnz) return;
     const uint32_t t0 = (uint32_t)(c * CH);
     const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
     const uint32_t u = a.seg_id[t1];
     const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
     const uint32_t n = e0 - s0;
-    if (s0 < t0 || n <= CH) return;                            // the run starts in an earlier tile, or is a short key
-    const int G = 64 / a.LPR, grp = lane / a.LPR, part = lane % a.LPR;
-    const bool loader = grp < G;                                // D = 10: lanes 60..63 idle
-    const uint32_t NB = (uint32_t)G * SEQ_ILP;                  // entries per batch
-    const uint32_t row = a.sorted_key[s0];
-    Vec<VEC> S = Vec<VEC>::zero();
+    if (s0 < t0 || n <= CH) return;                            // the run starts in an earlier tile, or is a short key (block-uniform)
+    const int D = a.D, G = 64 / a.LPR;
+    const uint32_t NBW = (uint32_t)G * SEQ_ILP, NB = 3 * NBW;   // entries per loader wave / per batch
+    const uint32_t LDE = NB + 4;                                // LDS row stride: 16-B aligned rows, <= 2-way write conflicts
+    const uint32_t nbatch = (n + NB - 1) / NB;
     const int npass = a.grad_mode == PS_GRAD_COMPAT ? 2 : 1;
-    for (int pass = 0; pass < npass; ++pass) {
-        bool have = pass > 0;                                   // pass 2 adds every g_k to S/n (App. A.6)
+    const uint32_t total = nbatch * (uint32_t)npass;            // both passes as one stream: the pipeline never drains
+    const uint32_t fmagic = (uint32_t)(0x100000000ull / (uint32_t)a.F);
+    if (w > 0) {
+        // ---- loaders ----
+        const int grp = lane / a.LPR, part = lane % a.LPR;
+        const bool act = grp < G;                               // D = 10: lanes 60..63 idle
+        const uint32_t lbase = (uint32_t)(w - 1) * NBW + (uint32_t)(act ? grp : 0);
+        uint32_t ent[SEQ_ILP];
         Vec<VEC> r[SEQ_ILP];
-        auto fetch = [&](uint32_t base) {
-            uint32_t ent[SEQ_ILP];
+        auto load_idx = [&](uint32_t t) {
+            const uint32_t base = s0 + (t % nbatch) * NB + lbase;
 #pragma unroll
             for (int i = 0; i < SEQ_ILP; ++i) {
-                const uint32_t p = base + (uint32_t)i * G + (loader ? grp : 0);
+                const uint32_t p = base + (uint32_t)i * G;
                 ent[i] = a.sorted_ent[p < e0 ? p : e0 - 1];
             }
-#pragma unroll
-            for (int i = 0; i < SEQ_ILP; ++i) r[i] = load_g<VEC, BAG>(a, ent[i], loader ? part : 0);
         };
-        fetch(s0);
-        for (uint32_t base = s0; base < e0; base += NB) {
-            if (loader) {
+        auto load_rows = [&]() {
 #pragma unroll
-                for (int i = 0; i < SEQ_ILP; ++i) r[i].store(lds + ((size_t)(i * G + grp) * a.LPR + part) * VEC);
+            for (int i = 0; i < SEQ_ILP; ++i) {
+                uint32_t bag = ent[i];
+                if (BAG) bag = a.ent_bag[bag];
+                uint32_t f = 0, b = bag;
+                if (a.F > 1) b = div_by(bag, (uint32_t)a.F, fmagic, f);      // F = 1: the magic would be 2^32
+                r[i] = Vec<VEC>::load(a.delta + (size_t)b * a.ldd + (size_t)f * D + (act ? part : 0) * VEC);
             }
-            if (base + NB < e0) fetch(base + NB);               // in flight while this batch is folded
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (grp == 0) {
-                const uint32_t cnt = e0 - base < NB ? e0 - base : NB;
-                for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
-                    Vec<VEC> v[8];
+        };
+        auto park = [&](uint32_t t) {
+            float *buf = lds + (t & 1u) * SEQ_LDS_FLOATS;
+            if (act) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = Vec<VEC>::load(lds + ((size_t)(j0 + j < cnt ? j0 + j : cnt - 1) * a.LPR + part) * VEC);
+                for (int i = 0; i < SEQ_ILP; ++i)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (j0 + j < cnt) {
-                            if (have) { VFOR(i) S.at(i) = v[j].get(i) + S.at(i); }      // addi :94, batch order
-                            else { S = v[j]; have = true; }                             // put :91
-                        }
-                    }
-                }
+                    for (int k = 0; k < VEC; ++k) buf[(uint32_t)(part * VEC + k) * LDE + lbase + (uint32_t)i * G] = r[i].get(k);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                    // LDS is overwritten by the next batch
+        };
+        load_idx(0); load_rows();
+        if (total > 1) load_idx(1);
+        park(0);
+        if (total > 1) load_rows();
+        if (total > 2) load_idx(2);
+        __syncthreads();
+        for (uint32_t t = 0; t < total; ++t) {
+            if (t + 1 < total) park(t + 1);                     // rows of batch t+1 (issued one iteration ago)
+            if (t + 2 < total) load_rows();                     // batch t+2, from the indices fetched one iteration ago
+            if (t + 3 < total) load_idx(t + 3);
+            __syncthreads();
         }
-        if (grp == 0) { VFOR(i) S.at(i) = div_rn(S.get(i), (float)((pass + 1) * n)); }   // divi(n) :100 ; then divi(2n)
+        return;
     }
-    if (grp == 0) finish_key<VEC>(a, u, row, n, S, part);
+    // ---- wave 0: the strict chain.  lane d owns components d, d + 64, ... ----
+    constexpr int CPL = VEC == 4 ? 4 : 1;                       // D <= 256 (VEC 4) or <= 64 (VEC 1)
+    float S[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) S[q] = 0.f;                   // 0 + g_1 = g_1 exactly (put :91)
+    __syncthreads();
+    for (uint32_t t = 0; t < total; ++t) {
+        const uint32_t b = t % nbatch;
+        const uint32_t cnt = n - b * NB < NB ? n - b * NB : NB;
+        const float *buf = lds + (t & 1u) * SEQ_LDS_FLOATS;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int d = lane + 64 * q;
+            if (d < D) {
+                const float *row = buf + (uint32_t)d * LDE;
+                float acc = S[q];
+                uint32_t j = 0;
+                for (; j + 32 <= cnt; j += 32) {               // 8 reads in flight, then 32 dependent adds
+                    float4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(row + j + 4 * k);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { acc = v[k].x + acc; acc = v[k].y + acc; acc = v[k].z + acc; acc = v[k].w + acc; }   // addi :94
+                }
+                for (; j + 4 <= cnt; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row + j);
+                    acc = v.x + acc; acc = v.y + acc; acc = v.z + acc; acc = v.w + acc;
+                }
+                for (; j < cnt; ++j) acc = row[j] + acc;
+                if (b == nbatch - 1) acc = div_rn(acc, (float)((t >= nbatch ? 2u : 1u) * n));     // divi(n) :100 ; pass 2: divi(2n)
+                S[q] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    // KVStore.sum + update for this key (finish_key's arithmetic, one component per lane)
+    const uint32_t row = a.sorted_key[s0];
+    const float g0 = __shfl(S[0], 0);                           // FtrlUpdater.java:52 looks at dw[0]
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int d = lane + 64 * q;
+        if (d >= D) continue;
+        const float g = S[q];
+        if (a.grads_out) {
+            a.grads_out[(size_t)u * D + d] = g;
+            if (d == 0) { a.uniq_row[u] = row; if (a.uniq_cnt) a.uniq_cnt[u] = n; }
+        }
+        if (!a.apply) continue;
+        float *wp = a.W + (size_t)row * D + d;
+        float wv = *wp;
+        if (a.upd.kind == PS_UPD_SIMPLE) { *wp = (g * -a.upd.eta) + wv; continue; }
+        float *sp = a.state + (size_t)row * 2 * D + d;
+        float s1 = sp[0], s2 = sp[D];
+        if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, wv, s1, s2);
+        else { if (g0 == 0.f) continue; ftrl_elem(a.upd, g, wv, s1, s2); }
+        *wp = wv; sp[0] = s1; sp[D] = s2;
+    }
 }
 
 // SEQ: the reference's summation order for every key.  Blocks [0, a.long_blocks) are the long-key waves above,
 // the rest handle one key per lane group as before and leave keys above PS_EMB_CHUNK to them.
 template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 4 * 64 * VEC * SEQ_ILP : 4];
+    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
     if (a.skip && *a.skip) return;
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
-        long_key_sequential<VEC, BAG>(a, seq_lds + (threadIdx.x >> 6) * 64 * VEC * SEQ_ILP);
+        long_key_sequential<VEC, BAG>(a, seq_lds);
         return;
     }
     const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
@@ -948,7 +1026,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const int gp = cdiv((int64_t)cdiv(tiles, gpw) * 64, 256);
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
-    a.long_blocks = a.seq_order ? cdiv(tiles, 4) : 0;      // one wave per 32-entry tile looks for a long run starting in it
+    a.long_blocks = a.seq_order ? (int)tiles : 0;          // one workgroup per 32-entry tile looks for a long run starting in it
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
         if (a.seq_order) {                                                                     \
