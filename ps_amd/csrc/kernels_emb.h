@@ -48,7 +48,10 @@ struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer 
     const int *skip;
 };
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
-int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);
+int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);   // loss_out NULL: no loss reduction
+int launch_loss_reduce(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);
+int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st);
+int head_last_bwd_fusable(int rows_per_wg);
 
 struct EmbBwdArgs {
     int64_t nnz;

@@ -10,6 +10,8 @@
 // reduction walks sorted runs in batch order (no float atomics; bit-exact
 // against the oracle's sequential order).  Compiled with -ffp-contract=off:
 // every reference op is individually rounded.
+#include <string.h>
+
 #include "ps_common.h"
 #include "kernels_emb.h"
 
@@ -158,22 +160,26 @@ __device__ __forceinline__ float sigmoid_clip_d(float x) {
     return (float)(0.001f + (double)(.999f - 0.001f) / (1.0 + exp(-(double)x)));
 }
 
-// One wave per sample: lane j fetches wide id j and its weight (F independent gathers in
-// flight, coalesced id reads), then every lane folds the F weights in field order through
-// shuffles -- the reference's sequential f32 sum, without a serial chain of memory latencies.
-__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= a.B) return;
+// Eight lanes per sample, eight samples per wave: every load of the head is independent of the others (the out = 1
+// layer's dot product: 34 strided loads per lane at K = 257; the wide part: id -> weight for 26 fields, four per
+// lane) and the only serial pieces are two 3-step butterflies and the reference's sequential f32 sum of the F wide
+// weights (layer/LRLayer.java:73-84), done with shuffles inside the group.  (One WAVE per sample was as fast per
+// launch, but eight samples per wave is what lets a workgroup do the head of all the rows whose backward it owns.)
+// valid = false: the lanes take part in the shuffles with sample b clamped, and store nothing.
+// Returns delta_L * sigmoid' of the sample (every lane of the group holds it); 0 when there are no labels.
+__device__ __forceinline__ float head_one(const HeadArgs &a, int b, int lane, bool valid) {
+    const int l8 = lane & 7, gbase = lane & ~7;
     float zl;                                               // the last FcLayer's activation for this sample
     if (a.a_last) {
         // FcLayer.forward with out = 1 (layer/FcLayer.java:76-77): lanes stride over k, butterfly sum
+        const float *__restrict__ x = a.a_last + (size_t)b * a.lda_last;
+        const float *__restrict__ wl = a.w_last;
         float acc = 0.f;
-        for (int k = lane; k < a.k_last; k += 64) acc += a.a_last[(size_t)b * a.lda_last + k] * a.w_last[k];
+        for (int k = l8; k < a.k_last; k += 8) acc += x[k] * wl[k];
 #pragma unroll
-        for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+        for (int off = 4; off; off >>= 1) acc += __shfl_xor(acc, off);
         zl = a.last_sigmoid ? sigmoid_clip_d(acc) : acc;
-        if (lane == 0) a.zout[(size_t)b * a.ldz] = zl;
+        if (valid && l8 == 0) a.zout[(size_t)b * a.ldz] = zl;
     } else {
         zl = a.zlast[(size_t)b * a.ldz];
     }
@@ -181,42 +187,70 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     if (a.wide) {
         // LRLayer.forward (layer/LRLayer.java:73-84): sum over the F wide ids, sequential, then + bias
         float sumW = 0.f;
-        for (int j0 = 0; j0 < a.F; j0 += 64) {
-            float w = 0.f;
-            if (j0 + lane < a.F) {
-                int64_t id = a.wide_ids[(size_t)b * a.F + j0 + lane];
-                if (id < 0 || id >= a.wide_rows) { atomicAdd(a.err, 1); id = 0; }
-                w = a.wide_w[id];
-                if (a.touched && a.train) a.touched[id] = 1;   // LRLayer.weights.put (never cleared)
+        for (int j0 = 0; j0 < a.F; j0 += 32) {
+            float w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w[r] = 0.f;
+                const int f = j0 + 8 * r + l8;
+                if (f < a.F) {
+                    int64_t id = a.wide_ids[(size_t)b * a.F + f];
+                    if (id < 0 || id >= a.wide_rows) { if (valid) atomicAdd(a.err, 1); id = 0; }
+                    w[r] = a.wide_w[id];
+                    if (valid && a.touched && a.train) a.touched[id] = 1;   // LRLayer.weights.put (never cleared)
+                }
             }
-            const int n = a.F - j0 < 64 ? a.F - j0 : 64;
-            for (int j = 0; j < n; ++j) sumW += __shfl(w, j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = a.F - j0 - 8 * r < 8 ? a.F - j0 - 8 * r : 8;
+                for (int j = 0; j < n; ++j) sumW += __shfl(w[r], gbase + j);          // field order
+            }
         }
         sumW += a.wide_bias[0];
-        if (lane == 0) a.wide_z[b] = sumW;
+        if (valid && l8 == 0) a.wide_z[b] = sumW;
         const float z = zl + sumW;                          // AddLayer.forward l.add(r)
         p = sigmoid_clip_d(z);
     } else {
         p = zl;                                             // last FcLayer already applied the sigmoid
     }
-    if (lane != 0) return;
-    a.P[b] = p;
-    if (!a.labels) return;
+    if (valid && l8 == 0) a.P[b] = p;
+    if (!a.labels) return 0.f;
     const float l = a.labels[b];
-    // loss/CrossEntropy.java:15 (FastMath.log ~ log; double math, cast to float)
-    a.terms[b] = (float)(-l * log((double)p) - ((1 - l) * log((double)(1 - p))));
     float d = (p - l) / (p * (1 - p));                      // loss/CrossEntropy.java:25
     d *= p * (1 - p);                                       // Sigmoid.backward (activations/Sigmoid.java:18)
-    a.dlast[(size_t)b * a.ldd] = d;
+    if (valid && l8 == 0) {
+        // loss/CrossEntropy.java:15 (FastMath.log ~ log; double math, cast to float)
+        a.terms[b] = (float)(-l * log((double)p) - ((1 - l) * log((double)(1 - p))));
+        a.dlast[(size_t)b * a.ldd] = d;
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
+    const int b = blockIdx.x * 32 + (threadIdx.x >> 3);
+    (void)head_one(a, b < a.B ? b : a.B - 1, threadIdx.x & 63, b < a.B);
 }
 
 // FcLayer.backward of the out = 1 layer in one pass over its input: delta_prev = W^T delta (* relu'),
 // dW/db partial sums over this workgroup's rows (reduced by k_dense_update like the split-K slabs).
-__global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a) {
-    if (a.skip && *a.skip) return;
+// HEAD: the head of the same rows runs first in the same launch (training step: head -> loss' -> this layer's
+// backward is a chain of three tiny kernels on the critical path; the rows' delta stays in LDS).
+#define HEAD_ROWS_MAX 1024
+template <bool HEAD>
+__global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
+    __shared__ float dsh[HEAD ? HEAD_ROWS_MAX : 1];
+    if (!HEAD && a.skip && *a.skip) return;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * a.chunk;
     const int r1 = r0 + a.chunk < a.B ? r0 + a.chunk : a.B;
+    if (HEAD) {
+        for (int base = r0; base < r1; base += 32) {            // 32 rows per sweep: 8 lanes each
+            const int b = base + (tid >> 3);
+            const float d = head_one(h, b < r1 ? b : r1 - 1, tid & 63, b < r1);
+            if (b < r1 && (tid & 7) == 0) dsh[b - r0] = d;
+        }
+        __syncthreads();
+    }
     const float *__restrict__ A = a.A;
     const float *__restrict__ dl = a.dlast;
     float *__restrict__ dp = a.dprev;
@@ -230,7 +264,7 @@ __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a) {
             for (int j = 0; j < 16; ++j) {                      // 32 independent loads in flight
                 const int b = b0 + j < r1 ? b0 + j : r1 - 1;
                 x[j] = A[(size_t)b * a.lda + k];
-                d[j] = dl[(size_t)b * a.ldd];
+                d[j] = HEAD ? dsh[b - r0] : dl[(size_t)b * a.ldd];
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -1009,10 +1043,9 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
 }
 
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st) {
-    hipLaunchKernelGGL(k_head, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);   // one wave per sample
-    if (a.labels)
-        hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, a.terms, a.dlast, a.ldd, a.B, loss_out, gbar_out, skip, force_no_skip);
+    hipLaunchKernelGGL(k_head, dim3(cdiv(a.B, 32)), dim3(256), 0, st, a);   // eight lanes per sample
     HIPCHK(hipGetLastError());
+    if (a.labels && loss_out) return launch_loss_reduce(a, loss_out, gbar_out, skip, force_no_skip, st);
     return PS_OK;
 }
 
@@ -1166,7 +1199,25 @@ int launch_push_apply(PushApplyArgs a, hipStream_t st) {
 
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st) {
     if (a.B <= 0 || nsplit <= 0) return PS_OK;
-    hipLaunchKernelGGL(k_last_bwd, dim3(nsplit), dim3(256), 0, st, a);
+    HeadArgs none;
+    memset(&none, 0, sizeof none);
+    hipLaunchKernelGGL(k_last_bwd<false>, dim3(nsplit), dim3(256), 0, st, a, none);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+// head + the out = 1 layer's backward of the same rows in one launch (no loss reduction: launch_loss_reduce)
+int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st) {
+    if (a.B <= 0 || nsplit <= 0) return PS_OK;
+    if (a.chunk > HEAD_ROWS_MAX || !h.labels) return ps_set_err(PS_E_BAD_ARG, "launch_head_last_bwd: %d rows per workgroup / no labels", a.chunk);
+    hipLaunchKernelGGL(k_last_bwd<true>, dim3(nsplit), dim3(256), 0, st, a, h);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+int head_last_bwd_fusable(int rows_per_wg) { return rows_per_wg <= HEAD_ROWS_MAX; }
+
+int launch_loss_reduce(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st) {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, a.terms, a.dlast, a.ldd, a.B, loss_out, gbar_out, skip, force_no_skip);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -72,39 +72,58 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     // load takes under load when a slab is only ~0.4 us of MFMA work (measured: 50 % of peak).
     // The sets are named (not indexed by t) so they stay in registers; the loop is unrolled by 2.
     float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];
+    // Loads are UNCONDITIONAL and branch-free: rows beyond the operand are clamped to its last row (their products
+    // land in output rows/columns the epilogue never stores), columns beyond K are clamped to the last float4 and
+    // zeroed with a bit mask.  A select (ok ? v : 0) around the load was turned into exec-masked branches by
+    // hipcc, and with branches between the loads its wait-count pass falls back to s_waitcnt vmcnt(0) before the LDS
+    // write: the slab-(t+2) loads just issued were waited for as well, i.e. the second register set bought nothing
+    // (measured: 42..53 % of the f32 MFMA peak on the FC shapes whatever the tile shape).
+    const float *pa[A_F4], *pb[B_F4];
+    int ca[A_F4], cb[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int e = tid + i * 256;
+        int r = m0 + (e / RF4 < BM ? e / RF4 : BM - 1);
+        r = r < a.a_rows ? r : a.a_rows - 1;
+        ca[i] = (e % RF4) * 4;
+        pa[i] = a.A + (size_t)r * a.lda;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int e = tid + i * 256;
+        int r = n0 + (e / RF4 < BN ? e / RF4 : BN - 1);
+        r = r < a.b_rows ? r : a.b_rows - 1;
+        cb[i] = (e % RF4) * 4;
+        pb[i] = a.Bt + (size_t)r * a.ldb;
+    }
+    // (the mask is applied when the registers go to LDS, a slab or two later: touching the loaded value in gload
+    // would put the wait for it right behind the load)
     auto gload = [&](int kt, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
+        const int k0 = kt * BKT;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) { const int c = k0 + ca[i]; ra[i] = *reinterpret_cast<const float4 *>(pa[i] + (c < a.K ? c : a.K - 4)); }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) { const int c = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (c < a.K ? c : a.K - 4)); }
+    };
+    auto masked = [&](float4 v, int c) -> float4 {
+        const int m = c < a.K ? -1 : 0;
+        v.x = __int_as_float(__float_as_int(v.x) & m); v.y = __int_as_float(__float_as_int(v.y) & m);
+        v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
+        return v;
+    };
+    auto swrite = [&](int buf, int kt, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
-            const int r = m0 + e / RF4, c = k0 + (e % RF4) * 4;
-            // unconditional load from a clamped (always valid) address, zeroed by select:
-            // a branch around the load would serialise the slab's loads (one wait each)
-            const bool ok = ((BM * RF4) % 256 == 0 || e < BM * RF4) && r < a.a_rows && c < a.K;
-            const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)(r < a.a_rows ? r : a.a_rows - 1) * a.lda + (c < a.K ? c : a.K - 4));
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int e = tid + i * 256;
-            const int r = n0 + e / RF4, c = k0 + (e % RF4) * 4;
-            const bool ok = ((BN * RF4) % 256 == 0 || e < BN * RF4) && r < a.b_rows && c < a.K;
-            const float4 v = *reinterpret_cast<const float4 *>(a.Bt + (size_t)(r < a.b_rows ? r : a.b_rows - 1) * a.ldb + (c < a.K ? c : a.K - 4));
-            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto swrite = [&](int buf, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int e = tid + i * 256;
             if ((BM * RF4) % 256 == 0 || e < BM * RF4)
-                *reinterpret_cast<float4 *>(&As[buf][(e / RF4) * LD + (e % RF4) * 4]) = ra[i];
+                *reinterpret_cast<float4 *>(&As[buf][(e / RF4) * LD + (e % RF4) * 4]) = masked(ra[i], k0 + ca[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
             if ((BN * RF4) % 256 == 0 || e < BN * RF4)
-                *reinterpret_cast<float4 *>(&Bs[buf][(e / RF4) * LD + (e % RF4) * 4]) = rb[i];
+                *reinterpret_cast<float4 *>(&Bs[buf][(e / RF4) * LD + (e % RF4) * 4]) = masked(rb[i], k0 + cb[i]);
         }
     };
 
@@ -139,24 +158,33 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
                 }
         }
     };
+    // The loop body has NO conditional around a load or an LDS write: a slab index past the end loads from clamped
+    // (valid) addresses and writes zeros to the LDS buffer nobody reads again.  With conditionals hipcc's wait-count
+    // pass merges the two paths conservatively and waits for EVERY outstanding load before the next one is issued.
     gload(0, ra0, rb0);
-    if (nk > 1) gload(1, ra1, rb1);
-    swrite(0, ra0, rb0);
+    gload(1, ra1, rb1);
+    swrite(0, 0, ra0, rb0);
     __syncthreads();
-    const bool do_ld = !(a.ablate & 1), do_st = !(a.ablate & 2), do_bar = !(a.ablate & 4);
-    for (int kt = 0; kt < nk; kt += 2) {
+    // sched_barrier: the loads of slab t+2 are issued BEFORE the MFMAs of slab t and the LDS write of slab t+1
+    // comes AFTER them (left alone, hipcc's scheduler sinks the loads behind the LDS write: ~6 MFMAs of lookahead)
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
         // even slab kt: in LDS buffer 0; set 1 holds slab kt+1; set 0 is free for slab kt+2
-        if (kt + 2 < nk && do_ld) gload(kt + 2, ra0, rb0);
+        gload(kt + 2, ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
         compute(0);
-        if (kt + 1 < nk && do_st) swrite(1, ra1, rb1);
-        if (do_bar) __syncthreads();
-        if (kt + 1 >= nk) break;
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(1, kt + 1, ra1, rb1);
+        __syncthreads();
         // odd slab kt+1: in LDS buffer 1; set 0 holds slab kt+2; set 1 is free for slab kt+3
-        if (kt + 3 < nk && do_ld) gload(kt + 3, ra1, rb1);
+        gload(kt + 3, ra1, rb1);
+        __builtin_amdgcn_sched_barrier(0);
         compute(1);
-        if (kt + 2 < nk && do_st) swrite(0, ra0, rb0);
-        if (do_bar) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(0, kt + 2, ra0, rb0);
+        __syncthreads();
     }
+    if (kt < nk) compute(0);                                // odd slab count: the last slab sits in buffer 0
 
     // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
 #pragma unroll
@@ -216,37 +244,52 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     const int nk = m_end > m_begin ? (m_end - m_begin + BKT - 1) / BKT : 0;
 
     float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];     // two sets: see k_gemm_nt
+    // unconditional, branch-free loads (see k_gemm_nt): batch rows beyond this split are clamped and zeroed with a
+    // bit mask (they are part of the SUM here, unlike the clamped rows of the NT kernel); columns beyond the operand
+    // are clamped only (their outputs are never stored)
+    int ra_r[A_F4], ra_c[A_F4], rb_r[B_F4], rb_c[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int e = tid + i * 256 < BKT * BM / 4 ? tid + i * 256 : BKT * BM / 4 - 1;
+        ra_r[i] = e / (BM / 4);
+        const int gc = k0 + (e % (BM / 4)) * 4;
+        ra_c[i] = gc < a.a_cols ? gc : a.a_cols - 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int e = tid + i * 256 < BKT * BN / 4 ? tid + i * 256 : BKT * BN / 4 - 1;
+        rb_r[i] = e / (BN / 4);
+        const int gc = n0 + (e % (BN / 4)) * 4;
+        rb_c[i] = gc < a.d_cols ? gc : a.d_cols - 4;
+    }
+    auto ld4 = [&](const float *base, int ld, int gm, int c) -> float4 {
+        const int mm = gm < a.M ? gm : a.M - 1;
+        return *reinterpret_cast<const float4 *>(base + (size_t)mm * ld + c);
+    };
     auto gload = [&](int kt, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
+        const int mb = m_begin + kt * BKT;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) ra[i] = ld4(a.A, a.lda, mb + ra_r[i], ra_c[i]);
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) rb[i] = ld4(a.D, a.ldd, mb + rb_r[i], rb_c[i]);
+    };
+    auto masked = [&](float4 v, int gm) -> float4 {           // applied on the way to LDS (see k_gemm_nt)
+        const int m = gm < m_end ? -1 : 0;
+        v.x = __int_as_float(__float_as_int(v.x) & m); v.y = __int_as_float(__float_as_int(v.y) & m);
+        v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
+        return v;
+    };
+    auto swrite = [&](int buf, int kt, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
         const int mb = m_begin + kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * 256;
-            const int r = e / (BM / 4), c = (e % (BM / 4)) * 4;
-            const int gm = mb + r, gc = k0 + c;
-            const bool ok = e < BKT * BM / 4 && gm < m_end && gc < a.a_cols;
-            const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)(gm < a.M ? gm : a.M - 1) * a.lda + (gc < a.a_cols ? gc : a.a_cols - 4));
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < BKT * BM / 4) *reinterpret_cast<float4 *>(&As[buf][(e / (BM / 4)) * BM + (e % (BM / 4)) * 4]) = masked(ra[i], mb + ra_r[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * 256;
-            const int r = e / (BN / 4), c = (e % (BN / 4)) * 4;
-            const int gm = mb + r, gc = n0 + c;
-            const bool ok = e < BKT * BN / 4 && gm < m_end && gc < a.d_cols;
-            const float4 v = *reinterpret_cast<const float4 *>(a.D + (size_t)(gm < a.M ? gm : a.M - 1) * a.ldd + (gc < a.d_cols ? gc : a.d_cols - 4));
-            rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto swrite = [&](int buf, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            const int e = tid + i * 256;
-            if (e < BKT * BM / 4) *reinterpret_cast<float4 *>(&As[buf][(e / (BM / 4)) * BM + (e % (BM / 4)) * 4]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int e = tid + i * 256;
-            if (e < BKT * BN / 4) *reinterpret_cast<float4 *>(&Ds[buf][(e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = rb[i];
+            if (e < BKT * BN / 4) *reinterpret_cast<float4 *>(&Ds[buf][(e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = masked(rb[i], mb + rb_r[i]);
         }
     };
 
@@ -276,23 +319,26 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     };
-    if (nk > 0) {
-        gload(0, ra0, rb0);
-        if (nk > 1) gload(1, ra1, rb1);
-        swrite(0, ra0, rb0);
-    }
+    gload(0, ra0, rb0);                                     // (no conditionals around loads / LDS writes: see k_gemm_nt)
+    gload(1, ra1, rb1);
+    swrite(0, 0, ra0, rb0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) gload(kt + 2, ra0, rb0);
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        gload(kt + 2, ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
         compute(0);
-        if (kt + 1 < nk) swrite(1, ra1, rb1);
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(1, kt + 1, ra1, rb1);
         __syncthreads();
-        if (kt + 1 >= nk) break;
-        if (kt + 3 < nk) gload(kt + 3, ra1, rb1);
+        gload(kt + 3, ra1, rb1);
+        __builtin_amdgcn_sched_barrier(0);
         compute(1);
-        if (kt + 2 < nk) swrite(0, ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(0, kt + 2, ra0, rb0);
         __syncthreads();
     }
+    if (kt < nk) compute(0);
     float *Cz = a.Cpart + (size_t)z * a.part_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -356,7 +402,9 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 
 int gemm_tn_choose_split(int Kout, int N, int M) {
     const long long tiles = N <= 32 ? (long long)cdiv(Kout, 128) * cdiv(N, 32) : (long long)cdiv(Kout, 64) * cdiv(N, 64);
-    int s = (int)((768 + tiles - 1) / tiles);           // ~3 workgroups per CU; more splits = more partial traffic
+    // ~1.75 workgroups per CU: measured on MI355X (tools/gemm_sweep2.py, M = 4096): dW0 (56 tiles) 8 splits 24.2 us
+    // vs 14 splits 26.7 us, dW1 (36 tiles) 13-14 splits best; every split is a partial slab written and re-read
+    int s = (int)((448 + tiles - 1) / tiles);
     const int max_s = M / 128 > 0 ? M / 128 : 1;        // keep >= 128 batch rows per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;

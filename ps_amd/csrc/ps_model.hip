@@ -140,6 +140,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     }
     m->events.resize(64);
     for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));
     *out = m;
     return PS_OK;
@@ -154,6 +155,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
     for (int i = 0; i < 2; ++i) if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
     for (auto &e : m->events) (void)hipEventDestroy(e);
+    if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
     if (m->hstage.copy_stream) {
         (void)hipStreamSynchronize(m->hstage.copy_stream);
         for (int k = 0; k < 2; ++k) {
@@ -270,7 +272,23 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // ---------------------------------------------------------------------------
 // the three phases, enqueued on the store's stream
 // ---------------------------------------------------------------------------
-int enqueue_forward(ps_model *m, bool train) {
+// FcLayer.backward arguments of the out = 1 layer (layer/FcLayer.java:93-110): delta_prev = W^T delta (outer
+// product) and dW/db (column sums over the batch) in one pass over the layer's input instead of two sliver GEMMs
+static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
+    ps_store *s = m->s;
+    const ps_model_config_t &c = m->cfg;
+    const int l = c.nfc - 1, B = m->cur_B;
+    FcParams &p = s->fc[l];
+    FcBuf &b = m->fc[l];
+    memset(&q, 0, sizeof q);
+    q.B = B; q.K = p.K; q.Kp = p.Kpad; q.chunk = cdiv(B, b.nsplit);
+    q.A = b.A; q.lda = b.ldA; q.dlast = b.dOut; q.ldd = b.ldD; q.W = p.W; q.ldw = p.ldw;
+    if (l > 0) { q.dprev = m->fc[l - 1].dOut; q.ldp = m->fc[l - 1].ldD; q.dprev_cols = p.K; q.mask_cols = p.K; }
+    else { q.dprev = m->dx; q.ldp = m->ldx; q.dprev_cols = c.F * c.D; q.mask_cols = c.F * c.D; }
+    q.part = b.part; q.part_stride = b.part_stride; q.ldpart = b.ldp; q.skip = nullptr;
+}
+
+int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     ps_store *s = m->s;
     const ps_model_config_t &c = m->cfg;
     hipStream_t st = s->stream;
@@ -344,7 +362,28 @@ int enqueue_forward(ps_model *m, bool train) {
         h.last_sigmoid = c.kind == PS_MODEL_WIDEDEEP ? 0 : 1;    // FcLayer.java:58-62, WideDeepNN.java:128
         h.zout = m->out_last;
     }
-    { Prof pf(m, "head_loss"); PSCHK(launch_head(h, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, st)); }
+    m->head_args = h;
+    m->head_bwd_done = false;
+    const FcParams &pl = s->fc[nfc - 1];
+    FcBuf &bl = m->fc[nfc - 1];
+    if (train && pl.N == 1 && h.labels && head_last_bwd_fusable(cdiv(B, bl.nsplit))) {
+        // training: the head and the out = 1 layer's backward of the same rows in ONE launch (three tiny kernels
+        // of the critical chain become one; the loss reduction leaves the chain altogether, see enqueue_backward)
+        LastBwdArgs q;
+        fill_last_bwd(m, q);
+        Prof pf(m, "head_last_bwd");
+        PSCHK(launch_head_last_bwd(h, q, bl.nsplit, st));
+        m->head_bwd_done = true;
+    } else {
+        Prof pf(m, "head");
+        PSCHK(launch_head(h, nullptr, nullptr, nullptr, 0, st));
+    }
+    m->loss_pending = h.labels != nullptr;
+    if (m->loss_pending && !defer_loss) {
+        Prof pf(m, "loss_reduce");
+        PSCHK(launch_loss_reduce(h, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, st));
+        m->loss_pending = false;
+    }
     return PS_OK;
 }
 
@@ -358,9 +397,21 @@ int enqueue_backward(ps_model *m, bool apply) {
     PSCHK(store_resolve_updater(s, "emF", &u));
     if (apply && !s->emb.state && u.kind != PS_UPD_SIMPLE)       // before anything is enqueued
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
-    // side chain 1: wide update, then every dW GEMM as soon as its delta exists, then the dense update
-    hipStream_t sw = side_stream(m, 1);
+    // side chain 1: every dW GEMM as soon as its delta exists, then the dense update.
+    // side chain 0 (the sort ran there during the forward; idle now): loss reduction, then the wide update.
+    hipStream_t sw = side_stream(m, 1), s0 = side_stream(m, 0);
     PSCHK(fork(m, st, sw));
+    PSCHK(fork(m, st, s0));
+    bool loss_on_side = false;
+    if (m->loss_pending) {
+        // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
+        // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
+        // only the kernels that touch parameters (wide / dense / embedding updates) honour it.
+        Prof pf(m, "loss_reduce");
+        PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, s0));
+        m->loss_pending = false;
+        if (s0 != st) { HIPCHK(hipEventRecord(m->loss_ev, s0)); loss_on_side = true; }
+    }
     // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
     if (c.kind == PS_MODEL_WIDEDEEP && apply) {
         if (c.wide_grad_mode != PS_GRAD_COMPAT)
@@ -372,24 +423,19 @@ int enqueue_backward(ps_model *m, bool apply) {
         PSCHK(store_resolve_updater(s, "wide.weights", &u));
         w.upd = make_upd_params(u);
         Prof pf(m, "wide_update");
-        PSCHK(launch_wide_update(w, sw));
+        PSCHK(launch_wide_update(w, s0));
     }
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
         FcParams &p = s->fc[l];
         FcBuf &b = m->fc[l];
         if (l == nfc - 1 && p.N == 1) {
-            // out = 1: delta_prev = W^T delta (outer product) and dW/db (column sums over the batch)
-            // in one pass over the layer's input instead of two sliver GEMMs
-            LastBwdArgs q;
-            memset(&q, 0, sizeof q);
-            q.B = B; q.K = p.K; q.Kp = p.Kpad; q.chunk = cdiv(B, b.nsplit);
-            q.A = b.A; q.lda = b.ldA; q.dlast = b.dOut; q.ldd = b.ldD; q.W = p.W; q.ldw = p.ldw;
-            if (l > 0) { q.dprev = m->fc[l - 1].dOut; q.ldp = m->fc[l - 1].ldD; q.dprev_cols = p.K; q.mask_cols = p.K; }
-            else { q.dprev = m->dx; q.ldp = m->ldx; q.dprev_cols = c.F * c.D; q.mask_cols = c.F * c.D; }
-            q.part = b.part; q.part_stride = b.part_stride; q.ldpart = b.ldp; q.skip = skip;
-            Prof pf(m, "fc_bwd_last");
-            PSCHK(launch_last_bwd(q, b.nsplit, st));
+            if (!m->head_bwd_done) {       // otherwise the head's launch already did this layer's backward
+                LastBwdArgs q;
+                fill_last_bwd(m, q);
+                Prof pf(m, "fc_bwd_last");
+                PSCHK(launch_last_bwd(q, b.nsplit, st));
+            }
             if (nfc == 1) PSCHK(fork(m, st, sw));   // otherwise the next layer's fork orders the dense update behind this
             continue;
         }
@@ -400,16 +446,16 @@ int enqueue_backward(ps_model *m, bool apply) {
         if (l > 0) {
             Prof pf(m, nd[l]);
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, p.K, skip, st));
+                          EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
         } else {
             Prof pf(m, nd[l]);
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, skip, st));
+                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
         }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
-                             b.nsplit, skip, sw));
+                             b.nsplit, nullptr, sw));
     }
     // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
     DenseUpdArgs d;
@@ -431,11 +477,12 @@ int enqueue_backward(ps_model *m, bool apply) {
     // delta GEMM (which reads W_0; the earlier ones read W_l before it, in order) has finished.  Without this
     // edge the update raced with fc_bwd_data0 whenever the dW GEMMs finished first (rare, shape dependent).
     if (apply) PSCHK(fork(m, st, sw));
+    if (loss_on_side) HIPCHK(hipStreamWaitEvent(sw, m->loss_ev, 0));     // the stop flag (long since written)
     { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }   // in order behind the dW GEMMs
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
-    if (!m->sh.active) PSCHK(join(m, side_stream(m, 0), st));
+    PSCHK(join(m, s0, st));       // the sort (forward), the stop flag and the wide update
     m->side0_pending = false;
     EmbBwdArgs g;
     memset(&g, 0, sizeof g);
@@ -528,7 +575,7 @@ static int train_graph(ps_model *m) {
     }
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_forward(m, true);
+    int rc = enqueue_forward(m, true, true);
     if (rc == PS_OK) rc = enqueue_backward(m, true);
     hipError_t e = hipStreamEndCapture(s->stream, &graph);
     if (rc != PS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -551,7 +598,7 @@ extern "C" int ps_model_train(ps_model_t *m, const ps_batch_t *batch, float *los
     if (m->cfg.use_graph && !m->profile) {
         PSCHK(train_graph(m));
     } else {
-        PSCHK(enqueue_forward(m, true));
+        PSCHK(enqueue_forward(m, true, true));
         PSCHK(enqueue_backward(m, true));
     }
     m->fwd_done = true; m->bwd_done = true;
@@ -563,7 +610,7 @@ extern "C" int ps_model_forward(ps_model_t *m, const ps_batch_t *batch, float *l
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     HIPCHK(hipSetDevice(m->s->device));
     PSCHK(stage_batch(m, batch, true));
-    PSCHK(enqueue_forward(m, true));
+    PSCHK(enqueue_forward(m, true, false));
     m->fwd_done = true; m->bwd_done = false;
     return finish_step(m, loss);
 }
@@ -593,7 +640,7 @@ extern "C" int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p
     ps_batch_t b = *batch;
     b.labels = nullptr;
     PSCHK(stage_batch(m, &b, false));
-    PSCHK(enqueue_forward(m, false));
+    PSCHK(enqueue_forward(m, false, false));
     m->fwd_done = false;
     HIPCHK(hipMemcpyAsync(p_out, m->P, sizeof(float) * b.B, hipMemcpyDeviceToHost, m->s->stream));
     HIPCHK(hipStreamSynchronize(m->s->stream));

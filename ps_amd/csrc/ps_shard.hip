@@ -224,7 +224,7 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     HIPCHK(hipSetDevice(s->device));
     m->sh.active = true;
     m->sh.cache = cache_dev;
-    int rc = enqueue_forward(m, true);
+    int rc = enqueue_forward(m, true, true);
     if (rc == PS_OK) rc = enqueue_backward(m, false);     // gradients only: the owners apply them
     if (rc == PS_OK && m->cfg.kind == PS_MODEL_WIDEDEEP) {
         WideUpdArgs w;

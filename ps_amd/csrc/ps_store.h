@@ -143,6 +143,10 @@ struct ps_model {
     std::vector<hipEvent_t> events; size_t next_event = 0;
     bool multi_stream = true;
     bool side0_pending = false;   // a forward forked the sort chain and no backward joined it yet
+    HeadArgs head_args;           // the head of the last forward (the loss reduction may be launched by the backward)
+    bool head_bwd_done = false;   // the head's launch also did the out = 1 layer's backward
+    bool loss_pending = false;    // loss / gbar / stop flag not reduced yet
+    hipEvent_t loss_ev = nullptr;
     // graph replay: one instantiated graph per (batch pointers, B, nnz)
     struct GraphEntry { const void *sig[5]; int B; int64_t nnz; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
@@ -151,6 +155,6 @@ struct ps_model {
 // shared between ps_model.hip and ps_shard.hip
 int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
 int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback);   // ps_shard.hip
-int enqueue_forward(ps_model *m, bool train);
+int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
 int enqueue_backward(ps_model *m, bool apply);
 int finish_step(ps_model *m, float *loss);
