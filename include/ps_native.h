@@ -259,7 +259,8 @@ int ps_stream_sync(ps_store_t *s, void *hip_stream);
  * F+1..F+X the dense values (CTR.java:58-60), W = E mod wideSize
  * (MatrixUtil.hash, util/MatrixUtil.java:27-33).  ids_via_float = 1 keeps the
  * reference's long -> float -> id path (exact below 2^24); 0 keeps int64.
- * offset/step: this reader takes the non-blank lines offset, offset+step, ...
+ * offset/step: this reader takes the RAW lines offset, offset+step, ... (blank
+ * ones counted, as DataSource.readLine does), then drops the blank ones
  * (data/DataSource.java:25-46 worker sharding).  Blank lines are skipped
  * (LibsvmParser returns an empty list); runs of spaces are tolerated. */
 typedef struct ps_ingest_config {
@@ -392,6 +393,11 @@ typedef struct ps_comm_ops {
 int ps_comm_rccl_unique_id(char *out256);   /* two 128-byte ids: main + prefetch communicator */
 int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id256, ps_comm_ops_t *out);
 int ps_comm_rccl_destroy(ps_comm_ops_t *ops);
+/* One-shot wire check (collective: every rank calls it): each callback of the
+ * table once on known patterns -- uneven all-to-all-v counts, all-gather slot
+ * order, a float all-reduce -- verified on the host.  PS_E_STATE names the
+ * first wrong word.  bench.py runs it before the first timed step. */
+int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm);
 int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);
 /* The step in two halves.  _begin enqueues what reads no weight (plan, counts all-gather) without a host
  * wait; use_side = 1 runs it on the store's prefetch stream so that step t+1 can begin -- on another model of

@@ -324,8 +324,11 @@ class PS:
 def parse_libsvm(text, F, X, wide_size=0, offset=0, step=1):
     """Returns E [n][F] float32 (ids AS FLOATS, as the reference keeps them), X [n][X], Y [n], W [n][F] float32."""
     import numpy as _np
-    lines = [ln for ln in text.split("\n") if ln.strip() != ""]           # StringUtils.isBlank -> skipped
-    lines = lines[offset::step]                                             # offset, offset+step, ...
+    raw = text.split("\n")
+    if raw and raw[-1] == "":
+        raw.pop()                                                           # BufferedReader.readLine: no line after the last newline
+    lines = raw[offset::step]                                               # DataSource.readLine counts RAW lines (DataSource.java:25-46)
+    lines = [ln for ln in lines if ln.strip() != ""]                        # a selected blank line parses to an empty list: dropped
     n = len(lines)
     E = _np.zeros((n, F), _np.float32); Xd = _np.zeros((n, X), _np.float32); Y = _np.zeros(n, _np.float32)
     for i, ln in enumerate(lines):

@@ -16,6 +16,8 @@
 // the following steps are bit-identical to the uninterrupted run (tests/test_gpu_ckpt.py).
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <string>
 #include <vector>
@@ -64,6 +66,23 @@ struct IO {
     }
 };
 
+// bytes sections() moves for this store's geometry (what a complete file holds after its header)
+size_t section_bytes(const ps_store *s) {
+    size_t n = 0;
+    const EmbTables &e = s->emb;
+    if (e.W) {
+        n += sizeof(float) * (size_t)e.total_rows * e.D;
+        if (e.state) n += sizeof(float) * (size_t)e.total_rows * 2 * e.D;
+    }
+    const WideTable &w = s->wide;
+    if (w.W) n += sizeof(float) * (size_t)w.rows * 3 + (size_t)w.rows + sizeof(float) * 3;
+    for (auto &f : s->fc)
+        if (f.present) n += 3 * sizeof(float) * (size_t)f.Kpad * f.ldw;
+    return n;
+}
+
+const char kEnd[8] = {'P', 'S', 'A', 'M', 'D', 'E', 'N', 'D'};
+
 int sections(IO &io) {
     ps_store *s = io.s;
     EmbTables &e = s->emb;
@@ -100,8 +119,11 @@ extern "C" int ps_store_save(ps_store_t *s, const char *path) {
     HIPCHK(hipStreamSynchronize(s->stream));
     IO io;
     io.s = s; io.write = true;
-    io.f = fopen(path, "wb");
-    if (!io.f) return ps_set_err(PS_MISSING, "cannot create %s", path);
+    // written beside the target and renamed over it once complete and on disk: a crash (or a full disk) in the middle
+    // of a save never destroys the previous checkpoint
+    const std::string tmp = std::string(path) + ".tmp";
+    io.f = fopen(tmp.c_str(), "wb");
+    if (!io.f) return ps_set_err(PS_MISSING, "cannot create %s", tmp.c_str());
     Hdr h;
     memset(&h, 0, sizeof h);
     h.seed = (int64_t)s->seed; h.global_step = s->global_step;
@@ -127,9 +149,14 @@ extern "C" int ps_store_save(ps_store_t *s, const char *path) {
         io.raw(&u, sizeof u);
     }
     int rc = sections(io);
-    const bool ok = io.ok && fclose(io.f) == 0;
-    if (rc != PS_OK) return rc;
-    if (!ok) return ps_set_err(PS_E_HIP, "short write to %s", path);
+    io.raw((void *)kEnd, 8);
+    bool ok = io.ok && fflush(io.f) == 0 && fsync(fileno(io.f)) == 0;
+    ok = (fclose(io.f) == 0) && ok;
+    if (rc != PS_OK || !ok) {
+        (void)remove(tmp.c_str());
+        return rc != PS_OK ? rc : ps_set_err(PS_E_HIP, "short write to %s", tmp.c_str());
+    }
+    if (rename(tmp.c_str(), path) != 0) { (void)remove(tmp.c_str()); return ps_set_err(PS_E_HIP, "cannot rename %s to %s", tmp.c_str(), path); }
     return PS_OK;
 }
 
@@ -178,12 +205,23 @@ extern "C" int ps_store_load(ps_store_t *s, const char *path) {
         if (!io.ok) return fail(PS_E_BAD_ARG, "corrupt updater table");
         upd[key] = u;
     }
+    // Nothing on the device has been touched so far.  The header fixed the geometry, so the exact length of a complete
+    // file is known: check it (and the end marker) BEFORE the first byte goes to HBM -- a truncated or padded file is
+    // refused with the store untouched instead of half overwritten.
+    {
+        struct stat stt;
+        const long pos = ftell(io.f);
+        if (pos < 0 || fstat(fileno(io.f), &stt) != 0) return fail(PS_E_HIP, "cannot stat");
+        const uint64_t want = (uint64_t)pos + (uint64_t)section_bytes(s) + 8;
+        if ((uint64_t)stt.st_size != want) return fail(PS_E_BAD_ARG, "truncated or oversized checkpoint (the store was not modified)");
+        char endm[8];
+        if (fseek(io.f, -8, SEEK_END) != 0 || fread(endm, 1, 8, io.f) != 8 || memcmp(endm, kEnd, 8) != 0 || fseek(io.f, pos, SEEK_SET) != 0)
+            return fail(PS_E_BAD_ARG, "end marker missing: incomplete checkpoint (the store was not modified)");
+    }
     int rc = sections(io);
-    if (rc != PS_OK) { fclose(io.f); return rc; }
-    char extra;
-    const bool at_end = io.ok && fread(&extra, 1, 1, io.f) == 0;
     fclose(io.f);
-    if (!at_end) return ps_set_err(PS_E_BAD_ARG, "%s: truncated or oversized checkpoint", path);
+    if (rc != PS_OK || !io.ok)
+        return ps_set_err(rc != PS_OK ? rc : PS_E_HIP, "%s: read error while loading; the store now holds a MIX of old and new tensors -- reload or recreate it", path);
     for (auto &f : s->fc)
         if (f.present) PSCHK(launch_transpose_w(f.W, f.Wt, f.Kpad, f.ldw, f.N, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));

@@ -66,7 +66,7 @@ int rccl_load() {
 
 // `side` carries the counts all-gather of the NEXT step's prefetch (its own communicator: operations on one
 // communicator are ordered, so sharing it would chain the running step behind the prefetch)
-struct RcclCtx { rcclComm_t comm = nullptr, side = nullptr; int nranks = 1, rank = 0; };
+struct RcclCtx { rcclComm_t comm = nullptr, side = nullptr; int nranks = 1, rank = 0; bool use_side = false; };
 
 int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
@@ -75,7 +75,7 @@ int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void 
         HIPCHK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
         return PS_OK;
     }
-    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, c->side ? c->side : c->comm, st));
+    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, (c->use_side && c->side) ? c->side : c->comm, st));
     return PS_OK;
 }
 
@@ -103,22 +103,24 @@ int rccl_all_to_all_v(void *ctx, const void *send, const int64_t *sc, void *recv
 int rccl_all_reduce(void *ctx, float *buf, int64_t n, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
     if (c->nranks == 1 || n <= 0) return PS_OK;
-    // on the side communicator: it runs beside the gradient all-to-all-v of the main one (per step the side
-    // communicator sees all-gather, all-reduce -- the same order on every rank)
-    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, c->side ? c->side : c->comm, (hipStream_t)stream));
+    // on the MAIN communicator: ps_shard_step_finish issues it on the main stream behind the gradient all-to-all-v, so
+    // every rank enqueues the collectives of one communicator in one order on one stream.  (Two communicators driven
+    // from two streams at once is a documented NCCL/RCCL deadlock hazard: device launch order across ranks is then not
+    // deterministic.  The side communicator carries only the counts all-gather of an explicitly requested prefetch.)
+    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, c->comm, (hipStream_t)stream));
     return PS_OK;
 }
 
+// The exchange buffers are sized ONCE, for the worst case (every worker requests all of its keys from this owner):
+// no hipMalloc / hipFree -- both synchronise the device -- ever runs inside a step or between two collectives.
 template <typename T>
-int grow(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
+int size_once(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
     if (need <= *cap) return PS_OK;
     RtGuard rt_guard;
-    HIPCHK(hipStreamSynchronize(s->stream));
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    const int64_t c = need + need / 4 + 1024;
-    HIPCHK(hipMalloc((void **)p, elem * (size_t)c));
-    *cap = c;
+    if (*p) { HIPCHK(hipStreamSynchronize(s->stream)); (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(hipMalloc((void **)p, elem * (size_t)need));
+    s->bytes += (int64_t)(elem * (size_t)need);
+    *cap = need;
     return PS_OK;
 }
 
@@ -173,6 +175,66 @@ extern "C" int ps_comm_rccl_destroy(ps_comm_ops_t *ops) {
 }
 
 // ---------------------------------------------------------------------------
+// one-shot wire check: every collective of the table once, on known patterns, verified on the host.  bench.py runs it
+// before the first timed step, so that the first execution of the RCCL path on real multi-GPU hardware cannot
+// silently exchange the wrong bytes (uneven all-to-all-v counts, peer order, all-gather order, float all-reduce).
+// ---------------------------------------------------------------------------
+extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
+    if (!s || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32) return ps_set_err(PS_E_BAD_ARG, "bad argument");
+    const int n = comm->nranks, me = comm->rank;
+    if (n < 1 || me < 0 || me >= n) return ps_set_err(PS_E_BAD_ARG, "bad communicator");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    // rank r sends (p + 1 + r % 3) words to peer p: word i = r << 20 | p << 10 | i
+    std::vector<int64_t> sc((size_t)n), rc((size_t)n);
+    int64_t ns = 0, nr = 0;
+    for (int p = 0; p < n; ++p) { sc[p] = p + 1 + me % 3; rc[p] = me + 1 + p % 3; ns += sc[p]; nr += rc[p]; }
+    std::vector<uint32_t> send((size_t)ns), recv((size_t)nr, 0xFFFFFFFFu), gath((size_t)n, 0u);
+    int64_t o = 0;
+    for (int p = 0; p < n; ++p) for (int64_t i = 0; i < sc[p]; ++i) send[(size_t)o++] = ((uint32_t)me << 20) | ((uint32_t)p << 10) | (uint32_t)i;
+    const int nf = 257;
+    std::vector<float> red((size_t)nf);
+    for (int i = 0; i < nf; ++i) red[(size_t)i] = (float)(me + 1) + 0.25f * (float)i;      // exact in f32 for every rank count in use
+    uint32_t *dsend = nullptr, *drecv = nullptr, *dg_in = nullptr, *dg_out = nullptr;
+    float *dred = nullptr;
+    auto fr = [&]() { (void)hipStreamSynchronize(st); (void)hipFree(dsend); (void)hipFree(drecv); (void)hipFree(dg_in); (void)hipFree(dg_out); (void)hipFree(dred); };
+    {
+        RtGuard rt_guard;
+        HIPCHK(hipMalloc((void **)&dsend, 4 * (size_t)ns)); HIPCHK(hipMalloc((void **)&drecv, 4 * (size_t)nr));
+        HIPCHK(hipMalloc((void **)&dg_in, 4)); HIPCHK(hipMalloc((void **)&dg_out, 4 * (size_t)n)); HIPCHK(hipMalloc((void **)&dred, 4 * (size_t)nf));
+    }
+    const uint32_t tag = 0xC0DE0000u + (uint32_t)me;
+    int rcode = PS_OK;
+    do {
+        if (hipMemcpyAsync(dsend, send.data(), 4 * (size_t)ns, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemsetAsync(drecv, 0xFF, 4 * (size_t)nr, st) != hipSuccess ||
+            hipMemcpyAsync(dg_in, &tag, 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dred, red.data(), 4 * (size_t)nf, hipMemcpyHostToDevice, st) != hipSuccess) { rcode = ps_set_err(PS_E_HIP, "selfcheck: upload failed"); break; }
+        if ((rcode = comm->all_gather(comm->ctx, dg_in, dg_out, 4, st)) != PS_OK) break;
+        if ((rcode = comm->all_to_all_v(comm->ctx, dsend, sc.data(), drecv, rc.data(), 4, st)) != PS_OK) break;
+        if ((rcode = comm->all_reduce_sum_f32(comm->ctx, dred, nf, st)) != PS_OK) break;
+        if (hipMemcpyAsync(recv.data(), drecv, 4 * (size_t)nr, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(gath.data(), dg_out, 4 * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(red.data(), dred, 4 * (size_t)nf, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rcode = ps_set_err(PS_E_HIP, "selfcheck: readback failed"); break; }
+        for (int p = 0; p < n && rcode == PS_OK; ++p)
+            if (gath[(size_t)p] != 0xC0DE0000u + (uint32_t)p) rcode = ps_set_err(PS_E_STATE, "selfcheck: all-gather slot %d holds %08x", p, gath[(size_t)p]);
+        o = 0;
+        for (int p = 0; p < n && rcode == PS_OK; ++p)
+            for (int64_t i = 0; i < rc[p] && rcode == PS_OK; ++i, ++o) {
+                const uint32_t want = ((uint32_t)p << 20) | ((uint32_t)me << 10) | (uint32_t)i;
+                if (recv[(size_t)o] != want) rcode = ps_set_err(PS_E_STATE, "selfcheck: all-to-all-v word %lld from rank %d is %08x, expected %08x", (long long)i, p, recv[(size_t)o], want);
+            }
+        for (int i = 0; i < nf && rcode == PS_OK; ++i) {
+            const float want = (float)n * (float)(n + 1) * 0.5f + 0.25f * (float)i * (float)n;
+            if (n > 1 && red[(size_t)i] != want) rcode = ps_set_err(PS_E_STATE, "selfcheck: all-reduce element %d is %g, expected %g", i, red[(size_t)i], want);
+        }
+    } while (0);
+    { RtGuard rt_guard; fr(); }
+    return rcode;
+}
+
+// ---------------------------------------------------------------------------
 // one BSP (or async) step of worker + owner
 // ---------------------------------------------------------------------------
 // Measured on MI355X at N = 1: beginning step t+1 on the prefetch stream while step t trains is SLOWER (0.40 vs
@@ -203,6 +265,15 @@ extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const
     }
     // this model's previous step still reads its key lists until its finish has run on the training stream
     if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
+    {   // worst case: all nnz_cap keys of every worker live on this owner
+        const int64_t rmax = m->nnz_cap * (int64_t)nsh, D = m->cfg.D;
+        PSCHK(size_once(s, &sh.x_recv_rows, &sh.x_recv_cap, rmax, sizeof(uint32_t)));
+        PSCHK(size_once(s, &sh.x_rows_out, &sh.x_rows_cap, rmax * D, sizeof(float)));
+        PSCHK(size_once(s, &sh.x_recv_grads, &sh.x_grads_cap, rmax * D, sizeof(float)));
+        PSCHK(size_once(s, &sh.x_cache, &sh.x_cache_cap, m->nnz_cap * D, sizeof(float)));
+        PSCHK(shard_push_reserve(s, nsh));
+    }
+    if (comm->ctx && comm->all_gather == rccl_all_gather) ((RcclCtx *)comm->ctx)->use_side = use_side != 0;
     PSCHK(shard_plan_enqueue(m, batch, nsh, st, false));
     const size_t row = sizeof(uint32_t) * (size_t)(nsh + 1);        // every rank's owner_start[0..nranks]: the host takes the differences
     if (!sh.matrix_dev) {
@@ -238,36 +309,19 @@ extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, in
         U += sc[o]; nrecv += rc[o];
     }
     sh.U = U;
-    PSCHK(grow(s, &sh.x_recv_rows, &sh.x_recv_cap, nrecv, sizeof(uint32_t)));
-    PSCHK(grow(s, &sh.x_rows_out, &sh.x_rows_cap, nrecv * D, sizeof(float)));
-    PSCHK(grow(s, &sh.x_recv_grads, &sh.x_grads_cap, nrecv * D, sizeof(float)));
-    PSCHK(grow(s, &sh.x_cache, &sh.x_cache_cap, U * D, sizeof(float)));
+    if (U > m->nnz_cap || nrecv > sh.x_recv_cap)
+        return ps_set_err(PS_E_STATE, "exchange counts (%lld requested, %lld received) exceed the buffers sized at ps_shard_step_begin", (long long)U, (long long)nrecv);
     // getList: ids out, rows back
     PSCHK(comm->all_to_all_v(comm->ctx, sh.send_rows, sc.data(), sh.x_recv_rows, rc.data(), sizeof(uint32_t), st));
     PSCHK(ps_shard_serve_pull(s, sh.x_recv_rows, nrecv, sh.x_rows_out));
     PSCHK(comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st));
     // train on the cache
     PSCHK(ps_shard_forward_backward(m, sh.x_cache, nullptr));
-    // push: the dense + wide reduction runs on the prefetch stream (its own communicator) beside the per-key
-    // gradient exchange and the owner update; the replicated update waits for it
-    if (nsh > 1) {
-        if (!s->prefetch_stream) {
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPCHK(hipStreamCreateWithPriority(&s->prefetch_stream, hipStreamNonBlocking, hi));
-        }
-        if (!sh.ar_ev) {
-            HIPCHK(hipEventCreateWithFlags(&sh.ar_ev, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&sh.ar_done_ev, hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(sh.ar_ev, st));
-        HIPCHK(hipStreamWaitEvent(s->prefetch_stream, sh.ar_ev, 0));
-        PSCHK(comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, s->prefetch_stream));
-        HIPCHK(hipEventRecord(sh.ar_done_ev, s->prefetch_stream));
-    }
+    // push: the per-key gradients to their owners, then the dense + wide reduction -- same communicator, same stream,
+    // same order on every rank.  The owner's row update is enqueued between the two: it only needs the all-to-all-v.
     PSCHK(comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st));
+    if (nsh > 1) PSCHK(comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, st));
     PSCHK(ps_shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, rc.data(), nsh, is_async));
-    if (nsh > 1) HIPCHK(hipStreamWaitEvent(st, sh.ar_done_ev, 0));
     PSCHK(ps_shard_apply_flat(m, nsh));
     HIPCHK(hipEventRecord(sh.done_ev, st));
     sh.done_recorded = true;

@@ -212,20 +212,22 @@ class Pool {
     bool stop_ = false;
 };
 
-// start offsets of this worker's non-blank lines: global (non-blank) line g is ours iff g >= offset and (g - offset) % step == 0
+// start offsets of this worker's lines.  DataSource.readLine (data/DataSource.java:25-46) counts RAW lines, blank ones
+// included: raw line g is this reader's iff g >= offset and (g - offset) % step == 0; a selected line that is blank
+// then yields an empty feature list (LibsvmParser.parse, StringUtils.isBlank) and is dropped.
 void index_lines(const char *d, size_t len, int offset, int step, std::vector<size_t> *starts, std::vector<size_t> *ends) {
     size_t pos = 0;
     int64_t g = 0;
     while (pos < len) {
         const char *nl = (const char *)memchr(d + pos, '\n', len - pos);
         const size_t end = nl ? (size_t)(nl - d) : len;
-        bool blank = true;
-        for (size_t i = pos; i < end; ++i)
-            if (d[i] != ' ' && d[i] != '\t' && d[i] != '\r') { blank = false; break; }
-        if (!blank) {                                   // StringUtils.isBlank(line) -> empty list, skipped
-            if (g >= offset && (g - offset) % step == 0) { starts->push_back(pos); ends->push_back(end); }
-            ++g;
+        if (g >= offset && (g - offset) % step == 0) {
+            bool blank = true;
+            for (size_t i = pos; i < end; ++i)
+                if (d[i] != ' ' && d[i] != '\t' && d[i] != '\r') { blank = false; break; }
+            if (!blank) { starts->push_back(pos); ends->push_back(end); }
         }
+        ++g;
         pos = end + 1;
     }
 }

@@ -247,6 +247,25 @@ extern "C" int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_uniqu
     return PS_OK;
 }
 
+// the sort-free push's per-row mask and per-worker position tables (allocated once: never between two collectives)
+int shard_push_reserve(ps_store *s, int npeers) {
+    const int64_t R = s->emb.total_rows;
+    if (npeers < 1 || npeers > PS_PUSH_MAX_PEERS || (double)npeers * (double)R * 4.0 > 4.0e9) return PS_OK;   // sorted path
+    if (s->push_mask && s->push_pos_peers >= npeers) return PS_OK;
+    RtGuard rt_guard;
+    hipStream_t st = s->stream;
+    if (!s->push_mask) {
+        HIPCHK(hipMalloc((void **)&s->push_mask, sizeof(uint32_t) * (size_t)(R + 1)));
+        HIPCHK(hipMemsetAsync(s->push_mask, 0, sizeof(uint32_t) * (size_t)(R + 1), st));
+    }
+    if (s->push_pos_peers < npeers) {
+        if (s->push_pos) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(s->push_pos); s->push_pos = nullptr; }
+        HIPCHK(hipMalloc((void **)&s->push_pos, sizeof(uint32_t) * (size_t)npeers * (size_t)(R + 1)));
+        s->push_pos_peers = npeers;
+    }
+    return PS_OK;
+}
+
 extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n,
                                    const int64_t *peer_counts, int npeers, int is_async) {
     if (!s || n < 0 || (n > 0 && (!rows_dev || !grads_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
@@ -265,15 +284,7 @@ extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, cons
             tot += peer_counts[p];
         }
         if (tot != n) return ps_set_err(PS_E_BAD_ARG, "peer counts sum to %lld, n is %lld", (long long)tot, (long long)n);
-        if (!s->push_mask) {
-            HIPCHK(hipMalloc((void **)&s->push_mask, sizeof(uint32_t) * (size_t)(R + 1)));
-            HIPCHK(hipMemsetAsync(s->push_mask, 0, sizeof(uint32_t) * (size_t)(R + 1), st));
-        }
-        if (s->push_pos_peers < npeers) {
-            if (s->push_pos) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(s->push_pos); s->push_pos = nullptr; }
-            HIPCHK(hipMalloc((void **)&s->push_pos, sizeof(uint32_t) * (size_t)npeers * (size_t)(R + 1)));
-            s->push_pos_peers = npeers;
-        }
+        PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
         PushApplyArgs a;
         memset(&a, 0, sizeof a);
         a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = R;

@@ -157,4 +157,5 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
 int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback);   // ps_shard.hip
 int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
 int enqueue_backward(ps_model *m, bool apply);
+int shard_push_reserve(ps_store *s, int npeers);   // ps_shard.hip
 int finish_step(ps_model *m, float *loss);

@@ -391,7 +391,7 @@ class HipBackend:
         self.kv = self.models[0].store
         self.D = self.models[0].D
         self.torch, self.device = torch, device
-        self._keep = []
+        self._pull_buf, self._pull_cap = None, 0
 
     def _tensor(self, ptr, shape, typestr, dtype):
         if self.torch is None:
@@ -423,10 +423,13 @@ class HipBackend:
     def serve_pull(self, recv_rows, n):
         t = self.torch
         if t is None:
-            out = C.c_void_p()
-            N.check(N.lib().ps_dev_alloc(self.kv.h, max(n, 1) * self.D * 4, C.byref(out)))
-            self._keep.append(out)
-            buf = (out.value, (n, self.D))
+            if n > self._pull_cap:           # grow-only: no device allocation inside a steady-state step
+                if self._pull_buf is not None:
+                    N.lib().ps_dev_free(self.kv.h, self._pull_buf)
+                self._pull_cap = max(n + n // 2, 1024)
+                self._pull_buf = C.c_void_p()
+                N.check(N.lib().ps_dev_alloc(self.kv.h, self._pull_cap * self.D * 4, C.byref(self._pull_buf)))
+            buf = (self._pull_buf.value, (n, self.D))
         else:
             buf = t.empty((n, self.D), dtype=t.float32, device=self.device)
         N.check(N.lib().ps_shard_serve_pull(self.kv.h, self._ptr(recv_rows), n, self._ptr(buf)))
@@ -447,9 +450,6 @@ class HipBackend:
     def apply_push(self, recv_rows, recv_grads, n, peer_counts, is_async):
         pc = (C.c_int64 * len(peer_counts))(*peer_counts)
         N.check(N.lib().ps_shard_apply_push(self.kv.h, self._ptr(recv_rows), self._ptr(recv_grads), n, pc, len(peer_counts), int(is_async)))
-        for p in self._keep:
-            N.lib().ps_dev_free(self.kv.h, p)
-        self._keep = []
 
     def flat_grad(self, ctx):
         f = C.c_void_p()
@@ -485,6 +485,10 @@ class NativeWorker:
         buf = C.create_string_buffer(256)
         N.check(N.lib().ps_comm_rccl_unique_id(buf))
         return buf.raw
+
+    def selfcheck(self):
+        """Every collective of the table once on known patterns (collective call: all ranks)."""
+        N.check(N.lib().ps_comm_selfcheck(self.kv.h, C.byref(self.ops)))
 
     def step(self, batch, want_loss=True):
         loss = C.c_float()
@@ -544,6 +548,7 @@ def run_bench(args, cfg, synth_batch):
     overlap = bool(getattr(args, "overlap", 1))
     native = bool(getattr(args, "native", 1))
     threaded = False
+    wire_check = None
     if native:
         # the library drives the exchange (ps_shard_step: one C call per step, RCCL bound inside libps_amd.so);
         # torch.distributed only hands the 128-byte RCCL id round and keeps the bench's barriers
@@ -563,6 +568,17 @@ def run_bench(args, cfg, synth_batch):
             ok.zero_()
             print("rank %d: RCCL communicator inside libps_amd failed (%s); falling back to the torch.distributed wire" % (rank, e), flush=True)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if int(ok.item()) != 0:
+            # the RCCL calls inside libps_amd (ncclSend/Recv groups, all-gather, all-reduce) have never run at N > 1 on
+            # the development box (one GPU): verify the wire on known patterns before trusting a single step
+            try:
+                worker.selfcheck()
+                wire_check = "ok"
+            except Exception as e:      # noqa: BLE001 -- decided collectively below
+                ok.zero_()
+                wire_check = "FAILED: %s" % e
+                print("rank %d: RCCL wire self-check failed (%s); falling back to the torch.distributed wire" % (rank, e), flush=True)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             if worker is not None:
                 worker.close()
@@ -623,6 +639,7 @@ def run_bench(args, cfg, synth_batch):
                                    "embedding rows sharded id mod N (PSRouterClient routing -> RCCL all-to-all-v), dense + wide all-reduce, BSP",
                        "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True,
                        "exchange_driver": "libps_amd (ps_shard_step, RCCL via dlopen)" if native else "torch.distributed",
+                       "rccl_ranks": world, "wire_selfcheck": wire_check,
                        "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
                        "priming_steps_untimed": int(getattr(args, "priming", 300))},
             "final_loss": loss,

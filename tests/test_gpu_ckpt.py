@@ -64,7 +64,21 @@ def test_load_rejects_another_geometry(tmp_path):
     kv3, gm3 = _mk(3, 8, 2, [8, 1], 30, 16, 11)
     with pytest.raises(N.PsError):
         kv3.load(str(tmp_path / "missing.ck"))
-    open(str(tmp_path / "trunc.ck"), "wb").write(open(path, "rb").read()[:-100])
-    with pytest.raises(N.PsError):
-        kv3.load(str(tmp_path / "trunc.ck"))
+    # a truncated / padded file is refused BEFORE anything reaches the device: the store is exactly what it was
+    rng = np.random.default_rng(2)
+    E = rng.integers(0, 30, size=(16, 3)).astype(np.int64)
+    gm3.train({"E": E, "X": rng.standard_normal((16, 2)).astype(f32), "Y": (rng.random(16) < 0.5).astype(f32), "W": E % 11})
+    before = _state(kv3, 3, 30, 11, 2); step = kv3.global_step()
+    blob = open(path, "rb").read()
+    for name, data in (("trunc.ck", blob[:-100]), ("padded.ck", blob + b"x" * 64), ("noend.ck", blob[:-8] + b"PSAMDXXX")):
+        open(str(tmp_path / name), "wb").write(data)
+        with pytest.raises(N.PsError):
+            kv3.load(str(tmp_path / name))
+        for a, b in zip(before, _state(kv3, 3, 30, 11, 2)):
+            np.testing.assert_array_equal(a, b)
+        assert kv3.global_step() == step
+    # saving is atomic: an existing checkpoint is replaced only by a complete new one, no .tmp is left behind
+    kv3.save(path)
+    import os
+    assert not os.path.exists(path + ".tmp") and os.path.getsize(path) == len(blob)
     gm3.close(); kv3.close()

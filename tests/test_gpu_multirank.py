@@ -282,6 +282,7 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
         gm = gms[0]
         comm = CallbackComm(rank, shared, kv)
         wk = NativeWorker(gms, world, rank, ops=comm.ops, is_async=is_async)
+        wk.selfcheck()                          # ps_comm_selfcheck over the plugged-in collectives (N > 1: real patterns)
         bs = [ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]) for b in make_batches(rank, STEPS)]
         if pipelined:
             wk.run(bs, STEPS)                   # begin(t+1) on the prefetch stream before finish(t)
