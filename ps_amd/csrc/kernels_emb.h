@@ -98,14 +98,25 @@ struct WideUpdArgs {
     const float *gbar;
     UpdParams upd;
     const int *skip;
-    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C
+    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C; 3 bias only
     float *G, *C;                      // [rows] (+ G[2*rows] = bias gradient), contiguous G|C|bias
     int nworkers;
 };
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st);
 
+struct WideIntendedArgs {              // wide_grad_mode = intended
+    const uint32_t *sorted_key, *sorted_ent, *seg_start, *nseg;
+    const float *delta; int ldd;       // delta at the output: [B][ldd], column 0
+    int B, F;
+    float *W, *state;
+    UpdParams upd;
+    const int *skip;
+};
+int launch_wide_keys(const int64_t *ids, int64_t n, int64_t rows, uint32_t *keys, int *err, hipStream_t st);
+int launch_wide_intended(const WideIntendedArgs &a, int64_t n, hipStream_t st);
+
 int launch_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
-                    int64_t id_first, int64_t id_stride, hipStream_t st);
+                    int64_t id_first, int64_t id_stride, const uint32_t *ids_dev /* NULL: id_first + r*id_stride */, hipStream_t st);
 int launch_init_dense(float *W, float *Wt, int K, int N, int ldw, int ldwt, uint64_t seed,
                       uint64_t table_w, float scale_w, uint64_t table_b, float scale_b, hipStream_t st);
 int launch_fill(float *p, int64_t n, float v, hipStream_t st);

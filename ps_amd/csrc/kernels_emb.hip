@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
         else a.bias[0] = (g * -a.upd.eta) + a.bias[0];
         return;
     }
-    if (r > a.rows) return;
+    if (r > a.rows || a.mode == 3) return;              // mode 3: "wide.bias" only (the keys go through k_wide_intended)
     // compat (layer/LRLayer.java:110-117): every key ever touched gets the same gbar
     if (a.mode == 0 && !a.touched[r]) return;
     float w = a.W[r], z = a.state[2 * r], n = a.state[2 * r + 1];
@@ -964,11 +964,12 @@ __global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
 // Grid-stride: a HIP launch carries at most 2^32 - 1 threads, and a configs[3]-sized table (320 M rows x 64 =
 // 2e10 elements) is far beyond that -- one thread per element silently initialised only the first 2^32 of them.
 __global__ void k_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
-                           int64_t id_first, int64_t id_stride) {
+                           int64_t id_first, int64_t id_stride, const uint32_t *ids /* or the progression */) {
     const int64_t total = rows * D, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int64_t r = t / D; const int d = (int)(t % D);
-        W[t] = ps_init_value(seed, table, (uint64_t)(id_first + r * id_stride), (uint64_t)d, scale);
+        const uint64_t id = ids ? (uint64_t)ids[r] : (uint64_t)(id_first + r * id_stride);
+        W[t] = ps_init_value(seed, table, id, (uint64_t)d, scale);
     }
 }
 
@@ -1120,6 +1121,49 @@ int launch_dense_update(const DenseUpdArgs &a0, hipStream_t st) {
     return PS_OK;
 }
 
+// ---------------------------------------------------------------------------
+// wide_grad_mode = intended: per-key presence-weighted gradient: g(key) = (sum over the key's
+// (sample, field) occurrences, in that order, of delta_sample) / B, Ftrl on the keys of THIS batch only.
+// The occurrences come sorted by key (stable radix sort of the B*F wide ids) with their segments.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_wide_keys(const int64_t *__restrict__ ids, int64_t n, int64_t rows, uint32_t *__restrict__ keys, int *err) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t id = ids[i];
+    if (id < 0 || id >= rows) { atomicAdd(err, 1); id = 0; }
+    keys[i] = (uint32_t)id;
+}
+__global__ __launch_bounds__(256) void k_wide_intended(WideIntendedArgs a) {
+    if (a.skip && *a.skip) return;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= (int64_t)*a.nseg) return;
+    const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
+    const uint32_t key = a.sorted_key[s0];
+    float S = 0.f;
+    for (uint32_t k = s0; k < e0; ++k) S = a.delta[(size_t)(a.sorted_ent[k] / (uint32_t)a.F) * a.ldd] + S;   // (sample, field) order
+    const float g = div_rn(S, (float)a.B);
+    float w = a.W[key], z = a.state[2 * (size_t)key], n = a.state[2 * (size_t)key + 1];
+    if (a.upd.kind == PS_UPD_FTRL) { if (g == 0.f) return; ftrl_elem(a.upd, g, w, z, n); }
+    else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, z, n);
+    else w = (g * -a.upd.eta) + w;
+    a.W[key] = w; a.state[2 * (size_t)key] = z; a.state[2 * (size_t)key + 1] = n;
+}
+}  // namespace
+
+int launch_wide_keys(const int64_t *ids, int64_t n, int64_t rows, uint32_t *keys, int *err, hipStream_t st) {
+    if (n <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_wide_keys, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, rows, keys, err);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+int launch_wide_intended(const WideIntendedArgs &a, int64_t n, hipStream_t st) {
+    if (n <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_wide_intended, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_wide_update, dim3(cdiv(a.rows + 1, 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
@@ -1127,10 +1171,10 @@ int launch_wide_update(const WideUpdArgs &a, hipStream_t st) {
 }
 
 int launch_init_emb(float *W, int64_t rows, int D, uint64_t seed, uint64_t table, float scale,
-                    int64_t id_first, int64_t id_stride, hipStream_t st) {
+                    int64_t id_first, int64_t id_stride, const uint32_t *ids_dev, hipStream_t st) {
     if (rows * D == 0) return PS_OK;
     const int64_t blocks = (rows * D + 255) / 256;
-    hipLaunchKernelGGL(k_init_emb, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, W, rows, D, seed, table, scale, id_first, id_stride);
+    hipLaunchKernelGGL(k_init_emb, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, W, rows, D, seed, table, scale, id_first, id_stride, ids_dev);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -177,7 +177,8 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
-    sort_ws_free(m->ws);
+    sort_ws_free(m->ws); sort_ws_free(m->wws);
+    fr(m->wkeys); fr(m->wents); fr(m->wseg_start); fr(m->wseg_id); fr(m->wnseg);
     fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
     fr(m->partials); fr(m->partials2); fr(m->grads_out); fr(m->dense_grad_flat);
     delete m;
@@ -387,6 +388,35 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     return PS_OK;
 }
 
+// wide_grad_mode = intended (not a reference path): the gradient of a wide key is the sum of delta
+// over the (sample, field) occurrences of the key IN THIS BATCH, / B -- a stable sort of the batch's wide ids, their
+// segments, one sequential sum per key, Ftrl on those keys only; "wide.bias" as in compat mode.
+static int enqueue_wide_intended(ps_model *m, WideUpdArgs w, hipStream_t st) {
+    ps_store *s = m->s;
+    const int64_t n = (int64_t)m->cur_B * m->cfg.F;
+    if (!m->wkeys) {
+        const int64_t cap = (int64_t)m->Bcap * m->cfg.F;
+        PSCHK(sort_ws_alloc(m->wws, cap));
+        PSCHK(model_alloc(m, (void **)&m->wkeys, sizeof(uint32_t) * (size_t)(cap + 1), false));
+        PSCHK(model_alloc(m, (void **)&m->wents, sizeof(uint32_t) * (size_t)(cap + 1), false));
+        PSCHK(model_alloc(m, (void **)&m->wseg_start, sizeof(uint32_t) * (size_t)(cap + 2), false));
+        PSCHK(model_alloc(m, (void **)&m->wseg_id, sizeof(uint32_t) * (size_t)(cap + 1), false));
+        PSCHK(model_alloc(m, (void **)&m->wnseg, sizeof(uint32_t) * 4, true));
+    }
+    PSCHK(launch_wide_keys(m->cur_wide, n, s->wide.rows, m->wkeys, s->err_dev, st));
+    uint32_t *sk = nullptr, *se = nullptr;
+    PSCHK(radix_sort_pairs(m->wws, m->wkeys, m->wents, n, bits_for(s->wide.rows), true, &sk, &se, st));
+    PSCHK(build_segments(m->wws, sk, n, m->wseg_start, m->wseg_id, m->wnseg, st));
+    WideIntendedArgs a;
+    memset(&a, 0, sizeof a);
+    a.sorted_key = sk; a.sorted_ent = se; a.seg_start = m->wseg_start; a.nseg = m->wnseg;
+    a.delta = m->fc[m->cfg.nfc - 1].dOut; a.ldd = m->fc[m->cfg.nfc - 1].ldD;
+    a.B = m->cur_B; a.F = m->cfg.F; a.W = w.W; a.state = w.state; a.upd = w.upd; a.skip = w.skip;
+    PSCHK(launch_wide_intended(a, n, st));
+    w.mode = 3;                                             // "wide.bias": rowMeans(delta), as in compat mode
+    return launch_wide_update(w, st);
+}
+
 int enqueue_backward(ps_model *m, bool apply) {
     ps_store *s = m->s;
     const ps_model_config_t &c = m->cfg;
@@ -414,8 +444,6 @@ int enqueue_backward(ps_model *m, bool apply) {
     }
     // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
     if (c.kind == PS_MODEL_WIDEDEEP && apply) {
-        if (c.wide_grad_mode != PS_GRAD_COMPAT)
-            return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is not implemented on the device path yet");
         WideUpdArgs w;
         memset(&w, 0, sizeof w);
         w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
@@ -423,7 +451,8 @@ int enqueue_backward(ps_model *m, bool apply) {
         PSCHK(store_resolve_updater(s, "wide.weights", &u));
         w.upd = make_upd_params(u);
         Prof pf(m, "wide_update");
-        PSCHK(launch_wide_update(w, s0));
+        if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, s0));
+        else PSCHK(launch_wide_update(w, s0));
     }
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
@@ -534,7 +563,8 @@ static int enqueue_update(ps_model *m) {
         w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = m->skip_dev;
         PSCHK(store_resolve_updater(s, "wide.weights", &u));
         w.upd = make_upd_params(u);
-        PSCHK(launch_wide_update(w, st));
+        if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, st));
+        else PSCHK(launch_wide_update(w, st));
     }
     {
         // the per-key gradients are unique already: one "push" per key
@@ -731,7 +761,8 @@ extern "C" int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out
     *n_out = n;
     if (!ids_out || !grads_out) return PS_OK;
     if (cap_rows < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
-    for (int64_t i = 0; i < n; ++i) ids_out[i] = e.shard + ((int64_t)rows[lo + i] - e.row_base[field]) * e.nshards;
+    for (int64_t i = 0; i < n; ++i)
+        ids_out[i] = e.java_route() ? (int64_t)e.ids_local_h[(size_t)rows[lo + i]] : e.shard + ((int64_t)rows[lo + i] - e.row_base[field]) * e.nshards;
     if (n) {
         HIPCHK(hipMemcpyAsync(grads_out, m->grads_out + (size_t)lo * e.D, sizeof(float) * n * e.D, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));

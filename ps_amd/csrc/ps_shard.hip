@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ 
                                                     int64_t nbags, int F, int nshards, int sbits,
                                                     const int64_t *__restrict__ lrb /*[nshards][F+1]*/,
                                                     const int64_t *__restrict__ vocab /*[F]*/,
+                                                    const uint8_t *__restrict__ owner_tab, const uint32_t *__restrict__ local_tab,
+                                                    const int64_t *__restrict__ grow_base /* java_string routing, else NULL */,
                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ ent_bag, int *err) {
     const int64_t bag = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (bag >= nbags) return;
@@ -37,8 +39,15 @@ __global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ 
     for (int64_t p = p0; p < p1; ++p) {
         int64_t id = ids[p];
         if (id < 0 || id >= vocab[f]) { atomicAdd(err, 1); id = 0; }
-        const int o = (int)(id % nshards);
-        const int64_t local = lrb[(size_t)o * (F + 1) + f] + id / nshards;
+        int o; int64_t local;
+        if (owner_tab) {                                        // net/Mod.java: owner = hash of the key STRING
+            const int64_t g = grow_base[f] + id;
+            o = owner_tab[g];
+            local = lrb[(size_t)o * (F + 1) + f] + local_tab[g];
+        } else {
+            o = (int)(id % nshards);
+            local = lrb[(size_t)o * (F + 1) + f] + id / nshards;
+        }
         keys[p] = ((uint32_t)o << sbits) | (uint32_t)local;
         if (ent_bag) ent_bag[p] = (uint32_t)bag;
     }
@@ -112,7 +121,8 @@ int ensure_shard_state(ps_model *m, int nshards) {
     int64_t maxrows = 1;
     for (int o = 0; o < nshards; ++o) {
         for (int f = 0; f < F; ++f) {
-            const int64_t cnt = s->emb.rows[f] > o ? (s->emb.rows[f] - o + nshards - 1) / nshards : 0;
+            const int64_t cnt = s->emb.java_route() ? s->emb.owner_cnt[(size_t)o * F + f]
+                                                    : (s->emb.rows[f] > o ? (s->emb.rows[f] - o + nshards - 1) / nshards : 0);
             lrb[(size_t)o * (F + 1) + f + 1] = lrb[(size_t)o * (F + 1) + f] + cnt;
         }
         if (lrb[(size_t)o * (F + 1) + F] > maxrows) maxrows = lrb[(size_t)o * (F + 1) + F];
@@ -123,6 +133,16 @@ int ensure_shard_state(ps_model *m, int nshards) {
     PSCHK(store_dev_alloc(s, (void **)&sh.lrb_dev, sizeof(int64_t) * lrb.size() + sizeof(int64_t) * F, false));
     HIPCHK(hipMemcpyAsync(sh.lrb_dev, lrb.data(), sizeof(int64_t) * lrb.size(), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(sh.lrb_dev + lrb.size(), s->emb.rows.data(), sizeof(int64_t) * F, hipMemcpyHostToDevice, s->stream));
+    if (s->emb.java_route() && !s->emb.owner_dev) {
+        EmbTables &e = s->emb;
+        const size_t G = e.owner_h.size();
+        PSCHK(store_dev_alloc(s, (void **)&e.owner_dev, G + 16, false));
+        PSCHK(store_dev_alloc(s, (void **)&e.local_dev, sizeof(uint32_t) * G + 16, false));
+        PSCHK(store_dev_alloc(s, (void **)&e.grow_base_dev, sizeof(int64_t) * (size_t)(F + 1), false));
+        HIPCHK(hipMemcpyAsync(e.owner_dev, e.owner_h.data(), G, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(e.local_dev, e.local_h.data(), sizeof(uint32_t) * G, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(e.grow_base_dev, e.grow_base.data(), sizeof(int64_t) * (size_t)(F + 1), hipMemcpyHostToDevice, s->stream));
+    }
     PSCHK(store_dev_alloc(s, (void **)&sh.slot, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(store_dev_alloc(s, (void **)&sh.send_rows, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(store_dev_alloc(s, (void **)&sh.owner_start, sizeof(uint32_t) * (size_t)(nshards + 2), true));
@@ -156,7 +176,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     const int F = m->cfg.F;
     const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
     hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, st, m->cur_ids, m->cur_offsets, nbags, F, nshards,
-                       sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), m->keys,
+                       sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), s->emb.owner_dev, s->emb.local_dev, s->emb.grow_base_dev, m->keys,
                        m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev);
     HIPCHK(hipGetLastError());
     PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
@@ -221,6 +241,8 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     if (!m || (!cache_dev && m->sh.U > 0)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!m->sh.slot) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
     ps_store *s = m->s;
+    if (m->cfg.kind == PS_MODEL_WIDEDEEP && m->cfg.wide_grad_mode != PS_GRAD_COMPAT)
+        return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is single-GPU only (the sharded push carries the compat G/C pair)");
     HIPCHK(hipSetDevice(s->device));
     m->sh.active = true;
     m->sh.cache = cache_dev;

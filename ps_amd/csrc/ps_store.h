@@ -17,6 +17,15 @@ struct EmbTables {
     float *W = nullptr;             // [total_rows][D]
     float *state = nullptr;         // [total_rows][2][D]  {M,V} or {Z,N}
     int64_t *row_base_dev = nullptr;
+    // PS_ROUTE_JAVA_STRING with nshards > 1 (net/Mod.java:13-15: the owner of a key is a hash of its STRING, so a
+    // shard's ids are not an arithmetic progression): per global id g = grow_base[f] + id
+    std::vector<int64_t> grow_base;     // [F+1] prefix of the vocabularies
+    std::vector<uint8_t> owner_h;       // [G] owner shard of every (field, id)
+    std::vector<uint32_t> local_h;      // [G] index of the id among its owner's ids of that field (ascending id)
+    std::vector<uint32_t> ids_local_h;  // [total_rows] id held by every local row of THIS shard
+    std::vector<int64_t> owner_cnt;     // [nshards][F] ids of field f owned by shard o
+    uint8_t *owner_dev = nullptr; uint32_t *local_dev = nullptr; int64_t *grow_base_dev = nullptr;
+    bool java_route() const { return route_mode == PS_ROUTE_JAVA_STRING && nshards > 1; }
 };
 
 struct WideTable {
@@ -96,6 +105,9 @@ struct ps_model {
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
     float *partials = nullptr, *partials2 = nullptr, *grads_out = nullptr;
     float *dense_grad_flat = nullptr; int64_t dense_elems = 0;
+    // wide_grad_mode = intended: sort of the batch's wide ids (allocated on first use)
+    SortWorkspace wws;
+    uint32_t *wkeys = nullptr, *wents = nullptr, *wseg_start = nullptr, *wseg_id = nullptr, *wnseg = nullptr;
     // per-kernel-group event timing (ps_model_set_profile)
     struct ProfEvent { const char *name; hipEvent_t a, b; };
     bool profile = false;

@@ -234,6 +234,7 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     (void)hipStreamSynchronize(s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(s->emb.W); fr(s->emb.state); fr(s->emb.row_base_dev);
+    fr(s->emb.owner_dev); fr(s->emb.local_dev); fr(s->emb.grow_base_dev);
     fr(s->wide.W); fr(s->wide.state); fr(s->wide.touched); fr(s->wide.bias); fr(s->wide.bias_state);
     for (auto &f : s->fc) { fr(f.W); fr(f.Wt); fr(f.S1); fr(f.S2); }
     fr(s->err_dev); fr(s->idx_dev); fr(s->rowbuf_dev);
@@ -293,8 +294,13 @@ extern "C" int ps_store_create_embedding(ps_store_t *s, int F, const int64_t *ro
     if (!s || !rows || F <= 0 || D <= 0) return ps_set_err(PS_E_BAD_ARG, "bad embedding shape");
     if (s->emb.W) return ps_set_err(PS_E_STATE, "embedding tables already exist");
     if (nshards < 1 || shard < 0 || shard >= nshards) return ps_set_err(PS_E_BAD_ARG, "bad shard %d/%d", shard, nshards);
-    if (route_mode != PS_ROUTE_ID_MOD && nshards > 1)
-        return ps_set_err(PS_E_UNSUPPORTED, "dense shard packing needs PS_ROUTE_ID_MOD (java_string routing is host-side only)");
+    if (route_mode != PS_ROUTE_ID_MOD && route_mode != PS_ROUTE_JAVA_STRING) return ps_set_err(PS_E_BAD_ARG, "bad route_mode %d", route_mode);
+    if (route_mode == PS_ROUTE_JAVA_STRING && nshards > 1) {
+        // the key string is "emF<f>.<id>.0" only while Float.toString(id) is plain decimal (ids < 10^7)
+        if (nshards > 255) return ps_set_err(PS_E_UNSUPPORTED, "java_string routing supports up to 255 shards");
+        for (int f = 0; f < F; ++f)
+            if (rows[f] > 10000000) return ps_set_err(PS_E_UNSUPPORTED, "java_string routing needs vocabularies <= 10^7 (Float.toString switches to exponent form)");
+    }
     if ((D % 4 == 0 && D > 256) || (D % 4 != 0 && D > 64)) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d too wide for one wave per row", D);
     if (state_slots != 0 && state_slots != 2) return ps_set_err(PS_E_BAD_ARG, "state_slots must be 0 or 2");
     HIPCHK(hipSetDevice(s->device));
@@ -302,9 +308,46 @@ extern "C" int ps_store_create_embedding(ps_store_t *s, int F, const int64_t *ro
     e.F = F; e.D = D; e.state_slots = state_slots; e.shard = shard; e.nshards = nshards; e.route_mode = route_mode;
     e.rows.assign(rows, rows + F);
     e.row_base.assign(F + 1, 0);
-    for (int f = 0; f < F; ++f) {
+    for (int f = 0; f < F; ++f)
         if (rows[f] <= 0) return ps_set_err(PS_E_BAD_ARG, "rows[%d] = %lld", f, (long long)rows[f]);
-        e.row_base[f + 1] = e.row_base[f] + local_count(rows[f], shard, nshards);
+    if (e.java_route()) {
+        // Mod.shard(key) = String.hashCode(key) mod n for every (field, id) -- once, on the host (31-polynomial over
+        // "emF<f>." + decimal id + ".0"; ps_router_shard_key is the same arithmetic on a C string)
+        e.grow_base.assign(F + 1, 0);
+        for (int f = 0; f < F; ++f) e.grow_base[f + 1] = e.grow_base[f] + rows[f];
+        const int64_t G = e.grow_base[F];
+        e.owner_h.resize((size_t)G); e.local_h.resize((size_t)G);
+        e.owner_cnt.assign((size_t)nshards * F, 0);
+        for (int f = 0; f < F; ++f) {
+            char pre[32];
+            snprintf(pre, sizeof pre, "emF%d.", f);
+            uint32_t hp = 0;
+            for (const char *c = pre; *c; ++c) hp = 31u * hp + (uint32_t)(unsigned char)*c;
+            for (int64_t id = 0; id < rows[f]; ++id) {
+                char dig[24];
+                int nd = 0;
+                int64_t v = id;
+                do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+                uint32_t h = hp;
+                while (nd) h = 31u * h + (uint32_t)dig[--nd];
+                h = 31u * h + (uint32_t)'.';
+                h = 31u * h + (uint32_t)'0';
+                int o = (int)((int32_t)h % nshards);
+                if (o < 0) o += nshards;                 // floorMod (net/Mod.java would go negative)
+                const size_t g = (size_t)(e.grow_base[f] + id);
+                e.owner_h[g] = (uint8_t)o;
+                e.local_h[g] = (uint32_t)e.owner_cnt[(size_t)o * F + f]++;
+            }
+            e.row_base[f + 1] = e.row_base[f] + e.owner_cnt[(size_t)shard * F + f];
+        }
+        e.ids_local_h.resize((size_t)e.row_base[F]);
+        for (int f = 0; f < F; ++f)
+            for (int64_t id = 0; id < rows[f]; ++id) {
+                const size_t g = (size_t)(e.grow_base[f] + id);
+                if (e.owner_h[g] == shard) e.ids_local_h[(size_t)(e.row_base[f] + e.local_h[g])] = (uint32_t)id;
+            }
+    } else {
+        for (int f = 0; f < F; ++f) e.row_base[f + 1] = e.row_base[f] + local_count(rows[f], shard, nshards);
     }
     e.total_rows = e.row_base[F];
     if (e.total_rows >= (1ll << 32)) return ps_set_err(PS_E_UNSUPPORTED, "more than 2^32 rows on one shard");
@@ -313,10 +356,17 @@ extern "C" int ps_store_create_embedding(ps_store_t *s, int F, const int64_t *ro
     PSCHK(store_dev_alloc(s, (void **)&e.row_base_dev, sizeof(int64_t) * (F + 1), false));
     HIPCHK(hipMemcpyAsync(e.row_base_dev, e.row_base.data(), sizeof(int64_t) * (F + 1), hipMemcpyHostToDevice, s->stream));
     const float scale = ps_xavier_scale(1, D);          // EmbeddingField.java:40 (in = 1, out = D)
+    uint32_t *ids_dev = nullptr;
+    if (e.java_route() && e.total_rows > 0) {
+        RtGuard rt_guard;
+        HIPCHK(hipMalloc((void **)&ids_dev, sizeof(uint32_t) * (size_t)e.total_rows));
+        HIPCHK(hipMemcpyAsync(ids_dev, e.ids_local_h.data(), sizeof(uint32_t) * (size_t)e.total_rows, hipMemcpyHostToDevice, s->stream));
+    }
     for (int f = 0; f < F; ++f)
         PSCHK(launch_init_emb(e.W + (size_t)e.row_base[f] * D, e.row_base[f + 1] - e.row_base[f], D, s->seed,
-                              (uint64_t)f, scale, shard, nshards, s->stream));
+                              (uint64_t)f, scale, shard, nshards, ids_dev ? ids_dev + e.row_base[f] : nullptr, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (ids_dev) { RtGuard rt_guard; (void)hipFree(ids_dev); }
     return PS_OK;
 }
 
@@ -370,6 +420,10 @@ extern "C" int ps_store_create_fc(ps_store_t *s, int layer, int in_dims, int out
 int64_t store_local_row(const ps_store *s, int field, int64_t id) {
     const EmbTables &e = s->emb;
     if (field < 0 || field >= e.F || id < 0 || id >= e.rows[field]) return -1;
+    if (e.java_route()) {
+        const size_t g = (size_t)(e.grow_base[field] + id);
+        return e.owner_h[g] == e.shard ? e.row_base[field] + (int64_t)e.local_h[g] : -1;
+    }
     if (ps_router_shard_id(e.route_mode, field, id, e.nshards) != e.shard) return -1;
     return e.row_base[field] + id / e.nshards;
 }

@@ -647,3 +647,44 @@ def test_intended_embedding_gradient_mode(orc):
             np.testing.assert_array_equal(g[i], orc.emb_geff(dx[ks, f * D:(f + 1) * D], orc.GRAD_INTENDED, 0), err_msg="emF%d.%d n=%d" % (f, idv, len(ks)))
     assert longest > 32
     gm.close(); kv.close()
+
+
+def test_intended_wide_gradient_mode_on_device(orc):
+    """wide_grad_mode = intended (the oracle's switch, not a reference path): the gradient of a wide
+    key is the sum of delta over its (sample, field) occurrences in THIS batch / B, Ftrl on those keys only -- bit-exact
+    against orc.ftrl_update of that sum built from the GPU's own P; keys outside the batch keep their state."""
+    import ps_amd
+    from ps_amd import native as N
+    F, D, X, fc, V, B, WS = 4, 8, 2, [16, 8, 1], 50, 64, 23
+    rng = np.random.default_rng(12)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B, wide_grad_mode=N.PS_GRAD_INTENDED)
+    allw = np.arange(WS)
+    for step in range(3):
+        E, Xd, Y = data(rng, B, F, X, V, True)
+        Wd = (E * 7 + 3) % WS
+        Wd[:, 0] = 5                                                   # one key in every sample
+        w0, z0, n0 = kv.get_wide(allw), kv.get_wide(allw, 1), kv.get_wide(allw, 2)
+        for fused in (step != 1,):
+            if fused:
+                gm.train({"E": E, "X": Xd, "Y": Y, "W": Wd})
+            else:
+                gm.forward({"E": E, "X": Xd, "Y": Y, "W": Wd}); gm.backward(); gm.update()
+        p = gm.p(B)
+        d = ((p - Y) / (p * (f32(1) - p))).astype(f32)
+        d = (d * (p * (f32(1) - p))).astype(f32)                       # CrossEntropy' then Sigmoid' (f32, op by op)
+        w1, z1, n1 = kv.get_wide(allw), kv.get_wide(allw, 1), kv.get_wide(allw, 2)
+        for key in range(WS):
+            occ = np.argwhere(Wd == key)                               # (sample, field) order
+            if len(occ) == 0:
+                assert w1[key] == w0[key] and z1[key] == z0[key] and n1[key] == n0[key]
+                continue
+            S = f32(0)
+            for i, _ in occ:
+                S = f32(d[i] + S)
+            g = f32(S / f32(B))
+            we, ze, ne, _ = orc.ftrl_update([w0[key]], [g], [z0[key]], [n0[key]])
+            assert w1[key] == we[0] and z1[key] == ze[0] and n1[key] == ne[0], "wide.weights.%d" % key
+    assert kv.get("wide.bias")[0] != 0          # "wide.bias" keeps its compat gradient rowMeans(delta) (Ftrl: w lags z by one step)
+    gm.close(); kv.close()
