@@ -247,6 +247,47 @@ int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets
  * in+1..ldx-1 zero).  y_dev [B][ldy], ldy >= out. */
 int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx,
                   int B, float *y_dev, int ldy);
+/* FcLayer.backward (layer/FcLayer.java:93-110) of layer `layer`, stand-alone:
+ *   delta_dev [B][ldd], ldd = out rounded up to 16, padding columns zero: on
+ *     entry the gradient wrt the layer's output (next.delta, or the loss
+ *     gradient when the layer is last, :95-99); act' is applied IN PLACE from
+ *     y_dev, the layer's output as ps_fc_forward left it (:100-102; y_dev may
+ *     be NULL with PS_ACT_NONE);
+ *   x_dev [B][ldx]: the layer's input exactly as given to ps_fc_forward;
+ *   biasGradient = rowMeans(delta) and weightsGradient = delta * x^T / B are
+ *     ADDED to the store's pending gradient of "fc<i>.bias" / "fc<i>.weights"
+ *     (kvStore.sum, :104,:106) -- ps_dense_update applies and clears them;
+ *   dx_dev [B][lddx] (NULL: skip): weights^T * delta (:108), the layer's
+ *     `delta` field = the next.delta of the layer below (no mask applied:
+ *     that layer's backward applies its own act').
+ * ps_fc_pending_grad reads the pending SUM ([in][out] / [out]) and its count. */
+int ps_fc_backward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx,
+                   const float *y_dev, int ldy, float *delta_dev, int ldd, int B,
+                   float *dx_dev, int lddx);
+int ps_fc_pending_grad(ps_store_t *s, int layer, int bias, float *out, int cap, int *count);
+/* KVStore.update(Map<String,Updater>) + clear for the dense tensors
+ * (store/KVStore.java:240-277): g = pending sum / count, the updater resolved
+ * for "fc<i>.weights" (exact key, prefix, "default"), W' and its transpose
+ * rewritten, pending cleared, globalStep++.  layer < 0: every layer with a
+ * pending gradient; a named layer without one: PS_MISSING. */
+int ps_dense_update(ps_store_t *s, int layer);
+/* EmbeddingLayer.backward (layer/EmbeddingLayer.java:59-69) =
+ * EmbeddingField.backward of every field (layer/EmbeddingField.java:86-104),
+ * run TWICE per step by the reference (grad_mode
+ * PS_GRAD_COMPAT reproduces the resulting factor (n+1)/(2n^2), PS_GRAD_INTENDED
+ * is the mean), + KVStore.sum + KVStore.update fused (apply != 0: the "emF"
+ * updater runs on every touched row in place; apply == 0: gradients only).
+ *   ids_dev / offsets_dev / nnz as in ps_batch_t (device); a_dev [B][lda] the
+ *   layer's output (relu' mask, act = PS_ACT_RELU; NULL with PS_ACT_NONE);
+ *   delta_dev [B][ldd] the gradient wrt that output (columns f*D..f*D+D-1);
+ *   sum_order PS_SUM_* (see ps_model_config_t.emb_sum_order).
+ * ps_emb_last_grads: the per-key gradients it handed to the updater -- n unique
+ * table rows (row = first row of the field + id, fields back to back) and
+ * [n][D] gradients; call with NULL outputs to size. */
+int ps_emb_backward_update(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets_dev,
+                           int64_t nnz, int B, int act, const float *a_dev, int lda,
+                           const float *delta_dev, int ldd, int grad_mode, int sum_order, int apply);
+int ps_emb_last_grads(ps_store_t *s, int64_t *rows_out, float *grads_out, int64_t cap_rows, int64_t *n_out);
 int ps_store_sync(ps_store_t *s);
 /* Host wait for one HIP stream (NULL = the store's): for ps_comm_ops_t callbacks that stage through the host. */
 int ps_stream_sync(ps_store_t *s, void *hip_stream);

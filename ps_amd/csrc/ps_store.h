@@ -43,6 +43,8 @@ struct FcParams {
     float *W = nullptr;      // W'  [Kpad][ldw]   (reference layout [in][out] + bias row)
     float *Wt = nullptr;     // W'^T [N][Kpad]
     float *S1 = nullptr, *S2 = nullptr;  // updater state, W' layout
+    // KVStore.sum of the layer-granular path (ps_fc_backward): flat [(K+1)][N] sum and its count, until ps_dense_update
+    float *pending = nullptr; int pending_cnt = 0;
 };
 
 struct ps_store {
@@ -64,6 +66,14 @@ struct ps_store {
     SortWorkspace push_ws; uint32_t *push_keys = nullptr, *push_ents = nullptr, *push_seg_start = nullptr,
                               *push_seg_id = nullptr, *push_nseg = nullptr; int64_t push_cap = 0;
     uint32_t *push_mask = nullptr, *push_pos = nullptr; int push_pos_peers = 0;   // sort-free push (worker-grouped lists)
+    // scratch of the layer-granular backward operators (ps_layer_ops.hip), grow-only
+    struct OpScratch {
+        float *part = nullptr; int64_t part_cap = 0;           // split-K slabs of ps_fc_backward
+        float *masked = nullptr; int64_t masked_cap = 0;       // relu'-masked delta of ps_emb_backward_update
+        SortWorkspace ws; int64_t nnz_cap = 0, last_nnz = 0;
+        uint32_t *keys = nullptr, *ents = nullptr, *ent_bag = nullptr, *seg_start = nullptr, *seg_id = nullptr, *nseg = nullptr, *uniq_row = nullptr;
+        float *partials = nullptr, *partials2 = nullptr, *grads = nullptr;
+    } ops;
 };
 
 int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero);

@@ -236,7 +236,13 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     fr(s->emb.W); fr(s->emb.state); fr(s->emb.row_base_dev);
     fr(s->emb.owner_dev); fr(s->emb.local_dev); fr(s->emb.grow_base_dev);
     fr(s->wide.W); fr(s->wide.state); fr(s->wide.touched); fr(s->wide.bias); fr(s->wide.bias_state);
-    for (auto &f : s->fc) { fr(f.W); fr(f.Wt); fr(f.S1); fr(f.S2); }
+    for (auto &f : s->fc) { fr(f.W); fr(f.Wt); fr(f.S1); fr(f.S2); fr(f.pending); }
+    {
+        ps_store::OpScratch &o = s->ops;
+        sort_ws_free(o.ws);
+        fr(o.part); fr(o.masked); fr(o.keys); fr(o.ents); fr(o.ent_bag); fr(o.seg_start); fr(o.seg_id); fr(o.nseg); fr(o.uniq_row);
+        fr(o.partials); fr(o.partials2); fr(o.grads);
+    }
     fr(s->err_dev); fr(s->idx_dev); fr(s->rowbuf_dev);
     sort_ws_free(s->push_ws);
     fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);

@@ -112,6 +112,11 @@ SIGNATURES = {
     "ps_dev_download": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "ps_emb_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i]),
     "ps_fc_forward": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i]),
+    "ps_fc_backward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i]),
+    "ps_fc_pending_grad": (_i, [_vp, _i, _i, _pf, _i, _pi]),
+    "ps_dense_update": (_i, [_vp, _i]),
+    "ps_emb_backward_update": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _i, _i]),
+    "ps_emb_last_grads": (_i, [_vp, _pi64, _pf, _i64, _pi64]),
     "ps_store_set_stream": (_i, [_vp, _vp]),
     "ps_shard_plan": (_i, [_vp, C.POINTER(ps_batch_t), _i, _vp, _pi64, _pvp, _pi64]),
     "ps_shard_plan_launch": (_i, [_vp, C.POINTER(ps_batch_t), _i, _vp]),
