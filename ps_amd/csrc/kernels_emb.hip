@@ -640,27 +640,12 @@ __device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *
                 const float *row = buf + (uint32_t)d * LDE;
                 float acc = S[q];
                 uint32_t j = 0;
-                // 32 entries per chunk: 8 ds_read_b128, then 32 dependent adds (addi :94).  The reads of chunk c+1 are
-                // issued before the adds of chunk c (two register sets), so the chain never waits for LDS.
-                float4 cur[8], nxt[8];
-                auto load8 = [&](float4 (&v)[8], uint32_t at) {
+                for (; j + 32 <= cnt; j += 32) {               // 8 reads in flight, then 32 dependent adds
+                    float4 v[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(row + at + 4 * k);
-                };
-                auto add8 = [&](const float4 (&v)[8]) {
+                    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(row + j + 4 * k);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { acc = v[k].x + acc; acc = v[k].y + acc; acc = v[k].z + acc; acc = v[k].w + acc; }
-                };
-                if (cnt >= 32) load8(cur, 0);
-                while (j + 32 <= cnt) {
-                    const bool n1 = j + 64 <= cnt;
-                    if (n1) load8(nxt, j + 32);
-                    add8(cur); j += 32;
-                    if (!n1) break;
-                    const bool n2 = j + 64 <= cnt;
-                    if (n2) load8(cur, j + 32);
-                    add8(nxt); j += 32;
-                    if (!n2) break;
+                    for (int k = 0; k < 8; ++k) { acc = v[k].x + acc; acc = v[k].y + acc; acc = v[k].z + acc; acc = v[k].w + acc; }   // addi :94
                 }
                 for (; j + 4 <= cnt; j += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(row + j);
