@@ -50,14 +50,34 @@ def fc_flops_per_step(cfg):
     return 6.0 * cfg["B"] * s, dims
 
 
+# kernel launches behind one profiled group (the others are one launch): per-launch time decides the dominant KERNEL
+GROUP_LAUNCHES = {"emb_sort": 9, "emb_segments": 2, "dense_update": 2}
+
+
 def group_algorithmic(cfg, name, nnz, uniq):
-    """Algorithmic work of one launch group (bytes for HBM-bound, flop for MFMA-bound)."""
+    """Algorithmic work of one launch group (bytes for HBM-bound, flop for MFMA-bound), SURVEY 8d's per-unit figures.
+    Every group of the step is a candidate for the dominant kernel."""
     B, D, F = cfg["B"], cfg["D"], cfg["F"]
     dims = [F * D + cfg["X"]] + cfg["fc"]
+    dense = sum((a + 1) * b for a, b in zip(dims[:-1], dims[1:]))
     if name == "emb_fwd":
-        return "hbm", nnz * (4.0 * D + 8.0)                       # SURVEY 8d: row + int64 id (read roofline)
-    # (emb_bwd_update, emb_sort, ... are groups of several kernels: reported in kernel_groups_us,
-    #  not candidates for the single-kernel roofline)
+        return "hbm", nnz * (4.0 * D + 8.0)                       # row + int64 id (read roofline)
+    if name == "emb_bwd_update":
+        return "hbm", nnz * 4.0 * D + uniq * 6 * 4.0 * D + nnz * 8.0     # delta rows + {W,M,V} read and written per key + sort pairs
+    if name == "emb_sort":
+        return "hbm", 3 * 24.0 * nnz                              # 3 radix passes: pairs read twice (histogram, scatter), written once
+    if name == "emb_segments":
+        return "hbm", 20.0 * nnz                                  # keys read twice, run ids written
+    if name == "dense_update":
+        return "hbm", 4.0 * dense * (8 + 7)                       # ~8 split slabs read, W/M/V read, W/Wt/M/V written
+    if name == "head_last_bwd":
+        return "hbm", 4.0 * B * (3 * dims[-2] + 2 * F + 8)        # the out = 1 layer's input twice, delta_prev written, wide ids
+    if name in ("head", "fc_bwd_last"):
+        return "hbm", 4.0 * B * (2 * dims[-2] + 2 * F + 8)
+    if name == "wide_update":
+        return "hbm", 13.0 * cfg["wide"]
+    if name == "loss_reduce":
+        return "hbm", 8.0 * B
     for l in range(len(cfg["fc"])):
         if name == "fc_fwd%d" % l:
             return "mfma", 2.0 * B * dims[l] * dims[l + 1]
@@ -68,7 +88,19 @@ def group_algorithmic(cfg, name, nnz, uniq):
     return None, 0.0
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def host_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baseline(cfg, budget_s=15.0):
     """The restated reference CPU path (oracle, string keys + hash maps, thread = 1 as CTR.java:72
     forces) timed on this host's cores on a bounded sample of the same workload."""
     from oracle import oracle as orc
@@ -78,7 +110,7 @@ def cpu_baseline(cfg, budget_s=20.0):
     n, t_total = 0, 0.0
     E, X, Y, W = synth_batch(cfg, rng)
     om.train(E.astype(np.float32), X, Y, W.astype(np.float32))          # warm-up (creates keys)
-    while t_total < budget_s and n < 8:
+    while t_total < budget_s and n < 6:
         E, X, Y, W = synth_batch(cfg, rng)
         t0 = time.perf_counter()
         om.train(E.astype(np.float32), X, Y, W.astype(np.float32))
@@ -86,7 +118,40 @@ def cpu_baseline(cfg, budget_s=20.0):
         n += 1
     return {"value": cfg["B"] * n / t_total, "unit": "examples/s", "cores": 1, "kind": "port",
             "sample": "%d Wide&Deep steps of batch %d (same synthetic config) after 1 warm-up, oracle/ps_oracle.c "
-                      "restatement in compat mode (string keys, hash maps, thread=1)" % (n, cfg["B"])}
+                      "restatement in compat mode (string keys, hash maps, thread=1 as CTR.java:72)" % (n, cfg["B"])}
+
+
+def cpu_baseline_threads(cfg, threads, steps=2):
+    """The reference's thread-DP (train/Trainer.java:77-95: T replicas, one minibatch each per round) as an UPPER BOUND:
+    T independent replicas of the restated step, one host thread each (the C oracle releases the GIL), with none of the
+    serialisation the reference adds on top (every kvStore.sum / get goes through one monitor, store/KVStore.java:136,192)."""
+    import threading
+    from oracle import oracle as orc
+
+    def work(i, out):
+        rng = np.random.default_rng(cfg["seed"] + 17 * i)
+        st = orc.Store(cfg["seed"])
+        om = orc.Model(st, orc.WIDEDEEP, cfg["F"], cfg["D"], cfg["X"], cfg["fc"], wide_size=cfg["wide"])
+        bs = [synth_batch(cfg, rng) for _ in range(steps + 1)]
+        E, X, Y, W = bs[0]
+        om.train(E.astype(np.float32), X, Y, W.astype(np.float32))      # warm-up
+        gate.wait()
+        t0 = time.perf_counter()
+        for E, X, Y, W in bs[1:]:
+            om.train(E.astype(np.float32), X, Y, W.astype(np.float32))
+        out[i] = (t0, time.perf_counter())
+
+    gate = threading.Barrier(threads)
+    out = [None] * threads
+    th = [threading.Thread(target=work, args=(i, out)) for i in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = max(o[1] for o in out) - min(o[0] for o in out)
+    return {"value": cfg["B"] * steps * threads / wall, "unit": "examples/s", "cores": threads, "kind": "port",
+            "sample": "%d independent replicas x %d steps of batch %d, one host thread each: an upper bound of the reference's "
+                      "thread-DP (Trainer.java:77-95), which serialises kvStore.sum/get on one monitor" % (threads, steps, cfg["B"])}
 
 
 def run_single(args):
@@ -126,7 +191,9 @@ def run_single(args):
     gm.sync()
     dt = time.perf_counter() - t0
     # ---- roofline of the dominant kernel: same steps again with HIP events around that kernel ----
-    dom = max(((k, v) for k, v in prof.items() if group_algorithmic(cfg, k, 1, 1)[0]), key=lambda kv_: kv_[1][1] / max(kv_[1][0], 1))[0]
+    # dominant KERNEL: the largest average time per launch over every group of the step
+    dom = max(((k, v) for k, v in prof.items() if group_algorithmic(cfg, k, 1, 1)[0]),
+              key=lambda kv_: kv_[1][1] / max(kv_[1][0], 1) / GROUP_LAUNCHES.get(kv_[0], 1))[0]
     gm.set_profile(True, only=dom)
     for i in range(args.steps):
         gm.train_async(batches[i % nb])
@@ -157,7 +224,19 @@ def run_single(args):
     except (OSError, KeyError, ValueError):
         pass
     roof["avg_launch_us"] = avg_s * 1e6
+    roof["launches_in_group"] = GROUP_LAUNCHES.get(dom, 1)
     groups = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in prof.items()}
+    # every group against its own roofline (HIP events around the group, all groups on one stream: includes ~4 us of
+    # launch latency per group, so these are lower bounds of the kernels' own fractions)
+    roof_groups = {}
+    for k, g in groups.items():
+        kind_k, work_k = group_algorithmic(cfg, k, nnz, uniq)
+        if not kind_k:
+            continue
+        t = g["avg_us"] * 1e-6
+        frac_k = work_k / t / 1e12 / F32_MFMA_PEAK_TFS if kind_k == "mfma" else work_k / t / 1e9 / HBM_PEAK_GBS
+        roof_groups[k] = {"bound": kind_k, "avg_us": round(g["avg_us"], 2), "frac": round(frac_k, 4)}
+    fc_flops, _ = fc_flops_per_step(cfg)
     out = {
         "metric": "Wide&Deep training examples/sec", "value": cfg["B"] * args.steps / dt, "unit": "examples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -166,11 +245,21 @@ def run_single(args):
                                "13 dense, FC[512,256,1], batch 4096, Zipf(1.05) ids, Adam + Ftrl(wide), 1 MI355X",
                    "global_batch": cfg["B"], "parallelism": "single", "resident_inputs": True, "hip_graph": bool(args.graph)},
         "roofline": roof,
+        "roofline_groups": roof_groups,
+        # all FC flops of the step / step time / f32 MFMA peak: the matrix cores' utilisation over the WHOLE step
+        "mfma_utilisation": fc_flops / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFS,
         "kernel_groups_us": {k: round(v["avg_us"], 2) for k, v in groups.items()},
+        # serialised kernel-group time / step time: > 1 means the three streams overlap that much work
+        "kernel_sum_over_step": sum(v["avg_us"] for v in groups.values()) / (1e3 * dt / args.steps),
+        "launches_per_step": sum(GROUP_LAUNCHES.get(k, 1) for k in groups),
         "final_loss": loss,
+        "host": host_info(),
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg)
+        nthr = min(os.cpu_count() or 1, 64)
+        if nthr > 1:
+            out["cpu_baseline_threads"] = cpu_baseline_threads(cfg, nthr)
     if args.gather:
         out["gather_hbm"] = gather_roofline(kv, args)
     if args.multi_hot:
@@ -244,8 +333,8 @@ def gather_roofline(kv, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--zipf", type=float, default=1.05, help="id distribution exponent; <= 1 means uniform")
     ap.add_argument("--no-cpu", action="store_true")

@@ -246,6 +246,7 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
 // stream (and the prefetch communicator) so it can run beside the previous step's training: call begin for
 // step t+1 (on ANOTHER model of the same store: its own key lists and activations) before finish of step t.
 extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side) {
+    RoctxRange roctx_range("ps_shard_step_begin");
     if (!m || !batch || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32)
         return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
@@ -288,6 +289,7 @@ extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const
 }
 
 extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss) {
+    RoctxRange roctx_range("ps_shard_step_finish");
     if (!m || !comm) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
     ps_model::Shard &sh = m->sh;

@@ -36,6 +36,15 @@ struct RtGuard {
         if (r__ != PS_OK) return r__; \
     } while (0)
 
+// roctx ranges around the C-ABI entry points (visible in rocprofv3 --marker-trace timelines).  Off unless
+// PS_AMD_ROCTX=1: libroctx64 is dlopen'ed on first use, a range costs one predictable branch otherwise.
+void ps_roctx_push(const char *name);
+void ps_roctx_pop();
+struct RoctxRange {
+    RoctxRange(const char *name) { ps_roctx_push(name); }
+    ~RoctxRange() { ps_roctx_pop(); }
+};
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_emb_keys(const int64_t *__restrict__ id
 
 extern "C" int ps_fc_backward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx, const float *y_dev, int ldy,
                               float *delta_dev, int ldd, int B, float *dx_dev, int lddx) {
+    RoctxRange roctx_range("ps_fc_backward");
     if (!s || !x_dev || !delta_dev || B <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (layer < 0 || layer >= (int)s->fc.size() || !s->fc[layer].present) return ps_set_err(PS_MISSING, "fc%d absent", layer);
     FcParams &p = s->fc[layer];
@@ -131,6 +132,7 @@ extern "C" int ps_fc_pending_grad(ps_store_t *s, int layer, int bias, float *out
 }
 
 extern "C" int ps_dense_update(ps_store_t *s, int layer) {
+    RoctxRange roctx_range("ps_dense_update");
     if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
     HIPCHK(hipSetDevice(s->device));
     int done = 0;
@@ -161,6 +163,7 @@ extern "C" int ps_dense_update(ps_store_t *s, int layer) {
 
 extern "C" int ps_emb_backward_update(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets_dev, int64_t nnz, int B, int act,
                                       const float *a_dev, int lda, const float *delta_dev, int ldd, int grad_mode, int sum_order, int apply) {
+    RoctxRange roctx_range("ps_emb_backward_update");
     if (!s || !ids_dev || !delta_dev || B <= 0 || nnz < 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     EmbTables &e = s->emb;
     if (!e.W) return ps_set_err(PS_MISSING, "no embedding tables");

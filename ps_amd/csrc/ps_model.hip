@@ -622,6 +622,7 @@ static int train_graph(ps_model *m) {
 }
 
 extern "C" int ps_model_train(ps_model_t *m, const ps_batch_t *batch, float *loss) {
+    RoctxRange roctx_range("ps_model_train");
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     HIPCHK(hipSetDevice(m->s->device));
     PSCHK(stage_batch(m, batch, true));
@@ -637,6 +638,7 @@ extern "C" int ps_model_train(ps_model_t *m, const ps_batch_t *batch, float *los
 }
 
 extern "C" int ps_model_forward(ps_model_t *m, const ps_batch_t *batch, float *loss) {
+    RoctxRange roctx_range("ps_model_forward");
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     HIPCHK(hipSetDevice(m->s->device));
     PSCHK(stage_batch(m, batch, true));
@@ -646,6 +648,7 @@ extern "C" int ps_model_forward(ps_model_t *m, const ps_batch_t *batch, float *l
 }
 
 extern "C" int ps_model_backward(ps_model_t *m) {
+    RoctxRange roctx_range("ps_model_backward");
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     if (!m->fwd_done) return ps_set_err(PS_E_STATE, "backward before forward");
     HIPCHK(hipSetDevice(m->s->device));
@@ -655,6 +658,7 @@ extern "C" int ps_model_backward(ps_model_t *m) {
 }
 
 extern "C" int ps_model_update(ps_model_t *m) {
+    RoctxRange roctx_range("ps_model_update");
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     if (!m->bwd_done) return ps_set_err(PS_E_STATE, "update before backward");
     HIPCHK(hipSetDevice(m->s->device));
@@ -665,6 +669,7 @@ extern "C" int ps_model_update(ps_model_t *m) {
 }
 
 extern "C" int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p_out) {
+    RoctxRange roctx_range("ps_model_predict");
     if (!m || !p_out || !batch) return ps_set_err(PS_E_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(m->s->device));
     ps_batch_t b = *batch;

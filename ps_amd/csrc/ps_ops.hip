@@ -46,6 +46,7 @@ extern "C" int ps_store_sync(ps_store_t *s) {
 
 extern "C" int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64_t *offsets_dev, int B,
                               int act, float *out_dev, int ld) {
+    RoctxRange roctx_range("ps_emb_forward");
     if (!s || !ids_dev || !out_dev || B <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (ld < s->emb.F * s->emb.D || (s->emb.D % 4 == 0 && (ld & 3))) return ps_set_err(PS_E_BAD_ARG, "bad ld %d", ld);
@@ -60,6 +61,7 @@ extern "C" int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64
 
 extern "C" int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_dev, int ldx, int B,
                              float *y_dev, int ldy) {
+    RoctxRange roctx_range("ps_fc_forward");
     if (!s || !x_dev || !y_dev || B <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (layer < 0 || layer >= (int)s->fc.size() || !s->fc[layer].present) return ps_set_err(PS_MISSING, "fc%d absent", layer);
     FcParams &p = s->fc[layer];

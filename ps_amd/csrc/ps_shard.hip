@@ -197,6 +197,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
 }
 
 extern "C" int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream) {
+    RoctxRange roctx_range("ps_shard_plan_launch");
     if (!m || !batch || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(m->s->device));
     return shard_plan_enqueue(m, batch, nshards, hip_stream ? (hipStream_t)hip_stream : m->s->stream, true);
@@ -224,6 +225,7 @@ extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards
 }
 
 extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int64_t n, float *rows_out_dev) {
+    RoctxRange roctx_range("ps_shard_serve_pull");
     if (!s || n < 0 || (n > 0 && (!rows_dev || !rows_out_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (n == 0) return PS_OK;
@@ -238,6 +240,7 @@ extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int6
 }
 
 extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, float *loss) {
+    RoctxRange roctx_range("ps_shard_forward_backward");
     if (!m || (!cache_dev && m->sh.U > 0)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!m->sh.slot) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
     ps_store *s = m->s;
@@ -290,6 +293,7 @@ int shard_push_reserve(ps_store *s, int npeers) {
 
 extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n,
                                    const int64_t *peer_counts, int npeers, int is_async) {
+    RoctxRange roctx_range("ps_shard_apply_push");
     if (!s || n < 0 || (n > 0 && (!rows_dev || !grads_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
     HIPCHK(hipSetDevice(s->device));
@@ -344,6 +348,7 @@ extern "C" int ps_shard_flat_grad(ps_model_t *m, float **flat_dev, int64_t *nflo
 }
 
 extern "C" int ps_shard_apply_flat(ps_model_t *m, int nworkers) {
+    RoctxRange roctx_range("ps_shard_apply_flat");
     if (!m || nworkers < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!m->sh.flat) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
     ps_store *s = m->s;

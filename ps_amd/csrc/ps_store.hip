@@ -13,6 +13,35 @@
 // ---------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
 
+#include <dlfcn.h>
+#include <stdlib.h>
+namespace {
+struct Roctx {
+    int state = 0;                                   // 0 unknown, 1 on, -1 off
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+} g_roctx;
+bool roctx_on() {
+    if (g_roctx.state == 0) {
+        g_roctx.state = -1;
+        const char *e = getenv("PS_AMD_ROCTX");
+        if (e && e[0] == '1') {
+            void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                *(void **)(&g_roctx.push) = dlsym(h, "roctxRangePushA");
+                *(void **)(&g_roctx.pop) = dlsym(h, "roctxRangePop");
+                if (g_roctx.push && g_roctx.pop) g_roctx.state = 1;
+            }
+        }
+    }
+    return g_roctx.state == 1;
+}
+}  // namespace
+void ps_roctx_push(const char *name) { if (roctx_on()) (void)g_roctx.push(name); }
+void ps_roctx_pop() { if (g_roctx.state == 1) (void)g_roctx.pop(); }
+
 std::recursive_mutex &ps_rt_mutex() {
     static std::recursive_mutex mu;
     return mu;
