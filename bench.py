@@ -250,7 +250,7 @@ def run_single(args):
         "mfma_utilisation": fc_flops / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFS,
         "kernel_groups_us": {k: round(v["avg_us"], 2) for k, v in groups.items()},
         # serialised kernel-group time / step time: > 1 means the three streams overlap that much work
-        "kernel_sum_over_step": sum(v["avg_us"] for v in groups.values()) / (1e3 * dt / args.steps),
+        "kernel_sum_over_step": sum(v["avg_us"] for v in groups.values()) / (1e6 * dt / args.steps),
         "launches_per_step": sum(GROUP_LAUNCHES.get(k, 1) for k in groups),
         "final_loss": loss,
         "host": host_info(),

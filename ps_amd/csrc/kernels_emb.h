@@ -64,6 +64,7 @@ struct EmbBwdArgs {
     int long_runs;                     // a run above PS_EMB_SUPER_MIN chunks is possible (launch k_emb_super)
     int seq_order;                     // 1: every key summed in the reference's strict sample order (one launch)
     int long_blocks;                   // filled by the launcher
+    int ablate;                        // measurement only (g_seq_ablate)
     float *W, *state;                  // [rows][D], [rows][2][D]
     UpdParams upd;
     float *grads_out; uint32_t *uniq_row; uint32_t *uniq_cnt;   // [nseg][D], [nseg], [nseg]

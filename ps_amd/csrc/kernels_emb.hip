@@ -545,8 +545,13 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
 //     instructions per four entries on the only serial path of the kernel.
 // One barrier per batch, two LDS buffers.  (A first version with one wave doing both, fetching rows as float4 and
 // folding [entry][part], spent ~60 cycles per entry in its own instruction stream: 114 us for the 2240-entry keys of
-// configs[1]; this one ~5.)
+// configs[1]; this one ~15.  tools/seq_ablate.py: with the fold switched off the loaders alone still take 28 of the 34 us
+// -- 24 serial iterations of ~1.2 us, each bounded by the latency of the delta rows, freshly written by the GEMM of
+// another XCD -- and with the loads switched off the fold alone takes the same; a DPP-broadcast variant that cut the
+// fold's LDS read instructions fourfold measured SLOWER (46 us).)
 #define SEQ_ILP 4
+#define SEQ_TILE 16               // SEQ mode: keys above this many entries go to a long-key workgroup (at most one such run
+                                  // can start in a SEQ_TILE-entry tile); 16 keeps the short role at 64 row registers
 #define SEQ_LDS_FLOATS 4096       // per buffer: D * (3 * (64 / LPR) * SEQ_ILP + 4) <= 768 * VEC + 4 * D
 __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magic, uint32_t &rem) {
     uint32_t q = __umulhi(x, magic);            // magic = floor(2^32 / d): q is the quotient or one less
@@ -559,7 +564,7 @@ __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magi
 template <int VEC, bool BAG>
 __device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *lds /* [2][SEQ_LDS_FLOATS] */) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t CH = PS_EMB_CHUNK;
+    const uint32_t CH = SEQ_TILE;
     const int64_t c = blockIdx.x;
     if (c * CH >= a.nnz) return;
     const uint32_t t0 = (uint32_t)(c * CH);
@@ -636,7 +641,7 @@ __device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int d = lane + 64 * q;
-            if (d < D) {
+            if (d < D && !(a.ablate & 1)) {
                 const float *row = buf + (uint32_t)d * LDE;
                 float acc = S[q];
                 uint32_t j = 0;
@@ -711,12 +716,12 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         S = small_key<VEC, BAG, 4>(a, s0, n, part);
     } else if (n <= 16) {
         S = small_key<VEC, BAG, 16>(a, s0, n, part);
+    } else if (SEQ) {
+        return;                                                 // n > SEQ_TILE: a long-key workgroup owns this key
     } else if (n <= PS_EMB_ILP) {
         // up to a whole chunk in registers: the kernel's duration is its slowest lane group, and a
         // 17..32-entry key walked in two batches per pass was that group (8 dependent round trips)
         S = small_key<VEC, BAG, PS_EMB_ILP>(a, s0, n, part);
-    } else if (SEQ) {
-        return;                                                 // n > PS_EMB_CHUNK: a long-key wave owns this key
     } else if (n <= CH) {
         S = chunk_sum<VEC, BAG>(a, s0, e0, part);
         VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
@@ -1010,6 +1015,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_seq_ablate = 0;    // measurement only (results wrong): 1 = the fold wave skips its LDS reads + adds, 2 = the loaders skip their global loads
 
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
     const int vec = (a.D % 4 == 0) ? 4 : 1;
@@ -1060,7 +1066,8 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const int gp = cdiv((int64_t)cdiv(tiles, gpw) * 64, 256);
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
-    a.long_blocks = a.seq_order ? (int)tiles : 0;          // one workgroup per 32-entry tile looks for a long run starting in it
+    a.ablate = g_seq_ablate;
+    a.long_blocks = a.seq_order ? cdiv(a.nnz, SEQ_TILE) : 0;    // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
         if (a.seq_order) {                                                                     \

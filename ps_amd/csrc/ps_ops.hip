@@ -216,6 +216,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "gemm_xcd") == 0) { g_gemm_xcd = value; return PS_OK; }
     if (strcmp(knob, "gemm_ablate") == 0) { g_gemm_ablate = value; return PS_OK; }
     if (strcmp(knob, "mh_ilp16") == 0) { g_mh_ilp16 = value; return PS_OK; }
+    if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }
     return ps_set_err(PS_E_BAD_ARG, "unknown knob %s", knob);
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick look at the fused step on the GPU box: ms/step and the per-group kernel times (no CPU baseline, no big gather)
 mkdir -p gpurun_out/r2
-python bench.py --steps ${1:-300} --warmup 30 --no-cpu --gather 0 --multi-hot ${2:-0} > gpurun_out/r2/quick.json 2> gpurun_out/r2/quick.err || tail -5 gpurun_out/r2/quick.err
+python bench.py --steps ${1:-300} --warmup 30 --no-cpu --gather 0 --multi-hot ${2:-0} ${3:-} > gpurun_out/r2/quick.json 2> gpurun_out/r2/quick.err || tail -5 gpurun_out/r2/quick.err
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/r2/quick.json"))
