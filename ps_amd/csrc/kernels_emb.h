@@ -18,6 +18,8 @@ struct EmbFwdArgs {
     uint32_t *ent_bag;         // [nnz] bag of each entry (multi-hot) or nullptr
     const uint32_t *slot;      // when set: row of entry p is slot[p] (W = pulled-row cache), ids unused
     int *err;                  // out-of-range id counter
+    size_t table_bytes;        // size of W (decides the streaming hints)
+    int nt;                    // bit 0: non-temporal row loads, bit 1: non-temporal output stores (set by the launcher)
     int LPR, gather_blocks;    // filled by the launcher
 };
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st);

@@ -18,10 +18,20 @@
 namespace {
 
 template <int VEC> struct Vec;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <> struct Vec<4> {
     float4 v;
     __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.v = *reinterpret_cast<const float4 *>(p); return r; }
     __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+    // streaming variants (slc/nt): rows of a table far larger than the caches are read once, outputs are written once
+    __device__ __forceinline__ static Vec load_nt(const float *p) {
+        const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+        Vec r; r.v = make_float4(t.x, t.y, t.z, t.w); return r;
+    }
+    __device__ __forceinline__ void store_nt(float *p) const {
+        f32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t *>(p));
+    }
     __device__ __forceinline__ static Vec zero() { Vec r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
     __device__ __forceinline__ float &at(int i) { return (&v.x)[i]; }
     __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
@@ -30,6 +40,8 @@ template <> struct Vec<1> {
     float v;
     __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.v = *p; return r; }
     __device__ __forceinline__ void store(float *p) const { *p = v; }
+    __device__ __forceinline__ static Vec load_nt(const float *p) { Vec r; r.v = __builtin_nontemporal_load(p); return r; }
+    __device__ __forceinline__ void store_nt(float *p) const { __builtin_nontemporal_store(v, p); }
     __device__ __forceinline__ static Vec zero() { Vec r; r.v = 0.f; return r; }
     __device__ __forceinline__ float &at(int) { return v; }
     __device__ __forceinline__ float get(int) const { return v; }
@@ -79,13 +91,17 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
         }
         Vec<VEC> r[GATHER_ILP];
 #pragma unroll
-        for (int j = 0; j < GATHER_ILP; ++j) r[j] = Vec<VEC>::load(a.W + (size_t)rows[j] * a.D + part * VEC);   // rcopy (EmbeddingField.java:73)
+        for (int j = 0; j < GATHER_ILP; ++j) {                                                                       // rcopy (EmbeddingField.java:73)
+            const float *src = a.W + (size_t)rows[j] * a.D + part * VEC;
+            r[j] = (a.nt & 1) ? Vec<VEC>::load_nt(src) : Vec<VEC>::load(src);
+        }
 #pragma unroll
         for (int j = 0; j < GATHER_ILP; ++j) {
             const int64_t bag = bag0 + j;
             if (bag < nb) {
                 if (a.act == PS_ACT_RELU) { VFOR(i) r[j].at(i) = r[j].get(i) > 0.f ? r[j].get(i) : 0.f; }   // Relu.java:7-12
-                r[j].store(a.out + (size_t)(bag / a.F) * a.ld + (size_t)(bag % a.F) * a.D + part * VEC);
+                float *dst = a.out + (size_t)(bag / a.F) * a.ld + (size_t)(bag % a.F) * a.D + part * VEC;
+                if (a.nt & 2) r[j].store_nt(dst); else r[j].store(dst);
                 if (part == 0 && a.key_out) a.key_out[bag] = (uint32_t)rows[j];
             }
         }
@@ -116,7 +132,10 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
                 for (int j = 0; j < MH; ++j) rows[j] = (uint32_t)__shfl((int)myrow, gbase + (j0 + j < cnt ? j0 + j : cnt - 1));
                 Vec<VEC> r[MH];
 #pragma unroll
-                for (int j = 0; j < MH; ++j) r[j] = Vec<VEC>::load(a.W + (size_t)rows[j] * a.D + part * VEC);
+                for (int j = 0; j < MH; ++j) {
+                    const float *src = a.W + (size_t)rows[j] * a.D + part * VEC;
+                    r[j] = (a.nt & 1) ? Vec<VEC>::load_nt(src) : Vec<VEC>::load(src);
+                }
 #pragma unroll
                 for (int j = 0; j < MH; ++j) {
                     if (j0 + j < cnt) {
@@ -1017,7 +1036,58 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 int g_mh_ilp16 = 0;
 int g_seq_ablate = 0;    // measurement only (results wrong): 1 = the fold wave skips its LDS reads + adds, 2 = the loaders skip their global loads
 
+// The LDS-staged form of the single-hot gather that BASELINE.json's north_star names ("coalesced CSR gather with
+// LDS-staged rows"): every wave DMAs its rows global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, 4 KiB in
+// flight per wave), then reads them back, applies relu and stores.  Kept as a measured alternative (ps_tune_set
+// "gather_lds"): on the 256 GB table it is NOT faster than plain 16-byte vector loads -- the gather is bound by the
+// DRAM/TLB behaviour of random 256-byte reads, not by registers or issue slots (numbers in DESIGN.md).
+namespace {
+__global__ __launch_bounds__(256) void k_emb_fwd_lds(EmbFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float stage[4][GATHER_ILP][64 * 4];      // [wave][slot][lane * 4 floats]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t grp = gt / a.LPR;
+    const int part = (int)(gt % a.LPR);
+    const int64_t nb = (int64_t)a.B * a.F;
+    const int64_t bag0 = grp * GATHER_ILP;
+    int64_t rows[GATHER_ILP];
+#pragma unroll
+    for (int j = 0; j < GATHER_ILP; ++j) {
+        const int64_t bag = bag0 + j < nb ? bag0 + j : nb - 1;
+        const int f = (int)(bag % a.F);
+        const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
+        int64_t id = a.ids[bag];
+        if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
+        rows[j] = rb + id;
+    }
+#pragma unroll
+    for (int j = 0; j < GATHER_ILP; ++j) {
+        const float *src = a.W + (size_t)rows[j] * a.D + part * 4;
+        // lane l's 16 bytes land at stage[w][j] + 16 * l (the LDS base is wave-uniform, the lane offset is implicit)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)&stage[w][j][0], 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < GATHER_ILP; ++j) {
+        const int64_t bag = bag0 + j;
+        if (bag < nb) {
+            float4 v = *reinterpret_cast<const float4 *>(&stage[w][j][lane * 4]);
+            if (a.act == PS_ACT_RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+            *reinterpret_cast<float4 *>(a.out + (size_t)(bag / a.F) * a.ld + (size_t)(bag % a.F) * a.D + part * 4) = v;
+        }
+    }
+}
+}  // namespace
+int g_gather_lds = 0;      // measurement: 1 = the LDS-staged single-hot gather above
+
+int g_gather_nt = -1;      // -1: automatic (streaming hints when the tables exceed the caches); 0..3: forced (bit 0 loads, bit 1 stores)
+
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
+    // rows of tables far beyond the 256 MiB Infinity Cache are read once: non-temporal loads (measured on the 256 GB
+    // table, tools/gather_nt.py: bags of 32 0.671 -> 0.707 of 8 TB/s, single-hot read+write 0.663 -> 0.694; nt stores: no effect)
+    a.nt = a.table_bytes > ((size_t)1 << 30) ? 1 : 0;
+    if (g_gather_nt >= 0) a.nt = g_gather_nt;
     const int vec = (a.D % 4 == 0) ? 4 : 1;
     a.LPR = a.D / vec;
     const bool multi = a.offsets != nullptr, slot = a.slot != nullptr;
@@ -1042,7 +1112,9 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
         else { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, a);       \
                else hipLaunchKernelGGL((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, a); }          \
     } while (0)
-    if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
+    if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0)
+        hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);
+    else if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
 #undef EMB_FWD_LAUNCH
 #undef EMB_FWD_MH
     HIPCHK(hipGetLastError());

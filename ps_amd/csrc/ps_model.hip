@@ -300,13 +300,14 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     e.W = s->emb.W; e.row_base = s->emb.row_base_dev; e.ids = m->cur_ids; e.offsets = m->cur_offsets;
     e.B = B; e.F = c.F; e.D = c.D; e.X = c.X; e.act = PS_ACT_RELU;   // EmbeddingLayer.build: Relu (EmbeddingLayer.java:53)
     e.out = m->fc[0].A; e.ld = m->fc[0].ldA; e.dense = m->cur_dense;
+    e.table_bytes = sizeof(float) * (size_t)s->emb.total_rows * c.D;
     e.key_out = train ? m->keys : nullptr;
     e.ent_bag = (train && m->cur_offsets) ? m->ent_bag : nullptr;
     e.err = s->err_dev;
     if (m->sh.active) {
         // sharded worker: rows come from the cache pulled from their owners (store/KVStore.java:96),
         // keys and the sort were made by ps_shard_plan
-        e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr;
+        e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr; e.table_bytes = 0;
     }
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
     if (train && !m->sh.active) {

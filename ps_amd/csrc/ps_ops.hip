@@ -56,6 +56,7 @@ extern "C" int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64
     e.W = s->emb.W; e.row_base = s->emb.row_base_dev; e.ids = ids_dev; e.offsets = offsets_dev;
     e.B = B; e.F = s->emb.F; e.D = s->emb.D; e.X = 0; e.act = act;
     e.out = out_dev; e.ld = ld; e.err = s->err_dev;
+    e.table_bytes = sizeof(float) * (size_t)s->emb.total_rows * s->emb.D;
     return launch_emb_fwd(e, s->stream);
 }
 
@@ -141,6 +142,7 @@ struct GatherRun {
         memset(&a, 0, sizeof a);
         a.W = W; a.row_base = rb; a.ids = ids; a.offsets = bag > 1 ? off : nullptr;
         a.B = (int)n; a.F = 1; a.D = D; a.X = 0; a.act = PS_ACT_RELU; a.out = out; a.ld = D; a.err = err;
+        a.table_bytes = wbytes;
         return PS_OK;
     }
 };
@@ -217,6 +219,8 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "gemm_ablate") == 0) { g_gemm_ablate = value; return PS_OK; }
     if (strcmp(knob, "mh_ilp16") == 0) { g_mh_ilp16 = value; return PS_OK; }
     if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }
+    if (strcmp(knob, "gather_nt") == 0) { g_gather_nt = value; return PS_OK; }
+    if (strcmp(knob, "gather_lds") == 0) { g_gather_lds = value; return PS_OK; }
     return ps_set_err(PS_E_BAD_ARG, "unknown knob %s", knob);
 }
 
