@@ -445,6 +445,15 @@ int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *c
  * the same store -- before step t finishes.  _finish waits for the counts and enqueues the rest. */
 int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side);
 int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss);
+/* _finish of step t with _begin of step t+1 (next_batch; NULL = plain _finish)
+ * issued between "gradients ready" and "push": the next plan reads no
+ * weight, so its counts are on their way to the host while the GPU still has
+ * step t's push and updates to do -- the host's one wait per step no longer
+ * leaves the GPU idle.  Same stream, same communicator, same order on every
+ * rank.  One model suffices (the plan only overwrites key lists that step t
+ * no longer reads). */
+int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *comm, int is_async,
+                               const ps_batch_t *next_batch, float *loss);
 
 /* Replicated tensors: one flat device buffer
  * [fc weights+biases | wide G | wide C | wide.bias g] to all-reduce(sum);

@@ -288,7 +288,12 @@ extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const
     return PS_OK;
 }
 
-extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss) {
+// finish, with the NEXT step's begin slipped in between "gradients ready" and "push": the plan of batch t+1 and its
+// counts all-gather read no weight, so they may run before step t's push and updates -- and when the host then waits
+// for those counts (the step's one host wait) the GPU still has the push, the owner update and the replicated update
+// of step t queued: the host enqueues the start of step t+1 under them instead of in front of an idle GPU.
+// (Measured at N = 1: the host wait + the starved first launches were ~60 us of a 0.285 ms step.)
+extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, const ps_batch_t *next_batch, float *loss) {
     RoctxRange roctx_range("ps_shard_step_finish");
     if (!m || !comm) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
@@ -319,6 +324,8 @@ extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, in
     PSCHK(comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st));
     // train on the cache
     PSCHK(ps_shard_forward_backward(m, sh.x_cache, nullptr));
+    // the next step's key lists + counts (same stream, same communicator: every rank issues the same order)
+    if (next_batch) PSCHK(ps_shard_step_begin(m, next_batch, comm, 0));
     // push: the per-key gradients to their owners, then the dense + wide reduction -- same communicator, same stream,
     // same order on every rank.  The owner's row update is enqueued between the two: it only needs the all-to-all-v.
     PSCHK(comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st));
@@ -332,6 +339,10 @@ extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, in
         HIPCHK(hipStreamSynchronize(st));
     }
     return PS_OK;
+}
+
+extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss) {
+    return ps_shard_step_finish_begin(m, comm, is_async, nullptr, loss);
 }
 
 extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss) {

@@ -221,6 +221,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }
     if (strcmp(knob, "gather_nt") == 0) { g_gather_nt = value; return PS_OK; }
     if (strcmp(knob, "gather_lds") == 0) { g_gather_lds = value; return PS_OK; }
+    if (strcmp(knob, "plan_sort") == 0) { g_plan_sort = value; return PS_OK; }
     return ps_set_err(PS_E_BAD_ARG, "unknown knob %s", knob);
 }
 

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ 
                                                     const int64_t *__restrict__ vocab /*[F]*/,
                                                     const uint8_t *__restrict__ owner_tab, const uint32_t *__restrict__ local_tab,
                                                     const int64_t *__restrict__ grow_base /* java_string routing, else NULL */,
-                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ ent_bag, int *err) {
+                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ ent_bag, int *err,
+                                                    uint8_t *__restrict__ stamp /* or NULL */, uint8_t epoch) {
     const int64_t bag = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (bag >= nbags) return;
     const int f = (int)(bag % F);
@@ -48,7 +49,10 @@ __global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ 
             o = (int)(id % nshards);
             local = lrb[(size_t)o * (F + 1) + f] + id / nshards;
         }
-        keys[p] = ((uint32_t)o << sbits) | (uint32_t)local;
+        const uint32_t key = ((uint32_t)o << sbits) | (uint32_t)local;
+        keys[p] = key;
+        if (stamp) stamp[key] = epoch;      // presence: every writer stores the same byte (no atomics: 2 000 samples sharing one
+                                            // key made atomicOr on its bitmap word a 30 us serial chain)
         if (ent_bag) ent_bag[p] = (uint32_t)bag;
     }
 }
@@ -76,6 +80,97 @@ __global__ __launch_bounds__(256) void k_shard_finish(const uint32_t *__restrict
         for (int oo = o + 1; oo <= nshards; ++oo) owner_start[oo] = n;
 }
 
+// ---------------------------------------------------------------------------
+// The plan WITHOUT a sort.  What the pull needs before anything else can move -- the batch's UNIQUE keys grouped by
+// owner in ascending (owner, row) order, how many go to each owner, and the unique index ("slot") of every entry --
+// is a presence bitmap over the composite key space (owner << sbits | row: 4 M bits = 512 KiB at configs[2]) and a
+// prefix sum of its popcounts: four small launches (~15 us) instead of the 12 launches of a 3-pass radix sort
+// (~80 us), which the sharded step used to pay serially before its pull.  The per-key ENTRY LISTS the embedding
+// backward needs still come from the stable sort -- moved to side stream 0, where it overlaps the exchange and the
+// forward exactly as in the single-GPU step; both orders are ascending composite key, so the unique indices agree.
+// ---------------------------------------------------------------------------
+constexpr int PLAN_WPB = 256;      // bitmap words per workgroup
+
+// stamp bytes of this step's epoch -> bitmap word (32 keys per thread), popcount per workgroup
+__global__ __launch_bounds__(256) void k_plan_count(const uint8_t *__restrict__ stamp, uint8_t epoch, uint32_t *__restrict__ bitmap,
+                                                    int64_t nwords, uint32_t *__restrict__ blk_sum) {
+    __shared__ uint32_t red[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * PLAN_WPB + tid;
+    uint32_t c = 0;
+    if (i < nwords) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(stamp + i * 32), hi = *reinterpret_cast<const uint4 *>(stamp + i * 32 + 16);
+        const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bits |= (((q[k] >> (8 * b)) & 0xFFu) == (uint32_t)epoch ? 1u : 0u) << (4 * k + b);
+        bitmap[i] = bits;
+        c = (uint32_t)__popc(bits);
+    }
+    for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+    if (lane == 0) red[w] = c;
+    __syncthreads();
+    if (tid == 0) blk_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// word_prefix[w] = set bits in all earlier words; every set bit emits its unique key's owner-local row at its rank;
+// owner o's run starts at the prefix of word (o << sbits) >> 5 (sbits >= 5: owner boundaries are word boundaries)
+__global__ __launch_bounds__(256) void k_plan_emit(const uint32_t *__restrict__ bitmap, int64_t nwords, const uint32_t *__restrict__ blk_sum,
+                                                   uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ send_rows,
+                                                   uint32_t *__restrict__ owner_start, uint32_t *__restrict__ nseg, int sbits, int nshards) {
+    __shared__ uint32_t red[4], wsum[4], carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t acc = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) acc += blk_sum[i];
+    for (int off = 32; off; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (tid == 0) carry_s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PLAN_WPB;
+    const uint32_t wmask = (1u << (sbits - 5)) - 1u;             // word index inside one owner's range
+    for (int j = 0; j < PLAN_WPB / 256; ++j) {
+        const int64_t i = base + j * 256 + tid;
+        const uint32_t bits = i < nwords ? bitmap[i] : 0u;
+        const uint32_t v = (uint32_t)__popc(bits);
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wb = carry_s;
+        for (int ww = 0; ww < w; ++ww) wb += wsum[ww];
+        const uint32_t excl = wb + inc - v;
+        if (i < nwords) {
+            word_prefix[i] = excl;
+            if (((uint32_t)i & wmask) == 0u) owner_start[(uint32_t)i >> (sbits - 5)] = excl;
+            uint32_t b = bits, r = excl;
+            while (b) {
+                const int bit = __ffs((int)b) - 1;
+                b &= b - 1;
+                send_rows[r++] = (((uint32_t)i << 5) | (uint32_t)bit) & ((1u << sbits) - 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 255) carry_s = wb + inc;
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) { owner_start[nshards] = carry_s; *nseg = carry_s; }
+}
+
+__global__ __launch_bounds__(256) void k_plan_slots(const uint32_t *__restrict__ keys, int64_t nnz, const uint32_t *__restrict__ bitmap,
+                                                    const uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ slot) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    const uint32_t key = keys[p], wd = key >> 5;
+    slot[p] = word_prefix[wd] + (uint32_t)__popc(bitmap[wd] & ((1u << (key & 31u)) - 1u));
+}
+
 // rows_out[i][:] = W[rows[i]][:]   (PServer.getList: the rows for a key list)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, const uint32_t *__restrict__ rows, int64_t n,
@@ -89,6 +184,10 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W
     if (VEC == 4) *reinterpret_cast<float4 *>(out + (size_t)i * D + part * 4) = *reinterpret_cast<const float4 *>(W + (size_t)r * D + part * 4);
     else out[(size_t)i * D + part] = W[(size_t)r * D + part];
 }
+
+}  // namespace
+int g_plan_sort = 0;       // ps_tune_set("plan_sort", 1): the sort-based plan (A/B runs, tests of both paths)
+namespace {
 
 int ensure_push_ws(ps_store *s, int64_t n) {
     RtGuard rt_guard;
@@ -143,6 +242,16 @@ int ensure_shard_state(ps_model *m, int nshards) {
         HIPCHK(hipMemcpyAsync(e.local_dev, e.local_h.data(), sizeof(uint32_t) * G, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(e.grow_base_dev, e.grow_base.data(), sizeof(int64_t) * (size_t)(F + 1), hipMemcpyHostToDevice, s->stream));
     }
+    {   // the sort-free plan: bitmap over the composite key space (falls back to the sort above 2^29 keys = 64 MiB of bitmap)
+        const int64_t kspace = (int64_t)nshards << sh.sbits;
+        if (sh.sbits >= 5 && kspace <= ((int64_t)1 << 29)) {
+            sh.bm_words = kspace >> 5;
+            PSCHK(store_dev_alloc(s, (void **)&sh.bitmap, sizeof(uint32_t) * (size_t)sh.bm_words, true));
+            PSCHK(store_dev_alloc(s, (void **)&sh.stamp, (size_t)kspace + 32, true));
+            PSCHK(store_dev_alloc(s, (void **)&sh.word_prefix, sizeof(uint32_t) * (size_t)sh.bm_words, false));
+            PSCHK(store_dev_alloc(s, (void **)&sh.blk_sum, sizeof(uint32_t) * (size_t)(cdiv(sh.bm_words, PLAN_WPB) + 1), false));
+        }
+    }
     PSCHK(store_dev_alloc(s, (void **)&sh.slot, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(store_dev_alloc(s, (void **)&sh.send_rows, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(store_dev_alloc(s, (void **)&sh.owner_start, sizeof(uint32_t) * (size_t)(nshards + 2), true));
@@ -175,13 +284,40 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
     const int F = m->cfg.F;
     const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
+    const bool bm = sh.bitmap != nullptr && nnz > 0 && g_plan_sort == 0;
+    if (bm && ++sh.epoch == 0) {          // the byte stamps wrap every 255 plans: start over from a clean map
+        HIPCHK(hipMemsetAsync(sh.stamp, 0, (size_t)sh.bm_words * 32, st));
+        sh.epoch = 1;
+    }
     hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, st, m->cur_ids, m->cur_offsets, nbags, F, nshards,
                        sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), s->emb.owner_dev, s->emb.local_dev, s->emb.grow_base_dev, m->keys,
-                       m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev);
+                       m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev, bm ? sh.stamp : (uint8_t *)nullptr, sh.epoch);
     HIPCHK(hipGetLastError());
-    PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
-    PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
-    if (nnz > 0) {
+    if (bm) {
+        const int nblk = cdiv(sh.bm_words, PLAN_WPB);
+        hipLaunchKernelGGL(k_plan_count, dim3(nblk), dim3(256), 0, st, sh.stamp, sh.epoch, sh.bitmap, sh.bm_words, sh.blk_sum);
+        hipLaunchKernelGGL(k_plan_emit, dim3(nblk), dim3(256), 0, st, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
+                           sh.owner_start, m->nseg_dev, sh.sbits, nshards);
+        hipLaunchKernelGGL(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot);
+        HIPCHK(hipGetLastError());
+        // the entry lists of the backward: stable sort + runs, beside the exchange and the forward (side stream 0; the
+        // backward joins it).  After k_plan_slots in stream order: the sort ping-pongs through m->keys.
+        hipStream_t ss = (m->profile || !m->multi_stream) ? st : m->side[0];
+        if (ss != st) {
+            hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+            HIPCHK(hipEventRecord(e, st));
+            HIPCHK(hipStreamWaitEvent(ss, e, 0));
+        }
+        PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
+        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss));
+        m->side0_pending = ss != st;
+    } else {
+        PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
+        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
+    }
+    if (bm) {
+        // (send_rows, owner_start, slot, nseg came from the bitmap)
+    } else if (nnz > 0) {
         hipLaunchKernelGGL(k_shard_finish, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->sorted_keys, m->sorted_ents, m->seg_start, m->seg_id,
                            m->nseg_dev, nnz, sh.sbits, nshards, sh.send_rows, sh.owner_start, sh.slot);
         HIPCHK(hipGetLastError());

@@ -113,6 +113,7 @@ struct ps_model {
     uint32_t *keys = nullptr, *ents = nullptr, *ent_bag = nullptr, *seg_start = nullptr, *seg_id = nullptr,
              *nseg_dev = nullptr, *uniq_row = nullptr, *uniq_cnt = nullptr;
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
+    uint32_t *seg_nseg_scratch = nullptr;                     // run count of a side sort whose nseg the bitmap plan already wrote
     float *partials = nullptr, *partials2 = nullptr, *grads_out = nullptr;
     float *dense_grad_flat = nullptr; int64_t dense_elems = 0;
     // wide_grad_mode = intended: sort of the batch's wide ids (allocated on first use)
@@ -137,6 +138,8 @@ struct ps_model {
         int64_t flat_elems = 0;
         int sbits = 0;
         int64_t U = 0;
+        uint32_t *bitmap = nullptr, *word_prefix = nullptr, *blk_sum = nullptr; int64_t bm_words = 0;   // sort-free plan
+        uint8_t *stamp = nullptr, epoch = 0;    // presence bytes of the composite key space, stamped with the plan's epoch
         uint32_t *owner_start_host = nullptr;   // pinned readback of owner_start
         hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
         bool plan_pending = false;

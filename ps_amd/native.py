@@ -146,6 +146,7 @@ SIGNATURES = {
     "ps_shard_step": (_i, [_vp, C.POINTER(ps_batch_t), C.POINTER(ps_comm_ops_t), _i, _pf]),
     "ps_shard_step_begin": (_i, [_vp, C.POINTER(ps_batch_t), C.POINTER(ps_comm_ops_t), _i]),
     "ps_shard_step_finish": (_i, [_vp, C.POINTER(ps_comm_ops_t), _i, _pf]),
+    "ps_shard_step_finish_begin": (_i, [_vp, C.POINTER(ps_comm_ops_t), _i, C.POINTER(ps_batch_t), _pf]),
     "ps_auc_compute": (_i, [_vp, _vp, _vp, _i64, _i, _pd, _pi64, _pi64]),
     "ps_bench_gather": (_i, [_vp, _i64, _i, _i64, _i, _i, C.c_uint64, _pd, _pd, _pd]),
     "ps_bench_gather_check": (_i, [_vp, _i64, _i, _i64, _i, C.c_uint64, _i64, _pi64, _pi64, _pf]),

@@ -503,12 +503,24 @@ class NativeWorker:
         N.check(N.lib().ps_shard_step_finish(self.models[k].h, C.byref(self.ops), int(self.is_async), C.byref(loss) if want_loss else None))
         return loss.value if want_loss else None
 
+    def finish_begin(self, k, next_batch, want_loss=False):
+        """finish of the running step with the next step's begin slipped in before its push (one model)."""
+        loss = C.c_float()
+        N.check(N.lib().ps_shard_step_finish_begin(self.models[k].h, C.byref(self.ops), int(self.is_async),
+                                                   C.byref(next_batch.c) if next_batch is not None else None,
+                                                   C.byref(loss) if want_loss else None))
+        return loss.value if want_loss else None
+
     def run(self, batches, steps, want_loss=False):
         nb, nm = len(batches), len(self.models)
         loss = None
         if nm < 2:
+            # software pipeline on ONE stream and ONE model: the plan of step i+1 (no weights read) is enqueued between
+            # step i's backward and its push, so the host's wait for the counts overlaps GPU work
+            if steps > 0:
+                self.begin(0, batches[0], side=False)
             for i in range(steps):
-                loss = self.step(batches[i % nb], want_loss)
+                loss = self.finish_begin(0, batches[(i + 1) % nb] if i + 1 < steps else None, want_loss and i + 1 == steps)
             return loss
         if steps > 0:
             self.begin(0, batches[0])

@@ -278,7 +278,9 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
         F, D, V = CFG["F"], CFG["D"], CFG["V"]
         kv = ps_amd.KVStore(0, SEED)
         kv.create_embedding([V] * F, D, shard=rank, nshards=world)
-        gms = [ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"]) for _ in range(2 if pipelined else 1)]
+        # pipelined: True = two models, begin(t+1) on the prefetch stream before finish(t); "one" = ONE model, the next
+        # step's begin slipped in before this step's push (ps_shard_step_finish_begin: what bench.py --gpus N runs)
+        gms = [ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"]) for _ in range(2 if pipelined is True else 1)]
         gm = gms[0]
         comm = CallbackComm(rank, shared, kv)
         wk = NativeWorker(gms, world, rank, ops=comm.ops, is_async=is_async)
@@ -309,7 +311,7 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
         shared.barrier.abort()
 
 
-@pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (3, True, False), (2, True, True)])
+@pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (3, True, False), (2, True, True), (3, False, "one"), (2, True, "one")])
 def test_library_driven_step_n_ranks_on_one_gpu(orc, world, is_async, pipelined):
     shared = Shared(world)
     out, errs = [None] * world, []
