@@ -81,6 +81,7 @@ struct DenseLayer {
     int64_t part_stride;
     int K, N, ldw, ldwt, ldp, nsplit;
     int64_t elem_begin, elem_end;      // flat [k][n] element range, k in [0,K]
+    int tile_begin, tile_end;          // 32 x 32 tiles of this layer in the launch (filled by launch_dense_update)
 };
 struct DenseUpdArgs {
     DenseLayer L[8];

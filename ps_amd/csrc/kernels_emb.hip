@@ -909,42 +909,74 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
 // ---------------------------------------------------------------------------
 // dense tensors: split-K reducer + /B + updater, writes W' ([in+1][out]) and its transpose
 // ---------------------------------------------------------------------------
+// One workgroup per 32 x 32 tile of a layer's [K+1][N] tensor, 4 elements per thread (rows ty, ty+8, ...).  W', the
+// state and the slabs are read and written along n (128-byte rows per half wave); the transpose the forward GEMM reads
+// goes through LDS so that its stores run along k the same way -- one 4-byte store per thread straight into Wt[n][k]
+// touched a different cache line per lane and tripled the kernel's write traffic (profiles/ r01: 13.4 MB written for
+// 5.6 MB of tensors).
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     if (a.skip && *a.skip) return;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    // locate the layer
+    __shared__ float tile[32][33];
     int l = 0;
-    while (l < a.nlayers - 1 && t >= a.L[l].elem_end) ++l;
-    if (t >= a.L[l].elem_end) return;
+    while (l < a.nlayers - 1 && (int)blockIdx.x >= a.L[l].tile_end) ++l;
     const DenseLayer &L = a.L[l];
-    const int64_t e = t - L.elem_begin;
-    const int k = (int)(e / L.N), n = (int)(e % L.N);   // k in [0, K] (K = bias row), n in [0, N)
-    float g;
-    if (a.flat_grad) {
-        // multi-worker path: the (all-reduced) mean gradient was materialised flat
-        g = a.flat_grad[t];
-        if (a.flat_div > 0.f) g = div_rn(g, a.flat_div);
-    } else {
-        float s = 0.f;
-        const float *__restrict__ pp = L.part + (size_t)k * L.ldp + n;
-        for (int z0 = 0; z0 < L.nsplit; z0 += 8) {        // fixed slab order, 8 loads in flight
-            float v[8];
+    const int tb = (int)blockIdx.x - L.tile_begin;
+    const int tiles_n = (L.N + 31) >> 5;
+    const int k0 = (tb / tiles_n) << 5, n0 = (tb % tiles_n) << 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = n0 + tx;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!a.flat_grad && n < L.N) {
+        const float *__restrict__ pn = L.part + n;
+        for (int z0 = 0; z0 < L.nsplit; z0 += 4) {        // fixed slab order per element, 16 loads in flight
+            float v[4][4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pp[(size_t)(z0 + j < L.nsplit ? z0 + j : L.nsplit - 1) * L.part_stride];
+            for (int zz = 0; zz < 4; ++zz) {
+                const int z = z0 + zz < L.nsplit ? z0 + zz : L.nsplit - 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (z0 + j < L.nsplit) s += v[j];
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + ty + 8 * j;
+                    v[zz][j] = pn[(size_t)z * L.part_stride + (size_t)(k <= L.K ? k : L.K) * L.ldp];
+                }
+            }
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz)
+                if (z0 + zz < L.nsplit) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += v[zz][j];
+                }
         }
-        g = div_rn(s, (float)a.B);                       // divi(delta.columns) FcLayer.java:105 / rowMeans :103
     }
-    if (a.grad_out) a.grad_out[t] = g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + ty + 8 * j;                    // k in [0, K] (K = bias row), n in [0, N)
+        if (k > L.K || n >= L.N) continue;
+        const int64_t t = L.elem_begin + (int64_t)k * L.N + n;
+        float g;
+        if (a.flat_grad) {
+            // multi-worker path: the (all-reduced) mean gradient was materialised flat
+            g = a.flat_grad[t];
+            if (a.flat_div > 0.f) g = div_rn(g, a.flat_div);
+        } else {
+            g = div_rn(s[j], (float)a.B);                 // divi(delta.columns) FcLayer.java:105 / rowMeans :103
+        }
+        if (a.grad_out) a.grad_out[t] = g;
+        if (!a.apply) continue;
+        const size_t wi = (size_t)k * L.ldw + n;
+        float w = L.W[wi], s1 = L.S1[wi], s2 = L.S2[wi];
+        if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, s1, s2);
+        else if (a.upd.kind == PS_UPD_SIMPLE) w = (g * -a.upd.eta) + w;
+        else ftrl_elem(a.upd, g, w, s1, s2);   // per-tensor "dw[0]==0" skip is not meaningful for dense tensors
+        L.W[wi] = w; L.S1[wi] = s1; L.S2[wi] = s2;
+        tile[ty + 8 * j][tx] = w;
+    }
     if (!a.apply) return;
-    const size_t wi = (size_t)k * L.ldw + n;
-    float w = L.W[wi], s1 = L.S1[wi], s2 = L.S2[wi];
-    if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, s1, s2);
-    else if (a.upd.kind == PS_UPD_SIMPLE) w = (g * -a.upd.eta) + w;
-    else ftrl_elem(a.upd, g, w, s1, s2);   // per-tensor "dw[0]==0" skip is not meaningful for dense tensors
-    L.W[wi] = w; L.S1[wi] = s1; L.S2[wi] = s2;
-    L.Wt[(size_t)n * L.ldwt + k] = w;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + ty + 8 * j, kk = k0 + tx;
+        if (nn < L.N && kk <= L.K) L.Wt[(size_t)nn * L.ldwt + kk] = tile[tx][ty + 8 * j];
+    }
 }
 
 // materialise the flat dense gradient (sum of split partials / B) without updating
@@ -1194,8 +1226,15 @@ int launch_dense_update(const DenseUpdArgs &a0, hipStream_t st) {
                 L.nsplit = 1;
             }
         }
-    const int64_t total = a.L[a.nlayers - 1].elem_end;
-    hipLaunchKernelGGL(k_dense_update, dim3(cdiv(total, 256)), dim3(256), 0, st, a);
+    int tiles = 0;
+    for (int l = 0; l < a.nlayers; ++l) {
+        DenseLayer &L = a.L[l];
+        L.tile_begin = tiles;
+        tiles += cdiv(L.K + 1, 32) * cdiv(L.N, 32);
+        L.tile_end = tiles;
+    }
+    if (tiles == 0) return PS_OK;
+    hipLaunchKernelGGL(k_dense_update, dim3(tiles), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

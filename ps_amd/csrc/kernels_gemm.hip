@@ -400,11 +400,15 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     return PS_OK;
 }
 
+int g_gemm_tn_target = 0;   // ps_tune_set("gemm_tn_target", workgroups): override the workgroup target of the split choice
 int gemm_tn_choose_split(int Kout, int N, int M) {
     const long long tiles = N <= 32 ? (long long)cdiv(Kout, 128) * cdiv(N, 32) : (long long)cdiv(Kout, 64) * cdiv(N, 64);
-    // ~1.75 workgroups per CU: measured on MI355X (tools/gemm_sweep2.py, M = 4096): dW0 (56 tiles) 8 splits 24.2 us
-    // vs 14 splits 26.7 us, dW1 (36 tiles) 13-14 splits best; every split is a partial slab written and re-read
-    int s = (int)((448 + tiles - 1) / tiles);
+    // Every split is a partial slab written here and re-read by the dense update.  Alone on the chip dW0 (56 tiles)
+    // is fastest at 8 splits (24.2 us vs 27.1 us at 4, tools/gemm_sweep2.py), but in the step the dW GEMMs share the
+    // CUs with the data-gradient GEMMs on the main stream, and ~224 workgroups (dW0 4 splits, dW1 7) gives the same
+    // or a slightly shorter step (tools/tn_split_step.py: 0.194-0.198 ms vs 0.200 ms at 448) at half the slab traffic
+    const long long target = g_gemm_tn_target > 0 ? g_gemm_tn_target : 224;
+    int s = (int)((target + tiles - 1) / tiles);
     const int max_s = M / 128 > 0 ? M / 128 : 1;        // keep >= 128 batch rows per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;

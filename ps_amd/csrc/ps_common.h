@@ -124,7 +124,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
                    const int *skip_flag, hipStream_t st);
 int gemm_tn_choose_split(int Kout, int N, int M);
-extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate;
+extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default
