@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [hipcc] + FLAGS + os.environ.get("PS_AMD_EXTRA_FLAGS", "").split() + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

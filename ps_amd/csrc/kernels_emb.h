@@ -55,10 +55,12 @@ int launch_loss_reduce(const HeadArgs &a, float *loss_out, float *gbar_out, int 
 int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st);
 int head_last_bwd_fusable(int rows_per_wg);
 
+#define PS_EMB_SEQ_TILE 16             // sequential order: runs above this many entries are "long" (own workgroup)
 struct EmbBwdArgs {
     int64_t nnz;
     int F, D, grad_mode, apply;
     const uint32_t *sorted_key, *sorted_ent, *seg_start, *seg_id, *nseg;
+    const uint32_t *long_list;         // seq_order: ids of the runs above PS_EMB_SEQ_TILE entries, nseg[1] of them (or nullptr)
     const uint32_t *ent_bag;           // nullptr => bag = entry
     const float *delta; int ldd;       // [B][ldd], embedding columns already relu'-masked
     float *partials;                   // [2*ceil(nnz/CH)][D]

@@ -179,6 +179,15 @@ __device__ __forceinline__ float sigmoid_clip_d(float x) {
     return (float)(0.001f + (double)(.999f - 0.001f) / (1.0 + exp(-(double)x)));
 }
 
+#ifdef PS_HEAD_TIMING
+__device__ unsigned long long g_head_t[256 * 8];
+extern "C" int ps_dbg_head_timing(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_t), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -1;
+}
+#define HEAD_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_head_t[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define HEAD_T(k) do { } while (0)
+#endif
 // Eight lanes per sample, eight samples per wave: every load of the head is independent of the others (the out = 1
 // layer's dot product: 34 strided loads per lane at K = 257; the wide part: id -> weight for 26 fields, four per
 // lane) and the only serial pieces are two 3-step butterflies and the reference's sequential f32 sum of the F wide
@@ -188,20 +197,78 @@ __device__ __forceinline__ float sigmoid_clip_d(float x) {
 // Returns delta_L * sigmoid' of the sample (every lane of the group holds it); 0 when there are no labels.
 __device__ __forceinline__ float head_one(const HeadArgs &a, int b, int lane, bool valid) {
     const int l8 = lane & 7, gbase = lane & ~7;
+    // Load order, all branch-free so that the compiler's in-order s_waitcnt bookkeeping stays exact:
+    //   wide ids (F <= 32: the usual case; more fields fall back to the loop below) -> the row of the last layer's
+    //   input and its weights -> (ids arrived) the wide weights -> dot product -> wide sum.
+    // Every round trip overlaps the next one; the stores (touched marks, error count) wait until the end.
+    // (With the id -> weight chain issued as one block BEFORE the row loads the head was faster on cache-resident
+    // batches and slower on fresh ones: the row loads sat behind the wait for the ids.)
+    int64_t wid[4] = {0, 0, 0, 0};
+    float ww[4] = {0.f, 0.f, 0.f, 0.f};
+    bool wbad = false;
+    const bool wide_early = a.wide && a.F <= 32;
+    if (wide_early) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 8 * r + l8;
+            wid[r] = a.wide_ids[(size_t)b * a.F + (f < a.F ? f : a.F - 1)];
+        }
+    }
     float zl;                                               // the last FcLayer's activation for this sample
     if (a.a_last) {
-        // FcLayer.forward with out = 1 (layer/FcLayer.java:76-77): lanes stride over k, butterfly sum
+        // FcLayer.forward with out = 1 (layer/FcLayer.java:76-77): the group's 8 lanes read 128 contiguous bytes
+        // of the row per load, 8 loads per lane in flight (K <= 256: ONE memory round trip; scalar loads strided
+        // over the lanes, 34 per lane behind a runtime trip count, took 7.6 of the head's 11.5 us), butterfly sum
         const float *__restrict__ x = a.a_last + (size_t)b * a.lda_last;
         const float *__restrict__ wl = a.w_last;
+        const int k4 = a.k_last & ~3;
         float acc = 0.f;
-        for (int k = l8; k < a.k_last; k += 8) acc += x[k] * wl[k];
+        for (int kb = 0; kb < k4; kb += 256) {
+            float4 xv[8], wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = kb + 32 * i + 4 * l8;
+                const int kk = k < k4 ? k : 0;
+                xv[i] = *reinterpret_cast<const float4 *>(x + kk);
+                wv[i] = *reinterpret_cast<const float4 *>(wl + kk);
+            }
+            if (kb == 0 && wide_early) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool bad = wid[r] < 0 || wid[r] >= a.wide_rows;
+                    wbad |= bad && 8 * r + l8 < a.F;
+                    if (bad) wid[r] = 0;
+                    ww[r] = a.wide_w[wid[r]];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (kb + 32 * i + 4 * l8 >= k4) xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc += xv[i].x * wv[i].x; acc += xv[i].y * wv[i].y; acc += xv[i].z * wv[i].z; acc += xv[i].w * wv[i].w;
+            }
+        }
+        for (int k = k4 + l8; k < a.k_last; k += 8) acc += x[k] * wl[k];       // <= 3 elements (the ones column)
 #pragma unroll
         for (int off = 4; off; off >>= 1) acc += __shfl_xor(acc, off);
         zl = a.last_sigmoid ? sigmoid_clip_d(acc) : acc;
         if (valid && l8 == 0) a.zout[(size_t)b * a.ldz] = zl;
     } else {
         zl = a.zlast[(size_t)b * a.ldz];
+        if (wide_early) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool bad = wid[r] < 0 || wid[r] >= a.wide_rows;
+                wbad |= bad && 8 * r + l8 < a.F;
+                if (bad) wid[r] = 0;
+                ww[r] = a.wide_w[wid[r]];
+            }
+        }
     }
+    if (wide_early) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (8 * r + l8 >= a.F) ww[r] = 0.f;
+    }
+    HEAD_T(4);
     float p;
     if (a.wide) {
         // LRLayer.forward (layer/LRLayer.java:73-84): sum over the F wide ids, sequential, then + bias
@@ -210,9 +277,9 @@ __device__ __forceinline__ float head_one(const HeadArgs &a, int b, int lane, bo
             float w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                w[r] = 0.f;
+                w[r] = ww[r];
                 const int f = j0 + 8 * r + l8;
-                if (f < a.F) {
+                if (!wide_early && f < a.F) {
                     int64_t id = a.wide_ids[(size_t)b * a.F + f];
                     if (id < 0 || id >= a.wide_rows) { if (valid) atomicAdd(a.err, 1); id = 0; }
                     w[r] = a.wide_w[id];
@@ -221,17 +288,30 @@ __device__ __forceinline__ float head_one(const HeadArgs &a, int b, int lane, bo
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = a.F - j0 - 8 * r < 8 ? a.F - j0 - 8 * r : 8;
-                for (int j = 0; j < n; ++j) sumW += __shfl(w[r], gbase + j);          // field order
+                const int n = a.F - j0 - 8 * r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {                                    // field order; the 8 shuffles are independent
+                    const float v = __shfl(w[r], gbase + j);
+                    if (j < n) sumW += v;
+                }
             }
         }
         sumW += a.wide_bias[0];
+        if (wide_early && valid) {
+            if (wbad) atomicAdd(a.err, 1);
+            if (a.touched && a.train) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (8 * r + l8 < a.F) a.touched[wid[r]] = 1;   // LRLayer.weights.put (never cleared)
+            }
+        }
+        HEAD_T(5);
         if (valid && l8 == 0) a.wide_z[b] = sumW;
         const float z = zl + sumW;                          // AddLayer.forward l.add(r)
         p = sigmoid_clip_d(z);
     } else {
         p = zl;                                             // last FcLayer already applied the sigmoid
     }
+    HEAD_T(6);
     if (valid && l8 == 0) a.P[b] = p;
     if (!a.labels) return 0.f;
     const float l = a.labels[b];
@@ -255,6 +335,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
 // HEAD: the head of the same rows runs first in the same launch (training step: head -> loss' -> this layer's
 // backward is a chain of three tiny kernels on the critical path; the rows' delta stays in LDS).
 #define HEAD_ROWS_MAX 1024
+#define LAST_ROWS 32
 template <bool HEAD>
 __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
     __shared__ float dsh[HEAD ? HEAD_ROWS_MAX : 1];
@@ -262,31 +343,36 @@ __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * a.chunk;
     const int r1 = r0 + a.chunk < a.B ? r0 + a.chunk : a.B;
+    HEAD_T(0);
     if (HEAD) {
         for (int base = r0; base < r1; base += 32) {            // 32 rows per sweep: 8 lanes each
             const int b = base + (tid >> 3);
             const float d = head_one(h, b < r1 ? b : r1 - 1, tid & 63, b < r1);
             if (b < r1 && (tid & 7) == 0) dsh[b - r0] = d;
         }
+        HEAD_T(1);
         __syncthreads();
+        HEAD_T(2);
     }
     const float *__restrict__ A = a.A;
     const float *__restrict__ dl = a.dlast;
     float *__restrict__ dp = a.dprev;
+    // (requesting the first LAST_ROWS x column before the head, to overlap the two round trips, measured slower:
+    // kernel span 12.9 -> 15.5 us)
     for (int k = tid; k < a.Kp; k += 256) {
         const bool in = k <= a.K;                               // k == K is the ones column (bias)
         const float w = (k < a.K) ? a.W[(size_t)k * a.ldw] : 0.f;
         float acc = 0.f;
-        for (int b0 = r0; b0 < r1; b0 += 16) {
-            float x[16], d[16];
+        for (int b0 = r0; b0 < r1; b0 += LAST_ROWS) {
+            float x[LAST_ROWS], d[LAST_ROWS];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {                      // 32 independent loads in flight
+            for (int j = 0; j < LAST_ROWS; ++j) {               // a workgroup's usual 32 rows in ONE round trip
                 const int b = b0 + j < r1 ? b0 + j : r1 - 1;
                 x[j] = A[(size_t)b * a.lda + k];
                 d[j] = HEAD ? dsh[b - r0] : dl[(size_t)b * a.ldd];
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < LAST_ROWS; ++j) {
                 if (b0 + j < r1) {
                     acc += x[j] * d[j];                         // rows in order: the sequential batch sum
                     if (k < a.dprev_cols) {
@@ -299,6 +385,7 @@ __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
         }
         if (in) a.part[(size_t)blockIdx.x * a.part_stride + (size_t)k * a.ldpart] = acc;
     }
+    HEAD_T(3);
 }
 
 // loss = sum(terms)/B, gbar = rowMeans(delta) ; sets the skip flag (model/DNN.java:58-63)
@@ -569,8 +656,9 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
 // another XCD -- and with the loads switched off the fold alone takes the same; a DPP-broadcast variant that cut the
 // fold's LDS read instructions fourfold measured SLOWER (46 us).)
 #define SEQ_ILP 4
-#define SEQ_TILE 16               // SEQ mode: keys above this many entries go to a long-key workgroup (at most one such run
+#define SEQ_TILE PS_EMB_SEQ_TILE  // SEQ mode: keys above this many entries go to a long-key workgroup (at most one such run
                                   // can start in a SEQ_TILE-entry tile); 16 keeps the short role at 64 row registers
+#define SEQ_LONG_GRID 512         // long-key workgroups when the sort handed over a list of the long runs
 #define SEQ_LDS_FLOATS 4096       // per buffer: D * (3 * (64 / LPR) * SEQ_ILP + 4) <= 768 * VEC + 4 * D
 __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magic, uint32_t &rem) {
     uint32_t q = __umulhi(x, magic);            // magic = floor(2^32 / d): q is the quotient or one less
@@ -580,18 +668,11 @@ __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magi
     return q;
 }
 
+// One long run (segment u, entries [s0, e0)), by the whole workgroup; every wave passes the same number of barriers.
 template <int VEC, bool BAG>
-__device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *lds /* [2][SEQ_LDS_FLOATS] */) {
+__device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* [2][SEQ_LDS_FLOATS] */, uint32_t u, uint32_t s0, uint32_t e0) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t CH = SEQ_TILE;
-    const int64_t c = blockIdx.x;
-    if (c * CH >= a.nnz) return;
-    const uint32_t t0 = (uint32_t)(c * CH);
-    const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
-    const uint32_t u = a.seg_id[t1];
-    const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
     const uint32_t n = e0 - s0;
-    if (s0 < t0 || n <= CH) return;                            // the run starts in an earlier tile, or is a short key (block-uniform)
     const int D = a.D, G = 64 / a.LPR;
     const uint32_t NBW = (uint32_t)G * SEQ_ILP, NB = 3 * NBW;   // entries per loader wave / per batch
     const uint32_t LDE = NB + 4;                                // LDS row stride: 16-B aligned rows, <= 2-way write conflicts
@@ -645,7 +726,7 @@ __device__ __forceinline__ void long_key_sequential(const EmbBwdArgs &a, float *
             if (t + 3 < total) load_idx(t + 3);
             __syncthreads();
         }
-        return;
+        return;                                                 // (the fold wave's last barrier is this loop's last one)
     }
     // ---- wave 0: the strict chain.  lane d owns components d, d + 64, ... ----
     constexpr int CPL = VEC == 4 ? 4 : 1;                       // D <= 256 (VEC 4) or <= 64 (VEC 1)
@@ -713,7 +794,26 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
     if (a.skip && *a.skip) return;
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
-        long_key_sequential<VEC, BAG>(a, seq_lds);
+        if (a.long_list) {
+            // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
+            const uint32_t nl = a.nseg[1];
+            for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.long_blocks) {
+                const uint32_t u = a.long_list[i];
+                long_key_run<VEC, BAG>(a, seq_lds, u, a.seg_start[u], a.seg_start[u + 1]);
+                __syncthreads();                               // the next run reuses the LDS buffers
+            }
+            return;
+        }
+        // no list: the workgroup of the SEQ_TILE-entry tile in which a long run starts owns it
+        const uint32_t CH = SEQ_TILE;
+        const int64_t c = blockIdx.x;
+        if (c * CH >= a.nnz) return;
+        const uint32_t t0 = (uint32_t)(c * CH);
+        const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
+        const uint32_t u = a.seg_id[t1];
+        const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
+        if (s0 < t0 || e0 - s0 <= CH) return;                  // the run starts in an earlier tile, or is a short key (block-uniform)
+        long_key_run<VEC, BAG>(a, seq_lds, u, s0, e0);
         return;
     }
     const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
@@ -1171,7 +1271,9 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
     a.ablate = g_seq_ablate;
-    a.long_blocks = a.seq_order ? cdiv(a.nnz, SEQ_TILE) : 0;    // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it
+    // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
+    // long runs, a fixed grid walks that list
+    a.long_blocks = !a.seq_order ? 0 : a.long_list ? SEQ_LONG_GRID : cdiv(a.nnz, SEQ_TILE);
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
         if (a.seq_order) {                                                                     \

@@ -400,6 +400,9 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     return PS_OK;
 }
 
+int g_sort_ablate = 0;      // measurement only
+int g_field_sort = 1;       // ps_tune_set("field_sort", 0): single-hot batches go through the general radix sort too
+int g_last_rows = 0;        // ps_tune_set("last_rows", rows per k_last_bwd workgroup)
 int g_gemm_tn_target = 0;   // ps_tune_set("gemm_tn_target", workgroups): override the workgroup target of the split choice
 int gemm_tn_choose_split(int Kout, int N, int M) {
     const long long tiles = N <= 32 ? (long long)cdiv(Kout, 128) * cdiv(N, 32) : (long long)cdiv(Kout, 64) * cdiv(N, 64);

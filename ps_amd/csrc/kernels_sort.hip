@@ -255,6 +255,209 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Single-hot batches: the whole "sort the (row key, entry) pairs, cut them into per-key runs" chain in ONE launch.
+// Field f's B keys occupy their own interval of the key space (row = row_base[f] + id, kernels_emb.hip), so the
+// global stable sort is F independent sorts of B pairs -- each small enough (B <= 8192) to live in one workgroup's
+// LDS.  Workgroup f:
+//   1. loads its column of the [B][F] key matrix as 64-bit composites (key << 32 | sample): ascending composites
+//      = ascending keys, ties in batch order, i.e. exactly the stable radix sort's result;
+//   2. bitonic-sorts them in LDS (1024 threads, log2(NP)(log2(NP)+1)/2 stages);
+//   3. marks the run heads, scans them, counts the runs longer than `long_min` entries;
+//   4. publishes (epoch, #long runs, #runs) in pub[f] and adds up the words of the fields before it (they were
+//      dispatched earlier and wait only on earlier ones still: no circular wait, however many fields are resident);
+//   5. writes sorted_keys / sorted_ents / seg_id / seg_start (+ the list of long runs for k_emb_reduce_update's
+//      long-key role); the last field also writes nseg, the sentinel seg_start[nseg] and the long-run count.
+// 11 launches of the radix chain (3 x hist/scan/scatter + 2 segment kernels, ~63 us of a side stream and most of the
+// chip's CUs touched by each) become one that occupies F CUs.
+// ---------------------------------------------------------------------------
+constexpr int FS_TPB = 1024;
+constexpr int FS_MAX = 8192;
+
+struct FieldSortArgs {
+    const uint32_t *keys;               // [B][F] row keys in entry order (entry = b * F + f)
+    const int64_t *keys_base;           // [F] first row key of every field (subtracted before the sort) or nullptr
+    int B, F, NP, long_min, npass, digit_bits;
+    uint32_t *sorted_keys, *sorted_ents, *seg_start, *seg_id, *nseg;   // nseg[0] = runs, nseg[1] = long runs
+    uint32_t *long_list;                // run ids with more than long_min entries (any order)
+    unsigned long long *pub;            // [F] look-back words
+    uint32_t epoch;
+};
+
+#ifdef PS_FS_TIMING
+__device__ unsigned long long g_fs_t[64 * 8];
+#define FS_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_fs_t[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define FS_T(k) do { } while (0)
+#endif
+
+// The sort itself: stable LSD radix passes entirely in LDS, ballot-ranked like k_radix_scatter (a bitonic network
+// on the same workgroup was VALU-bound on its one CU: 78 stages x ~20 instructions per element, 52 us at B = 4096;
+// a radix pass costs ~1 wave instruction per element).  Wave w owns the contiguous span [w * SPAN, (w + 1) * SPAN)
+// of positions, 64 consecutive ones per chunk, so (wave, chunk, lane) order IS position order and the ranking
+// below is stable.
+template <int EPT>
+__global__ __launch_bounds__(FS_TPB) void k_field_sort_segments(FieldSortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fs_lds[];
+    constexpr int NP = FS_TPB * EPT, NW = FS_TPB / 64, SPAN = NP / NW, CH = SPAN / 64;      // CH == EPT
+    uint32_t *kA = reinterpret_cast<uint32_t *>(fs_lds), *vA = kA + NP, *kB = vA + NP, *vB = kB + NP;
+    __shared__ uint32_t dcnt[NW][256];
+    __shared__ uint32_t wtot[16], wlong[16], base_s[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int f = blockIdx.x, B = a.B;
+    if (tid < 2) base_s[tid] = 0;
+    FS_T(0);
+    const uint32_t fbase = a.keys_base ? (uint32_t)a.keys_base[f] : 0u;
+    {
+        uint32_t kk[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = w * SPAN + c * 64 + lane;
+            kk[c] = a.keys[(size_t)(p < B ? p : B - 1) * a.F + f];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = w * SPAN + c * 64 + lane;
+            kA[p] = p < B ? kk[c] - fbase : 0xffffffffu;      // pads: the largest digit in every pass, behind everything
+            vA[p] = (uint32_t)p;
+        }
+    }
+    FS_T(1);
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t *kin = kA, *vin = vA, *kout = kB, *vout = vB;
+    for (int pass = 0, shift = 0; pass < a.npass; ++pass, shift += a.digit_bits) {
+        const uint32_t dmask = (1u << a.digit_bits) - 1u;
+        for (int q = tid; q < NW * 256; q += FS_TPB) (&dcnt[0][0])[q] = 0;
+        __syncthreads();
+        uint32_t key[CH], val[CH], dig[CH], rank[CH], gcnt[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int p = w * SPAN + c * 64 + lane;
+            key[c] = kin[p]; val[c] = vin[p];
+            dig[c] = (key[c] >> shift) & dmask;
+            uint64_t same = ~0ull;
+            for (int b = 0; b < a.digit_bits; ++b) {
+                const bool bit = (dig[c] >> b) & 1u;
+                const uint64_t m = __ballot(bit);
+                same &= bit ? m : ~m;
+            }
+            rank[c] = (uint32_t)__popcll(same & below);
+            gcnt[c] = (uint32_t)__popcll(same);
+            if (rank[c] == 0) dcnt[w][dig[c]] += gcnt[c];      // one lane per digit group; chunks of a wave in order
+        }
+        __syncthreads();
+        {
+            // exclusive scan of the NW x 256 counters in (digit, wave) order: thread t owns digit t / 4, waves 4 (t % 4) ..
+            const int d = tid >> 2, w0 = (tid & 3) * 4;
+            const uint32_t c0 = dcnt[w0][d], c1 = dcnt[w0 + 1][d], c2 = dcnt[w0 + 2][d], c3 = dcnt[w0 + 3][d];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            uint32_t inc = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(inc, off);
+                if (lane >= off) inc += t;
+            }
+            if (lane == 63) wtot[w] = inc;
+            __syncthreads();
+            uint32_t ex = inc - tot;
+            for (int q = 0; q < w; ++q) ex += wtot[q];
+            dcnt[w0][d] = ex; dcnt[w0 + 1][d] = ex + c0; dcnt[w0 + 2][d] = ex + c0 + c1; dcnt[w0 + 3][d] = ex + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint32_t pos = dcnt[w][dig[c]] + rank[c];
+            kout[pos] = key[c]; vout[pos] = val[c];
+            if (rank[c] + 1 == gcnt[c]) dcnt[w][dig[c]] += gcnt[c];      // last lane of the group advances the cursor
+        }
+        __syncthreads();
+        uint32_t *t;
+        t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    const uint32_t *ks = kin, *vs = vin;                     // sorted (local id, sample); kout / vout are free now
+    uint32_t *starts = kout;                                 // [NP + 1] <= 2 * NP words (kout and vout are adjacent)
+    const int r0 = tid * EPT;
+    FS_T(2);
+    // run heads: each thread owns EPT consecutive sorted positions
+    uint32_t heads = 0;                                      // bit e: position r0 + e starts a run
+    for (int e = 0; e < EPT; ++e) {
+        const int r = r0 + e;
+        if (r < B && (r == 0 || ks[r] != ks[r - 1])) heads |= 1u << e;
+    }
+    uint32_t cnt = __popc(heads), inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t before = inc - cnt, nrun = 0;
+    for (int q = 0; q < FS_TPB / 64; ++q) { if (q < w) before += wtot[q]; nrun += wtot[q]; }
+    // starts[idx] = first sorted position of run idx; starts[nrun] = B
+    {
+        uint32_t idx = before;
+        for (int e = 0; e < EPT; ++e) if (heads >> e & 1u) starts[idx++] = (uint32_t)(r0 + e);
+        if (tid == 0) starts[nrun] = (uint32_t)B;
+    }
+    __syncthreads();
+    // long runs of this field: count, then slots by the same scan
+    uint32_t lcnt = 0;
+    {
+        uint32_t idx = before;
+        for (int e = 0; e < EPT; ++e) if (heads >> e & 1u) { if (starts[idx + 1] - starts[idx] > (uint32_t)a.long_min) ++lcnt; ++idx; }
+    }
+    uint32_t linc = lcnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(linc, off);
+        if (lane >= off) linc += t;
+    }
+    if (lane == 63) wlong[w] = linc;
+    __syncthreads();
+    uint32_t lbefore = linc - lcnt, nlong = 0;
+    for (int q = 0; q < FS_TPB / 64; ++q) { if (q < w) lbefore += wlong[q]; nlong += wlong[q]; }
+    FS_T(3);
+    // look-back over the fields before this one
+    if (tid == 0)
+        __hip_atomic_store(&a.pub[f], ((unsigned long long)a.epoch << 32) | ((unsigned long long)nlong << 16) | nrun,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t sr = 0, sl = 0;
+    for (int g = tid; g < f; g += FS_TPB) {
+        unsigned long long v;
+        do { v = __hip_atomic_load(&a.pub[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != a.epoch);
+        sr += (uint32_t)v & 0xffffu; sl += (uint32_t)(v >> 16) & 0xffffu;
+    }
+    if (sr | sl) { atomicAdd(&base_s[0], sr); atomicAdd(&base_s[1], sl); }
+    __syncthreads();
+    FS_T(4);
+    const uint32_t rbase = base_s[0], lbase = base_s[1];
+    const uint32_t pos0 = (uint32_t)f * (uint32_t)B;
+    {
+        uint32_t idx = before, li = lbefore;                 // idx = runs started before position r0
+        for (int e = 0; e < EPT; ++e) {
+            const int r = r0 + e;
+            if (r >= B) break;
+            if (heads >> e & 1u) {
+                a.seg_start[rbase + idx] = pos0 + (uint32_t)r;
+                if (starts[idx + 1] - starts[idx] > (uint32_t)a.long_min) a.long_list[lbase + li++] = rbase + idx;
+                ++idx;
+            }
+            a.sorted_keys[pos0 + r] = ks[r] + fbase;
+            a.sorted_ents[pos0 + r] = vs[r] * (uint32_t)a.F + (uint32_t)f;
+            a.seg_id[pos0 + r] = rbase + idx - 1;
+        }
+    }
+    FS_T(5);
+    if (f == a.F - 1 && tid == 0) {
+        a.nseg[0] = rbase + nrun;
+        a.nseg[1] = lbase + nlong;
+        a.seg_start[rbase + nrun] = (uint32_t)a.F * (uint32_t)B;
+    }
+}
+
 }  // namespace
 
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap) {
@@ -321,3 +524,43 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// field_sort_segments: see k_field_sort_segments.  keys = [B][F] row keys of a single-hot batch.
+// ---------------------------------------------------------------------------
+bool field_sort_fits(int B, int F) { return B >= 1 && B <= FS_MAX && F >= 1 && F < 65536; }
+
+int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_bits, int B, int F, int long_min,
+                        uint32_t *sorted_keys, uint32_t *sorted_ents, uint32_t *seg_start, uint32_t *seg_id,
+                        uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st) {
+    if (!field_sort_fits(B, F) || key_bits < 1 || key_bits > 32)
+        return ps_set_err(PS_E_BAD_ARG, "field_sort_segments: B = %d, F = %d, key_bits = %d", B, F, key_bits);
+    int ept = 1;
+    while (FS_TPB * ept < B) ept <<= 1;
+    const int NP = FS_TPB * ept;
+    const int npass = (key_bits + 7) / 8, digit_bits = (key_bits + npass - 1) / npass;
+    FieldSortArgs a{keys, keys_base, B, F, NP, long_min, npass, digit_bits, sorted_keys, sorted_ents, seg_start, seg_id, nseg_dev,
+                    long_list, pub, epoch};
+    const size_t lds = (size_t)NP * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_sort_segments<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   FS_MAX * 16));
+        attr_set = true;
+    }
+    switch (ept) {
+    case 1: hipLaunchKernelGGL(k_field_sort_segments<1>, dim3(F), dim3(FS_TPB), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(k_field_sort_segments<2>, dim3(F), dim3(FS_TPB), lds, st, a); break;
+    case 4: hipLaunchKernelGGL(k_field_sort_segments<4>, dim3(F), dim3(FS_TPB), lds, st, a); break;
+    default: hipLaunchKernelGGL(k_field_sort_segments<8>, dim3(F), dim3(FS_TPB), lds, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+#ifdef PS_FS_TIMING
+extern "C" int ps_dbg_fs_timing(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fs_t), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

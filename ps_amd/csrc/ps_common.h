@@ -109,6 +109,15 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
 // *nseg_dev.
 int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, uint32_t *seg_start,
                    uint32_t *seg_id, uint32_t *nseg_dev, hipStream_t st);
+// Single-hot batch (keys = [B][F], field f's keys in their own interval): stable sort + segments + the list of runs
+// longer than long_min entries, ONE launch of F workgroups.  Same sorted_keys / sorted_ents / seg_* as
+// radix_sort_pairs(iota) + build_segments; nseg_dev[1] = number of long runs.  keys_base[f] (device) = first key of
+// field f's interval, key_bits = bits of the largest (key - keys_base[f]).  pub: F look-back words (zeroed once),
+// epoch: a value that differs from every earlier launch on the same pub (nonzero).
+bool field_sort_fits(int B, int F);
+int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_bits, int B, int F, int long_min,
+                        uint32_t *sorted_keys, uint32_t *sorted_ents, uint32_t *seg_start, uint32_t *seg_id,
+                        uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // GEMM (kernels_gemm.hip): f32 MFMA 32x32x2, exact f32
@@ -124,6 +133,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
                    const int *skip_flag, hipStream_t st);
 int gemm_tn_choose_split(int Kout, int N, int M);
+extern int g_last_rows, g_sort_ablate, g_field_sort;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;

@@ -96,7 +96,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
         PSCHK(model_alloc(m, (void **)&b.dOut, sizeof(float) * (size_t)B * b.ldD, true));
         b.nsplit = gemm_tn_choose_split(p.K + 1, p.N, B);
         if (l == nfc - 1 && p.N == 1) {              // k_last_bwd: one partial slab per 32 batch rows
-            b.nsplit = cdiv(B, 32);
+            b.nsplit = cdiv(B, g_last_rows > 0 ? g_last_rows : 32);
             if (b.nsplit > 256) b.nsplit = 256;
         }
         b.ldp = p.ldw;
@@ -128,6 +128,10 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->seg_id, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->nseg_dev, sizeof(uint32_t) * 4, true));
     PSCHK(model_alloc(m, (void **)&m->seg_nseg_scratch, sizeof(uint32_t) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->fs_keys, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
+    PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
@@ -180,6 +184,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
     sort_ws_free(m->ws); sort_ws_free(m->wws);
     fr(m->wkeys); fr(m->wents); fr(m->wseg_start); fr(m->wseg_id); fr(m->wnseg);
+    fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub);
     fr(m->seg_nseg_scratch); fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
     fr(m->partials); fr(m->partials2); fr(m->grads_out); fr(m->dense_grad_flat);
     delete m;
@@ -316,22 +321,39 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         hipStream_t ss = side_stream(m, 0);
         PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
-        {
+        static int64_t sort_runs = 0;
+        m->long_list_valid = false;
+        if (g_sort_ablate && ++sort_runs > 4) {
+            // measurement only (tools/sort_ablate.py, ONE batch repeated): the step without its sort chain
+        } else if (!m->cur_offsets && g_field_sort && field_sort_fits(B, c.F)) {
+            // single-hot: every field's keys live in their own interval, F sorts of B pairs in one launch
+            // (sorted pairs, segments and the list of long runs; kernels_sort.hip)
             Prof pf(m, "emb_sort");
-            // payload of the sort = the BAG of every entry (single-hot: entry == bag, an iota).  The backward only
-            // needs each entry's delta row (its bag's) in entry order, which the stable sort keeps: carrying the bag
-            // through the sort saves the entry -> bag indirection (a random 4-byte load per entry) in both backward
-            // kernels.  ent_bag is consumed as ping-pong storage here.
-            if (m->cur_offsets)
-                PSCHK(radix_sort_pairs(m->ws, m->keys, m->ent_bag, nnz, bits_for(s->emb.total_rows), false, &m->sorted_keys,
-                                       &m->sorted_ents, ss));
-            else
-                PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
-                                       &m->sorted_ents, ss));
-        }
-        {
-            Prof pf(m, "emb_segments");
-            PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss));
+            if (++m->fs_epoch == 0) ++m->fs_epoch;
+            int64_t span = 1;
+            for (int f = 0; f < c.F; ++f) span = std::max(span, s->emb.row_base[f + 1] - s->emb.row_base[f]);
+            PSCHK(field_sort_segments(m->keys, s->emb.row_base_dev, bits_for(span), B, c.F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
+                                      m->seg_start, m->seg_id, m->nseg_dev, m->long_list, m->fs_pub, m->fs_epoch, ss));
+            m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
+            m->long_list_valid = true;
+        } else {
+            {
+                Prof pf(m, "emb_sort");
+                // payload of the sort = the BAG of every entry (single-hot: entry == bag, an iota).  The backward only
+                // needs each entry's delta row (its bag's) in entry order, which the stable sort keeps: carrying the bag
+                // through the sort saves the entry -> bag indirection (a random 4-byte load per entry) in both backward
+                // kernels.  ent_bag is consumed as ping-pong storage here.
+                if (m->cur_offsets)
+                    PSCHK(radix_sort_pairs(m->ws, m->keys, m->ent_bag, nnz, bits_for(s->emb.total_rows), false, &m->sorted_keys,
+                                           &m->sorted_ents, ss));
+                else
+                    PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, bits_for(s->emb.total_rows), true, &m->sorted_keys,
+                                           &m->sorted_ents, ss));
+            }
+            {
+                Prof pf(m, "emb_segments");
+                PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss));
+            }
         }
         m->side0_pending = true;
     }
@@ -520,6 +542,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = apply ? 1 : 0;
     g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
     g.nseg = m->nseg_dev;
+    g.long_list = (m->long_list_valid && !m->sh.active) ? m->long_list : nullptr;
     g.ent_bag = (m->cur_offsets && m->sh.active) ? m->ent_bag : nullptr;     // fused path: sorted_ent already holds bags
     g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.partials2 = m->partials2; g.W = s->emb.W; g.state = s->emb.state;
     // a key's run is at most B entries when single-hot: no second level (and no extra launch) up to 128 chunks

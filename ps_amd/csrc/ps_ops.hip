@@ -217,6 +217,9 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "gemm_tn_cfg") == 0) { g_gemm_tn_cfg = value; return PS_OK; }
     if (strcmp(knob, "gemm_xcd") == 0) { g_gemm_xcd = value; return PS_OK; }
     if (strcmp(knob, "gemm_tn_target") == 0) { g_gemm_tn_target = value; return PS_OK; }
+    if (strcmp(knob, "last_rows") == 0) { g_last_rows = value; return PS_OK; }
+    if (strcmp(knob, "sort_ablate") == 0) { g_sort_ablate = value; return PS_OK; }
+    if (strcmp(knob, "field_sort") == 0) { g_field_sort = value; return PS_OK; }
     if (strcmp(knob, "gemm_ablate") == 0) { g_gemm_ablate = value; return PS_OK; }
     if (strcmp(knob, "mh_ilp16") == 0) { g_mh_ilp16 = value; return PS_OK; }
     if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }

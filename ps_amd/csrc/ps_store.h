@@ -114,6 +114,10 @@ struct ps_model {
              *nseg_dev = nullptr, *uniq_row = nullptr, *uniq_cnt = nullptr;
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
     uint32_t *seg_nseg_scratch = nullptr;                     // run count of a side sort whose nseg the bitmap plan already wrote
+    // single-hot batches: one-launch field sort (kernels_sort.hip field_sort_segments)
+    uint32_t *fs_keys = nullptr, *fs_ents = nullptr, *long_list = nullptr;
+    unsigned long long *fs_pub = nullptr; uint32_t fs_epoch = 0;
+    bool long_list_valid = false;                             // the last sort filled long_list / nseg_dev[1]
     float *partials = nullptr, *partials2 = nullptr, *grads_out = nullptr;
     float *dense_grad_flat = nullptr; int64_t dense_elems = 0;
     // wide_grad_mode = intended: sort of the batch's wide ids (allocated on first use)

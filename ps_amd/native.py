@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libps_amd.so")
+# PS_AMD_LIB: another build of the SAME library (tools/ab_bench.sh compares two builds on one GPU box)
+LIB_PATH = os.environ.get("PS_AMD_LIB") or os.path.join(HERE, "lib", "libps_amd.so")
 
 PS_OK, PS_MISSING, PS_NO_UPDATER = 0, 204, 500
 PS_E_BAD_ARG, PS_E_HIP, PS_E_UNSUPPORTED, PS_E_STATE = -1, -2, -3, -4

@@ -9,7 +9,7 @@ __global__ void k(float *out, long long *cyc, int n) {
     for (int i = lane; i < 16 * LDE; i += 64) lds[i] = 1.0f + 1e-7f * i;
     __syncthreads();
     float acc = 0.f;
-    const long long t0 = clock64();
+    const long long t0 = clock64(); const long long w0 = wall_clock64();
     if (MODE == 0 || MODE == 1 || MODE == 2 || MODE == 3) {
         const float *row = lds + (lane & 15) * LDE;
         if (lane < 16) {
@@ -95,15 +95,52 @@ __global__ void k(float *out, long long *cyc, int n) {
             }
         }
     }
-    const long long t1 = clock64();
-    if (lane == 0) cyc[0] = t1 - t0;
+    else if (MODE == 6) {
+        // software pipelined: the next 8 x ds_read_b128 are in flight while the current 32 adds run
+        const float *row = lds + (lane & 15) * LDE;
+        if (lane < 16) {
+            for (int rep = 0; rep < n / 256; ++rep) {
+                float4 va[8], vb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) va[k] = *reinterpret_cast<const float4 *>(row + 4 * k);
+                for (int j = 0; j < 256; j += 64) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vb[k] = *reinterpret_cast<const float4 *>(row + j + 32 + 4 * k);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { acc = va[k].x + acc; acc = va[k].y + acc; acc = va[k].z + acc; acc = va[k].w + acc; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) va[k] = *reinterpret_cast<const float4 *>(row + ((j + 64) & 255) + 4 * k);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { acc = vb[k].x + acc; acc = vb[k].y + acc; acc = vb[k].z + acc; acc = vb[k].w + acc; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else if (MODE == 7) {
+        // mode 1 with all 64 lanes active (4 copies of the 16 rows): does the read cost depend on the active lanes?
+        const float *row = lds + (lane & 15) * LDE;
+        for (int rep = 0; rep < n / 256; ++rep) {
+            for (int j = 0; j < 256; j += 32) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(row + j + 4 * k);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { acc = v[k].x + acc; acc = v[k].y + acc; acc = v[k].z + acc; acc = v[k].w + acc; }
+            }
+        }
+    }
+    const long long t1 = clock64(); const long long w1 = wall_clock64();
+    if (lane == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
     out[lane] = acc;
 }
 int main() {
-    float *o; long long *c, h;
-    hipMalloc(&o, 256); hipMalloc(&c, 8);
+    float *o; long long *c, h[2];
+    hipMalloc(&o, 256); hipMalloc(&c, 16);
     const int n = 65536;
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
         for (int r = 0; r < 2; ++r) {
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, o, c, n);
             if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, o, c, n);
@@ -111,11 +148,13 @@ int main() {
             if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(1), dim3(64), 0, 0, o, c, n);
             if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, o, c, n);
             if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(1), dim3(64), 0, 0, o, c, n);
+            if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(1), dim3(64), 0, 0, o, c, n);
+            if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(1), dim3(64), 0, 0, o, c, n);
             hipDeviceSynchronize();
         }
-        hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(h, c, 16, hipMemcpyDeviceToHost);
         float ho[64]; hipMemcpy(ho, o, 256, hipMemcpyDeviceToHost);
-        printf("mode %d: %.2f ticks/add (acc lane0 %.3f)\n", mode, (double)h / n, ho[0]);
+        printf("mode %d: %.2f ticks/add, %.2f ns/add (acc lane0 %.3f)\n", mode, (double)h[0] / n, 10.0 * (double)h[1] / n, ho[0]);
     }
     return 0;
 }
