@@ -51,7 +51,23 @@ def fc_flops_per_step(cfg):
 
 
 # kernel launches behind one profiled group (the others are one launch): per-launch time decides the dominant KERNEL
-GROUP_LAUNCHES = {"emb_sort": 9, "emb_segments": 2, "dense_update": 2}
+# launches per profiled group.  emb_sort: ONE launch for single-hot batches (field sort: pairs, segments and the long-run
+# list); multi-hot batches go through the general chain (9 radix launches + the 2 of emb_segments).
+GROUP_LAUNCHES = {"emb_sort": 1, "emb_segments": 2}
+
+
+def tn_splits(cfg):
+    """Split-K factors of the dW GEMMs (kernels_gemm.hip gemm_tn_choose_split: ~224 workgroups of 64 x 64 tiles,
+    at least 128 batch rows per split); the out = 1 layer goes through k_last_bwd instead."""
+    dims = [cfg["F"] * cfg["D"] + cfg["X"]] + cfg["fc"]
+    out = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        if b == 1:
+            out.append(1)               # folded to one slab by k_dense_prereduce
+            continue
+        tiles = -(-(a + 1) // 64) * -(-b // 64) if b > 32 else -(-(a + 1) // 128) * -(-b // 32)
+        out.append(max(1, min(-(-224 // tiles), max(1, cfg["B"] // 128), 64)))
+    return out
 
 
 def group_algorithmic(cfg, name, nnz, uniq):
@@ -65,11 +81,14 @@ def group_algorithmic(cfg, name, nnz, uniq):
     if name == "emb_bwd_update":
         return "hbm", nnz * 4.0 * D + uniq * 6 * 4.0 * D + nnz * 8.0     # delta rows + {W,M,V} read and written per key + sort pairs
     if name == "emb_sort":
-        return "hbm", 3 * 24.0 * nnz                              # 3 radix passes: pairs read twice (histogram, scatter), written once
+        if cfg.get("multi_hot"):
+            return "hbm", 3 * 24.0 * nnz                          # 3 radix passes: pairs read twice (histogram, scatter), written once
+        return "hbm", 20.0 * nnz                                  # field sort: keys read; sorted keys, entries, run ids, run starts written
     if name == "emb_segments":
         return "hbm", 20.0 * nnz                                  # keys read twice, run ids written
     if name == "dense_update":
-        return "hbm", 4.0 * dense * (8 + 7)                       # ~8 split slabs read, W/M/V read, W/Wt/M/V written
+        slabs = sum(s * (a + 1) * b for s, a, b in zip(tn_splits(cfg), dims[:-1], dims[1:]))
+        return "hbm", 4.0 * (slabs + dense * 8)                   # the split slabs + W/M/V read, W/Wt/M/V and the flat gradient written
     if name == "head_last_bwd":
         return "hbm", 4.0 * B * (3 * dims[-2] + 2 * F + 8)        # the out = 1 layer's input twice, delta_prev written, wide ids
     if name in ("head", "fc_bwd_last"):

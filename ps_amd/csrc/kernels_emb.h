@@ -21,6 +21,7 @@ struct EmbFwdArgs {
     size_t table_bytes;        // size of W (decides the streaming hints)
     int nt;                    // bit 0: non-temporal row loads, bit 1: non-temporal output stores (set by the launcher)
     int LPR, gather_blocks;    // filled by the launcher
+    unsigned long long *ts;    // stamp slot (ps_common.h) or nullptr, set by the launcher
 };
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st);
 
@@ -48,6 +49,7 @@ struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer 
     int mask_cols;                     // columns whose relu' mask applies
     float *part; long long part_stride; int ldpart;   // dW partial slabs, one per workgroup
     const int *skip;
+    unsigned long long *ts;
 };
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);   // loss_out NULL: no loss reduction
@@ -74,6 +76,7 @@ struct EmbBwdArgs {
     float *grads_out; uint32_t *uniq_row; uint32_t *uniq_cnt;   // [nseg][D], [nseg], [nseg]
     const int *skip;
     int LPR;
+    unsigned long long *ts;
 };
 int launch_emb_bwd(EmbBwdArgs a, hipStream_t st);
 
@@ -93,8 +96,10 @@ struct DenseUpdArgs {
     float flat_div;                    // > 0: divide flat_grad by it (mean over workers after the all-reduce)
     float *grad_out;                   // flat gradient as handed to the updater (or nullptr)
     const int *skip;
+    unsigned long long *ts;
 };
 int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
+int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)
 
 struct WideUpdArgs {
     int64_t rows;

@@ -59,6 +59,7 @@ template <> struct Vec<1> {
 #define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
 template <int VEC, bool MULTI, bool SLOT, int MHI>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
+    StampScope stamp(a.ts);
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x >= a.gather_blocks) {
         // ConcatLayer.forward (layer/ConcatLayer.java:30-37): dense features behind the embeddings
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
 template <bool HEAD>
 __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
     __shared__ float dsh[HEAD ? HEAD_ROWS_MAX : 1];
+    StampScope stamp(a.ts);
     if (!HEAD && a.skip && *a.skip) return;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * a.chunk;
@@ -792,6 +794,7 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
 template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
+    StampScope stamp(a.ts, SEQ ? (unsigned int)a.long_blocks : 0u);
     if (a.skip && *a.skip) return;
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
         if (a.long_list) {
@@ -1015,6 +1018,7 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
 // touched a different cache line per lane and tripled the kernel's write traffic (profiles/ r01: 13.4 MB written for
 // 5.6 MB of tensors).
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
+    StampScope stamp(a.ts);
     if (a.skip && *a.skip) return;
     __shared__ float tile[32][33];
     int l = 0;
@@ -1220,6 +1224,7 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
     // table, tools/gather_nt.py: bags of 32 0.671 -> 0.707 of 8 TB/s, single-hot read+write 0.663 -> 0.694; nt stores: no effect)
     a.nt = a.table_bytes > ((size_t)1 << 30) ? 1 : 0;
     if (g_gather_nt >= 0) a.nt = g_gather_nt;
+    a.ts = stamp_next("emb_fwd");
     const int vec = (a.D % 4 == 0) ? 4 : 1;
     a.LPR = a.D / vec;
     const bool multi = a.offsets != nullptr, slot = a.slot != nullptr;
@@ -1241,8 +1246,8 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
 #define EMB_FWD_LAUNCH(V)                                                                                          \
     do {                                                                                                           \
         if (multi) { if (slot) EMB_FWD_MH(V, true); else EMB_FWD_MH(V, false); }                                   \
-        else { if (slot) hipLaunchKernelGGL((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, a);       \
-               else hipLaunchKernelGGL((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, a); }          \
+        else { if (slot) PS_LAUNCH((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, a);                \
+               else PS_LAUNCH((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, a); }                   \
     } while (0)
     if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0)
         hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);
@@ -1271,6 +1276,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
     a.ablate = g_seq_ablate;
+    a.ts = stamp_next("emb_bwd_update");
     // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
     // long runs, a fixed grid walks that list
     a.long_blocks = !a.seq_order ? 0 : a.long_list ? SEQ_LONG_GRID : cdiv(a.nnz, SEQ_TILE);
@@ -1317,17 +1323,22 @@ __global__ __launch_bounds__(256) void k_dense_prereduce(float *__restrict__ par
 }
 }  // namespace
 
+// Folds the slabs of layer l in place when there are many of them (see k_dense_prereduce) and marks the layer as
+// one slab.  Separate from the update so that the step can run it as soon as the slabs exist (the out = 1 layer's come
+// from the head's launch) instead of in front of the update at the very end of the side chain.
+int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st) {
+    DenseLayer &L = a.L[l];
+    if (a.flat_grad || !(L.nsplit > 32 && L.nsplit <= 256)) return PS_OK;
+    const int64_t elems = (int64_t)(L.K + 1) * L.N;
+    hipLaunchKernelGGL(k_dense_prereduce, dim3(cdiv(elems, 4)), dim3(256), 0, st, const_cast<float *>(L.part), L.part_stride, L.ldp, L.N, elems, L.nsplit);
+    HIPCHK(hipGetLastError());
+    L.nsplit = 1;
+    return PS_OK;
+}
+
 int launch_dense_update(const DenseUpdArgs &a0, hipStream_t st) {
     DenseUpdArgs a = a0;
-    if (!a.flat_grad)
-        for (int l = 0; l < a.nlayers; ++l) {
-            DenseLayer &L = a.L[l];
-            if (L.nsplit > 32 && L.nsplit <= 256) {
-                const int64_t elems = L.elem_end - L.elem_begin;
-                hipLaunchKernelGGL(k_dense_prereduce, dim3(cdiv(elems, 4)), dim3(256), 0, st, const_cast<float *>(L.part), L.part_stride, L.ldp, L.N, elems, L.nsplit);
-                L.nsplit = 1;
-            }
-        }
+    for (int l = 0; l < a.nlayers; ++l) PSCHK(dense_prereduce(a, l, st));
     int tiles = 0;
     for (int l = 0; l < a.nlayers; ++l) {
         DenseLayer &L = a.L[l];
@@ -1336,6 +1347,7 @@ int launch_dense_update(const DenseUpdArgs &a0, hipStream_t st) {
         L.tile_end = tiles;
     }
     if (tiles == 0) return PS_OK;
+    a.ts = stamp_next("dense_update");
     hipLaunchKernelGGL(k_dense_update, dim3(tiles), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
@@ -1474,7 +1486,9 @@ int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st) {
 int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st) {
     if (a.B <= 0 || nsplit <= 0) return PS_OK;
     if (a.chunk > HEAD_ROWS_MAX || !h.labels) return ps_set_err(PS_E_BAD_ARG, "launch_head_last_bwd: %d rows per workgroup / no labels", a.chunk);
-    hipLaunchKernelGGL(k_last_bwd<true>, dim3(nsplit), dim3(256), 0, st, a, h);
+    LastBwdArgs q = a;
+    q.ts = stamp_next("head_last_bwd");
+    PS_LAUNCH(k_last_bwd<true>, dim3(nsplit), dim3(256), 0, st, q, h);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -32,6 +32,7 @@ struct NtArgs {
     const int *skip;
     int xcd_swizzle;
     int ablate;      // measurement only: 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barriers
+    unsigned long long *ts;
 };
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     constexpr int A_F4 = (BM * RF4 + 255) / 256, B_F4 = (BN * RF4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    StampScope stamp(a.ts);
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
@@ -223,6 +225,7 @@ struct TnArgs {
     int Kout, N, M, mchunk;
     const int *skip;
     int xcd_swizzle;
+    unsigned long long *ts;
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     constexpr int A_F4 = (BKT * BM / 4 + 255) / 256, B_F4 = (BKT * BN / 4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BKT * BM];
     __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
+    StampScope stamp(a.ts);
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
@@ -363,8 +367,7 @@ int g_gemm_xcd = 1;      // XCD-aware work-group order on/off (for A/B runs)
 int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5 128x32/32
 
 #define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
-    hipLaunchKernelGGL((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), \
-                       dim3(256), 0, st, a)
+    PS_LAUNCH((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(256), 0, st, a)
 
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
@@ -372,7 +375,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate};
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt")};
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -400,6 +403,8 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     return PS_OK;
 }
 
+hipEvent_t g_launch_stop_event = nullptr;
+int g_ext_events = 1;       // ps_tune_set("ext_events", 0): cross-stream events by hipEventRecord again
 int g_sort_ablate = 0;      // measurement only
 int g_field_sort = 1;       // ps_tune_set("field_sort", 0): single-hot batches go through the general radix sort too
 int g_last_rows = 0;        // ps_tune_set("last_rows", rows per k_last_bwd workgroup)
@@ -430,7 +435,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
         return ps_set_err(PS_E_BAD_ARG, "gemm_tn: leading dims / cols must be multiples of 4");
     if (Kout <= 0 || N <= 0 || nsplit <= 0) return PS_OK;
     const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), 32);
-    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd};
+    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn")};
     int cfg = g_gemm_tn_cfg;
     if (cfg == 0) cfg = N <= 32 ? 5 : 2;
     switch (cfg) {

@@ -283,6 +283,7 @@ struct FieldSortArgs {
     uint32_t *long_list;                // run ids with more than long_min entries (any order)
     unsigned long long *pub;            // [F] look-back words
     uint32_t epoch;
+    unsigned long long *ts;
 };
 
 #ifdef PS_FS_TIMING
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(FS_TPB) void k_field_sort_segments(FieldSortArgs a)
     __shared__ uint32_t wtot[16], wlong[16], base_s[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int f = blockIdx.x, B = a.B;
+    StampScope stamp(a.ts);
     if (tid < 2) base_s[tid] = 0;
     FS_T(0);
     const uint32_t fbase = a.keys_base ? (uint32_t)a.keys_base[f] : 0u;
@@ -541,7 +543,7 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
     const int NP = FS_TPB * ept;
     const int npass = (key_bits + 7) / 8, digit_bits = (key_bits + npass - 1) / npass;
     FieldSortArgs a{keys, keys_base, B, F, NP, long_min, npass, digit_bits, sorted_keys, sorted_ents, seg_start, seg_id, nseg_dev,
-                    long_list, pub, epoch};
+                    long_list, pub, epoch, stamp_next("field_sort")};
     const size_t lds = (size_t)NP * 16;
     static bool attr_set = false;
     if (!attr_set) {

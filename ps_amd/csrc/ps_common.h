@@ -2,6 +2,7 @@
 // libps_amd.so (gfx950 only).  The public boundary is include/ps_native.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -120,6 +121,40 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
                         uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st);
 
 // ---------------------------------------------------------------------------
+// GPU-side time stamps (measurement only: ps_tune_set("stamps", 1), tools/gpu_timeline.py).  A stamped kernel takes
+// a slot pointer in its arguments (nullptr when off = one scalar compare per workgroup): slot[0] = start of
+// workgroup 0, slot[1] = latest sampled workgroup end, 10 ns ticks of the device's wall clock.  Unlike a profiler's
+// trace this costs the HOST nothing, so the stream stays as far ahead of the GPU as in a normal run.
+// ---------------------------------------------------------------------------
+// A launch can carry the event another stream will wait on: the dispatch packet's own completion signal, instead of
+// a hipEventRecord behind it (a separate barrier packet: ~3-4 us of the recording stream before its next kernel
+// starts; tools/gpu_timeline.py).  The caller arms g_launch_stop_event, the next PS_LAUNCH consumes it.
+extern hipEvent_t g_launch_stop_event;
+#define PS_LAUNCH(kernel, grid, block, shmem, st, ...)                                                         \
+    do {                                                                                                       \
+        hipEvent_t se_ = g_launch_stop_event;                                                                  \
+        if (se_) { g_launch_stop_event = nullptr; hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, se_, 0, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                  \
+    } while (0)
+unsigned long long *stamp_next(const char *name);      // nullptr when stamps are off or the buffer is full
+int stamps_enable(int on);
+#ifdef __HIPCC__
+struct StampScope {
+    unsigned long long *p;
+    unsigned int always;            // the first `always` workgroups all report their end (the long-key role of the embedding update)
+    // start: workgroup 0 (dispatched first); end: the maximum over every 32nd workgroup and the last one -- one atomic
+    // per workgroup on one address made a 7 000-workgroup launch 2.4x slower
+    __device__ __forceinline__ explicit StampScope(unsigned long long *q, unsigned int all_below = 0) : p(q), always(all_below) {
+        if (p && threadIdx.x == 0 && blockIdx.x == 0) p[0] = (unsigned long long)wall_clock64();
+    }
+    __device__ __forceinline__ ~StampScope() {
+        if (p && threadIdx.x == 0 && ((blockIdx.x & 31u) == 31u || blockIdx.x == gridDim.x - 1 || blockIdx.x < always))
+            atomicMax(p + 1, (unsigned long long)wall_clock64());
+    }
+};
+#endif
+
+// ---------------------------------------------------------------------------
 // GEMM (kernels_gemm.hip): f32 MFMA 32x32x2, exact f32
 // ---------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_MASK_POS = 3 };
@@ -133,7 +168,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
                    const int *skip_flag, hipStream_t st);
 int gemm_tn_choose_split(int Kout, int N, int M);
-extern int g_last_rows, g_sort_ablate, g_field_sort;
+extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;

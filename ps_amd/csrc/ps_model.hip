@@ -47,6 +47,35 @@ int fork(ps_model *m, hipStream_t from, hipStream_t to) {
     return PS_OK;
 }
 int join(ps_model *m, hipStream_t from, hipStream_t to) { return fork(m, from, to); }
+// "the next launch on the main stream carries an event": arm before the launch, then settle(): if the launcher took
+// it (PS_LAUNCH), the event is the kernel's own completion signal; if not, it is recorded the ordinary way.
+hipEvent_t arm_event(ps_model *m) {
+    if (m->profile || !m->multi_stream || !g_ext_events) return nullptr;
+    hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+    g_launch_stop_event = e;
+    return e;
+}
+int settle_event(ps_model *m, hipEvent_t e) {
+    if (e && g_launch_stop_event == e) {        // not consumed by the launch
+        g_launch_stop_event = nullptr;
+        HIPCHK(hipEventRecord(e, m->s->stream));
+    }
+    return PS_OK;
+}
+int wait_event(ps_model *m, hipStream_t to, hipEvent_t e) {
+    if (e && to != m->s->stream) HIPCHK(hipStreamWaitEvent(to, e, 0));
+    return PS_OK;
+}
+// one record on `from`, two waiters: an event record costs the recording stream ~5 us before its next kernel starts
+// (tools/gpu_timeline.py: 3 records between the head and the first delta GEMM were a 20 us hole in the main chain)
+int fork2(ps_model *m, hipStream_t from, hipStream_t to_a, hipStream_t to_b) {
+    if (from == to_a && from == to_b) return PS_OK;
+    hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+    HIPCHK(hipEventRecord(e, from));
+    if (to_a != from) HIPCHK(hipStreamWaitEvent(to_a, e, 0));
+    if (to_b != from && to_b != to_a) HIPCHK(hipStreamWaitEvent(to_b, e, 0));
+    return PS_OK;
+}
 
 int bits_for(int64_t n) {
     int b = 1;
@@ -146,6 +175,8 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     m->events.resize(64);
     for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->s0_ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->dw_ev, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));
     *out = m;
     return PS_OK;
@@ -161,6 +192,8 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     for (int i = 0; i < 2; ++i) if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
     for (auto &e : m->events) (void)hipEventDestroy(e);
     if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
+    if (m->s0_ev) (void)hipEventDestroy(m->s0_ev);
+    if (m->dw_ev) (void)hipEventDestroy(m->dw_ev);
     if (m->hstage.copy_stream) {
         (void)hipStreamSynchronize(m->hstage.copy_stream);
         for (int k = 0; k < 2; ++k) {
@@ -315,11 +348,13 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // keys and the sort were made by ps_shard_plan
         e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr; e.table_bytes = 0;
     }
+    hipEvent_t fwd_ev = (train && !m->sh.active) ? arm_event(m) : nullptr;
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
+    PSCHK(settle_event(m, fwd_ev));
     if (train && !m->sh.active) {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
-        PSCHK(fork(m, st, ss));
+        if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
         static int64_t sort_runs = 0;
         m->long_list_valid = false;
@@ -397,7 +432,9 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         LastBwdArgs q;
         fill_last_bwd(m, q);
         Prof pf(m, "head_last_bwd");
+        m->head_ev = arm_event(m);
         PSCHK(launch_head_last_bwd(h, q, bl.nsplit, st));
+        PSCHK(settle_event(m, m->head_ev));
         m->head_bwd_done = true;
     } else {
         Prof pf(m, "head");
@@ -451,12 +488,17 @@ int enqueue_backward(ps_model *m, bool apply) {
     PSCHK(store_resolve_updater(s, "emF", &u));
     if (apply && !s->emb.state && u.kind != PS_UPD_SIMPLE)       // before anything is enqueued
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
-    // side chain 1: every dW GEMM as soon as its delta exists, then the dense update.
-    // side chain 0 (the sort ran there during the forward; idle now): loss reduction, then the wide update.
+    // side chain 1: the out = 1 layer's slab fold, every other dW GEMM as soon as its delta exists, then the dense update.
+    // side chain 0 (the sort ran there during the forward; idle now): loss reduction, the wide update, then the
+    // remaining dW GEMMs.  The dW GEMMs ALTERNATE between the two chains: one chain ran prereduce, dW1, dW0 and the
+    // update back to back with a ~10 us cross-launch gap each and ended after the embedding update -- the next step's
+    // first GEMM then waited for it (tools/gpu_timeline.py); on two chains the update is ready ~20 us earlier.
     hipStream_t sw = side_stream(m, 1), s0 = side_stream(m, 0);
-    PSCHK(fork(m, st, sw));
-    PSCHK(fork(m, st, s0));
-    bool loss_on_side = false;
+    if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
+    else PSCHK(fork2(m, st, sw, s0));
+    m->head_ev = nullptr;
+    bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
+    hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
     if (m->loss_pending) {
         // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
         // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
@@ -464,7 +506,6 @@ int enqueue_backward(ps_model *m, bool apply) {
         Prof pf(m, "loss_reduce");
         PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, s0));
         m->loss_pending = false;
-        if (s0 != st) { HIPCHK(hipEventRecord(m->loss_ev, s0)); loss_on_side = true; }
     }
     // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
     if (c.kind == PS_MODEL_WIDEDEEP && apply) {
@@ -477,38 +518,6 @@ int enqueue_backward(ps_model *m, bool apply) {
         Prof pf(m, "wide_update");
         if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, s0));
         else PSCHK(launch_wide_update(w, s0));
-    }
-    // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
-    for (int l = nfc - 1; l >= 0; --l) {
-        FcParams &p = s->fc[l];
-        FcBuf &b = m->fc[l];
-        if (l == nfc - 1 && p.N == 1) {
-            if (!m->head_bwd_done) {       // otherwise the head's launch already did this layer's backward
-                LastBwdArgs q;
-                fill_last_bwd(m, q);
-                Prof pf(m, "fc_bwd_last");
-                PSCHK(launch_last_bwd(q, b.nsplit, st));
-            }
-            if (nfc == 1) PSCHK(fork(m, st, sw));   // otherwise the next layer's fork orders the dense update behind this
-            continue;
-        }
-        if (l < nfc - 1) PSCHK(fork(m, st, sw));     // delta_l was just produced on the main chain
-        // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
-        static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
-        static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
-        if (l > 0) {
-            Prof pf(m, nd[l]);
-            PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
-        } else {
-            Prof pf(m, nd[l]);
-            PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
-        }
-        Prof pf2(m, nw[l]);
-        // dW (+ db through the ones column), split over the batch
-        PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
-                             b.nsplit, nullptr, sw));
     }
     // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
     DenseUpdArgs d;
@@ -526,16 +535,56 @@ int enqueue_backward(ps_model *m, bool apply) {
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }
-    // The dense update overwrites W / Wt of EVERY layer: it must not start before the main chain's last
-    // delta GEMM (which reads W_0; the earlier ones read W_l before it, in order) has finished.  Without this
-    // edge the update raced with fc_bwd_data0 whenever the dW GEMMs finished first (rare, shape dependent).
-    if (apply) PSCHK(fork(m, st, sw));
-    if (loss_on_side) HIPCHK(hipStreamWaitEvent(sw, m->loss_ev, 0));     // the stop flag (long since written)
-    { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }   // in order behind the dW GEMMs
+    // the out = 1 layer's 128 row-block slabs (written by the head's launch) folded here, on side chain 0 behind the
+    // wide update, not in front of the dense update at the end of the step
+    if (m->head_bwd_done && s->fc[nfc - 1].N == 1) { Prof pf(m, "dense_prereduce"); PSCHK(dense_prereduce(d, nfc - 1, s0)); }
+    // everything the main chain needs from side chain 0 ends here (sort, stop flag, wide update, slab fold)
+    if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
+    // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
+    for (int l = nfc - 1; l >= 0; --l) {
+        FcParams &p = s->fc[l];
+        FcBuf &b = m->fc[l];
+        if (l == nfc - 1 && p.N == 1) {
+            if (!m->head_bwd_done) {       // otherwise the head's launch already did this layer's backward
+                LastBwdArgs q;
+                fill_last_bwd(m, q);
+                Prof pf(m, "fc_bwd_last");
+                PSCHK(launch_last_bwd(q, b.nsplit, st));
+                main_dirty = true;
+            }
+            continue;       // (its slabs: folded above, or -- produced just now -- inside the dense update)
+        }
+        hipStream_t dws = sw;
+        if (main_dirty) {                                   // delta_l was just produced on the main chain
+            if (data_ev) PSCHK(wait_event(m, dws, data_ev)); else PSCHK(fork(m, st, dws));
+            main_dirty = false;
+        }
+        data_ev = l > 0 ? arm_event(m) : nullptr;      // delta_{l-1}: the next dW GEMM waits for it (nobody after the last)
+        // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
+        static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
+        static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
+        if (l > 0) {
+            Prof pf(m, nd[l]);
+            PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
+                          EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
+        } else {
+            Prof pf(m, nd[l]);
+            PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
+                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
+        }
+        PSCHK(settle_event(m, data_ev));
+        main_dirty = true;
+        Prof pf2(m, nw[l]);
+        // dW (+ db through the ones column), split over the batch
+        PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
+                             b.nsplit, nullptr, dws));
+    }
+    if (sw != st) HIPCHK(hipEventRecord(m->dw_ev, sw));      // the last dW GEMM
+    PSCHK(settle_event(m, data_ev));
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
-    PSCHK(join(m, s0, st));       // the sort (forward), the stop flag and the wide update
+    if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));       // the sort (forward), the stop flag and the wide update
     m->side0_pending = false;
     EmbBwdArgs g;
     memset(&g, 0, sizeof g);
@@ -553,7 +602,14 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
     { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st)); }
-    PSCHK(join(m, sw, st));       // the step is complete when the main stream is
+    // The dense update runs LAST ON THE MAIN CHAIN.  A stream that reaches a wait before its event has fired resumes
+    // 10-20 us after it (tools/gpu_timeline.py), a wait that is already satisfied costs ~3: on a side chain the update
+    // ended within a few microseconds of the embedding update, so the next step's first GEMM -- which must wait for
+    // it -- sometimes hit the slow case and sometimes not (a bimodal step, 174 / 192 us, fixed per process).  Here the
+    // dW GEMMs it needs ended ~15 us earlier on their side chain, the delta GEMM that reads W_0 is in order before
+    // it, and nothing crosses a stream at the step boundary.
+    if (sw != st) HIPCHK(hipStreamWaitEvent(st, m->dw_ev, 0));
+    { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }
     return PS_OK;
 }
 

@@ -220,6 +220,8 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "last_rows") == 0) { g_last_rows = value; return PS_OK; }
     if (strcmp(knob, "sort_ablate") == 0) { g_sort_ablate = value; return PS_OK; }
     if (strcmp(knob, "field_sort") == 0) { g_field_sort = value; return PS_OK; }
+    if (strcmp(knob, "ext_events") == 0) { g_ext_events = value; return PS_OK; }
+    if (strcmp(knob, "stamps") == 0) return stamps_enable(value);
     if (strcmp(knob, "gemm_ablate") == 0) { g_gemm_ablate = value; return PS_OK; }
     if (strcmp(knob, "mh_ilp16") == 0) { g_mh_ilp16 = value; return PS_OK; }
     if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }
@@ -258,4 +260,43 @@ extern "C" int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int n
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(A); (void)hipFree(B); (void)hipFree(Cc);
     return rc;
+}
+
+
+// ---------------------------------------------------------------------------
+// GPU-side time stamps (ps_common.h): STAMP_SLOTS launches, then stamp_next returns nullptr
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int STAMP_SLOTS = 8192;
+unsigned long long *g_stamp_buf = nullptr;      // [STAMP_SLOTS][2]
+std::vector<const char *> g_stamp_names;
+bool g_stamps_on = false;
+}
+int stamps_enable(int on) {
+    g_stamps_on = false;
+    g_stamp_names.clear();
+    if (!on) return PS_OK;
+    if (!g_stamp_buf) HIPCHK(hipMalloc((void **)&g_stamp_buf, sizeof(unsigned long long) * 2 * STAMP_SLOTS));
+    std::vector<unsigned long long> init(2 * STAMP_SLOTS);
+    for (int i = 0; i < STAMP_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(g_stamp_buf, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
+    g_stamps_on = true;
+    return PS_OK;
+}
+unsigned long long *stamp_next(const char *name) {
+    if (!g_stamps_on || (int)g_stamp_names.size() >= STAMP_SLOTS) return nullptr;
+    g_stamp_names.push_back(name);
+    return g_stamp_buf + 2 * (g_stamp_names.size() - 1);
+}
+// names: '\n'-separated, vals: [n][2]; returns the number of stamped launches (after a device synchronize)
+extern "C" int ps_dbg_stamps(char *names, int names_cap, unsigned long long *vals, int vals_cap) {
+    if (!g_stamp_buf) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const int n = (int)std::min<size_t>(g_stamp_names.size(), (size_t)vals_cap);
+    if (hipMemcpy(vals, g_stamp_buf, sizeof(unsigned long long) * 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    std::string s;
+    for (int i = 0; i < n; ++i) { s += g_stamp_names[i]; s += '\n'; }
+    snprintf(names, (size_t)names_cap, "%s", s.c_str());
+    return n;
 }
