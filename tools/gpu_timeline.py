@@ -19,6 +19,8 @@ rng = np.random.default_rng(1)
 bs = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
 for i in range(100): gm.train_async(bs[i % nb])
 gm.sync()
+for kv_ in os.environ.get("PS_TUNE", "").split(","):
+    if "=" in kv_: L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
 L.ps_tune_set(b"stamps", 1)
 for i in range(300): gm.train_async(bs[i % nb])
 gm.sync()

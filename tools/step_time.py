@@ -6,6 +6,8 @@ import ps_amd
 from bench import C2, synth_batch
 from ps_amd import native as N
 if os.environ.get("SORT_ABLATE"): N.lib().ps_tune_set(b"sort_ablate", 1)
+for kv_ in os.environ.get("PS_TUNE", "").split(","):
+    if "=" in kv_: N.lib().ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
 cfg = dict(C2)
 for nb in [int(a) for a in sys.argv[1:]] or [1, 16]:
     kv = ps_amd.KVStore(0, cfg["seed"]); kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
