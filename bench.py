@@ -368,15 +368,24 @@ def main():
     ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON.  Libraries chat on fd 1 too (RCCL prints a five-line version banner
+    # through C stdio, flushed at exit -- after the JSON): fd 1 is pointed at stderr for the run and the line is
+    # written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(out):
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.sharded:
         from ps_amd import sharded
         out = sharded.run_bench(args, C2, synth_batch)
         if out is not None:
-            print(json.dumps(out), flush=True)
+            emit(out)
         return
-    out = run_single(args)
-    print(json.dumps(out), flush=True)
+    emit(run_single(args))
 
 
 if __name__ == "__main__":
