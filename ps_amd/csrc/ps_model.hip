@@ -499,12 +499,17 @@ int enqueue_backward(ps_model *m, bool apply) {
     m->head_ev = nullptr;
     bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
     hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
+    // The small kernels that hang off the head (loss / stop flag, wide update, the out = 1 layer's slab fold) go behind
+    // the sort on side chain 0 when the sort is the one-launch field sort (done long before the head).  Behind the
+    // 11-launch radix chain of a multi-hot batch (136 us at configs[4]'s shape, ending after the last delta GEMM) they
+    // would sit on the critical path: there they go to the front of side chain 1 instead.
+    hipStream_t sl = (m->long_list_valid || m->sh.active || s0 == st) ? s0 : sw;      // (sharded: that sort ran during the exchange)
     if (m->loss_pending) {
         // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
         // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
         // only the kernels that touch parameters (wide / dense / embedding updates) honour it.
         Prof pf(m, "loss_reduce");
-        PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, s0));
+        PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, sl));
         m->loss_pending = false;
     }
     // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
@@ -516,8 +521,8 @@ int enqueue_backward(ps_model *m, bool apply) {
         PSCHK(store_resolve_updater(s, "wide.weights", &u));
         w.upd = make_upd_params(u);
         Prof pf(m, "wide_update");
-        if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, s0));
-        else PSCHK(launch_wide_update(w, s0));
+        if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, sl));
+        else PSCHK(launch_wide_update(w, sl));
     }
     // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
     DenseUpdArgs d;
@@ -537,9 +542,10 @@ int enqueue_backward(ps_model *m, bool apply) {
     }
     // the out = 1 layer's 128 row-block slabs (written by the head's launch) folded here, on side chain 0 behind the
     // wide update, not in front of the dense update at the end of the step
-    if (m->head_bwd_done && s->fc[nfc - 1].N == 1) { Prof pf(m, "dense_prereduce"); PSCHK(dense_prereduce(d, nfc - 1, s0)); }
+    if (m->head_bwd_done && s->fc[nfc - 1].N == 1) { Prof pf(m, "dense_prereduce"); PSCHK(dense_prereduce(d, nfc - 1, sl)); }
     // everything the main chain needs from side chain 0 ends here (sort, stop flag, wide update, slab fold)
     if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
+    if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
         FcParams &p = s->fc[l];
@@ -589,6 +595,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
     if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));       // the sort (forward), the stop flag and the wide update
+    if (sl != s0) HIPCHK(hipStreamWaitEvent(st, m->loss_ev, 0));
     m->side0_pending = false;
     EmbBwdArgs g;
     memset(&g, 0, sizeof g);
