@@ -794,7 +794,7 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
 template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
-    StampScope stamp(a.ts, SEQ ? (unsigned int)a.long_blocks : 0u);
+    StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);
     if (a.skip && *a.skip) return;
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
         if (a.long_list) {

@@ -403,7 +403,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     return PS_OK;
 }
 
-hipEvent_t g_launch_stop_event = nullptr;
+thread_local hipEvent_t g_launch_stop_event = nullptr;
 int g_ext_events = 1;       // ps_tune_set("ext_events", 0): cross-stream events by hipEventRecord again
 int g_sort_ablate = 0;      // measurement only
 int g_field_sort = 1;       // ps_tune_set("field_sort", 0): single-hot batches go through the general radix sort too

@@ -128,8 +128,9 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
 // ---------------------------------------------------------------------------
 // A launch can carry the event another stream will wait on: the dispatch packet's own completion signal, instead of
 // a hipEventRecord behind it (a separate barrier packet: ~3-4 us of the recording stream before its next kernel
-// starts; tools/gpu_timeline.py).  The caller arms g_launch_stop_event, the next PS_LAUNCH consumes it.
-extern hipEvent_t g_launch_stop_event;
+// starts; tools/gpu_timeline.py).  The caller arms g_launch_stop_event, the next PS_LAUNCH of the SAME host thread
+// consumes it (thread-local: several host threads may each drive their own store).
+extern thread_local hipEvent_t g_launch_stop_event;
 #define PS_LAUNCH(kernel, grid, block, shmem, st, ...)                                                         \
     do {                                                                                                       \
         hipEvent_t se_ = g_launch_stop_event;                                                                  \

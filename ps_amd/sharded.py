@@ -20,6 +20,7 @@ gloo tests drive the same orchestration with a CPU backend built on the
 oracle (tests/ only).
 """
 import ctypes as C
+import json
 import os
 import time
 
@@ -625,6 +626,21 @@ def run_bench(args, cfg, synth_batch):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     loss = worker.step(batches[0], want_loss=True)
+    if os.environ.get("PS_STAMPS") and rank == 0:
+        # measurement: the sharded step as the GPU ran it (in-kernel time stamps, tools/gpu_timeline.py's mechanism)
+        import ctypes as C
+        L = N.lib()
+        L.ps_tune_set(b"stamps", 1)
+        worker_run(200)
+        kv.sync()
+        fn = L.ps_dbg_stamps
+        fn.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int]
+        names = C.create_string_buffer(1 << 18)
+        vals = (C.c_ulonglong * (2 * 8192))()
+        n = fn(names, len(names), vals, 8192)
+        L.ps_tune_set(b"stamps", 0)
+        with open(os.environ["PS_STAMPS"], "w") as f:
+            json.dump({"names": names.value.decode().split("\n")[:n], "vals": list(vals[:2 * n])}, f)
     phases = {}
     if getattr(args, "phases", 0) and not native:
         for i in range(50):
