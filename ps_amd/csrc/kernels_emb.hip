@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
         if (a.long_list) {
             // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
-            const uint32_t nl = a.nseg[1];
+            const uint32_t nl = *a.nlong;
             for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.long_blocks) {
                 const uint32_t u = a.long_list[i];
                 long_key_run<VEC, BAG>(a, seq_lds, u, a.seg_start[u], a.seg_start[u + 1]);

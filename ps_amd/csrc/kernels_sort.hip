@@ -202,6 +202,15 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_count(const uint32_t *__restrict
     if (tid == 0) blk_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// the runs longer than long_min entries, appended in any order (k_emb_reduce_update's long-key role walks the list):
+// nseg[1] counts them (zeroed by k_seg_emit)
+__global__ __launch_bounds__(256) void k_long_runs(const uint32_t *__restrict__ seg_start, uint32_t *__restrict__ nseg,
+                                                   uint32_t *__restrict__ long_list, uint32_t long_min) {
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= nseg[0]) return;
+    if (seg_start[u + 1] - seg_start[u] > long_min) long_list[atomicAdd(&nseg[1], 1u)] = u;
+}
+
 __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict__ keys, int64_t n,
                                                      const uint32_t *__restrict__ blk_heads,
                                                      uint32_t *__restrict__ seg_start,
@@ -248,7 +257,8 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict_
             if (h) seg_start[sid] = (uint32_t)idx;
             if (idx == n - 1) {
                 seg_start[sid + 1] = (uint32_t)n;
-                *nseg_dev = sid + 1;
+                nseg_dev[0] = sid + 1;
+                nseg_dev[1] = 0;                        // long-run counter (k_long_runs, when asked for)
             }
         }
         run += (uint32_t)__popcll(hm);
@@ -513,16 +523,18 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
 }
 
 int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, uint32_t *seg_start,
-                   uint32_t *seg_id, uint32_t *nseg_dev, hipStream_t st) {
+                   uint32_t *seg_id, uint32_t *nseg_dev, hipStream_t st, uint32_t *long_list, int long_min) {
     if (n > ws.cap) return ps_set_err(PS_E_BAD_ARG, "build_segments: n > cap");
     if (n <= 0) {
-        HIPCHK(hipMemsetAsync(nseg_dev, 0, sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(nseg_dev, 0, 2 * sizeof(uint32_t), st));
         return PS_OK;
     }
     const int nblk = cdiv(n, RS_TILE);
     hipLaunchKernelGGL(k_seg_count, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads);
     hipLaunchKernelGGL(k_seg_emit, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads,
                        seg_start, seg_id, nseg_dev);
+    if (long_list)      // at most n / (long_min + 1) runs can be that long; one thread per run, any order
+        hipLaunchKernelGGL(k_long_runs, dim3(cdiv(n, 256)), dim3(256), 0, st, seg_start, nseg_dev, long_list, (uint32_t)long_min);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -357,7 +357,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
         static int64_t sort_runs = 0;
-        m->long_list_valid = false;
+        m->long_list_valid = false; m->field_sorted = false;
         if (g_sort_ablate && ++sort_runs > 4) {
             // measurement only (tools/sort_ablate.py, ONE batch repeated): the step without its sort chain
         } else if (!m->cur_offsets && g_field_sort && field_sort_fits(B, c.F)) {
@@ -370,7 +370,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
             PSCHK(field_sort_segments(m->keys, s->emb.row_base_dev, bits_for(span), B, c.F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
                                       m->seg_start, m->seg_id, m->nseg_dev, m->long_list, m->fs_pub, m->fs_epoch, ss));
             m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
-            m->long_list_valid = true;
+            m->long_list_valid = true; m->nlong_ptr = m->nseg_dev + 1; m->field_sorted = true;
         } else {
             {
                 Prof pf(m, "emb_sort");
@@ -387,7 +387,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
             }
             {
                 Prof pf(m, "emb_segments");
-                PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss));
+                // (the list of long runs only where the sequential order will walk it)
+                const bool want_seq = c.emb_sum_order == PS_SUM_SEQUENTIAL || (c.emb_sum_order == PS_SUM_AUTO && !m->cur_offsets);
+                PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss, want_seq ? m->long_list : nullptr,
+                                     PS_EMB_SEQ_TILE));
+                m->long_list_valid = want_seq; m->nlong_ptr = m->nseg_dev + 1;
             }
         }
         m->side0_pending = true;
@@ -503,7 +507,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     // the sort on side chain 0 when the sort is the one-launch field sort (done long before the head).  Behind the
     // 11-launch radix chain of a multi-hot batch (136 us at configs[4]'s shape, ending after the last delta GEMM) they
     // would sit on the critical path: there they go to the front of side chain 1 instead.
-    hipStream_t sl = (m->long_list_valid || m->sh.active || s0 == st) ? s0 : sw;      // (sharded: that sort ran during the exchange)
+    hipStream_t sl = (m->field_sorted || m->sh.active || s0 == st) ? s0 : sw;      // (sharded: that sort ran during the exchange)
     if (m->loss_pending) {
         // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
         // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
@@ -602,7 +606,8 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = apply ? 1 : 0;
     g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
     g.nseg = m->nseg_dev;
-    g.long_list = (m->long_list_valid && !m->sh.active) ? m->long_list : nullptr;
+    g.long_list = m->long_list_valid ? m->long_list : nullptr;
+    g.nlong = m->nlong_ptr;
     g.ent_bag = (m->cur_offsets && m->sh.active) ? m->ent_bag : nullptr;     // fused path: sorted_ent already holds bags
     g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.partials2 = m->partials2; g.W = s->emb.W; g.state = s->emb.state;
     // a key's run is at most B entries when single-hot: no second level (and no extra launch) up to 128 chunks

@@ -309,11 +309,13 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
             HIPCHK(hipStreamWaitEvent(ss, e, 0));
         }
         PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
-        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss));
+        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
+        m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
         m->side0_pending = ss != st;
     } else {
         PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
-        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st));
+        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st, m->long_list, PS_EMB_SEQ_TILE));
+        m->long_list_valid = true; m->nlong_ptr = m->nseg_dev + 1;
     }
     if (bm) {
         // (send_rows, owner_start, slot, nseg came from the bitmap)

@@ -117,7 +117,9 @@ struct ps_model {
     // single-hot batches: one-launch field sort (kernels_sort.hip field_sort_segments)
     uint32_t *fs_keys = nullptr, *fs_ents = nullptr, *long_list = nullptr;
     unsigned long long *fs_pub = nullptr; uint32_t fs_epoch = 0;
-    bool long_list_valid = false;                             // the last sort filled long_list / nseg_dev[1]
+    bool long_list_valid = false;                             // the last sort filled long_list / *nlong_ptr
+    bool field_sorted = false;                                // ... and it was the one-launch field sort
+    const uint32_t *nlong_ptr = nullptr;
     float *partials = nullptr, *partials2 = nullptr, *grads_out = nullptr;
     float *dense_grad_flat = nullptr; int64_t dense_elems = 0;
     // wide_grad_mode = intended: sort of the batch's wide ids (allocated on first use)
