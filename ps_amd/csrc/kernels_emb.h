@@ -81,6 +81,18 @@ struct EmbBwdArgs {
 };
 int launch_emb_bwd(EmbBwdArgs a, hipStream_t st);
 
+struct WideUpdArgs {
+    int64_t rows;
+    float *W, *state;                  // [rows], [rows][2]
+    const uint8_t *touched;
+    float *bias, *bias_state;          // [1], [2]
+    const float *gbar;
+    UpdParams upd;
+    const int *skip;
+    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C; 3 bias only
+    float *G, *C;                      // [rows] (+ G[2*rows] = bias gradient), contiguous G|C|bias
+    int nworkers;
+};
 struct DenseLayer {
     float *W, *Wt, *S1, *S2;           // W' [K+1 rows][ldw], Wt [N rows][ldwt], state like W'
     const float *part;                 // split-K partials [nsplit][..][ldp]
@@ -98,23 +110,16 @@ struct DenseUpdArgs {
     float *grad_out;                   // flat gradient as handed to the updater (or nullptr)
     const int *skip;
     unsigned long long *ts;
+    // optional: a wide-table pass in the SAME launch (the sharded step's flat buffer is [fc | wide G | wide C | bias]:
+    // filling it and applying it are one kernel each instead of two); wide_blocks = 0: none
+    WideUpdArgs wide;
+    int wide_blocks, tile_blocks;
 };
 int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)
 
-struct WideUpdArgs {
-    int64_t rows;
-    float *W, *state;                  // [rows], [rows][2]
-    const uint8_t *touched;
-    float *bias, *bias_state;          // [1], [2]
-    const float *gbar;
-    UpdParams upd;
-    const int *skip;
-    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C; 3 bias only
-    float *G, *C;                      // [rows] (+ G[2*rows] = bias gradient), contiguous G|C|bias
-    int nworkers;
-};
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st);
+int wide_update_blocks(const WideUpdArgs &a);                    // for DenseUpdArgs.wide_blocks
 
 struct WideIntendedArgs {              // wide_grad_mode = intended
     const uint32_t *sorted_key, *sorted_ent, *seg_start, *nseg;

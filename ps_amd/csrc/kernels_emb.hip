@@ -1017,8 +1017,13 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
 // goes through LDS so that its stores run along k the same way -- one 4-byte store per thread straight into Wt[n][k]
 // touched a different cache line per lane and tripled the kernel's write traffic (profiles/ r01: 13.4 MB written for
 // 5.6 MB of tensors).
+__device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int64_t r);
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     StampScope stamp(a.ts);
+    if ((int)blockIdx.x >= a.tile_blocks) {                // the optional wide-table pass of the same launch
+        wide_update_body(a.wide, (int64_t)((int)blockIdx.x - a.tile_blocks) * 256 + threadIdx.x);
+        return;
+    }
     if (a.skip && *a.skip) return;
     __shared__ float tile[32][33];
     int l = 0;
@@ -1084,9 +1089,8 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
 }
 
 // materialise the flat dense gradient (sum of split partials / B) without updating
-__global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
+__device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int64_t r) {
     if (a.skip && *a.skip) return;
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a.mode == 1) {
         // sharded worker, before the all-reduce: G[k] = touched[k] * gbar, C[k] = touched[k]
         // (the PS averages a key over the workers that pushed it: net/PServer.java:164-214)
@@ -1116,6 +1120,10 @@ __global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
     else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, z, n);
     else w = (g * -a.upd.eta) + w;
     a.W[r] = w; a.state[2 * r] = z; a.state[2 * r + 1] = n;
+}
+
+__global__ __launch_bounds__(256) void k_wide_update(WideUpdArgs a) {
+    wide_update_body(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1346,9 +1354,10 @@ int launch_dense_update(const DenseUpdArgs &a0, hipStream_t st) {
         tiles += cdiv(L.K + 1, 32) * cdiv(L.N, 32);
         L.tile_end = tiles;
     }
-    if (tiles == 0) return PS_OK;
+    if (tiles + a.wide_blocks == 0) return PS_OK;
     a.ts = stamp_next("dense_update");
-    hipLaunchKernelGGL(k_dense_update, dim3(tiles), dim3(256), 0, st, a);
+    a.tile_blocks = tiles;
+    hipLaunchKernelGGL(k_dense_update, dim3(tiles + a.wide_blocks), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -1396,6 +1405,7 @@ int launch_wide_intended(const WideIntendedArgs &a, int64_t n, hipStream_t st) {
     return PS_OK;
 }
 
+int wide_update_blocks(const WideUpdArgs &a) { return cdiv(a.rows + 1, 256); }
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_wide_update, dim3(cdiv(a.rows + 1, 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());

@@ -625,6 +625,13 @@ int enqueue_backward(ps_model *m, bool apply) {
     // dW GEMMs it needs ended ~15 us earlier on their side chain, the delta GEMM that reads W_0 is in order before
     // it, and nothing crosses a stream at the step boundary.
     if (sw != st) HIPCHK(hipStreamWaitEvent(st, m->dw_ev, 0));
+    if (m->sh.active && c.kind == PS_MODEL_WIDEDEEP) {
+        // sharded worker: the wide part of the flat buffer ([fc | wide G | wide C | bias]) is filled by the same launch
+        WideUpdArgs &w = d.wide;
+        w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev; w.mode = 1;
+        w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
+        d.wide_blocks = wide_update_blocks(w);
+    }
     { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }
     return PS_OK;
 }

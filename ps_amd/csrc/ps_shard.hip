@@ -296,18 +296,25 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     if (bm) {
         const int nblk = cdiv(sh.bm_words, PLAN_WPB);
         hipLaunchKernelGGL(k_plan_count, dim3(nblk), dim3(256), 0, st, sh.stamp, sh.epoch, sh.bitmap, sh.bm_words, sh.blk_sum);
-        hipLaunchKernelGGL(k_plan_emit, dim3(nblk), dim3(256), 0, st, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
-                           sh.owner_start, m->nseg_dev, sh.sbits, nshards);
-        hipLaunchKernelGGL(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, st, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot);
-        HIPCHK(hipGetLastError());
-        // the entry lists of the backward: stable sort + runs, beside the exchange and the forward (side stream 0; the
-        // backward joins it).  After k_plan_slots in stream order: the sort ping-pongs through m->keys.
+        // Everything after the emit leaves the main chain: the slot of every entry (the forward reads it ~50 us later)
+        // and the entry lists of the backward (stable sort + runs) run on side stream 0, beside the exchange and the
+        // forward.  The emit's launch carries the event the side stream waits for, the slot kernel's launch the one the
+        // forward waits for (no record packets on either chain).  k_plan_slots before the sort in stream order: the sort
+        // ping-pongs through m->keys.
         hipStream_t ss = (m->profile || !m->multi_stream) ? st : m->side[0];
+        hipEvent_t e1 = nullptr;
+        if (ss != st) { e1 = m->events[m->next_event++ % m->events.size()]; if (g_ext_events) g_launch_stop_event = e1; }
+        PS_LAUNCH(k_plan_emit, dim3(nblk), dim3(256), 0, st, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
+                  sh.owner_start, m->nseg_dev, sh.sbits, nshards);
         if (ss != st) {
-            hipEvent_t e = m->events[m->next_event++ % m->events.size()];
-            HIPCHK(hipEventRecord(e, st));
-            HIPCHK(hipStreamWaitEvent(ss, e, 0));
+            if (g_launch_stop_event == e1 || !g_ext_events) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(e1, st)); }
+            HIPCHK(hipStreamWaitEvent(ss, e1, 0));
+            sh.slot_ev = m->events[m->next_event++ % m->events.size()];
+            if (g_ext_events) g_launch_stop_event = sh.slot_ev;
         }
+        PS_LAUNCH(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot);
+        if (ss != st && (g_launch_stop_event == sh.slot_ev || !g_ext_events)) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(sh.slot_ev, ss)); }
+        HIPCHK(hipGetLastError());
         PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
         PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
         m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
@@ -387,15 +394,10 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     HIPCHK(hipSetDevice(s->device));
     m->sh.active = true;
     m->sh.cache = cache_dev;
+    if (m->sh.slot_ev) { HIPCHK(hipStreamWaitEvent(s->stream, m->sh.slot_ev, 0)); m->sh.slot_ev = nullptr; }   // the plan's slots (side stream)
     int rc = enqueue_forward(m, true, true);
-    if (rc == PS_OK) rc = enqueue_backward(m, false);     // gradients only: the owners apply them
-    if (rc == PS_OK && m->cfg.kind == PS_MODEL_WIDEDEEP) {
-        WideUpdArgs w;
-        memset(&w, 0, sizeof w);
-        w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev; w.mode = 1;
-        w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
-        rc = launch_wide_update(w, s->stream);
-    }
+    if (rc == PS_OK) rc = enqueue_backward(m, false);     // gradients only: the owners apply them (the flat buffer's wide part
+                                                          // [G | C | bias] is filled by the dense gradient's launch)
     m->sh.active = false;
     PSCHK(rc);
     m->fwd_done = true; m->bwd_done = true;
@@ -506,16 +508,15 @@ extern "C" int ps_shard_apply_flat(ps_model_t *m, int nworkers) {
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }
-    PSCHK(launch_dense_update(d, s->stream));
-    if (m->cfg.kind == PS_MODEL_WIDEDEEP) {
-        WideUpdArgs w;
-        memset(&w, 0, sizeof w);
+    if (m->cfg.kind == PS_MODEL_WIDEDEEP) {          // the wide part of the flat buffer, same launch
+        WideUpdArgs &w = d.wide;
         w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
         w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.mode = 2; w.nworkers = nworkers;
         w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
         PSCHK(store_resolve_updater(s, "wide.weights", &u));
         w.upd = make_upd_params(u);
-        PSCHK(launch_wide_update(w, s->stream));
+        d.wide_blocks = wide_update_blocks(w);
     }
+    PSCHK(launch_dense_update(d, s->stream));
     return PS_OK;
 }

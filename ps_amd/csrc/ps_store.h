@@ -137,6 +137,7 @@ struct ps_model {
         int nshards = 1;
         const float *cache = nullptr; // [U][D] rows pulled from their owners, in send order
         uint32_t *slot = nullptr;     // [nnz] unique slot of every entry
+        hipEvent_t slot_ev = nullptr; // set while the slots are being written on a side stream (one of the model's events)
         uint32_t *send_rows = nullptr;// [U] owner-local row of every unique key, grouped by owner
         uint32_t *owner_start = nullptr; // [nshards+1] device
         int64_t *lrb_dev = nullptr;   // [nshards][F+1] local row bases of every shard
