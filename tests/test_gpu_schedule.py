@@ -1,0 +1,104 @@
+"""The step's scheduling is not allowed to change a single bit.
+
+The fused step runs on three HIP streams, carries its cross-stream events on the launches themselves
+(hipExtLaunchKernelGGL stop events), sorts single-hot batches with the one-launch field sort and runs the dense update last
+on the main chain.  Every one of those is a switch; whatever the switches say, K training steps must
+leave identical tables:
+  * default                                   (three streams, launch-carried events, field sort)
+  * ps_tune_set("ext_events", 0)              (plain hipEventRecord / hipStreamWaitEvent)
+  * ps_tune_set("field_sort", 0)              (general radix sort + segment builder + long-run list by k_long_runs)
+  * profile mode                              (everything on ONE stream: the serial order is the definition)
+Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
+consecutive plans must still equal the fused step (the map is re-zeroed when the epoch wraps)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+SEED = 0x5EED
+
+
+def batches(rng, n, B, F, X, V, WS):
+    out = []
+    for _ in range(n):
+        E = np.minimum(rng.zipf(1.2, (B, F)) - 1, V - 1).astype(np.int64)
+        out.append((E, rng.standard_normal((B, X)).astype(f32), (rng.random(B) < 0.3).astype(f32), E % WS))
+    return out
+
+
+def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
+    import ps_amd
+    from ps_amd import native as N
+    for k, v in knobs.items():
+        N.lib().ps_tune_set(k.encode(), v)
+    try:
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        if kind == "widedeep":
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+        else:
+            gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+        if profile:
+            gm.set_profile(True)
+        losses = [gm.train(ps_amd.Batch(E, Xd, Y, W if kind == "widedeep" else None)) for E, Xd, Y, W in data]
+        out = (losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(len(fc))],
+               [kv.get("fc%d.bias" % i) for i in range(len(fc))])
+        if kind == "widedeep":
+            out += (kv.get_wide(np.arange(WS)), kv.get("wide.bias"))
+        gm.close(); kv.close()
+        return out
+    finally:
+        for k in knobs:
+            N.lib().ps_tune_set(k.encode(), 1)
+
+
+@pytest.mark.parametrize("kind,F,D,X,fc,V,B", [("dnn", 4, 8, 3, [16, 1], 50, 200), ("widedeep", 6, 16, 5, [64, 32, 1], 3000, 2048),
+                                               ("dnn", 3, 8, 2, [24, 12, 6, 1], 40, 130)])
+def test_schedules_agree(kind, F, D, X, fc, V, B):
+    rng = np.random.default_rng(F * 100 + B)
+    WS = 97
+    data = batches(rng, 6, B, F, X, V, WS)
+    ref = run(kind, {}, False, data, F, D, X, fc, V, B, WS)
+    variants = {"plain events": ({"ext_events": 0}, False), "general sort": ({"field_sort": 0}, False),
+                "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
+    for name, (knobs, profile) in variants.items():
+        got = run(kind, knobs, profile, data, F, D, X, fc, V, B, WS)
+        assert got[0] == ref[0], "%s: losses %s vs %s" % (name, got[0], ref[0])
+        for a, b in zip(ref[1:], got[1:]):
+            if isinstance(a, list):
+                for x, y in zip(a, b):
+                    np.testing.assert_array_equal(x, y, err_msg=name)
+            else:
+                np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+def test_plan_epoch_wraps():
+    """300 consecutive sharded steps (the plan's 8-bit epoch wraps after 255) == 300 fused steps, bit for bit."""
+    import ps_amd
+    from ps_amd.sharded import NativeWorker
+    F, D, X, fc, V, B, WS = 3, 8, 2, [8, 1], 30, 48, 17
+    rng = np.random.default_rng(9)
+    data = batches(rng, 7, B, F, X, V, WS)
+    res = []
+    for native in (False, True):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+        wk = NativeWorker([gm], 1, 0) if native else None
+        bs = [ps_amd.Batch(E, Xd, Y, W) for E, Xd, Y, W in data]
+        for i in range(300):
+            if native:
+                wk.step(bs[i % len(bs)], want_loss=False)
+            else:
+                gm.train_async(bs[i % len(bs)])
+        kv.sync()
+        res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(2)],
+                    kv.get_wide(np.arange(WS)), kv.global_step()))
+        if wk:
+            wk.close()
+        gm.close(); kv.close()
+    a, b = res
+    assert a[3] == b[3] == 300
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2])
