@@ -132,6 +132,20 @@ int ps_store_get_wide(ps_store_t *s, const int64_t *ids, int64_t n, int which, f
 int ps_store_put_wide(ps_store_t *s, const int64_t *ids, int64_t n, int which, const float *val);
 /* AtomicLong globalStep (net/PServer.java:40): one per applied update round. */
 int64_t ps_store_global_step(const ps_store_t *s);
+int ps_store_advance_global_step(ps_store_t *s, int64_t by);
+/* The PS server's side of the wire, by string key (what the gRPC facade
+ * ps_amd/ps_server.py binds):
+ *   PServer.push(key, gradient, isAsync, updaterKey)  net/PServer.java:164-195
+ *   PServer.psUpdate()                                net/PServer.java:197-214
+ * n messages (keys[i], grads[i][lens[i]]) in ARRIVAL order, any of the key
+ * kinds of ps_store_get.  is_async = 0: one BSP round -- every key's pushes
+ * are summed in arrival order (KVStore.sum: addi), divided by their count
+ * (KVStore.update: divi(sumCnt)) and given to the key's updater once;
+ * is_async = 1: one updater step per message, in order.  All arithmetic on
+ * the device (the kernels of the hot path); the updater of a key is the one
+ * ps_store_set_updater resolves for it.  Does not touch globalStep. */
+int ps_store_push_update(ps_store_t *s, int n, const char *const *keys, const float *const *grads,
+                         const int *lens, int is_async);
 /* bytes of HBM held by the store */
 int64_t ps_store_bytes(const ps_store_t *s);
 

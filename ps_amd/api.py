@@ -197,6 +197,22 @@ class KVStore:
     def global_step(self):
         return N.lib().ps_store_global_step(self.h)
 
+    def advance_global_step(self, by=1):
+        N.check(N.lib().ps_store_advance_global_step(self.h, by))
+
+    def push_update(self, messages, is_async=False):
+        """PServer.push x n + psUpdate (net/PServer.java:164-214) by string key: messages = [(key, gradient), ...] in
+        ARRIVAL order.  BSP: every key's pushes summed in arrival order, / count, one updater step; async: one step per
+        message.  All arithmetic on the device."""
+        n = len(messages)
+        if n == 0:
+            return
+        arrs = [np.ascontiguousarray(g, np.float32).ravel() for _, g in messages]
+        keys = (C.c_char_p * n)(*[k.encode() for k, _ in messages])
+        ptrs = (C.POINTER(C.c_float) * n)(*[_fp(a) for a in arrs])
+        lens = (C.c_int * n)(*[a.size for a in arrs])
+        N.check(N.lib().ps_store_push_update(self.h, n, keys, ptrs, lens, 1 if is_async else 0))
+
     def bytes(self):
         return N.lib().ps_store_bytes(self.h)
 

@@ -100,6 +100,8 @@ struct DenseLayer {
     int K, N, ldw, ldwt, ldp, nsplit;
     int64_t elem_begin, elem_end;      // flat [k][n] element range, k in [0,K]
     int tile_begin, tile_end;          // 32 x 32 tiles of this layer in the launch (filled by launch_dense_update)
+    int row_lo, row_cnt;               // row_cnt > 0: only rows [row_lo, row_lo + row_cnt) of W' (the keyed push updates
+                                       // "fc<i>.weights" = rows [0, K) and "fc<i>.bias" = row K separately)
 };
 struct DenseUpdArgs {
     DenseLayer L[8];
@@ -119,6 +121,16 @@ int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)
 
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st);
+// PServer.push x m + psUpdate for wide keys given as a CSR of pushes per key (net/PServer.java:164-214):
+// key_ids[u] (wide row, or `rows` for "wide.bias"), entries [key_off[u], key_off[u+1]) index grads[] in arrival order;
+// BSP: g = (sum in arrival order) / count, one updater step; async: one step per push
+struct WideListArgs {
+    int64_t rows; int nkeys, is_async;
+    const int64_t *key_ids; const uint32_t *key_off; const float *grads;
+    float *W, *state, *bias, *bias_state;
+    UpdParams upd;
+};
+int launch_wide_list(const WideListArgs &a, hipStream_t st);
 int wide_update_blocks(const WideUpdArgs &a);                    // for DenseUpdArgs.wide_blocks
 
 struct WideIntendedArgs {              // wide_grad_mode = intended

@@ -1034,6 +1034,7 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     const int k0 = (tb / tiles_n) << 5, n0 = (tb % tiles_n) << 5;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = n0 + tx;
+    const int row_lo = L.row_cnt > 0 ? L.row_lo : 0, row_hi = L.row_cnt > 0 ? L.row_lo + L.row_cnt - 1 : L.K;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (!a.flat_grad && n < L.N) {
         const float *__restrict__ pn = L.part + n;
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = k0 + ty + 8 * j;
-                    v[zz][j] = pn[(size_t)z * L.part_stride + (size_t)(k <= L.K ? k : L.K) * L.ldp];
+                    v[zz][j] = pn[(size_t)z * L.part_stride + (size_t)(k < row_lo ? row_lo : k > row_hi ? row_hi : k) * L.ldp];
                 }
             }
 #pragma unroll
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = k0 + ty + 8 * j;                    // k in [0, K] (K = bias row), n in [0, N)
-        if (k > L.K || n >= L.N) continue;
+        if (k < row_lo || k > row_hi || n >= L.N) continue;
         const int64_t t = L.elem_begin + (int64_t)k * L.N + n;
         float g;
         if (a.flat_grad) {
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int nn = n0 + ty + 8 * j, kk = k0 + tx;
-        if (nn < L.N && kk <= L.K) L.Wt[(size_t)nn * L.ldwt + kk] = tile[tx][ty + 8 * j];
+        if (nn < L.N && kk >= row_lo && kk <= row_hi) L.Wt[(size_t)nn * L.ldwt + kk] = tile[tx][ty + 8 * j];
     }
 }
 
@@ -1401,6 +1402,37 @@ int launch_wide_keys(const int64_t *ids, int64_t n, int64_t rows, uint32_t *keys
 int launch_wide_intended(const WideIntendedArgs &a, int64_t n, hipStream_t st) {
     if (n <= 0) return PS_OK;
     hipLaunchKernelGGL(k_wide_intended, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+// keyed pushes of wide keys: one thread per key (these lists are tiny: the gRPC facade's psUpdate)
+__global__ __launch_bounds__(256) void k_wide_list(WideListArgs a) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= a.nkeys) return;
+    const int64_t id = a.key_ids[u];
+    const bool is_bias = id == a.rows;
+    float *wp = is_bias ? a.bias : a.W + id;
+    float *sp = is_bias ? a.bias_state : a.state + 2 * id;
+    float w = *wp, z = sp[0], n = sp[1];
+    auto apply = [&](float g) {
+        if (a.upd.kind == PS_UPD_FTRL) { if (g != 0.f) ftrl_elem(a.upd, g, w, z, n); }      // FtrlUpdater.java:52
+        else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, z, n);
+        else w = (g * -a.upd.eta) + w;
+    };
+    const uint32_t e0 = a.key_off[u], e1 = a.key_off[u + 1];
+    if (a.is_async) {
+        for (uint32_t e = e0; e < e1; ++e) apply(a.grads[e]);
+    } else {
+        float s = a.grads[e0];
+        for (uint32_t e = e0 + 1; e < e1; ++e) s = a.grads[e] + s;      // KVStore.sum: addi in arrival order
+        apply(div_rn(s, (float)(e1 - e0)));                              // KVStore.update: divi(sumCnt)
+    }
+    *wp = w; sp[0] = z; sp[1] = n;
+}
+int launch_wide_list(const WideListArgs &a, hipStream_t st) {
+    if (a.nkeys <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_wide_list, dim3(cdiv(a.nkeys, 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -433,6 +433,11 @@ int shard_push_reserve(ps_store *s, int npeers) {
 
 extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n,
                                    const int64_t *peer_counts, int npeers, int is_async) {
+    return shard_apply_push(s, rows_dev, grads_dev, n, peer_counts, npeers, is_async, true);
+}
+
+int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n, const int64_t *peer_counts,
+                     int npeers, int is_async, bool bump_step) {
     RoctxRange roctx_range("ps_shard_apply_push");
     if (!s || n < 0 || (n > 0 && (!rows_dev || !grads_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
@@ -475,7 +480,7 @@ extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, cons
         r.upd = make_upd_params(u);
         PSCHK(launch_rows_apply(r, n, st));
     }
-    s->global_step++;                    // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)
+    if (bump_step) s->global_step++;     // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)
     return PS_OK;
 }
 

@@ -77,6 +77,12 @@ struct ps_store {
 };
 
 int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero);
+// "emF<f>.<id>.0" | "wide.weights.<id>.0" | "wide.bias" | "fc<i>.weights" | "fc<i>.bias"
+struct ParsedKey { int kind; int idx; int64_t id; };  // kind 0 emb, 1 wide w, 2 wide bias, 3 fc w, 4 fc b
+bool store_parse_key(const char *key, ParsedKey *k);
+// PServer.push (+ psUpdate) of a list of (owner-local row, gradient) pairs; bump_step: globalStep.incrementAndGet()
+int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n, const int64_t *peer_counts,
+                     int npeers, int is_async, bool bump_step);
 // updater resolution as KVStore.update(Map): exact key, then prefix, then "default"
 int store_resolve_updater(const ps_store *s, const char *key, ps_updater_t *out);
 // local global row of (field, id) on this shard, or -1 when not held here

@@ -532,7 +532,6 @@ extern "C" int ps_store_put_wide(ps_store_t *s, const int64_t *ids, int64_t n, i
 
 // ---- string keys ------------------------------------------------------------
 // "emF<f>.<id>.0" | "wide.weights.<id>.0" | "wide.bias" | "fc<i>.weights" | "fc<i>.bias"
-struct ParsedKey { int kind; int idx; int64_t id; };  // kind 0 emb, 1 wide w, 2 wide bias, 3 fc w, 4 fc b
 static bool parse_float_id(const char *p, int64_t *id) {
     char *e = nullptr;
     const double v = strtod(p, &e);                  // "28305.0" (also accepts "2.8305E4")
@@ -561,6 +560,7 @@ static bool parse_key(const char *key, ParsedKey *k) {
     }
     return false;
 }
+bool store_parse_key(const char *key, ParsedKey *k) { return parse_key(key, k); }
 
 static int fc_io(ps_store *s, int layer, int bias, float *host, int cap, int *len, int to_dev) {
     if (layer < 0 || layer >= (int)s->fc.size() || !s->fc[layer].present) return ps_set_err(PS_MISSING, "fc%d absent", layer);

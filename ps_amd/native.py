@@ -90,6 +90,8 @@ SIGNATURES = {
     "ps_store_get_wide": (_i, [_vp, _pi64, _i64, _i, _pf]),
     "ps_store_put_wide": (_i, [_vp, _pi64, _i64, _i, _pf]),
     "ps_store_global_step": (_i64, [_vp]),
+    "ps_store_advance_global_step": (_i, [_vp, _i64]),
+    "ps_store_push_update": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_pf), _pi, _i]),
     "ps_store_bytes": (_i64, [_vp]),
     "ps_store_sync": (_i, [_vp]),
     "ps_stream_sync": (_i, [_vp, _vp]),
