@@ -196,6 +196,8 @@ typedef struct ps_batch {
     const float *labels;      /* [B]      ("Y"); NULL for predict            */
     const int64_t *wide_ids;  /* [B][F]   ("W" = E mod wideSize); WideDeep   */
     int on_device;
+    int64_t nnz;              /* multi-hot + on_device: the id count (= offsets[B*F]) when the caller knows it;
+                                 0 = read it back from the device (one host wait in front of the step)          */
 } ps_batch_t;
 
 /* DNN.buildModel / WideDeepNN.buildModel over the store's parameters

@@ -269,6 +269,7 @@ class DeviceBatch:
         b.ids, b.offsets, b.dense = up(host.E), up(host.offsets), up(host.X)
         b.labels, b.wide_ids = up(host.Y), up(host.W)
         b.on_device = 1
+        b.nnz = int(host.E.size) if host.offsets is not None else 0     # spares ps_model_train the read-back of offsets[B*F]
         self.c = b
         self.nnz = int(host.E.size)
         store._adopt(self)

@@ -24,6 +24,7 @@ struct EmbFwdArgs {
     unsigned long long *ts;    // stamp slot (ps_common.h) or nullptr, set by the launcher
 };
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st);
+int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st);      // multi-hot: key_out / ent_bag from the ids alone
 
 struct HeadArgs {
     int B, F, wide, train;

@@ -1228,6 +1228,34 @@ int g_gather_lds = 0;      // measurement: 1 = the LDS-staged single-hot gather 
 
 int g_gather_nt = -1;      // -1: automatic (streaming hints when the tables exceed the caches); 0..3: forced (bit 0 loads, bit 1 stores)
 
+// Sort keys (and the bag of every entry) of a multi-hot batch straight from the ids: row = row_base[f] + id with the
+// gather's clamping (errors are counted by the gather).  Lets the backward's sort start BESIDE the gather instead of
+// behind it (configs[4]'s shape: the 80 us gather and the 136 us sort were back to back on the critical path).
+// Eight lanes per bag.
+__global__ __launch_bounds__(256) void k_emb_keys(EmbFwdArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t bag = t >> 3;
+    const int l8 = (int)(t & 7);
+    if (bag >= (int64_t)a.B * a.F) return;
+    const int f = (int)(bag % a.F);
+    const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
+    const int64_t p0 = a.offsets[bag], p1 = a.offsets[bag + 1];
+    for (int64_t p = p0 + l8; p < p1; p += 8) {
+        int64_t id = a.ids[p];
+        if (id < 0 || id >= rn) id = 0;
+        a.key_out[p] = (uint32_t)(rb + id);
+        a.ent_bag[p] = (uint32_t)bag;
+    }
+}
+int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st) {
+    if (!a.offsets || !a.key_out || !a.ent_bag) return ps_set_err(PS_E_BAD_ARG, "launch_emb_keys: multi-hot batches only");
+    const int64_t nb = (int64_t)a.B * a.F;
+    if (nb <= 0) return PS_OK;
+    hipLaunchKernelGGL(k_emb_keys, dim3(cdiv(nb * 8, 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
     // rows of tables far beyond the 256 MiB Infinity Cache are read once: non-temporal loads (measured on the 256 GB
     // table, tools/gather_nt.py: bags of 32 0.671 -> 0.707 of 8 TB/s, single-hot read+write 0.663 -> 0.694; nt stores: no effect)

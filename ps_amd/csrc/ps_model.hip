@@ -242,7 +242,9 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
     const int64_t nbags = (int64_t)b->B * c.F;
     int64_t nnz = nbags;
     if (b->offsets) {
-        if (b->on_device) {
+        if (b->on_device && b->nnz > 0) {
+            nnz = b->nnz;                       // the caller knows it: no read-back, no host wait in front of the step
+        } else if (b->on_device) {
             int64_t last = 0;
             HIPCHK(hipMemcpyAsync(&last, b->offsets + nbags, sizeof(int64_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -348,13 +350,21 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // keys and the sort were made by ps_shard_plan
         e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr; e.table_bytes = 0;
     }
-    hipEvent_t fwd_ev = (train && !m->sh.active) ? arm_event(m) : nullptr;
+    // multi-hot: the sort's keys come from the ids alone (k_emb_keys), so the whole sort chain starts BESIDE the gather
+    const bool keys_early = train && !m->sh.active && m->cur_offsets && side_stream(m, 0) != st;
+    if (keys_early) {
+        PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
+        { Prof pf(m, "emb_keys"); PSCHK(launch_emb_keys(e, side_stream(m, 0))); }
+        e.key_out = nullptr; e.ent_bag = nullptr;
+    }
+    hipEvent_t fwd_ev = (train && !m->sh.active && !keys_early) ? arm_event(m) : nullptr;
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
     PSCHK(settle_event(m, fwd_ev));
     if (train && !m->sh.active) {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
-        if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
+        if (keys_early) {}
+        else if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
         static int64_t sort_runs = 0;
         m->long_list_valid = false; m->field_sorted = false;

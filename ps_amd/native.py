@@ -42,7 +42,7 @@ class ps_model_config_t(C.Structure):
 
 class ps_batch_t(C.Structure):
     _fields_ = [("B", C.c_int), ("ids", C.c_void_p), ("offsets", C.c_void_p), ("dense", C.c_void_p),
-                ("labels", C.c_void_p), ("wide_ids", C.c_void_p), ("on_device", C.c_int)]
+                ("labels", C.c_void_p), ("wide_ids", C.c_void_p), ("on_device", C.c_int), ("nnz", C.c_int64)]
 
 
 _vp, _i, _i64, _f, _cp = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_char_p

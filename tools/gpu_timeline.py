@@ -12,15 +12,28 @@ cfg = dict(C2)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 L = N.lib()
 fn = L.ps_dbg_stamps
+for kv_ in os.environ.get("PS_TUNE", "").split(","):          # knobs read at model creation included
+    if "=" in kv_: L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
 fn.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int]
 kv = ps_amd.KVStore(0, cfg["seed"]); kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
-gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
 rng = np.random.default_rng(1)
-bs = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
+if os.environ.get("MULTI_HOT"):           # configs[4]'s shape: Poisson(30) ids per (sample, field), FTRL rows
+    kv.set_updater("emF", ps_amd.FtrlUpdater())
+    B, F, V = cfg["B"], cfg["F"], cfg["V"]
+    bs, nnz_max = [], 0
+    for _ in range(nb):
+        lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nnz_max = max(nnz_max, int(offsets[-1]))
+        ids = np.minimum(rng.zipf(1.05, size=int(offsets[-1])) - 1, V - 1).astype(np.int64)
+        bs.append(ps_amd.DeviceBatch(kv, ids, rng.standard_normal((B, cfg["X"])).astype(np.float32), (rng.random(B) < 0.25).astype(np.float32),
+                                     rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64), offsets))
+    gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=B, max_nnz=nnz_max)
+else:
+    gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+    bs = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
 for i in range(100): gm.train_async(bs[i % nb])
 gm.sync()
-for kv_ in os.environ.get("PS_TUNE", "").split(","):
-    if "=" in kv_: L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
 L.ps_tune_set(b"stamps", 1)
 for i in range(300): gm.train_async(bs[i % nb])
 gm.sync()
