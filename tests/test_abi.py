@@ -84,7 +84,7 @@ def test_struct_layouts_match_the_header(L):
     """ctypes mirrors of ps_updater_t / ps_model_config_t / ps_batch_t have the C sizes."""
     from ps_amd import native as N
     assert C.sizeof(N.ps_updater_t) == 9 * 4
-    assert C.sizeof(N.ps_batch_t) == 8 + 5 * 8 + 8
+    assert C.sizeof(N.ps_batch_t) == 8 + 5 * 8 + 8 + 8            # B (+pad), 5 pointers, on_device (+pad), nnz
     assert C.sizeof(N.ps_model_config_t) == 5 * 4 + 8 * 4 + 4 + 8 + 4 + 4 + 8 + 4 * 3 + 4
     u = N.ps_updater_t()
     L.ps_updater_default_adam(C.byref(u))
