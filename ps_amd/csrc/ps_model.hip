@@ -50,7 +50,7 @@ int join(ps_model *m, hipStream_t from, hipStream_t to) { return fork(m, from, t
 // "the next launch on the main stream carries an event": arm before the launch, then settle(): if the launcher took
 // it (PS_LAUNCH), the event is the kernel's own completion signal; if not, it is recorded the ordinary way.
 hipEvent_t arm_event(ps_model *m) {
-    if (m->profile || !m->multi_stream || !g_ext_events) return nullptr;
+    if (m->profile || !m->multi_stream || !g_ext_events || m->cfg.use_graph) return nullptr;      // (stream capture: plain records)
     hipEvent_t e = m->events[m->next_event++ % m->events.size()];
     g_launch_stop_event = e;
     return e;
