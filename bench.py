@@ -352,8 +352,8 @@ def gather_roofline(kv, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--zipf", type=float, default=1.05, help="id distribution exponent; <= 1 means uniform")
     ap.add_argument("--no-cpu", action="store_true")
