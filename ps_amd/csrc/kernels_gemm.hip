@@ -33,6 +33,7 @@ struct NtArgs {
     int xcd_swizzle;
     int ablate;      // measurement only: 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barriers
     unsigned long long *ts;
+    unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (launch_spin_until)
 };
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
     StampScope stamp(a.ts);
+    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
@@ -375,7 +377,8 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt")};
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"), g_launch_flag, g_launch_flag_val};
+    g_launch_flag = nullptr;
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -404,6 +407,24 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 }
 
 thread_local hipEvent_t g_launch_stop_event = nullptr;
+thread_local unsigned int *g_launch_flag = nullptr;     // armed like the stop event: the next gemm_nt announces its start there
+thread_local unsigned int g_launch_flag_val = 0;
+int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again
+
+// A stream that reaches a hipStreamWaitEvent before the event has fired resumes 10-20 us after it (the dW chain
+// started 10 us after the head on a good day and 18 on a bad one, which then pushed dW0 under the embedding update:
+// a 170 / 178 us step, fixed per process).  A kernel that is already RUNNING when its condition comes true ends at
+// once, and the next kernel of its stream starts ~3 us later like any in-order successor: the side chain parks this
+// one-wave spinner in front of its first GEMM, and the main chain's next launch -- which starts only after the head
+// has finished and released its writes -- flips the flag from its first workgroup.
+__global__ void k_spin_until(const unsigned int *flag, unsigned int val) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != val) __builtin_amdgcn_s_sleep(16);
+}
+int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st) {
+    hipLaunchKernelGGL(k_spin_until, dim3(1), dim3(64), 0, st, flag, val);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
 int g_ext_events = 1;       // ps_tune_set("ext_events", 0): cross-stream events by hipEventRecord again
 int g_sort_ablate = 0;      // measurement only
 int g_field_sort = 1;       // ps_tune_set("field_sort", 0): single-hot batches go through the general radix sort too

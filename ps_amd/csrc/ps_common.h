@@ -132,6 +132,10 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
 // starts; tools/gpu_timeline.py).  The caller arms g_launch_stop_event, the next PS_LAUNCH of the SAME host thread
 // consumes it (thread-local: several host threads may each drive their own store).
 extern thread_local hipEvent_t g_launch_stop_event;
+extern thread_local unsigned int *g_launch_flag;       // armed: the next gemm_nt stores g_launch_flag_val there when it starts
+extern thread_local unsigned int g_launch_flag_val;
+extern int g_dev_wait;
+int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st);   // a one-wave kernel that ends when *flag == val
 #define PS_LAUNCH(kernel, grid, block, shmem, st, ...)                                                         \
     do {                                                                                                       \
         hipEvent_t se_ = g_launch_stop_event;                                                                  \

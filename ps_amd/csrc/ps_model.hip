@@ -161,6 +161,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
     PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
+    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 4, true));
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
@@ -217,7 +218,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
     sort_ws_free(m->ws); sort_ws_free(m->wws);
     fr(m->wkeys); fr(m->wents); fr(m->wseg_start); fr(m->wseg_id); fr(m->wnseg);
-    fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub);
+    fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub); fr(m->start_flag);
     fr(m->seg_nseg_scratch); fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
     fr(m->partials); fr(m->partials2); fr(m->grads_out); fr(m->dense_grad_flat);
     delete m;
@@ -502,22 +503,25 @@ int enqueue_backward(ps_model *m, bool apply) {
     PSCHK(store_resolve_updater(s, "emF", &u));
     if (apply && !s->emb.state && u.kind != PS_UPD_SIMPLE)       // before anything is enqueued
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
-    // side chain 1: the out = 1 layer's slab fold, every other dW GEMM as soon as its delta exists, then the dense update.
-    // side chain 0 (the sort ran there during the forward; idle now): loss reduction, the wide update, then the
-    // remaining dW GEMMs.  The dW GEMMs ALTERNATE between the two chains: one chain ran prereduce, dW1, dW0 and the
-    // update back to back with a ~10 us cross-launch gap each and ended after the embedding update -- the next step's
-    // first GEMM then waited for it (tools/gpu_timeline.py); on two chains the update is ready ~20 us earlier.
+    // Main chain: delta GEMMs, embedding update, dense update (last: nothing crosses a stream at the step boundary).
+    // Side chain 1: every dW GEMM as soon as its delta exists.  Side chain 0 (the sort ran there during the forward):
+    // loss reduction, wide update, the out = 1 layer's slab fold.  DESIGN.md 4.1 has the measured timeline.
     hipStream_t sw = side_stream(m, 1), s0 = side_stream(m, 0);
-    if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
-    else PSCHK(fork2(m, st, sw, s0));
-    m->head_ev = nullptr;
-    bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
-    hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
     // The small kernels that hang off the head (loss / stop flag, wide update, the out = 1 layer's slab fold) go behind
     // the sort on side chain 0 when the sort is the one-launch field sort (done long before the head).  Behind the
     // 11-launch radix chain of a multi-hot batch (136 us at configs[4]'s shape, ending after the last delta GEMM) they
     // would sit on the critical path: there they go to the front of side chain 1 instead.
     hipStream_t sl = (m->field_sorted || m->sh.active || s0 == st) ? s0 : sw;      // (sharded: that sort ran during the exchange)
+    // side chain 1 (the dW GEMMs) does not wait for the head by event: a spinner in front of its first GEMM is released
+    // by the first delta GEMM's start (launch_spin_until in kernels_gemm.hip)
+    // (only when nothing else on that chain needs the head: with the small kernels above on it, it waits by event)
+    const bool dev_wait = g_dev_wait && sw != st && sl != sw && m->head_bwd_done && nfc >= 2 && s->fc[nfc - 1].N == 1;
+    if (m->head_ev && m->head_bwd_done) { if (!dev_wait) PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
+    else PSCHK(fork2(m, st, dev_wait ? s0 : sw, s0));
+    bool spinner_due = dev_wait;
+    m->head_ev = nullptr;
+    bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
+    hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
     if (m->loss_pending) {
         // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
         // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
@@ -584,6 +588,7 @@ int enqueue_backward(ps_model *m, bool apply) {
             main_dirty = false;
         }
         data_ev = l > 0 ? arm_event(m) : nullptr;      // delta_{l-1}: the next dW GEMM waits for it (nobody after the last)
+        if (spinner_due) { if (++m->start_epoch == 0) ++m->start_epoch; g_launch_flag = m->start_flag; g_launch_flag_val = m->start_epoch; }
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
@@ -598,6 +603,11 @@ int enqueue_backward(ps_model *m, bool apply) {
         }
         PSCHK(settle_event(m, data_ev));
         main_dirty = true;
+        if (spinner_due) {          // enqueued AFTER the launch that will release it: it cannot be left spinning
+            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(fork(m, st, sw)); }         // (not consumed: plain event)
+            else PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw));
+            spinner_due = false;
+        }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,

@@ -7,6 +7,7 @@ leave identical tables:
   * default                                   (three streams, launch-carried events, field sort)
   * ps_tune_set("ext_events", 0)              (plain hipEventRecord / hipStreamWaitEvent)
   * ps_tune_set("field_sort", 0)              (general radix sort + segment builder + long-run list by k_long_runs)
+  * ps_tune_set("dev_wait", 0)                (the dW chain waits for the head by event, not behind a device-side spinner)
   * profile mode                              (everything on ONE stream: the serial order is the definition)
 Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
 consecutive plans must still equal the fused step (the map is re-zeroed when the epoch wraps)."""
@@ -60,6 +61,7 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
     data = batches(rng, 6, B, F, X, V, WS)
     ref = run(kind, {}, False, data, F, D, X, fc, V, B, WS)
     variants = {"plain events": ({"ext_events": 0}, False), "general sort": ({"field_sort": 0}, False),
+                "dW chain released by event": ({"dev_wait": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
     for name, (knobs, profile) in variants.items():
         got = run(kind, knobs, profile, data, F, D, X, fc, V, B, WS)
