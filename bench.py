@@ -368,6 +368,11 @@ def main():
     ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
     args = ap.parse_args()
+    if os.environ.get("PS_TUNE"):           # measurement: ps_tune_set knobs for A/B runs, "knob=value,knob=value"
+        from ps_amd import native as N_
+        for kv_ in os.environ["PS_TUNE"].split(","):
+            if "=" in kv_:
+                N_.lib().ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
     # stdout carries exactly ONE line, the JSON.  Libraries chat on fd 1 too (RCCL prints a five-line version banner
     # through C stdio, flushed at exit -- after the JSON): fd 1 is pointed at stderr for the run and the line is
     # written to the real stdout at the end.

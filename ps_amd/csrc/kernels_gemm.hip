@@ -420,6 +420,15 @@ int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits fo
 __global__ void k_spin_until(const unsigned int *flag, unsigned int val) {
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != val) __builtin_amdgcn_s_sleep(16);
 }
+__global__ void k_flag_set(unsigned int *flag, unsigned int val) {
+    __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// in stream order behind the work it stands for: that work has finished and released its writes when this runs
+int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st) {
+    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, st, flag, val);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
 int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st) {
     hipLaunchKernelGGL(k_spin_until, dim3(1), dim3(64), 0, st, flag, val);
     HIPCHK(hipGetLastError());

@@ -562,7 +562,15 @@ int enqueue_backward(ps_model *m, bool apply) {
     // wide update, not in front of the dense update at the end of the step
     if (m->head_bwd_done && s->fc[nfc - 1].N == 1) { Prof pf(m, "dense_prereduce"); PSCHK(dense_prereduce(d, nfc - 1, sl)); }
     // everything the main chain needs from side chain 0 ends here (sort, stop flag, wide update, slab fold)
-    if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
+    // A long sort chain (multi-hot) ends AFTER the last delta GEMM: the main chain would reach its wait first and
+    // resume 10-20 us after the event.  There the chain's end sets a flag from the device and the main chain parks a
+    // spinner in front of the embedding update instead (same mechanism as the dW chain's release).
+    const bool sort_dev_wait = g_dev_wait && s0 != st && sl != s0 && !m->sh.active;
+    if (sort_dev_wait) {
+        if (++m->start_epoch == 0) ++m->start_epoch;
+        PSCHK(launch_flag_set(m->start_flag + 1, m->start_epoch, s0));
+        m->sort_epoch = m->start_epoch;
+    } else if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
     if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
@@ -618,7 +626,8 @@ int enqueue_backward(ps_model *m, bool apply) {
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
-    if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));       // the sort (forward), the stop flag and the wide update
+    if (sort_dev_wait) PSCHK(launch_spin_until(m->start_flag + 1, m->sort_epoch, st));
+    else if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));  // the sort (forward), the stop flag and the wide update
     if (sl != s0) HIPCHK(hipStreamWaitEvent(st, m->loss_ev, 0));
     m->side0_pending = false;
     EmbBwdArgs g;
