@@ -417,8 +417,9 @@ int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits fo
 // once, and the next kernel of its stream starts ~3 us later like any in-order successor: the side chain parks this
 // one-wave spinner in front of its first GEMM, and the main chain's next launch -- which starts only after the head
 // has finished and released its writes -- flips the flag from its first workgroup.
+// (epochs only grow: "reached or passed", wrap-safe, so that a flag already moved on can never strand a waiter)
 __global__ void k_spin_until(const unsigned int *flag, unsigned int val) {
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != val) __builtin_amdgcn_s_sleep(16);
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) __builtin_amdgcn_s_sleep(16);
 }
 __global__ void k_flag_set(unsigned int *flag, unsigned int val) {
     __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
