@@ -79,6 +79,7 @@ struct EmbBwdArgs {
     const int *skip;
     int LPR;
     unsigned long long *ts;
+    unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (set by the launcher)
 };
 int launch_emb_bwd(EmbBwdArgs a, hipStream_t st);
 

@@ -530,6 +530,7 @@ __device__ __forceinline__ Vec<VEC> small_key(const EmbBwdArgs &a, uint32_t s0, 
 
 template <int VEC, bool BAG>
 __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
+    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
@@ -795,6 +796,8 @@ template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
     StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);
+    if (SEQ && a.flag && blockIdx.x == 0 && threadIdx.x == 0)         // (chunked order: k_emb_partials is the first launch)
+        __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
         if (a.long_list) {
@@ -1314,6 +1317,8 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const bool bag = a.ent_bag != nullptr;
     a.ablate = g_seq_ablate;
     a.ts = stamp_next("emb_bwd_update");
+    a.flag = g_launch_flag; a.flag_val = g_launch_flag_val;      // armed by the caller (ps_common.h): consumed here
+    g_launch_flag = nullptr;
     // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
     // long runs, a fixed grid walks that list
     a.long_blocks = !a.seq_order ? 0 : a.long_list ? SEQ_LONG_GRID : cdiv(a.nnz, SEQ_TILE);

@@ -409,6 +409,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 thread_local hipEvent_t g_launch_stop_event = nullptr;
 thread_local unsigned int *g_launch_flag = nullptr;     // armed like the stop event: the next gemm_nt announces its start there
 thread_local unsigned int g_launch_flag_val = 0;
+int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again
 
 // A stream that reaches a hipStreamWaitEvent before the event has fired resumes 10-20 us after it (the dW chain

@@ -621,7 +621,13 @@ int enqueue_backward(ps_model *m, bool apply) {
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
                              b.nsplit, nullptr, dws));
     }
-    if (sw != st) HIPCHK(hipEventRecord(m->dw_ev, sw));      // the last dW GEMM
+    // tail_dev: the dense update goes to the END OF SIDE CHAIN 1 and both of its edges are device-side flags (no event
+    // wait anywhere in the tail): it starts when the embedding update has STARTED (that launch starts only after the
+    // last delta GEMM, which reads W_0, has finished and after the main chain saw side chain 0's stop flag and slab
+    // fold), and the main chain ends the step behind a spinner on "dense update done".  The update then runs beside
+    // the embedding update instead of after it.
+    const bool tail_dev = g_dev_wait && g_tail_dev && sw != st && !m->profile;
+    if (!tail_dev && sw != st) HIPCHK(hipEventRecord(m->dw_ev, sw));      // the last dW GEMM
     PSCHK(settle_event(m, data_ev));
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
@@ -646,20 +652,33 @@ int enqueue_backward(ps_model *m, bool apply) {
     PSCHK(store_resolve_updater(s, "emF", &u));
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
+    if (tail_dev) { if (++m->start_epoch == 0) ++m->start_epoch; g_launch_flag = m->start_flag + 2; g_launch_flag_val = m->start_epoch; }
     { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st)); }
+    if (tail_dev && g_launch_flag) {        // nothing was launched (an empty batch): announce the start ourselves
+        g_launch_flag = nullptr;
+        PSCHK(launch_flag_set(m->start_flag + 2, m->start_epoch, st));
+    }
     // The dense update runs LAST ON THE MAIN CHAIN.  A stream that reaches a wait before its event has fired resumes
     // 10-20 us after it (tools/gpu_timeline.py), a wait that is already satisfied costs ~3: on a side chain the update
     // ended within a few microseconds of the embedding update, so the next step's first GEMM -- which must wait for
     // it -- sometimes hit the slow case and sometimes not (a bimodal step, 174 / 192 us, fixed per process).  Here the
     // dW GEMMs it needs ended ~15 us earlier on their side chain, the delta GEMM that reads W_0 is in order before
     // it, and nothing crosses a stream at the step boundary.
-    if (sw != st) HIPCHK(hipStreamWaitEvent(st, m->dw_ev, 0));
+    if (!tail_dev && sw != st) HIPCHK(hipStreamWaitEvent(st, m->dw_ev, 0));
     if (m->sh.active && c.kind == PS_MODEL_WIDEDEEP) {
         // sharded worker: the wide part of the flat buffer ([fc | wide G | wide C | bias]) is filled by the same launch
         WideUpdArgs &w = d.wide;
         w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev; w.mode = 1;
         w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
         d.wide_blocks = wide_update_blocks(w);
+    }
+    if (tail_dev) {
+        // (every waiter is enqueued after the launch that releases it)
+        PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw));
+        { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
+        PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
+        PSCHK(launch_spin_until(m->start_flag + 3, m->start_epoch, st));
+        return PS_OK;
     }
     { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }
     return PS_OK;
