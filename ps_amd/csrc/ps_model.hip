@@ -515,7 +515,9 @@ int enqueue_backward(ps_model *m, bool apply) {
     // side chain 1 (the dW GEMMs) does not wait for the head by event: a spinner in front of its first GEMM is released
     // by the first delta GEMM's start (launch_spin_until in kernels_gemm.hip)
     // (only when nothing else on that chain needs the head: with the small kernels above on it, it waits by event)
-    const bool dev_wait = g_dev_wait && sw != st && sl != sw && m->head_bwd_done && nfc >= 2 && s->fc[nfc - 1].N == 1;
+    // (and not under stream capture: a captured graph needs its side streams joined by events)
+    const bool dev_flags = g_dev_wait && !m->cfg.use_graph;
+    const bool dev_wait = dev_flags && sw != st && sl != sw && m->head_bwd_done && nfc >= 2 && s->fc[nfc - 1].N == 1;
     if (m->head_ev && m->head_bwd_done) { if (!dev_wait) PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
     else PSCHK(fork2(m, st, dev_wait ? s0 : sw, s0));
     bool spinner_due = dev_wait;
@@ -565,7 +567,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     // A long sort chain (multi-hot) ends AFTER the last delta GEMM: the main chain would reach its wait first and
     // resume 10-20 us after the event.  There the chain's end sets a flag from the device and the main chain parks a
     // spinner in front of the embedding update instead (same mechanism as the dW chain's release).
-    const bool sort_dev_wait = g_dev_wait && s0 != st && sl != s0 && !m->sh.active;
+    const bool sort_dev_wait = dev_flags && s0 != st && sl != s0 && !m->sh.active;
     if (sort_dev_wait) {
         if (++m->start_epoch == 0) ++m->start_epoch;
         PSCHK(launch_flag_set(m->start_flag + 1, m->start_epoch, s0));
@@ -626,7 +628,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     // last delta GEMM, which reads W_0, has finished and after the main chain saw side chain 0's stop flag and slab
     // fold), and the main chain ends the step behind a spinner on "dense update done".  The update then runs beside
     // the embedding update instead of after it.
-    const bool tail_dev = g_dev_wait && g_tail_dev && sw != st && !m->profile;
+    const bool tail_dev = dev_flags && g_tail_dev && sw != st && !m->profile;
     if (!tail_dev && sw != st) HIPCHK(hipEventRecord(m->dw_ev, sw));      // the last dW GEMM
     PSCHK(settle_event(m, data_ev));
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
