@@ -54,11 +54,12 @@ __device__ __forceinline__ float sigmoid_clip_dev(float x) {
 // C[M][N] = epi(A[M][K] * Bt[N][K]^T); LDS rows are BKT+4 floats (16-B aligned,
 // conflict-free ds_read_b128 for both BKT=16 (stride 20) and BKT=32 (stride 36)).
 template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
+    constexpr int NTH = WM * WN * 64;                          // 4 waves (the default tiles) or 8
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LD = BKT + 4;
     constexpr int RF4 = BKT / 4;                               // float4 per tile row
-    constexpr int A_F4 = (BM * RF4 + 255) / 256, B_F4 = (BN * RF4 + 255) / 256;
+    constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
     StampScope stamp(a.ts);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     int ca[A_F4], cb[B_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * NTH;
         int r = m0 + (e / RF4 < BM ? e / RF4 : BM - 1);
         r = r < a.a_rows ? r : a.a_rows - 1;
         ca[i] = (e % RF4) * 4;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * NTH;
         int r = n0 + (e / RF4 < BN ? e / RF4 : BN - 1);
         r = r < a.b_rows ? r : a.b_rows - 1;
         cb[i] = (e % RF4) * 4;
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(256) void k_gemm_nt(NtArgs a) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int e = tid + i * 256;
-            if ((BM * RF4) % 256 == 0 || e < BM * RF4)
+            const int e = tid + i * NTH;
+            if ((BM * RF4) % NTH == 0 || e < BM * RF4)
                 *reinterpret_cast<float4 *>(&As[buf][(e / RF4) * LD + (e % RF4) * 4]) = masked(ra[i], k0 + ca[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            const int e = tid + i * 256;
-            if ((BN * RF4) % 256 == 0 || e < BN * RF4)
+            const int e = tid + i * NTH;
+            if ((BN * RF4) % NTH == 0 || e < BN * RF4)
                 *reinterpret_cast<float4 *>(&Bs[buf][(e / RF4) * LD + (e % RF4) * 4]) = masked(rb[i], k0 + cb[i]);
         }
     };
@@ -369,7 +370,7 @@ int g_gemm_xcd = 1;      // XCD-aware work-group order on/off (for A/B runs)
 int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5 128x32/32
 
 #define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
-    PS_LAUNCH((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(256), 0, st, a)
+    PS_LAUNCH((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64), 0, st, a)
 
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
@@ -384,8 +385,13 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
         // (measured best on MI355X for M=4096, N in 256..512, K in 256..528); narrow N: 128x32.
         auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
+        // 8-wave workgroups on 128 x 64 tiles where that still gives ~one workgroup per CU: the A panel is shared by
+        // twice the waves (global traffic per flop -25%); measured alone (tools/gemm_sweep2.py, M = 4096):
+        // fwd0 22.7 -> 21.1 us, delta1 14.8 -> 14.0, delta0 (224 workgroups) 23.9 -> 23.1; N = 256 (128 workgroups) 15.4 -> 23.3.
+        // In the step the difference disappears (0.1613 vs 0.1614 ms, six runs each): off by default.
         if (N <= 32) cfg = 8;
         else if (tiles(64, 128) >= 2048) cfg = 6;
+        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = 13;
         else cfg = 5;
     }
     switch (cfg) {
@@ -400,6 +406,11 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 10: NT_LAUNCH(2, 2, 1, 1, 64); break;
     case 11: NT_LAUNCH(4, 1, 1, 2, 32); break;
     case 12: NT_LAUNCH(1, 4, 2, 1, 32); break;
+    case 13: NT_LAUNCH(4, 2, 1, 1, 32); break;      // 8 waves: 128 x 64
+    case 14: NT_LAUNCH(2, 4, 1, 1, 32); break;      // 8 waves: 64 x 128
+    case 15: NT_LAUNCH(4, 2, 1, 2, 32); break;      // 8 waves: 128 x 128
+    case 16: NT_LAUNCH(2, 1, 1, 1, 32); break;      // 2 waves: 64 x 32
+    case 17: NT_LAUNCH(1, 2, 1, 1, 32); break;      // 2 waves: 32 x 64
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());
@@ -409,6 +420,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 thread_local hipEvent_t g_launch_stop_event = nullptr;
 thread_local unsigned int *g_launch_flag = nullptr;     // armed like the stop event: the next gemm_nt announces its start there
 thread_local unsigned int g_launch_flag_val = 0;
+int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again
 

@@ -9,8 +9,9 @@ def run(kind, M, Nn, K, ns, it=200):
 B = 4096
 NT = [("fwd0", B, 512, 432), ("fwd1", B, 256, 528), ("data1", B, 512, 256), ("data0", B, 416, 512)]
 names = {1: "128x128/16", 2: "64x128/16", 3: "64x64/16", 4: "128x32/16", 5: "64x64/32", 6: "64x128/32", 7: "128x128/32", 8: "128x32/32",
-         9: "128x64/32", 10: "64x64/64", 11: "128x64w41/32", 12: "64x128w14/32"}
-cfgs = [int(x) for x in os.environ.get("NT_CFGS", "3,5,10,6,9,11,12,8,2,7").split(",")]
+         9: "128x64/32", 10: "64x64/64", 11: "128x64w41/32", 12: "64x128w14/32", 13: "128x64 8w", 14: "64x128 8w", 15: "128x128 8w",
+         16: "64x32 2w", 17: "32x64 2w"}
+cfgs = [int(x) for x in os.environ.get("NT_CFGS", "5,13,14,15,16,17,9,6").split(",")]
 for name, M, Nn, K in NT:
     fl = 2.0 * M * Nn * K
     res = []
