@@ -143,3 +143,40 @@ def test_async_pushes_apply_at_once(shard, orc):
     np.testing.assert_array_equal(kv.get("fc0.weights"), orc.adam_update(fc0, gf, np.zeros(6, f32), np.zeros(6, f32))[0])
     assert c.barrier() == 200 and kv.global_step() == step0 + 1                   # async barrier: globalStep++ only
     c.close()
+
+
+def test_push_update_sums_in_arrival_order(shard, orc):
+    """ps_store_push_update (the C ABI under psUpdate), three pushes per key whose f32 sum depends on the order:
+    (a + b) + c in ARRIVAL order, / 3, one updater step -- embedding row, dense tensor and wide key alike."""
+    kv, _ = shard
+    import ps_amd
+    kv.set_updater("emF", ps_amd.AdamUpdater()); kv.set_updater("fc0.weights", ps_amd.AdamUpdater())
+    kv.set_updater("wide", ps_amd.FtrlUpdater())
+    big, small = f32(1.0e8), f32(3.0)
+    trip = [big, small, -big]                                   # (1e8 + 3) - 1e8 = 0 in f32; 1e8 - 1e8 + 3 = 3: order matters
+    e = [np.full(4, v, f32) for v in trip]
+    d = [np.full(6, v, f32) for v in trip]
+    w = [np.full(1, v, f32) for v in trip]
+    e0, d0, w0 = kv.get_rows(0, [2])[0], kv.get("fc0.weights"), kv.get_wide([4])
+    kv.push_update([("emF0.2.0", e[0]), ("fc0.weights", d[0]), ("wide.weights.4.0", w[0]),
+                    ("emF0.2.0", e[1]), ("fc0.weights", d[1]), ("wide.weights.4.0", w[1]),
+                    ("emF0.2.0", e[2]), ("fc0.weights", d[2]), ("wide.weights.4.0", w[2])])
+
+    def mean(xs):
+        s = xs[0].copy()
+        for x in xs[1:]:
+            s = (x + s).astype(f32)
+        return (s / f32(len(xs))).astype(f32)
+
+    assert mean(e)[0] == 0.0 and mean([e[0], e[2], e[1]])[0] == 1.0   # the order is visible in the result
+    z = np.zeros
+    np.testing.assert_array_equal(kv.get_rows(0, [2])[0], orc.adam_update(e0, mean(e), z(4, f32), z(4, f32))[0])
+    np.testing.assert_array_equal(kv.get("fc0.weights"), orc.adam_update(d0, mean(d), z(6, f32), z(6, f32))[0])
+    np.testing.assert_array_equal(kv.get_wide([4]), orc.ftrl_update(w0, mean(w), z(1, f32), z(1, f32))[0])
+    # async: three updater steps, in order
+    e1 = kv.get_rows(0, [3])[0]
+    kv.push_update([("emF0.3.0", e[1]), ("emF0.3.0", e[0]), ("emF0.3.0", e[1])], is_async=True)
+    wv, M, V = e1, z(4, f32), z(4, f32)
+    for g in (e[1], e[0], e[1]):
+        wv, M, V = orc.adam_update(wv, g, M, V)
+    np.testing.assert_array_equal(kv.get_rows(0, [3])[0], wv)
