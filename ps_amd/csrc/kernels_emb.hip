@@ -55,7 +55,9 @@ template <> struct Vec<1> {
 // GATHER_ILP consecutive bags (their outputs are contiguous), multi-hot groups walk their bag
 // GATHER_ILP entries at a time.  One row per group and launch kept too little memory in flight
 // to cover HBM latency (Little: ~8 MB chip-wide at 8 TB/s): measured 4.9 -> see profiles/.
+#ifndef GATHER_ILP
 #define GATHER_ILP 4
+#endif
 #define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
 template <int VEC, bool MULTI, bool SLOT, int MHI>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
