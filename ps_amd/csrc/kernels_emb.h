@@ -63,7 +63,7 @@ struct EmbBwdArgs {
     int64_t nnz;
     int F, D, grad_mode, apply;
     const uint32_t *sorted_key, *sorted_ent, *seg_start, *seg_id, *nseg;
-    const uint32_t *long_list;         // seq_order: ids of the runs above PS_EMB_SEQ_TILE entries, *nlong of them (or nullptr)
+    const uint32_t *long_list;         // seq_order: (run id, first entry, end) of the runs above PS_EMB_SEQ_TILE entries, *nlong triples (or nullptr)
     const uint32_t *nlong;
     const uint32_t *ent_bag;           // nullptr => bag = entry
     const float *delta; int ldd;       // [B][ldd], embedding columns already relu'-masked

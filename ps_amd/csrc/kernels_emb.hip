@@ -806,8 +806,8 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
             // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
             const uint32_t nl = *a.nlong;
             for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.long_blocks) {
-                const uint32_t u = a.long_list[i];
-                long_key_run<VEC, BAG>(a, seq_lds, u, a.seg_start[u], a.seg_start[u + 1]);
+                const uint32_t *ll = a.long_list + 3 * (size_t)i;        // (run id, first entry, end): one load level
+                long_key_run<VEC, BAG>(a, seq_lds, ll[0], ll[1], ll[2]);
                 __syncthreads();                               // the next run reuses the LDS buffers
             }
             return;

@@ -208,7 +208,11 @@ __global__ __launch_bounds__(256) void k_long_runs(const uint32_t *__restrict__ 
                                                    uint32_t *__restrict__ long_list, uint32_t long_min) {
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
     if (u >= nseg[0]) return;
-    if (seg_start[u + 1] - seg_start[u] > long_min) long_list[atomicAdd(&nseg[1], 1u)] = u;
+    const uint32_t s0 = seg_start[u], e0 = seg_start[u + 1];
+    if (e0 - s0 > long_min) {
+        uint32_t *ll = long_list + 3 * (size_t)atomicAdd(&nseg[1], 1u);
+        ll[0] = u; ll[1] = s0; ll[2] = e0;
+    }
 }
 
 __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict__ keys, int64_t n,
@@ -454,7 +458,10 @@ __global__ __launch_bounds__(FS_TPB) void k_field_sort_segments(FieldSortArgs a)
             if (r >= B) break;
             if (heads >> e & 1u) {
                 a.seg_start[rbase + idx] = pos0 + (uint32_t)r;
-                if (starts[idx + 1] - starts[idx] > (uint32_t)a.long_min) a.long_list[lbase + li++] = rbase + idx;
+                if (starts[idx + 1] - starts[idx] > (uint32_t)a.long_min) {          // (run id, first entry, end) in one line
+                    uint32_t *ll = a.long_list + 3 * (size_t)(lbase + li++);
+                    ll[0] = rbase + idx; ll[1] = pos0 + starts[idx]; ll[2] = pos0 + starts[idx + 1];
+                }
                 ++idx;
             }
             a.sorted_keys[pos0 + r] = ks[r] + fbase;

@@ -108,7 +108,7 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
                      bool iota_vals, uint32_t **keys_res, uint32_t **vals_res, hipStream_t st);
 // Segments of equal keys in a sorted key array: seg_start[nseg+1], seg_id[n],
 // *nseg_dev.
-// long_list (optional): the ids of the runs longer than long_min entries, nseg_dev[1] of them, in any order.
+// long_list (optional): (run id, first entry, end) triples of the runs longer than long_min entries, nseg_dev[1] of them, any order.
 int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, uint32_t *seg_start,
                    uint32_t *seg_id, uint32_t *nseg_dev, hipStream_t st, uint32_t *long_list = nullptr, int long_min = 0);
 // Single-hot batch (keys = [B][F], field f's keys in their own interval): stable sort + segments + the list of runs

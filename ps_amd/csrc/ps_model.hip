@@ -159,7 +159,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->seg_nseg_scratch, sizeof(uint32_t) * 4, true));
     PSCHK(model_alloc(m, (void **)&m->fs_keys, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
-    PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
+    PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * 3 * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
     PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
     PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 4, true));
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
