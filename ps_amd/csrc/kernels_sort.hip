@@ -16,13 +16,18 @@ constexpr int RS_IPT = 16;
 constexpr int RS_TILE = RS_TPB * RS_IPT;  // 4096 keys per workgroup
 constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 1024 consecutive keys per wave
 
-// per-block digit histogram; counts is digit-major: counts[digit * nblk + blk]
+// per-block digit histogram; counts is digit-major: counts[digit * nblk + blk].  DB = digit bits: 8 (256 buckets)
+// or 11 (2048: two passes instead of three for the 22-bit keys of a 3 M-pair multi-hot batch; the ballot ranking of
+// the scatter costs the same per key bit, the memory passes and launches are two thirds)
+template <int DB>
 __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n,
                                                        int shift, uint32_t *__restrict__ counts,
                                                        int nblk) {
-    __shared__ uint32_t h[256];
+    constexpr int ND = 1 << DB, DPT = ND / RS_TPB;
+    __shared__ uint32_t h[ND];
     const int tid = threadIdx.x;
-    h[tid] = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) h[tid + q * RS_TPB] = 0;
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     uint32_t k[RS_IPT];
 #pragma unroll
@@ -34,10 +39,11 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restric
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = base + j * RS_TPB + tid;
-        if (idx < n) atomicAdd(&h[(k[j] >> shift) & 255u], 1u);
+        if (idx < n) atomicAdd(&h[(k[j] >> shift) & (uint32_t)(ND - 1)], 1u);
     }
     __syncthreads();
-    counts[(size_t)tid * nblk + blockIdx.x] = h[tid];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) counts[(size_t)(tid + q * RS_TPB) * nblk + blockIdx.x] = h[tid + q * RS_TPB];
 }
 
 // counts is digit-major [256][nblk].  Workgroup d turns row d into its exclusive prefix (positions of digit d's
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(RS_TPB) void k_scan_rows(uint32_t *__restrict__ cou
 // order (equal digits inside a batch of 64 by ballots, across batches and waves by per-(wave,digit) cursors);
 // the ranked pairs are first placed at their position INSIDE THE BLOCK's sorted order in LDS, then written out
 // by consecutive threads, so one store instruction covers runs of one digit instead of 64 scattered words.
-template <bool IOTA, bool STAGED>
+template <bool IOTA, bool STAGED, int DB>
 __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__restrict__ kin,
                                                           const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout,
@@ -84,12 +90,14 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
                                                           const uint32_t *__restrict__ offs,
                                                           const uint32_t *__restrict__ totals,
                                                           int nblk) {
-    __shared__ uint32_t cur[4][256];
-    __shared__ uint32_t gdelta[256];       // global position - block-local position, per digit
+    constexpr int ND = 1 << DB, DPT = ND / RS_TPB;   // thread t owns digits DPT*t .. DPT*t + DPT-1 (digit order = thread order)
+    constexpr uint32_t DMASK = ND - 1;
+    __shared__ uint32_t cur[4][ND];
+    __shared__ uint32_t gdelta[ND];        // global position - block-local position, per digit
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t sk[STAGED ? RS_TILE : 1], sv[STAGED ? RS_TILE : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < 1024; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
+    for (int i = tid; i < 4 * ND; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
     const int64_t bbase = (int64_t)blockIdx.x * RS_TILE;
     const int64_t wbase = bbase + (int64_t)w * RS_WAVE_SPAN;
     uint32_t k[RS_IPT], v[RS_IPT];
@@ -100,16 +108,23 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
         k[j] = kin[ci];
         v[j] = IOTA ? (uint32_t)idx : vin[ci];
     }
-    const uint32_t in_digit = offs[(size_t)tid * nblk + blockIdx.x];   // keys of digit tid in earlier blocks
-    const uint32_t dtot = totals[tid];
+    uint32_t in_digit[DPT], dtot[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+        in_digit[q] = offs[(size_t)(tid * DPT + q) * nblk + blockIdx.x];   // keys of that digit in earlier blocks
+        dtot[q] = totals[tid * DPT + q];
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = wbase + j * 64 + lane;
-        if (idx < n) atomicAdd(&cur[w][(k[j] >> shift) & 255u], 1u);
+        if (idx < n) atomicAdd(&cur[w][(k[j] >> shift) & DMASK], 1u);
     }
-    // exclusive scan of the 256 digit totals (global digit bases) and of this block's digit counts (local bases)
-    uint32_t ginc = dtot;
+    // exclusive scan of the ND digit totals (global digit bases) and of this block's digit counts (local bases)
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) tsum += dtot[q];
+    uint32_t ginc = tsum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t t = __shfl_up(ginc, off);
@@ -117,11 +132,17 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
     }
     if (lane == 63) wtot[w] = ginc;
     __syncthreads();
-    uint32_t gbase = ginc - dtot;
+    uint32_t gbase = ginc - tsum;
     for (int ww = 0; ww < w; ++ww) gbase += wtot[ww];
-    const uint32_t c0 = cur[0][tid], c1 = cur[1][tid], c2 = cur[2][tid], c3 = cur[3][tid];
-    const uint32_t btot = c0 + c1 + c2 + c3;
-    uint32_t linc = btot;
+    uint32_t c0[DPT], c1[DPT], c2[DPT], c3[DPT];
+    uint32_t bsum = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+        const int d = tid * DPT + q;
+        c0[q] = cur[0][d]; c1[q] = cur[1][d]; c2[q] = cur[2][d]; c3[q] = cur[3][d];
+        bsum += c0[q] + c1[q] + c2[q] + c3[q];
+    }
+    uint32_t linc = bsum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t t = __shfl_up(linc, off);
@@ -130,20 +151,26 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
     __syncthreads();                       // wtot is re-used
     if (lane == 63) wtot[w] = linc;
     __syncthreads();
-    uint32_t lbase = linc - btot;
+    uint32_t lbase = linc - bsum;
     for (int ww = 0; ww < w; ++ww) lbase += wtot[ww];
-    cur[0][tid] = lbase; cur[1][tid] = lbase + c0; cur[2][tid] = lbase + c0 + c1; cur[3][tid] = lbase + c0 + c1 + c2;
-    gdelta[tid] = gbase + in_digit - lbase;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+        const int d = tid * DPT + q;
+        cur[0][d] = lbase; cur[1][d] = lbase + c0[q]; cur[2][d] = lbase + c0[q] + c1[q]; cur[3][d] = lbase + c0[q] + c1[q] + c2[q];
+        gdelta[d] = gbase + in_digit[q] - lbase;
+        lbase += c0[q] + c1[q] + c2[q] + c3[q];
+        gbase += dtot[q];
+    }
     __syncthreads();
     const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < RS_IPT; ++j) {
         const int64_t idx = wbase + j * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = (k[j] >> shift) & 255u;
+        const uint32_t d = (k[j] >> shift) & DMASK;
         uint64_t same = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < DB; ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t m = __ballot(bit);
             same &= bit ? m : ~m;
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
         const int lp = j * RS_TPB + tid;
         if (lp < cnt_blk) {
             const uint32_t key = sk[lp];
-            const uint32_t gp = lp + gdelta[(key >> shift) & 255u];
+            const uint32_t gp = lp + gdelta[(key >> shift) & DMASK];
             kout[gp] = key;
             vout[gp] = sv[lp];
         }
@@ -479,15 +506,16 @@ __global__ __launch_bounds__(FS_TPB) void k_field_sort_segments(FieldSortArgs a)
 
 }  // namespace
 
+int g_radix11 = 0;          // ps_tune_set("radix11", 1): 11-bit digits for large sorts (2 passes instead of 3 at 22 bits): measured SLOWER
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap) {
     sort_ws_free(ws);
     ws.cap = cap;
     ws.nblk = cdiv(cap > 0 ? cap : 1, RS_TILE);
     HIPCHK(hipMalloc(&ws.keys_alt, sizeof(uint32_t) * (size_t)(cap + 1)));
     HIPCHK(hipMalloc(&ws.vals_alt, sizeof(uint32_t) * (size_t)(cap + 1)));
-    HIPCHK(hipMalloc(&ws.counts, sizeof(uint32_t) * 256 * (size_t)ws.nblk));
+    HIPCHK(hipMalloc(&ws.counts, sizeof(uint32_t) * 2048 * (size_t)ws.nblk));       // up to 11-bit digits
     HIPCHK(hipMalloc(&ws.blk_heads, sizeof(uint32_t) * (size_t)ws.nblk));
-    HIPCHK(hipMalloc(&ws.totals, sizeof(uint32_t) * 256));
+    HIPCHK(hipMalloc(&ws.totals, sizeof(uint32_t) * 2048));
     return PS_OK;
 }
 
@@ -505,20 +533,31 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
     if (n > ws.cap) return ps_set_err(PS_E_BAD_ARG, "radix_sort_pairs: n=%lld > cap=%lld", (long long)n, (long long)ws.cap);
     *keys_res = keys; *vals_res = vals;
     if (n <= 0) return PS_OK;
-    int passes = (key_bits + 7) / 8;
+    // 11-bit digits would save a pass over a large array (3.2 M pairs x 22 bits: 2 passes instead of 3) -- measured at
+    // configs[4]'s shape: 0.436 ms/step against 0.397 with three 8-bit passes (72 KB of LDS per workgroup, 2048-bucket
+    // LDS atomics): off unless ps_tune_set("radix11", 1)
+    const bool wide = g_radix11 && n >= (1 << 20) && (key_bits + 10) / 11 < (key_bits + 7) / 8;
+    const int db = wide ? 11 : 8;
+    int passes = (key_bits + db - 1) / db;
     if (passes < 1) passes = 1;
     const int nblk = cdiv(n, RS_TILE);
     uint32_t *kin = keys, *vin = vals, *kout = ws.keys_alt, *vout = ws.vals_alt;
     for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
-        hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
+        const int shift = db * p;
         // LDS staging pays once the scatter is bandwidth-bound (measured: 3.2 M pairs 3x faster, 1e5 pairs 25 % slower)
         const bool staged = n >= (1 << 19);
         const bool iota = p == 0 && iota_vals;
-#define RS_SCATTER(I, S) hipLaunchKernelGGL((k_radix_scatter<I, S>), dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk)
-        if (iota) { if (staged) RS_SCATTER(true, true); else RS_SCATTER(true, false); }
-        else { if (staged) RS_SCATTER(false, true); else RS_SCATTER(false, false); }
+#define RS_SCATTER(I, S, DBITS) hipLaunchKernelGGL((k_radix_scatter<I, S, DBITS>), dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk)
+        if (wide) {
+            hipLaunchKernelGGL(k_radix_hist<11>, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
+            hipLaunchKernelGGL(k_scan_rows, dim3(2048), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
+            if (iota) RS_SCATTER(true, true, 11); else RS_SCATTER(false, true, 11);        // wide implies staged
+        } else {
+            hipLaunchKernelGGL(k_radix_hist<8>, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
+            hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
+            if (iota) { if (staged) RS_SCATTER(true, true, 8); else RS_SCATTER(true, false, 8); }
+            else { if (staged) RS_SCATTER(false, true, 8); else RS_SCATTER(false, false, 8); }
+        }
 #undef RS_SCATTER
         uint32_t *t;
         t = kin; kin = kout; kout = t;

@@ -92,9 +92,9 @@ UpdParams make_upd_params(const ps_updater_t &u);
 // ---------------------------------------------------------------------------
 struct SortWorkspace {
     uint32_t *keys_alt = nullptr, *vals_alt = nullptr;  // ping-pong buffers [cap]
-    uint32_t *counts = nullptr;                         // [256 * nblk]
+    uint32_t *counts = nullptr;                         // [2048 * nblk] (8- or 11-bit digits)
     uint32_t *blk_heads = nullptr;                      // [nblk]
-    uint32_t *totals = nullptr;                         // [256] keys per digit of the current pass
+    uint32_t *totals = nullptr;                         // [2048] keys per digit of the current pass
     int64_t cap = 0;
     int nblk = 0;
 };
@@ -134,7 +134,7 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
 extern thread_local hipEvent_t g_launch_stop_event;
 extern thread_local unsigned int *g_launch_flag;       // armed: the next gemm_nt stores g_launch_flag_val there when it starts
 extern thread_local unsigned int g_launch_flag_val;
-extern int g_dev_wait, g_tail_dev, g_gemm_8w;
+extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11;
 int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st);
 int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order   // a one-wave kernel that ends when *flag == val
 #define PS_LAUNCH(kernel, grid, block, shmem, st, ...)                                                         \
