@@ -161,7 +161,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * 3 * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
     PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
-    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 8, true));
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
@@ -331,6 +331,15 @@ static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
     q.part = b.part; q.part_stride = b.part_stride; q.ldpart = b.ldp; q.skip = nullptr;
 }
 
+// Can the backward of this step release its side chains by device flags (launch_spin_until) instead of events?
+// Needs two side streams, no stream capture, the fused head (so that the first kernel after it is a delta GEMM), and the
+// head's small kernels on side chain 0 (single-hot field sort or sharded step): see enqueue_backward.
+static bool dev_release(const ps_model *m) {
+    const ps_model_config_t &c = m->cfg;
+    return g_dev_wait && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1 &&
+           (m->field_sorted || m->sh.active);
+}
+
 int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     ps_store *s = m->s;
     const ps_model_config_t &c = m->cfg;
@@ -358,13 +367,19 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         { Prof pf(m, "emb_keys"); PSCHK(launch_emb_keys(e, side_stream(m, 0))); }
         e.key_out = nullptr; e.ent_bag = nullptr;
     }
-    hipEvent_t fwd_ev = (train && !m->sh.active && !keys_early) ? arm_event(m) : nullptr;
+    // single-hot field sort released from the device: the FIRST forward GEMM's start (it starts only after the gather
+    // has finished) flips a flag, the sort sits behind a spinner on side chain 0 -- the gather's launch carries no
+    // event (a launch with a stop event starts ~2 us later than a plain one)
+    const bool sort_dev = train && !m->sh.active && !m->cur_offsets && g_field_sort && field_sort_fits(B, c.F) && !g_sort_ablate &&
+                          g_dev_wait && !c.use_graph && side_stream(m, 0) != st && !(nfc == 1 && s->fc[0].N == 1);
+    hipEvent_t fwd_ev = (train && !m->sh.active && !keys_early && !sort_dev) ? arm_event(m) : nullptr;
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
     PSCHK(settle_event(m, fwd_ev));
-    if (train && !m->sh.active) {
+    auto enqueue_sort = [&]() -> int {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
         if (keys_early) {}
+        else if (sort_dev) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss));
         else if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
         static int64_t sort_runs = 0;
@@ -406,7 +421,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
             }
         }
         m->side0_pending = true;
-    }
+        return PS_OK;
+    };
+    if (sort_dev) m->field_sorted = true;            // (dev_release() below looks at it before the sort is enqueued)
+    else if (train && !m->sh.active) PSCHK(enqueue_sort());
+    bool sort_due = sort_dev;
     // FcLayer.forward x nfc
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
@@ -417,8 +436,14 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
         if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
         Prof pf(m, names[l]);
+        if (sort_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; g_launch_flag = m->start_flag + 4; g_launch_flag_val = m->fwd_epoch; }
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st));
+        if (sort_due) {         // the waiter is enqueued after the launch that releases it
+            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st)); }
+            PSCHK(enqueue_sort());
+            sort_due = false;
+        }
     }
     // LRLayer.forward + AddLayer.forward + loss
     HeadArgs h;
@@ -447,7 +472,9 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         LastBwdArgs q;
         fill_last_bwd(m, q);
         Prof pf(m, "head_last_bwd");
-        m->head_ev = arm_event(m);
+        // (both side chains of the backward are released from the device when they can be -- dev_release() -- and the
+        //  head's launch then carries nothing: a launch with a stop event starts ~2 us later than a plain one)
+        m->head_ev = dev_release(m) ? nullptr : arm_event(m);
         PSCHK(launch_head_last_bwd(h, q, bl.nsplit, st));
         PSCHK(settle_event(m, m->head_ev));
         m->head_bwd_done = true;
@@ -517,33 +544,14 @@ int enqueue_backward(ps_model *m, bool apply) {
     // (only when nothing else on that chain needs the head: with the small kernels above on it, it waits by event)
     // (and not under stream capture: a captured graph needs its side streams joined by events)
     const bool dev_flags = g_dev_wait && !m->cfg.use_graph;
-    const bool dev_wait = dev_flags && sw != st && sl != sw && m->head_bwd_done && nfc >= 2 && s->fc[nfc - 1].N == 1;
-    if (m->head_ev && m->head_bwd_done) { if (!dev_wait) PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
-    else PSCHK(fork2(m, st, dev_wait ? s0 : sw, s0));
-    bool spinner_due = dev_wait;
+    const bool dev_wait = dev_release(m) && sw != st && sl != sw && m->head_bwd_done;
+    if (dev_wait) {}                                              // both chains: spinners behind the first delta GEMM's launch
+    else if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
+    else PSCHK(fork2(m, st, sw, s0));
+    bool first_release = dev_wait;
     m->head_ev = nullptr;
     bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
     hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
-    if (m->loss_pending) {
-        // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
-        // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
-        // only the kernels that touch parameters (wide / dense / embedding updates) honour it.
-        Prof pf(m, "loss_reduce");
-        PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, sl));
-        m->loss_pending = false;
-    }
-    // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
-    if (c.kind == PS_MODEL_WIDEDEEP && apply) {
-        WideUpdArgs w;
-        memset(&w, 0, sizeof w);
-        w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
-        w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = skip;
-        PSCHK(store_resolve_updater(s, "wide.weights", &u));
-        w.upd = make_upd_params(u);
-        Prof pf(m, "wide_update");
-        if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, sl));
-        else PSCHK(launch_wide_update(w, sl));
-    }
     // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
     DenseUpdArgs d;
     memset(&d, 0, sizeof d);
@@ -560,20 +568,46 @@ int enqueue_backward(ps_model *m, bool apply) {
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }
-    // the out = 1 layer's 128 row-block slabs (written by the head's launch) folded here, on side chain 0 behind the
-    // wide update, not in front of the dense update at the end of the step
-    if (m->head_bwd_done && s->fc[nfc - 1].N == 1) { Prof pf(m, "dense_prereduce"); PSCHK(dense_prereduce(d, nfc - 1, sl)); }
-    // everything the main chain needs from side chain 0 ends here (sort, stop flag, wide update, slab fold)
-    // A long sort chain (multi-hot) ends AFTER the last delta GEMM: the main chain would reach its wait first and
-    // resume 10-20 us after the event.  There the chain's end sets a flag from the device and the main chain parks a
-    // spinner in front of the embedding update instead (same mechanism as the dW chain's release).
+    // The small kernels that hang off the head.  Enqueued here when their chain waits for the head by event; behind the
+    // first delta GEMM's launch (and a spinner) when it is released from the device.
     const bool sort_dev_wait = dev_flags && s0 != st && sl != s0 && !m->sh.active;
-    if (sort_dev_wait) {
-        if (++m->start_epoch == 0) ++m->start_epoch;
-        PSCHK(launch_flag_set(m->start_flag + 1, m->start_epoch, s0));
-        m->sort_epoch = m->start_epoch;
-    } else if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
-    if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));
+    auto small_kernels = [&]() -> int {
+        if (m->loss_pending) {
+            // loss = mean(terms), gbar = rowMeans(delta), the stop flag (model/DNN.java:58-63).  Nothing on the main chain
+            // needs them before the embedding update: the GEMMs only write scratch, so they run regardless of the flag and
+            // only the kernels that touch parameters (wide / dense / embedding updates) honour it.
+            Prof pf(m, "loss_reduce");
+            PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, sl));
+            m->loss_pending = false;
+        }
+        // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
+        if (c.kind == PS_MODEL_WIDEDEEP && apply) {
+            WideUpdArgs w;
+            memset(&w, 0, sizeof w);
+            w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
+            w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.gbar = m->gbar_dev; w.skip = skip;
+            PSCHK(store_resolve_updater(s, "wide.weights", &u));
+            w.upd = make_upd_params(u);
+            Prof pf(m, "wide_update");
+            if (c.wide_grad_mode == PS_GRAD_INTENDED) PSCHK(enqueue_wide_intended(m, w, sl));
+            else PSCHK(launch_wide_update(w, sl));
+        }
+        // the out = 1 layer's 128 row-block slabs (written by the head's launch) folded here, on side chain 0 behind the
+        // wide update, not in front of the dense update at the end of the step
+        if (m->head_bwd_done && s->fc[nfc - 1].N == 1) { Prof pf(m, "dense_prereduce"); PSCHK(dense_prereduce(d, nfc - 1, sl)); }
+        // everything the main chain needs from side chain 0 ends here (sort, stop flag, wide update, slab fold)
+        // A long sort chain (multi-hot) ends AFTER the last delta GEMM: the main chain would reach its wait first and
+        // resume 10-20 us after the event.  There the chain's end sets a flag from the device and the main chain parks a
+        // spinner in front of the embedding update instead (same mechanism as the dW chain's release).
+        if (sort_dev_wait) {
+            if (++m->start_epoch == 0) ++m->start_epoch;
+            PSCHK(launch_flag_set(m->start_flag + 1, m->start_epoch, s0));
+            m->sort_epoch = m->start_epoch;
+        } else if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
+        if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));
+        return PS_OK;
+    };
+    if (!dev_wait) PSCHK(small_kernels());
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
         FcParams &p = s->fc[l];
@@ -593,12 +627,18 @@ int enqueue_backward(ps_model *m, bool apply) {
         // measured slower -- 0.180 and 0.195 against 0.170 ms/step; the embedding update took 49 us instead of 30
         // with a GEMM beside it.)
         hipStream_t dws = sw;
-        if (main_dirty) {                                   // delta_l was just produced on the main chain
-            if (data_ev) PSCHK(wait_event(m, dws, data_ev)); else PSCHK(fork(m, st, dws));
-            main_dirty = false;
+        if (dev_wait) {
+            // released from the device: this delta GEMM's first workgroup announces "everything before me on the main
+            // chain is done" (delta_l included), dW_l sits behind a spinner on that -- no event anywhere on the chain
+            if (++m->start_epoch == 0) ++m->start_epoch;
+            g_launch_flag = m->start_flag; g_launch_flag_val = m->start_epoch;
+        } else {
+            if (main_dirty) {                               // delta_l was just produced on the main chain
+                if (data_ev) PSCHK(wait_event(m, dws, data_ev)); else PSCHK(fork(m, st, dws));
+                main_dirty = false;
+            }
+            data_ev = l > 0 ? arm_event(m) : nullptr;  // delta_{l-1}: the next dW GEMM waits for it (nobody after the last)
         }
-        data_ev = l > 0 ? arm_event(m) : nullptr;      // delta_{l-1}: the next dW GEMM waits for it (nobody after the last)
-        if (spinner_due) { if (++m->start_epoch == 0) ++m->start_epoch; g_launch_flag = m->start_flag; g_launch_flag_val = m->start_epoch; }
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
@@ -613,16 +653,22 @@ int enqueue_backward(ps_model *m, bool apply) {
         }
         PSCHK(settle_event(m, data_ev));
         main_dirty = true;
-        if (spinner_due) {          // enqueued AFTER the launch that will release it: it cannot be left spinning
-            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(fork(m, st, sw)); }         // (not consumed: plain event)
-            else PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw));
-            spinner_due = false;
+        if (dev_wait) {             // every waiter is enqueued AFTER the launch that releases it: none can be left spinning
+            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag, m->start_epoch, st)); }   // (an empty GEMM)
+            PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw));
+            if (first_release) {
+                PSCHK(launch_spin_until(m->start_flag, m->start_epoch, s0));
+                PSCHK(small_kernels());
+                first_release = false;
+            }
+            main_dirty = false;
         }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
                              b.nsplit, nullptr, dws));
     }
+    if (first_release) { PSCHK(fork2(m, st, sw, s0)); PSCHK(small_kernels()); first_release = false; }     // (no delta GEMM at all)
     // tail_dev: the dense update goes to the END OF SIDE CHAIN 1 and both of its edges are device-side flags (no event
     // wait anywhere in the tail): it starts when the embedding update has STARTED (that launch starts only after the
     // last delta GEMM, which reads W_0, has finished and after the main chain saw side chain 0's stop flag and slab

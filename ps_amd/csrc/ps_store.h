@@ -185,7 +185,7 @@ struct ps_model {
     bool head_bwd_done = false;   // the head's launch also did the out = 1 layer's backward
     bool loss_pending = false;    // loss / gbar / stop flag not reduced yet
     hipEvent_t loss_ev = nullptr, s0_ev = nullptr, dw_ev = nullptr;
-    unsigned int sort_epoch = 0;
+    unsigned int sort_epoch = 0, fwd_epoch = 0;
     unsigned int *start_flag = nullptr, start_epoch = 0;      // device word + host epoch of the spinner in front of the dW chain
     hipEvent_t head_ev = nullptr;                             // carried by the head's launch (one of `events`), consumed by the backward
     // graph replay: one instantiated graph per (batch pointers, B, nnz)
