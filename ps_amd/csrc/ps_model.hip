@@ -332,12 +332,11 @@ static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
 }
 
 // Can the backward of this step release its side chains by device flags (launch_spin_until) instead of events?
-// Needs two side streams, no stream capture, the fused head (so that the first kernel after it is a delta GEMM), and the
-// head's small kernels on side chain 0 (single-hot field sort or sharded step): see enqueue_backward.
+// Needs two side streams, no stream capture and the fused head (so that the first kernel after it is a delta GEMM):
+// see enqueue_backward.
 static bool dev_release(const ps_model *m) {
     const ps_model_config_t &c = m->cfg;
-    return g_dev_wait && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1 &&
-           (m->field_sorted || m->sh.active);
+    return g_dev_wait && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1;
 }
 
 int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
@@ -541,10 +540,11 @@ int enqueue_backward(ps_model *m, bool apply) {
     hipStream_t sl = (m->field_sorted || m->sh.active || s0 == st) ? s0 : sw;      // (sharded: that sort ran during the exchange)
     // side chain 1 (the dW GEMMs) does not wait for the head by event: a spinner in front of its first GEMM is released
     // by the first delta GEMM's start (launch_spin_until in kernels_gemm.hip)
-    // (only when nothing else on that chain needs the head: with the small kernels above on it, it waits by event)
+    // (the head's small kernels go behind the same release: on side chain 0 behind their own spinner, or -- multi-hot --
+    // at the front of side chain 1)
     // (and not under stream capture: a captured graph needs its side streams joined by events)
     const bool dev_flags = g_dev_wait && !m->cfg.use_graph;
-    const bool dev_wait = dev_release(m) && sw != st && sl != sw && m->head_bwd_done;
+    const bool dev_wait = dev_release(m) && sw != st && m->head_bwd_done;
     if (dev_wait) {}                                              // both chains: spinners behind the first delta GEMM's launch
     else if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
     else PSCHK(fork2(m, st, sw, s0));
@@ -656,8 +656,8 @@ int enqueue_backward(ps_model *m, bool apply) {
         if (dev_wait) {             // every waiter is enqueued AFTER the launch that releases it: none can be left spinning
             if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag, m->start_epoch, st)); }   // (an empty GEMM)
             PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw));
-            if (first_release) {
-                PSCHK(launch_spin_until(m->start_flag, m->start_epoch, s0));
+            if (first_release) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
+                if (sl != sw) PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sl));
                 PSCHK(small_kernels());
                 first_release = false;
             }
