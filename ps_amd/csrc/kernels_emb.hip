@@ -770,6 +770,7 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
     }
     // KVStore.sum + update for this key (finish_key's arithmetic, one component per lane)
     const uint32_t row = a.sorted_key[s0];
+    if (a.out_slot) u = a.out_slot[a.sorted_ent[s0]];            // (see the short role)
     const float g0 = __shfl(S[0], 0);                           // FtrlUpdater.java:52 looks at dw[0]
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -890,7 +891,9 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
             VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));
         }
     }
-    finish_key<VEC>(a, (uint32_t)u, row, n, S, part);
+    // (sharded step after the field sort: runs come field by field, the gradients go out in the plan's send order)
+    const uint32_t uo = a.out_slot ? a.out_slot[a.sorted_ent[s0]] : (uint32_t)u;
+    finish_key<VEC>(a, uo, row, n, S, part);
 }
 
 // ---------------------------------------------------------------------------

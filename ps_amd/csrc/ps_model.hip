@@ -603,6 +603,12 @@ int enqueue_backward(ps_model *m, bool apply) {
             if (++m->start_epoch == 0) ++m->start_epoch;
             PSCHK(launch_flag_set(m->start_flag + 1, m->start_epoch, s0));
             m->sort_epoch = m->start_epoch;
+        } else if (s0 != st && dev_flags) {
+            // side chain 0's end as a flag too: a spinner that finds its flag set costs the main chain a tiny kernel
+            // (~1.5 us), a hipStreamWaitEvent on an event that fired long ago ~3.5 (tools/gpu_timeline.py)
+            if (++m->start_epoch == 0) ++m->start_epoch;
+            PSCHK(launch_flag_set(m->start_flag + 5, m->start_epoch, s0));
+            m->s0_epoch = m->start_epoch;
         } else if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
         if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));
         return PS_OK;
@@ -681,6 +687,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
     if (sort_dev_wait) PSCHK(launch_spin_until(m->start_flag + 1, m->sort_epoch, st));
+    else if (s0 != st && dev_flags) PSCHK(launch_spin_until(m->start_flag + 5, m->s0_epoch, st));
     else if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));  // the sort (forward), the stop flag and the wide update
     if (sl != s0) HIPCHK(hipStreamWaitEvent(st, m->loss_ev, 0));
     m->side0_pending = false;
@@ -691,6 +698,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.nseg = m->nseg_dev;
     g.long_list = m->long_list_valid ? m->long_list : nullptr;
     g.nlong = m->nlong_ptr;
+    g.out_slot = (m->sh.active && m->field_sorted) ? m->sh.slot : nullptr;     // (runs field by field, gradients in send order)
     g.ent_bag = (m->cur_offsets && m->sh.active) ? m->ent_bag : nullptr;     // fused path: sorted_ent already holds bags
     g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.partials2 = m->partials2; g.W = s->emb.W; g.state = s->emb.state;
     // a key's run is at most B entries when single-hot: no second level (and no extra launch) up to 128 chunks

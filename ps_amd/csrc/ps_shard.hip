@@ -315,14 +315,34 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
         PS_LAUNCH(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot);
         if (ss != st && (g_launch_stop_event == sh.slot_ev || !g_ext_events)) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(sh.slot_ev, ss)); }
         HIPCHK(hipGetLastError());
-        PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
-        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
+        m->field_sorted = false;
+        if (!m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F)) {
+            // single-hot: one launch sorts the F fields on their own (kernels_sort.hip) instead of the 11-launch radix
+            // chain.  A composite key (owner, local row) belongs to one field only, so the runs are the same; they come
+            // field by field rather than in send order, and the embedding backward writes each run's gradient at the
+            // plan's slot of its first entry (EmbBwdArgs.out_slot).  One shard: the owner-0 field bases shorten the key.
+            if (++m->fs_epoch == 0) ++m->fs_epoch;
+            int kb = sh.sbits + bits_for(nshards);
+            const bool based = nshards == 1 && !s->emb.java_route();
+            if (based) {
+                int64_t span = 1;
+                for (int f = 0; f < F; ++f) span = std::max(span, s->emb.rows[f]);
+                kb = bits_for(span);
+            }
+            PSCHK(field_sort_segments(m->keys, based ? sh.lrb_dev : nullptr, kb, m->cur_B, F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
+                                      m->seg_start, m->seg_id, m->seg_nseg_scratch, m->long_list, m->fs_pub, m->fs_epoch, ss));
+            m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
+            m->field_sorted = true;
+        } else {
+            PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
+            PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
+        }
         m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
         m->side0_pending = ss != st;
     } else {
         PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
         PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st, m->long_list, PS_EMB_SEQ_TILE));
-        m->long_list_valid = true; m->nlong_ptr = m->nseg_dev + 1;
+        m->long_list_valid = true; m->nlong_ptr = m->nseg_dev + 1; m->field_sorted = false;
     }
     if (bm) {
         // (send_rows, owner_start, slot, nseg came from the bitmap)

@@ -143,6 +143,7 @@ struct ps_model {
         int nshards = 1;
         const float *cache = nullptr; // [U][D] rows pulled from their owners, in send order
         uint32_t *slot = nullptr;     // [nnz] unique slot of every entry
+        uint32_t x_epoch = 0;         // epoch of the last counts publication (host spins on it)
         hipEvent_t slot_ev = nullptr; // set while the slots are being written on a side stream (one of the model's events)
         uint32_t *send_rows = nullptr;// [U] owner-local row of every unique key, grouped by owner
         uint32_t *owner_start = nullptr; // [nshards+1] device
@@ -185,7 +186,7 @@ struct ps_model {
     bool head_bwd_done = false;   // the head's launch also did the out = 1 layer's backward
     bool loss_pending = false;    // loss / gbar / stop flag not reduced yet
     hipEvent_t loss_ev = nullptr, s0_ev = nullptr, dw_ev = nullptr;
-    unsigned int sort_epoch = 0, fwd_epoch = 0;
+    unsigned int sort_epoch = 0, fwd_epoch = 0, s0_epoch = 0;
     unsigned int *start_flag = nullptr, start_epoch = 0;      // device word + host epoch of the spinner in front of the dW chain
     hipEvent_t head_ev = nullptr;                             // carried by the head's launch (one of `events`), consumed by the backward
     // graph replay: one instantiated graph per (batch pointers, B, nnz)
