@@ -34,6 +34,19 @@ struct NtArgs {
     int ablate;      // measurement only: 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barriers
     unsigned long long *ts;
     unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (launch_spin_until)
+    const unsigned int *wait_flag; unsigned int wait_val;   // workgroup 0 ends only once *wait_flag has reached wait_val
+};
+
+// "This launch does not end before another chain has reached X": the first workgroup, done with its tile, holds its
+// slot until the flag is there (normally long since) -- the join costs the waiting chain no launch of its own.  Same
+// rule as for the spinners: armed only when the launches that raise the flag were enqueued BEFORE this one.
+struct EndWait {
+    const unsigned int *f; unsigned int v;
+    __device__ __forceinline__ EndWait(const unsigned int *flag, unsigned int val) : f(flag), v(val) {}
+    __device__ __forceinline__ ~EndWait() {
+        if (f && blockIdx.x == 0 && threadIdx.x == 0)
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) __builtin_amdgcn_s_sleep(16);
+    }
 };
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
@@ -62,6 +75,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
     constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    EndWait end_wait(a.wait_flag, a.wait_val);       // (declared first: runs after the stamp's end)
     StampScope stamp(a.ts);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
@@ -378,8 +392,8 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"), g_launch_flag, g_launch_flag_val};
-    g_launch_flag = nullptr;
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"), g_launch_flag, g_launch_flag_val, g_launch_wait, g_launch_wait_val};
+    g_launch_flag = nullptr; g_launch_wait = nullptr;
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -420,7 +434,10 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 thread_local hipEvent_t g_launch_stop_event = nullptr;
 thread_local unsigned int *g_launch_flag = nullptr;     // armed like the stop event: the next gemm_nt announces its start there
 thread_local unsigned int g_launch_flag_val = 0;
+thread_local const unsigned int *g_launch_wait = nullptr;   // armed: the next gemm_nt's first workgroup ends only once *g_launch_wait reached the value
+thread_local unsigned int g_launch_wait_val = 0;
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
+int g_end_wait = 1;         // ps_tune_set("end_wait", 0): the main chain joins side chain 0 behind a spinner launch again
 int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again
 

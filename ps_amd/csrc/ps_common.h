@@ -134,7 +134,9 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
 extern thread_local hipEvent_t g_launch_stop_event;
 extern thread_local unsigned int *g_launch_flag;       // armed: the next gemm_nt stores g_launch_flag_val there when it starts
 extern thread_local unsigned int g_launch_flag_val;
-extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11;
+extern thread_local const unsigned int *g_launch_wait;   // armed: the next gemm_nt does not end before *g_launch_wait reached g_launch_wait_val
+extern thread_local unsigned int g_launch_wait_val;
+extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11, g_end_wait;
 int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st);
 int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order   // a one-wave kernel that ends when *flag == val
 #define PS_LAUNCH(kernel, grid, block, shmem, st, ...)                                                         \

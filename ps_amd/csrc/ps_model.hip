@@ -549,6 +549,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     else if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
     else PSCHK(fork2(m, st, sw, s0));
     bool first_release = dev_wait;
+    bool s0_joined = false;                   // the last delta GEMM's launch carries the join with side chain 0
     m->head_ev = nullptr;
     bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
     hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
@@ -654,8 +655,18 @@ int enqueue_backward(ps_model *m, bool apply) {
                           EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
         } else {
             Prof pf(m, nd[l]);
+            // the last launch in front of the embedding update also joins side chain 0 (sort, stop flag, wide update,
+            // slab fold -- enqueued behind the FIRST delta GEMM, so before this launch): its first workgroup ends only
+            // once that chain's end flag is up, and the main chain needs no spinner launch of its own for it
+            if (g_end_wait && dev_flags && s0 != st && !first_release) {
+                g_launch_wait = m->start_flag + (sort_dev_wait ? 1 : 5);          // (multi-hot: the end of the long sort chain)
+                g_launch_wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
+            }
+            const bool armed = g_launch_wait != nullptr;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
+            s0_joined = armed && g_launch_wait == nullptr;
+            g_launch_wait = nullptr;
         }
         PSCHK(settle_event(m, data_ev));
         main_dirty = true;
@@ -686,7 +697,8 @@ int enqueue_backward(ps_model *m, bool apply) {
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
-    if (sort_dev_wait) PSCHK(launch_spin_until(m->start_flag + 1, m->sort_epoch, st));
+    if (s0 != st && dev_flags && s0_joined) {}           // (the last delta GEMM's launch held the join)
+    else if (sort_dev_wait) PSCHK(launch_spin_until(m->start_flag + 1, m->sort_epoch, st));
     else if (s0 != st && dev_flags) PSCHK(launch_spin_until(m->start_flag + 5, m->s0_epoch, st));
     else if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));  // the sort (forward), the stop flag and the wide update
     if (sl != s0) HIPCHK(hipStreamWaitEvent(st, m->loss_ev, 0));

@@ -8,6 +8,7 @@ leave identical tables:
   * ps_tune_set("ext_events", 0)              (plain hipEventRecord / hipStreamWaitEvent)
   * ps_tune_set("field_sort", 0)              (general radix sort + segment builder + long-run list by k_long_runs)
   * ps_tune_set("dev_wait", 0)                (the dW chain waits for the head by event, not behind a device-side spinner)
+  * ps_tune_set("end_wait", 0)                (the main chain joins side chain 0 behind a spinner launch, not inside the last delta GEMM)
   * ps_tune_set("tail_dev", 0)                (the dense update last on the main chain, not beside the embedding update)
   * profile mode                              (everything on ONE stream: the serial order is the definition)
 Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
@@ -62,7 +63,8 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
     data = batches(rng, 6, B, F, X, V, WS)
     ref = run(kind, {}, False, data, F, D, X, fc, V, B, WS)
     variants = {"plain events": ({"ext_events": 0}, False), "general sort": ({"field_sort": 0}, False),
-                "dW chain released by event": ({"dev_wait": 0}, False), "dense update on the main chain": ({"tail_dev": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
+                "dW chain released by event": ({"dev_wait": 0}, False), "dense update on the main chain": ({"tail_dev": 0}, False),
+                "side chain 0 joined behind a spinner": ({"end_wait": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
     for name, (knobs, profile) in variants.items():
         got = run(kind, knobs, profile, data, F, D, X, fc, V, B, WS)
