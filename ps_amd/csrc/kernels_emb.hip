@@ -532,6 +532,7 @@ __device__ __forceinline__ Vec<VEC> small_key(const EmbBwdArgs &a, uint32_t s0, 
 
 template <int VEC, bool BAG>
 __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
+    StampScope stamp(a.ts_partials);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
 // stored under the same slot index in partials2.  Same tile walk as k_emb_partials; almost every group exits.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_emb_super(EmbBwdArgs a) {
+    StampScope stamp(a.ts_super);
     if (a.skip && *a.skip) return;
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
@@ -1239,27 +1241,38 @@ int g_gather_nt = -1;      // -1: automatic (streaming hints when the tables exc
 // Sort keys (and the bag of every entry) of a multi-hot batch straight from the ids: row = row_base[f] + id with the
 // gather's clamping (errors are counted by the gather).  Lets the backward's sort start BESIDE the gather instead of
 // behind it (configs[4]'s shape: the 80 us gather and the 136 us sort were back to back on the critical path).
-// Eight lanes per bag.
+// LANES lanes per bag, two entries per lane in flight (loads issued unconditionally from clamped addresses).  Beside the
+// gather its duration is the gather's whatever LANES is (4 / 8 / 16 / 32 measured: 33-42 us), alone 16 us.
+template <int LANES>
 __global__ __launch_bounds__(256) void k_emb_keys(EmbFwdArgs a) {
+    StampScope stamp(a.ts);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t bag = t >> 3;
-    const int l8 = (int)(t & 7);
-    if (bag >= (int64_t)a.B * a.F) return;
+    const int64_t nb = (int64_t)a.B * a.F;
+    int64_t bag = t / LANES;
+    const int l = (int)(t % LANES);
+    const bool live = bag < nb;
+    if (!live) bag = nb - 1;
     const int f = (int)(bag % a.F);
     const int64_t rb = a.row_base[f], rn = a.row_base[f + 1] - rb;
-    const int64_t p0 = a.offsets[bag], p1 = a.offsets[bag + 1];
-    for (int64_t p = p0 + l8; p < p1; p += 8) {
-        int64_t id = a.ids[p];
-        if (id < 0 || id >= rn) id = 0;
-        a.key_out[p] = (uint32_t)(rb + id);
+    const int64_t p0 = a.offsets[bag], p1 = live ? a.offsets[bag + 1] : p0;
+    for (int64_t p = p0 + l; p < p1; p += 2 * LANES) {
+        const int64_t q = p + LANES;
+        int64_t id0 = a.ids[p], id1 = a.ids[q < p1 ? q : p];
+        if (id0 < 0 || id0 >= rn) id0 = 0;
+        if (id1 < 0 || id1 >= rn) id1 = 0;
+        a.key_out[p] = (uint32_t)(rb + id0);
         a.ent_bag[p] = (uint32_t)bag;
+        if (q < p1) { a.key_out[q] = (uint32_t)(rb + id1); a.ent_bag[q] = (uint32_t)bag; }
     }
 }
+
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st) {
     if (!a.offsets || !a.key_out || !a.ent_bag) return ps_set_err(PS_E_BAD_ARG, "launch_emb_keys: multi-hot batches only");
     const int64_t nb = (int64_t)a.B * a.F;
     if (nb <= 0) return PS_OK;
-    hipLaunchKernelGGL(k_emb_keys, dim3(cdiv(nb * 8, 256)), dim3(256), 0, st, a);
+    EmbFwdArgs b = a;
+    b.ts = stamp_next("emb_keys");
+    hipLaunchKernelGGL(k_emb_keys<8>, dim3(cdiv(nb * 8, 256)), dim3(256), 0, st, b);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -1321,6 +1334,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
     a.ablate = g_seq_ablate;
+    if (!a.seq_order) { a.ts_partials = stamp_next("emb_partials"); if (a.long_runs) a.ts_super = stamp_next("emb_super"); }
     a.ts = stamp_next("emb_bwd_update");
     a.flag = g_launch_flag; a.flag_val = g_launch_flag_val;      // armed by the caller (ps_common.h): consumed here
     g_launch_flag = nullptr;

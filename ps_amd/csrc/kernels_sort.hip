@@ -15,6 +15,7 @@ constexpr int RS_TPB = 256;
 constexpr int RS_IPT = 16;
 constexpr int RS_TILE = RS_TPB * RS_IPT;  // 4096 keys per workgroup
 constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 1024 consecutive keys per wave
+constexpr int RS_SB_LOG = 5, RS_SB = 1 << RS_SB_LOG;   // tiles per superblock (second level of the digit counts)
 
 // per-block digit histogram; counts is digit-major: counts[digit * nblk + blk].  DB = digit bits: 8 (256 buckets)
 // or 11 (2048: two passes instead of three for the 22-bit keys of a 3 M-pair multi-hot batch; the ballot ranking of
@@ -22,9 +23,10 @@ constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 1024 consecutive keys per wave
 template <int DB>
 __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n,
                                                        int shift, uint32_t *__restrict__ counts,
-                                                       int nblk) {
+                                                       int nblk, uint32_t *__restrict__ hi, int nsb, unsigned long long *ts) {
     constexpr int ND = 1 << DB, DPT = ND / RS_TPB;
     __shared__ uint32_t h[ND];
+    StampScope stamp(ts);
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < DPT; ++q) h[tid + q * RS_TPB] = 0;
@@ -43,14 +45,29 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_hist(const uint32_t *__restric
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) counts[(size_t)(tid + q * RS_TPB) * nblk + blockIdx.x] = h[tid + q * RS_TPB];
+    for (int q = 0; q < DPT; ++q) {
+        const int d = tid + q * RS_TPB;
+        const uint32_t c = h[d];
+        // second level (hi != nullptr: the scan-free passes): keys of the digit per superblock of RS_SB tiles.  Integer
+        // atomics, ~RS_SB per address; the scatter adds the superblocks before its own and the tiles before it inside
+        // its superblock -- no scan launch between the two kernels of a pass.  Both levels are TILE-major there
+        // ([tile][digit]: one wave's stores, atomics and the scatter's loads are consecutive words); the scan wants
+        // digit-major rows.
+        if (hi) {
+            counts[(size_t)blockIdx.x * ND + d] = c;
+            if (c) atomicAdd(&hi[(size_t)(blockIdx.x >> RS_SB_LOG) * ND + d], c);
+        } else {
+            counts[(size_t)d * nblk + blockIdx.x] = c;
+        }
+    }
 }
 
 // counts is digit-major [256][nblk].  Workgroup d turns row d into its exclusive prefix (positions of digit d's
 // keys of block b among all keys with digit d) and leaves the row total in totals[d].  One workgroup per digit:
 // the scan scales with the key count (a single-workgroup scan of 256*nblk counters was THE cost at 3e6 keys).
-__global__ __launch_bounds__(RS_TPB) void k_scan_rows(uint32_t *__restrict__ counts, int nblk, uint32_t *__restrict__ totals) {
+__global__ __launch_bounds__(RS_TPB) void k_scan_rows(uint32_t *__restrict__ counts, int nblk, uint32_t *__restrict__ totals, unsigned long long *ts) {
     __shared__ uint32_t wsum[4];
+    StampScope stamp(ts);
     __shared__ uint32_t carry_s;
     uint32_t *row = counts + (size_t)blockIdx.x * nblk;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -89,7 +106,8 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
                                                           int shift,
                                                           const uint32_t *__restrict__ offs,
                                                           const uint32_t *__restrict__ totals,
-                                                          int nblk) {
+                                                          int nblk, const uint32_t *__restrict__ hi, int nsb, unsigned long long *ts) {
+    StampScope stamp(ts);
     constexpr int ND = 1 << DB, DPT = ND / RS_TPB;   // thread t owns digits DPT*t .. DPT*t + DPT-1 (digit order = thread order)
     constexpr uint32_t DMASK = ND - 1;
     __shared__ uint32_t cur[4][ND];
@@ -109,10 +127,55 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
         v[j] = IOTA ? (uint32_t)idx : vin[ci];
     }
     uint32_t in_digit[DPT], dtot[DPT];
+    if (hi) {
+        // scan-free: offs holds the raw per-tile counts, hi the per-superblock sums.  Keys of the digit in earlier tiles =
+        // the superblocks before mine + the tiles before me inside mine; the digit's total = all superblocks.  All loads
+        // independent, from clamped addresses.
+        const int sb = blockIdx.x >> RS_SB_LOG, b_in = blockIdx.x & (RS_SB - 1);
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) {
-        in_digit[q] = offs[(size_t)(tid * DPT + q) * nblk + blockIdx.x];   // keys of that digit in earlier blocks
-        dtot[q] = totals[tid * DPT + q];
+        for (int q = 0; q < DPT; ++q) {
+            const int d = tid * DPT + q;
+            const uint32_t *lo = offs + (size_t)sb * RS_SB * ND + d;
+            const uint32_t *hh = hi + d;
+            uint32_t pre = 0, tot = 0;
+            // two batches of RS_SB loads, one after the other: all 2*RS_SB in flight at once cost 64 more live VGPRs
+            // (135 in all: three waves per SIMD instead of four, and a second round of workgroups at 779 tiles)
+            {
+                uint32_t lv[RS_SB];
+#pragma unroll
+                for (int i = 0; i < RS_SB; ++i) lv[i] = lo[(size_t)(i < b_in ? i : 0) * ND];
+#pragma unroll
+                for (int i = 0; i < RS_SB; ++i) if (i < b_in) pre += lv[i];
+            }
+            asm volatile("" : "+v"(pre) :: "memory");
+            {
+                uint32_t hv[RS_SB];
+#pragma unroll
+                for (int i = 0; i < RS_SB; ++i) hv[i] = hh[(size_t)(i < nsb ? i : 0) * ND];
+#pragma unroll
+                for (int i = 0; i < RS_SB; ++i) {
+                    if (i < nsb) tot += hv[i];
+                    if (i < sb) pre += hv[i];
+                }
+            }
+            for (int s0 = RS_SB; s0 < nsb; s0 += 8) {            // more than RS_SB superblocks (> 4 M keys)
+                uint32_t h8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h8[i] = hh[(size_t)(s0 + i < nsb ? s0 + i : 0) * ND];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (s0 + i < nsb) tot += h8[i];
+                    if (s0 + i < sb) pre += h8[i];
+                }
+            }
+            in_digit[q] = pre; dtot[q] = tot;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            in_digit[q] = offs[(size_t)(tid * DPT + q) * nblk + blockIdx.x];   // keys of that digit in earlier blocks
+            dtot[q] = totals[tid * DPT + q];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -246,9 +309,10 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ blk_heads,
                                                      uint32_t *__restrict__ seg_start,
                                                      uint32_t *__restrict__ seg_id,
-                                                     uint32_t *__restrict__ nseg_dev) {
+                                                     uint32_t *__restrict__ nseg_dev, unsigned long long *ts) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t wave_heads[4];
+    StampScope stamp(ts);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_SPAN;
     uint32_t kc[RS_IPT], kp[RS_IPT];
@@ -516,6 +580,7 @@ int sort_ws_alloc(SortWorkspace &ws, int64_t cap) {
     HIPCHK(hipMalloc(&ws.counts, sizeof(uint32_t) * 2048 * (size_t)ws.nblk));       // up to 11-bit digits
     HIPCHK(hipMalloc(&ws.blk_heads, sizeof(uint32_t) * (size_t)ws.nblk));
     HIPCHK(hipMalloc(&ws.totals, sizeof(uint32_t) * 2048));
+    HIPCHK(hipMalloc(&ws.hi, sizeof(uint32_t) * 4 * 2048 * (size_t)cdiv(ws.nblk, RS_SB)));     // <= 4 passes x 2048 digits x superblocks
     return PS_OK;
 }
 
@@ -525,6 +590,7 @@ void sort_ws_free(SortWorkspace &ws) {
     if (ws.counts) (void)hipFree(ws.counts);
     if (ws.blk_heads) (void)hipFree(ws.blk_heads);
     if (ws.totals) (void)hipFree(ws.totals);
+    if (ws.hi) (void)hipFree(ws.hi);
     ws = SortWorkspace();
 }
 
@@ -541,20 +607,27 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
     int passes = (key_bits + db - 1) / db;
     if (passes < 1) passes = 1;
     const int nblk = cdiv(n, RS_TILE);
+    // A pass is TWO launches: the per-tile digit counts (+ per-superblock sums by integer atomics), then the scatter, which
+    // adds up "keys of my digit in earlier tiles" itself from the two levels.  (The scan launch in between cost the
+    // chain 10 us + a boundary per pass at configs[4]'s shape: tools/gpu_timeline.py, MULTI_HOT=1.)
+    const bool scan_free = g_radix_scan_free && passes <= 4;
+    const int nsb = cdiv(nblk, RS_SB), nd = 1 << db;
+    if (scan_free) HIPCHK(hipMemsetAsync(ws.hi, 0, sizeof(uint32_t) * (size_t)passes * nd * nsb, st));
     uint32_t *kin = keys, *vin = vals, *kout = ws.keys_alt, *vout = ws.vals_alt;
     for (int p = 0; p < passes; ++p) {
         const int shift = db * p;
+        uint32_t *hi = scan_free ? ws.hi + (size_t)p * nd * nsb : nullptr;
         // LDS staging pays once the scatter is bandwidth-bound (measured: 3.2 M pairs 3x faster, 1e5 pairs 25 % slower)
         const bool staged = n >= (1 << 19);
         const bool iota = p == 0 && iota_vals;
-#define RS_SCATTER(I, S, DBITS) hipLaunchKernelGGL((k_radix_scatter<I, S, DBITS>), dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk)
+#define RS_SCATTER(I, S, DBITS) hipLaunchKernelGGL((k_radix_scatter<I, S, DBITS>), dim3(nblk), dim3(RS_TPB), 0, st, kin, (const uint32_t *)vin, kout, vout, n, shift, ws.counts, ws.totals, nblk, hi, nsb, stamp_next("radix_scatter"))
         if (wide) {
-            hipLaunchKernelGGL(k_radix_hist<11>, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
-            hipLaunchKernelGGL(k_scan_rows, dim3(2048), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
+            hipLaunchKernelGGL(k_radix_hist<11>, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk, hi, nsb, stamp_next("radix_hist"));
+            if (!scan_free) hipLaunchKernelGGL(k_scan_rows, dim3(2048), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals, stamp_next("radix_scan"));
             if (iota) RS_SCATTER(true, true, 11); else RS_SCATTER(false, true, 11);        // wide implies staged
         } else {
-            hipLaunchKernelGGL(k_radix_hist<8>, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk);
-            hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals);
+            hipLaunchKernelGGL(k_radix_hist<8>, dim3(nblk), dim3(RS_TPB), 0, st, kin, n, shift, ws.counts, nblk, hi, nsb, stamp_next("radix_hist"));
+            if (!scan_free) hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(RS_TPB), 0, st, ws.counts, nblk, ws.totals, stamp_next("radix_scan"));
             if (iota) { if (staged) RS_SCATTER(true, true, 8); else RS_SCATTER(true, false, 8); }
             else { if (staged) RS_SCATTER(false, true, 8); else RS_SCATTER(false, false, 8); }
         }
@@ -578,7 +651,7 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
     const int nblk = cdiv(n, RS_TILE);
     hipLaunchKernelGGL(k_seg_count, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads);
     hipLaunchKernelGGL(k_seg_emit, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads,
-                       seg_start, seg_id, nseg_dev);
+                       seg_start, seg_id, nseg_dev, stamp_next("seg_emit"));
     if (long_list)      // at most n / (long_min + 1) runs can be that long; one thread per run, any order
         hipLaunchKernelGGL(k_long_runs, dim3(cdiv(n, 256)), dim3(256), 0, st, seg_start, nseg_dev, long_list, (uint32_t)long_min);
     HIPCHK(hipGetLastError());

@@ -359,7 +359,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // keys and the sort were made by ps_shard_plan
         e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr; e.table_bytes = 0;
     }
-    // multi-hot: the sort's keys come from the ids alone (k_emb_keys), so the whole sort chain starts BESIDE the gather
+    // multi-hot: the sort's keys come from the ids alone (k_emb_keys), so the whole sort chain starts BESIDE the gather.
+    // (Beside the gather the key kernel takes the gather's ~39 us -- the two share the memory system.  Running it alone
+    // in front of the gather, 16 us, and releasing the sort by a flag starts the sort chain 40 us earlier and ends the
+    // step no sooner: 0.388 vs 0.382 ms -- the later kernels then overlap the dW GEMMs and all of them slow down.  This
+    // shape is bound by the sum of its kernels, not by a chain.)
     const bool keys_early = train && !m->sh.active && m->cur_offsets && side_stream(m, 0) != st;
     if (keys_early) {
         PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
