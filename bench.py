@@ -107,6 +107,16 @@ def group_algorithmic(cfg, name, nnz, uniq):
     return None, 0.0
 
 
+def kernel_of_group(name):
+    """The device function a kernel group of the step launches (names as in rocprofv3's kernel stats)."""
+    if name.startswith("fc_fwd") or name.startswith("fc_bwd_data"):
+        return "k_gemm_nt"
+    if name.startswith("fc_bwd_dw"):
+        return "k_gemm_tn"
+    return {"emb_bwd_update": "k_emb_reduce_update", "emb_fwd": "k_emb_fwd", "emb_sort": "k_field_sort_segments",
+            "head_last_bwd": "k_last_bwd", "dense_update": "k_dense_update"}.get(name, name)
+
+
 def host_info():
     model = "unknown"
     try:
@@ -209,11 +219,18 @@ def run_single(args):
         gm.train_async(batches[i % nb])
     gm.sync()
     dt = time.perf_counter() - t0
-    # ---- roofline of the dominant kernel: same steps again with HIP events around that kernel ----
-    # dominant KERNEL: the largest average time per launch over every group of the step
-    dom = max(((k, v) for k, v in prof.items() if group_algorithmic(cfg, k, 1, 1)[0]),
-              key=lambda kv_: kv_[1][1] / max(kv_[1][0], 1) / GROUP_LAUNCHES.get(kv_[0], 1))[0]
-    gm.set_profile(True, only=dom)
+    # ---- roofline of the dominant kernel: same steps again with HIP events around every launch of that kernel ----
+    # dominant KERNEL = the kernel (device function) whose launches take the most time per step -- what tops rocprofv3's
+    # per-kernel stats table of the same command (profiles/r02_c2_bench_kernel_stats.csv).  A kernel launched for several
+    # groups of the step (k_gemm_nt: both forward GEMMs and both data-gradient GEMMs; k_gemm_tn: the dW GEMMs) counts
+    # with all of them: algorithmic work per launch = the groups' work / their launches, duration = their average.
+    by_kernel = {}
+    for k, v in prof.items():
+        if group_algorithmic(cfg, k, 1, 1)[0]:
+            by_kernel.setdefault(kernel_of_group(k), []).append(k)
+    dom_kernel = max(by_kernel, key=lambda kn: sum(prof[g][1] / max(prof[g][0], 1) for g in by_kernel[kn]))
+    dom_groups = sorted(by_kernel[dom_kernel])
+    gm.set_profile(True, only=",".join(dom_groups))
     for i in range(args.steps):
         gm.train_async(batches[i % nb])
     gm.sync()
@@ -223,27 +240,31 @@ def run_single(args):
     if not loss > 0.01:
         raise RuntimeError("loss %.4g is under the reference's stop threshold (no backward below 0.01): the timed steps are not "
                            "full training steps -- use more or fresh batches" % loss)
-    cnt, ms = rep[dom]
-    kind, work = group_algorithmic(cfg, dom, nnz, uniq)
+    cnt = sum(rep[g][0] * GROUP_LAUNCHES.get(g, 1) for g in dom_groups)            # launches of the kernel in this pass
+    ms = sum(rep[g][1] for g in dom_groups)
+    kind = group_algorithmic(cfg, dom_groups[0], nnz, uniq)[0]
+    work = sum(group_algorithmic(cfg, g, nnz, uniq)[1] * rep[g][0] for g in dom_groups) / cnt     # per launch
     avg_s = ms / cnt / 1e3
     if kind == "mfma":
-        roof = {"kernel": dom, "bound": "mfma", "achieved": work / avg_s / 1e12, "peak": F32_MFMA_PEAK_TFS,
+        roof = {"kernel": dom_kernel, "bound": "mfma", "achieved": work / avg_s / 1e12, "peak": F32_MFMA_PEAK_TFS,
                 "unit": "TFLOP/s", "traffic": None}
     else:
-        roof = {"kernel": dom, "bound": "hbm", "achieved": work / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+        roof = {"kernel": dom_kernel, "bound": "hbm", "achieved": work / avg_s / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "traffic": None}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["groups"] = dom_groups
+    roof["algorithmic_per_launch"] = work
     # HBM bytes per launch of that kernel from the committed PMC passes (tools/profile_round.sh +
     # tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950 corrections applied)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        roof["traffic"] = pmc["groups"][dom]["hbm_bytes_per_launch"]
+        roof["traffic"] = sum(pmc["groups"][g]["hbm_bytes_per_launch"] * rep[g][0] for g in dom_groups) / sum(rep[g][0] for g in dom_groups)
         roof["traffic_unit"] = "bytes/launch"
         roof["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + ")"
     except (OSError, KeyError, ValueError):
         pass
     roof["avg_launch_us"] = avg_s * 1e6
-    roof["launches_in_group"] = GROUP_LAUNCHES.get(dom, 1)
+    roof["launches_per_step"] = len(dom_groups)
     groups = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in prof.items()}
     # every group against its own roofline (HIP events around the group, all groups on one stream: includes ~4 us of
     # launch latency per group, so these are lower bounds of the kernels' own fractions)

@@ -17,6 +17,9 @@
 // the fragment reads stay simple: ds_read_b128 along k with a k-permutation
 // (per 8 k's: lanes 0-31 take k 0-3, lanes 32-63 take k 4-7).
 #include "ps_common.h"
+#include <string.h>
+#include <strings.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -441,6 +444,17 @@ int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch
 int g_end_wait = 1;         // ps_tune_set("end_wait", 0): the main chain joins side chain 0 behind a spinner launch again
 int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again
+// A profiler that collects hardware counters runs ONE kernel at a time, whichever queue it comes from, in an order of its
+// own: a kernel that waits for a flag raised by a kernel of another stream may then wait for ever.  rocprofv3 --pmc
+// announces itself through ROCPROF_COUNTER_COLLECTION in the child's environment: every device-side wait is then
+// replaced by its event form (the step's results are the same bit for bit, tests/test_gpu_schedule.py).
+namespace {
+const int g_profiler_guard = []() {
+    const char *e = getenv("ROCPROF_COUNTER_COLLECTION");
+    if (e && *e && strcmp(e, "0") != 0 && strcasecmp(e, "false") != 0 && strcasecmp(e, "off") != 0) { g_dev_wait = 0; g_end_wait = 0; }
+    return 0;
+}();
+}  // namespace
 
 // A stream that reaches a hipStreamWaitEvent before the event has fired resumes 10-20 us after it (the dW chain
 // started 10 us after the head on a good day and 18 on a bad one, which then pushed dW0 under the embedding update:

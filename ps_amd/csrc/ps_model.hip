@@ -22,7 +22,10 @@ struct Prof {
     long idx = -1;
     Prof(ps_model *mm, const char *name) : m(mm) {
         if (!m->profile) return;
-        if (!m->prof_filter.empty() && m->prof_filter != name) return;
+        if (!m->prof_filter.empty()) {          // a comma-separated list of group names
+            const std::string f = "," + m->prof_filter + ",", n = std::string(",") + name + ",";
+            if (f.find(n) == std::string::npos) return;
+        }
         ps_model::ProfEvent e;
         e.name = name;
         (void)hipEventCreate(&e.a);

@@ -134,7 +134,7 @@ struct ps_model {
     // per-kernel-group event timing (ps_model_set_profile)
     struct ProfEvent { const char *name; hipEvent_t a, b; };
     bool profile = false;
-    std::string prof_filter;    // when set: only this kernel group is bracketed
+    std::string prof_filter;    // when set: only these kernel groups (comma-separated names) are bracketed
     std::vector<ProfEvent> prof_events;
     std::map<std::string, std::pair<long, double>> prof_acc;
     // sharded (multi-GPU) step state: the worker half of PSRouterClient.getList / push
