@@ -61,3 +61,27 @@ def test_degenerate_and_device_resident(orc):
     assert abs(got - want) <= 1e-12
     N.lib().ps_dev_free(kv.h, dp); N.lib().ps_dev_free(kv.h, dy)
     kv.close()
+
+
+@pytest.mark.parametrize("n,levels", [(6_000_000, 0), (4_300_000, 1000)])
+def test_sort_above_one_superblock_level(n, levels):
+    """> 4.2 M pairs = more than 32 superblocks of 32 tiles: the radix scatter's prefix then also walks the loop over the
+    superblock sums beyond the first 32 (kernels_sort.hip), 4 passes of 32-bit keys; exact against the stable-rank form."""
+    import ps_amd
+    from ps_amd import native as N
+    kv = ps_amd.KVStore(0, 1)
+    rng = np.random.default_rng(n)
+    p = rng.random(n).astype(np.float32)
+    if levels:
+        p = (np.floor(p * levels) / levels).astype(np.float32)         # long runs of equal keys
+    y = (rng.random(n) < 0.3).astype(np.float32)
+    dp, dy = C.c_void_p(), C.c_void_p()
+    for d, a in ((dp, p), (dy, y)):
+        N.check(N.lib().ps_dev_alloc(kv.h, a.nbytes, C.byref(d))); N.check(N.lib().ps_dev_upload(kv.h, d, a.ctypes.data, a.nbytes))
+    got = ps_amd.AUC(dp, dy, store=kv, n=n, on_device=True).calculate()
+    order = np.argsort(p, kind="stable"); r = np.empty(n, np.int64); r[order] = np.arange(n)
+    P = int((y > 0).sum()); Nn = n - P
+    want = (float(r[y > 0].sum()) - P * (P - 1) / 2) / (float(P) * Nn)
+    assert abs(got - want) <= 1e-12
+    N.lib().ps_dev_free(kv.h, dp); N.lib().ps_dev_free(kv.h, dy)
+    kv.close()
