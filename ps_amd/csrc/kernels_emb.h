@@ -180,5 +180,6 @@ struct PushApplyArgs {
     float *W, *state;
     UpdParams upd;
     int *err;
+    unsigned long long *ts_mark, *ts_apply;   // stamp slots, set by the launcher
 };
 int launch_push_apply(PushApplyArgs a, hipStream_t st);

@@ -963,6 +963,7 @@ __device__ __forceinline__ int push_peer_of(const PushApplyArgs &a, uint32_t e) 
 }
 
 __global__ __launch_bounds__(256) void k_push_mark(PushApplyArgs a) {
+    StampScope stamp(a.ts_mark);
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.n) return;
     const uint32_t r = a.rows[e];
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(256) void k_push_mark(PushApplyArgs a) {
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
+    StampScope stamp(a.ts_apply);
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
     const int gpw = 64 / a.LPR;
@@ -1559,6 +1561,7 @@ int launch_push_apply(PushApplyArgs a, hipStream_t st) {
     a.LPR = a.D / vec;
     const int gpw = 64 / a.LPR;
     if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
+    a.ts_mark = stamp_next("push_mark"); a.ts_apply = stamp_next("push_apply");
     hipLaunchKernelGGL(k_push_mark, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
     const int g = cdiv((int64_t)cdiv(a.n, gpw) * 64, 256);
     if (vec == 4) hipLaunchKernelGGL((k_push_apply<4>), dim3(g), dim3(256), 0, st, a);

@@ -441,6 +441,7 @@ thread_local const unsigned int *g_launch_wait = nullptr;   // armed: the next g
 thread_local unsigned int g_launch_wait_val = 0;
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
+int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
 int g_end_wait = 1;         // ps_tune_set("end_wait", 0): the main chain joins side chain 0 behind a spinner launch again
 int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again

@@ -242,7 +242,11 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
 // delays every launch of the critical path more than the overlap saves; bench.py therefore runs the halves back
 // to back (--overlap 0).  The split stays: it is what a host with longer steps (bigger batches) would use.
 namespace {
-__global__ void k_publish_counts(const uint32_t *__restrict__ src, uint32_t *dst_host, int n, uint32_t *flag_host, uint32_t epoch) {
+__global__ void k_publish_counts(const uint32_t *__restrict__ src, uint32_t *dst_host, int n, uint32_t *flag_host, uint32_t epoch,
+                                 unsigned int *started, unsigned int started_val, unsigned long long *ts) {
+    StampScope stamp(ts);
+    // "everything in front of this launch on its stream has finished" for a device-side waiter (an early plan's second half)
+    if (started && threadIdx.x == 0) __hip_atomic_store(started, started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst_host[i] = src[i];
     __threadfence_system();
     __syncthreads();
@@ -284,7 +288,7 @@ extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const
         PSCHK(shard_push_reserve(s, nsh));
     }
     if (comm->ctx && comm->all_gather == rccl_all_gather) ((RcclCtx *)comm->ctx)->use_side = use_side != 0;
-    PSCHK(shard_plan_enqueue(m, batch, nsh, st, false));
+    PSCHK(shard_plan_enqueue(m, batch, nsh, st, false, !use_side));
     const size_t row = sizeof(uint32_t) * (size_t)(nsh + 1);        // every rank's owner_start[0..nranks]: the host takes the differences
     if (!sh.matrix_dev) {
         HIPCHK(hipMalloc((void **)&sh.matrix_dev, row * (size_t)nsh));
@@ -297,9 +301,16 @@ extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const
     // copy packet and a record packet on the stream, and the host woke up 20-40 us late in some processes: a bimodal
     // sharded step, 0.217 / 0.24 ms.)
     if (++sh.x_epoch == 0) ++sh.x_epoch;
+    unsigned int *started = nullptr;
+    if (sh.tail_due) {          // an early plan: its second half waits for this launch's start on side chain 0
+        if (++m->start_epoch == 0) ++m->start_epoch;
+        sh.pub_epoch = m->start_epoch;
+        started = m->start_flag + 6;
+    }
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(256), 0, st, sh.matrix_dev, sh.matrix_host, (int)(nsh * (nsh + 1)),
-                       sh.matrix_host + (size_t)nsh * (nsh + 1), sh.x_epoch);
+                       sh.matrix_host + (size_t)nsh * (nsh + 1), sh.x_epoch, started, sh.pub_epoch, stamp_next("publish_counts"));
     HIPCHK(hipGetLastError());
+    PSCHK(shard_plan_enqueue_tail(m, nsh, st));
     if (use_side) HIPCHK(hipEventRecord(sh.x_ev, st));       // (the training stream orders itself behind the prefetch stream)
     sh.x_begun = true; sh.x_side = use_side != 0;
     return PS_OK;

@@ -158,7 +158,8 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->ent_bag, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->seg_start, sizeof(uint32_t) * (size_t)(nc + 2), false));
     PSCHK(model_alloc(m, (void **)&m->seg_id, sizeof(uint32_t) * (size_t)(nc + 1), false));
-    PSCHK(model_alloc(m, (void **)&m->nseg_dev, sizeof(uint32_t) * 4, true));
+    PSCHK(model_alloc(m, (void **)&m->nseg_dev, sizeof(uint32_t) * 8, true));
+    m->nseg_cur = m->nseg_dev;
     PSCHK(model_alloc(m, (void **)&m->seg_nseg_scratch, sizeof(uint32_t) * 4, true));
     PSCHK(model_alloc(m, (void **)&m->fs_keys, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
@@ -432,6 +433,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     if (sort_dev) m->field_sorted = true;            // (dev_release() below looks at it before the sort is enqueued)
     else if (train && !m->sh.active) PSCHK(enqueue_sort());
     bool sort_due = sort_dev;
+    // sharded worker: the first forward GEMM announces its start too -- everything of this step in front of it (the id and
+    // row exchanges, the gather) is then done, which is what the NEXT step's plan waits for on side chain 0
+    bool fwd_flag_due = train && m->sh.active && g_dev_wait && !c.use_graph && !m->profile && m->multi_stream;
+    m->fwd_flag_valid = false;
     // FcLayer.forward x nfc
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
@@ -442,9 +447,13 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
         if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
         Prof pf(m, names[l]);
-        if (sort_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; g_launch_flag = m->start_flag + 4; g_launch_flag_val = m->fwd_epoch; }
+        if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; g_launch_flag = m->start_flag + 4; g_launch_flag_val = m->fwd_epoch; }
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st));
+        if (fwd_flag_due) {
+            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st)); }
+            fwd_flag_due = false; m->fwd_flag_valid = true;
+        }
         if (sort_due) {         // the waiter is enqueued after the launch that releases it
             if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st)); }
             PSCHK(enqueue_sort());
@@ -714,7 +723,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     memset(&g, 0, sizeof g);
     g.nnz = nnz; g.F = c.F; g.D = c.D; g.grad_mode = c.emb_grad_mode; g.apply = apply ? 1 : 0;
     g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
-    g.nseg = m->nseg_dev;
+    g.nseg = m->sh.active ? m->nseg_cur : m->nseg_dev;
     g.long_list = m->long_list_valid ? m->long_list : nullptr;
     g.nlong = m->nlong_ptr;
     g.out_slot = (m->sh.active && m->field_sorted) ? m->sh.slot : nullptr;     // (runs field by field, gradients in send order)

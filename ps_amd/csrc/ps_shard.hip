@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void k_shard_keys(const int64_t *__restrict__ 
                                                     const uint8_t *__restrict__ owner_tab, const uint32_t *__restrict__ local_tab,
                                                     const int64_t *__restrict__ grow_base /* java_string routing, else NULL */,
                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ ent_bag, int *err,
-                                                    uint8_t *__restrict__ stamp /* or NULL */, uint8_t epoch) {
+                                                    uint8_t *__restrict__ stamp /* or NULL */, uint8_t epoch, unsigned long long *ts) {
+    StampScope stamp_scope(ts);
     const int64_t bag = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (bag >= nbags) return;
     const int f = (int)(bag % F);
@@ -93,7 +94,8 @@ constexpr int PLAN_WPB = 256;      // bitmap words per workgroup
 
 // stamp bytes of this step's epoch -> bitmap word (32 keys per thread), popcount per workgroup
 __global__ __launch_bounds__(256) void k_plan_count(const uint8_t *__restrict__ stamp, uint8_t epoch, uint32_t *__restrict__ bitmap,
-                                                    int64_t nwords, uint32_t *__restrict__ blk_sum) {
+                                                    int64_t nwords, uint32_t *__restrict__ blk_sum, unsigned long long *ts) {
+    StampScope stamp_scope(ts);
     __shared__ uint32_t red[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t i = (int64_t)blockIdx.x * PLAN_WPB + tid;
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(256) void k_plan_count(const uint8_t *__restrict__ 
 // owner o's run starts at the prefix of word (o << sbits) >> 5 (sbits >= 5: owner boundaries are word boundaries)
 __global__ __launch_bounds__(256) void k_plan_emit(const uint32_t *__restrict__ bitmap, int64_t nwords, const uint32_t *__restrict__ blk_sum,
                                                    uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ send_rows,
-                                                   uint32_t *__restrict__ owner_start, uint32_t *__restrict__ nseg, int sbits, int nshards) {
+                                                   uint32_t *__restrict__ owner_start, uint32_t *__restrict__ nseg, int sbits, int nshards, unsigned long long *ts) {
+    StampScope stamp_scope(ts);
     __shared__ uint32_t red[4], wsum[4], carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t acc = 0;
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(256) void k_plan_emit(const uint32_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_plan_slots(const uint32_t *__restrict__ keys, int64_t nnz, const uint32_t *__restrict__ bitmap,
-                                                    const uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ slot) {
+                                                    const uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ slot, unsigned long long *ts) {
+    StampScope stamp_scope(ts);
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= nnz) return;
     const uint32_t key = keys[p], wd = key >> 5;
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(256) void k_plan_slots(const uint32_t *__restrict__
 // rows_out[i][:] = W[rows[i]][:]   (PServer.getList: the rows for a key list)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, const uint32_t *__restrict__ rows, int64_t n,
-                                                     int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err) {
+                                                     int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err, unsigned long long *ts) {
+    StampScope stamp_scope(ts);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int part = (int)(t % LPR);
@@ -276,69 +281,115 @@ extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
 }
 
 // the plan's kernels; readback: also copy owner_start to pinned memory and record plan_ev (ps_shard_plan_finish)
-int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback) {
+// The slot of every entry (the forward reads it ~50 us later) and the entry lists of the backward (stable sort + runs),
+// on side stream 0 beside the exchange and the forward.  k_plan_slots before the sort in stream order: the general
+// sort ping-pongs through m->keys.
+static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream_t st, hipStream_t ss) {
+    ps_store *s = m->s;
+    ps_model::Shard &sh = m->sh;
+    const int F = m->cfg.F;
+    if (ss != st) {
+        sh.slot_ev = m->events[m->next_event++ % m->events.size()];
+        if (g_ext_events) g_launch_stop_event = sh.slot_ev;
+    }
+    PS_LAUNCH(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot, stamp_next("plan_slots"));
+    if (ss != st && (g_launch_stop_event == sh.slot_ev || !g_ext_events)) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(sh.slot_ev, ss)); }
+    HIPCHK(hipGetLastError());
+    m->field_sorted = false;
+    if (!m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F)) {
+        // single-hot: one launch sorts the F fields on their own (kernels_sort.hip) instead of the 11-launch radix
+        // chain.  A composite key (owner, local row) belongs to one field only, so the runs are the same; they come
+        // field by field rather than in send order, and the embedding backward writes each run's gradient at the
+        // plan's slot of its first entry (EmbBwdArgs.out_slot).  One shard: the owner-0 field bases shorten the key.
+        if (++m->fs_epoch == 0) ++m->fs_epoch;
+        int kb = sh.sbits + bits_for(nshards);
+        const bool based = nshards == 1 && !s->emb.java_route();
+        if (based) {
+            int64_t span = 1;
+            for (int f = 0; f < F; ++f) span = std::max(span, s->emb.rows[f]);
+            kb = bits_for(span);
+        }
+        PSCHK(field_sort_segments(m->keys, based ? sh.lrb_dev : nullptr, kb, m->cur_B, F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
+                                  m->seg_start, m->seg_id, m->seg_nseg_scratch, m->long_list, m->fs_pub, m->fs_epoch, ss));
+        m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
+        m->field_sorted = true;
+    } else {
+        PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
+        PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
+    }
+    m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
+    m->side0_pending = ss != st;
+    return PS_OK;
+}
+
+// early plans (see shard_plan_enqueue): the second half, enqueued by the caller once the launch that raises
+// start_flag[6] = sh.pub_epoch ("the running step's embedding backward has finished") is on the main stream
+int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st) {
+    ps_model::Shard &sh = m->sh;
+    if (!sh.tail_due) return PS_OK;
+    sh.tail_due = false;
+    hipStream_t ss = m->side[0];
+    PSCHK(launch_spin_until(m->start_flag + 6, sh.pub_epoch, ss));
+    return plan_slots_and_lists(m, nshards, sh.tail_nnz, st, ss);
+}
+
+// the plan's kernels; readback: also copy owner_start to pinned memory and record plan_ev (ps_shard_plan_finish).
+// early (ps_shard_step's pipeline, called between a step's backward and its push): the kernels that only read the ids
+// -- keys, presence map, unique lists, counts -- go to side chain 0 behind a spinner on "the running step's first forward
+// GEMM has started" (its exchanges, which read the previous plan's lists, are done then), so they run while that step
+// trains instead of in its tail; the main stream only parks a spinner on "plan done".  What overwrites lists the
+// running backward still reads (slots, entry lists) is enqueued later by shard_plan_enqueue_tail; the run count is
+// double-buffered (nseg_cur).
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early) {
     ps_store *s = m->s;
     PSCHK(ensure_shard_state(m, nshards));
-    PSCHK(stage_batch(m, batch, true));
     ps_model::Shard &sh = m->sh;
+    const bool fwd_flag = m->fwd_flag_valid;       // (of the step enqueued before this call)
+    m->fwd_flag_valid = false;
+    PSCHK(stage_batch(m, batch, true));
     if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
     const int F = m->cfg.F;
     const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
     const bool bm = sh.bitmap != nullptr && nnz > 0 && g_plan_sort == 0;
+    early = early && bm && fwd_flag && g_plan_early && g_dev_wait && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback &&
+            batch->on_device && !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
+    hipStream_t ps = early ? m->side[0] : st;       // where the id-only kernels go
+    if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps));
+    m->nseg_cur = early ? (m->nseg_cur == m->nseg_dev ? m->nseg_dev + 4 : m->nseg_dev) : m->nseg_dev;
     if (bm && ++sh.epoch == 0) {          // the byte stamps wrap every 255 plans: start over from a clean map
-        HIPCHK(hipMemsetAsync(sh.stamp, 0, (size_t)sh.bm_words * 32, st));
+        HIPCHK(hipMemsetAsync(sh.stamp, 0, (size_t)sh.bm_words * 32, ps));
         sh.epoch = 1;
     }
-    hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, st, m->cur_ids, m->cur_offsets, nbags, F, nshards,
+    hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, ps, m->cur_ids, m->cur_offsets, nbags, F, nshards,
                        sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), s->emb.owner_dev, s->emb.local_dev, s->emb.grow_base_dev, m->keys,
-                       m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev, bm ? sh.stamp : (uint8_t *)nullptr, sh.epoch);
+                       m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev, bm ? sh.stamp : (uint8_t *)nullptr, sh.epoch, stamp_next("shard_keys"));
     HIPCHK(hipGetLastError());
     if (bm) {
         const int nblk = cdiv(sh.bm_words, PLAN_WPB);
-        hipLaunchKernelGGL(k_plan_count, dim3(nblk), dim3(256), 0, st, sh.stamp, sh.epoch, sh.bitmap, sh.bm_words, sh.blk_sum);
-        // Everything after the emit leaves the main chain: the slot of every entry (the forward reads it ~50 us later)
-        // and the entry lists of the backward (stable sort + runs) run on side stream 0, beside the exchange and the
-        // forward.  The emit's launch carries the event the side stream waits for, the slot kernel's launch the one the
-        // forward waits for (no record packets on either chain).  k_plan_slots before the sort in stream order: the sort
-        // ping-pongs through m->keys.
+        hipLaunchKernelGGL(k_plan_count, dim3(nblk), dim3(256), 0, ps, sh.stamp, sh.epoch, sh.bitmap, sh.bm_words, sh.blk_sum, stamp_next("plan_count"));
+        if (early) {
+            hipLaunchKernelGGL(k_plan_emit, dim3(nblk), dim3(256), 0, ps, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
+                               sh.owner_start, m->nseg_cur, sh.sbits, nshards, stamp_next("plan_emit"));
+            HIPCHK(hipGetLastError());
+            if (++m->start_epoch == 0) ++m->start_epoch;
+            sh.plan_epoch = m->start_epoch;
+            PSCHK(launch_flag_set(m->start_flag + 7, sh.plan_epoch, ps));
+            PSCHK(launch_spin_until(m->start_flag + 7, sh.plan_epoch, st));      // (enqueued after the launch that releases it)
+            sh.tail_due = true; sh.tail_nnz = nnz;
+            return PS_OK;
+        }
+        // Everything after the emit leaves the main chain (plan_slots_and_lists).  The emit's launch carries the event the
+        // side stream waits for, the slot kernel's launch the one the forward waits for (no record packets on either chain).
         hipStream_t ss = (m->profile || !m->multi_stream) ? st : m->side[0];
         hipEvent_t e1 = nullptr;
         if (ss != st) { e1 = m->events[m->next_event++ % m->events.size()]; if (g_ext_events) g_launch_stop_event = e1; }
         PS_LAUNCH(k_plan_emit, dim3(nblk), dim3(256), 0, st, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
-                  sh.owner_start, m->nseg_dev, sh.sbits, nshards);
+                  sh.owner_start, m->nseg_cur, sh.sbits, nshards, stamp_next("plan_emit"));
         if (ss != st) {
             if (g_launch_stop_event == e1 || !g_ext_events) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(e1, st)); }
             HIPCHK(hipStreamWaitEvent(ss, e1, 0));
-            sh.slot_ev = m->events[m->next_event++ % m->events.size()];
-            if (g_ext_events) g_launch_stop_event = sh.slot_ev;
         }
-        PS_LAUNCH(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot);
-        if (ss != st && (g_launch_stop_event == sh.slot_ev || !g_ext_events)) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(sh.slot_ev, ss)); }
-        HIPCHK(hipGetLastError());
-        m->field_sorted = false;
-        if (!m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F)) {
-            // single-hot: one launch sorts the F fields on their own (kernels_sort.hip) instead of the 11-launch radix
-            // chain.  A composite key (owner, local row) belongs to one field only, so the runs are the same; they come
-            // field by field rather than in send order, and the embedding backward writes each run's gradient at the
-            // plan's slot of its first entry (EmbBwdArgs.out_slot).  One shard: the owner-0 field bases shorten the key.
-            if (++m->fs_epoch == 0) ++m->fs_epoch;
-            int kb = sh.sbits + bits_for(nshards);
-            const bool based = nshards == 1 && !s->emb.java_route();
-            if (based) {
-                int64_t span = 1;
-                for (int f = 0; f < F; ++f) span = std::max(span, s->emb.rows[f]);
-                kb = bits_for(span);
-            }
-            PSCHK(field_sort_segments(m->keys, based ? sh.lrb_dev : nullptr, kb, m->cur_B, F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
-                                      m->seg_start, m->seg_id, m->seg_nseg_scratch, m->long_list, m->fs_pub, m->fs_epoch, ss));
-            m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
-            m->field_sorted = true;
-        } else {
-            PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, ss));
-            PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
-        }
-        m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
-        m->side0_pending = ss != st;
+        PSCHK(plan_slots_and_lists(m, nshards, nnz, st, ss));
     } else {
         PSCHK(radix_sort_pairs(m->ws, m->keys, m->ents, nnz, sh.sbits + bits_for(nshards), true, &m->sorted_keys, &m->sorted_ents, st));
         PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, st, m->long_list, PS_EMB_SEQ_TILE));
@@ -397,9 +448,9 @@ extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int6
     HIPCHK(hipSetDevice(s->device));
     const int D = s->emb.D, vec = D % 4 == 0 ? 4 : 1, LPR = D / vec;
     if (vec == 4)
-        hipLaunchKernelGGL(k_gather_rows<4>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev);
+        hipLaunchKernelGGL(k_gather_rows<4>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"));
     else
-        hipLaunchKernelGGL(k_gather_rows<1>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev);
+        hipLaunchKernelGGL(k_gather_rows<1>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"));
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -118,6 +118,9 @@ struct ps_model {
     SortWorkspace ws;
     uint32_t *keys = nullptr, *ents = nullptr, *ent_bag = nullptr, *seg_start = nullptr, *seg_id = nullptr,
              *nseg_dev = nullptr, *uniq_row = nullptr, *uniq_cnt = nullptr;
+    uint32_t *nseg_cur = nullptr;      // nseg_dev or nseg_dev + 4: the run count of the plan the NEXT backward uses (an early plan of
+                                       // step t+1 is written while step t's backward still reads its own)
+    bool fwd_flag_valid = false;       // the running step's first forward GEMM raises start_flag[4] = fwd_epoch when it starts
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
     uint32_t *seg_nseg_scratch = nullptr;                     // run count of a side sort whose nseg the bitmap plan already wrote
     // single-hot batches: one-launch field sort (kernels_sort.hip field_sort_segments)
@@ -166,6 +169,11 @@ struct ps_model {
         hipEvent_t x_ev = nullptr, done_ev = nullptr;   // begin's work is done | finish's work was enqueued
         hipEvent_t ar_ev = nullptr, ar_done_ev = nullptr;   // flat gradient ready | reduced
         bool x_begun = false, x_side = false, done_recorded = false;
+        // the NEXT step's plan enqueued on side chain 0 while this step trains (shard_plan_enqueue, early): its slot /
+        // entry-list half still to be enqueued behind the counts' publication | epoch of "plan done" (start_flag word 7)
+        bool tail_due = false;
+        uint32_t plan_epoch = 0, pub_epoch = 0;
+        int64_t tail_nnz = 0;
     } sh;
     // host batches: pinned staging + two device slots on a copy stream (stage_batch)
     struct HostStage {
@@ -196,7 +204,8 @@ struct ps_model {
 
 // shared between ps_model.hip and ps_shard.hip
 int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
-int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback);   // ps_shard.hip
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early = false);   // ps_shard.hip
+int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st);      // early plans: the slots + the backward's entry lists
 int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
 int enqueue_backward(ps_model *m, bool apply);
 int shard_push_reserve(ps_store *s, int npeers);   // ps_shard.hip
