@@ -330,6 +330,20 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     const int nsh = comm->nranks, rank = comm->rank;
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = s->stream;
+    // PS_HOST_TIMING=1 (measurement): every 1000 calls, the host time of this call outside / inside the wait for the counts
+    static const bool host_timing = getenv("PS_HOST_TIMING") != nullptr;
+    struct HostTimer {
+        bool on; double t0, wait = 0;
+        static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+        explicit HostTimer(bool o) : on(o), t0(o ? now() : 0) {}
+        ~HostTimer() {
+            if (!on) return;
+            static thread_local double sum_all = 0, sum_wait = 0; static thread_local long calls = 0;
+            sum_all += now() - t0; sum_wait += wait;
+            if (++calls % 1000 == 0) { fprintf(stderr, "[ps_shard_step] host: %.1f us per step enqueueing, %.1f us waiting for the counts\n", (sum_all - sum_wait) / 1000, sum_wait / 1000); sum_all = sum_wait = 0; }
+        }
+    } host_timer(host_timing);
+    const double wait_t0 = host_timing ? HostTimer::now() : 0;
     {   // the step's one host wait: split sizes of every exchange (spin on the epoch word k_publish_counts raises)
         volatile uint32_t *flag = sh.matrix_host + (size_t)nsh * (nsh + 1);
         int64_t spins = 0;
@@ -342,6 +356,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             __builtin_ia32_pause();
         }
     }
+    if (host_timing) host_timer.wait = HostTimer::now() - wait_t0;
     if (sh.x_side) HIPCHK(hipStreamWaitEvent(st, sh.x_ev, 0));
     sh.x_begun = false; sh.plan_pending = false;
     const int D = m->cfg.D;
