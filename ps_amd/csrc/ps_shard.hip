@@ -353,6 +353,9 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     const bool bm = sh.bitmap != nullptr && nnz > 0 && g_plan_sort == 0;
     early = early && bm && fwd_flag && g_plan_early && g_dev_wait && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback &&
             batch->on_device && !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
+    static const bool plan_debug = getenv("PS_PLAN_DEBUG") != nullptr;      // measurement: which way did the plan go
+    if (plan_debug) fprintf(stderr, "[plan] early=%d (bitmap %d, fwd flag %d, device batch %d, single-hot %d, field sort fits %d)\n", (int)early, (int)bm,
+                            (int)fwd_flag, (int)batch->on_device, (int)!m->cur_offsets, (int)field_sort_fits(m->cur_B, F));
     hipStream_t ps = early ? m->side[0] : st;       // where the id-only kernels go
     if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps));
     m->nseg_cur = early ? (m->nseg_cur == m->nseg_dev ? m->nseg_dev + 4 : m->nseg_dev) : m->nseg_dev;

@@ -285,7 +285,12 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
         comm = CallbackComm(rank, shared, kv)
         wk = NativeWorker(gms, world, rank, ops=comm.ops, is_async=is_async)
         wk.selfcheck()                          # ps_comm_selfcheck over the plugged-in collectives (N > 1: real patterns)
-        bs = [ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]) for b in make_batches(rank, STEPS)]
+        if pipelined == "one-dev":
+            # device-resident batches: the next step's plan then runs on side chain 0 WHILE the step trains (early plan,
+            # ps_shard.hip shard_plan_enqueue), released and joined by device-side flags
+            bs = [ps_amd.DeviceBatch(kv, b["E"], b["X"], b["Y"], b["W"]) for b in make_batches(rank, STEPS)]
+        else:
+            bs = [ps_amd.Batch(b["E"], b["X"], b["Y"], b["W"]) for b in make_batches(rank, STEPS)]
         if pipelined:
             wk.run(bs, STEPS)                   # begin(t+1) on the prefetch stream before finish(t)
         else:
@@ -311,7 +316,8 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
         shared.barrier.abort()
 
 
-@pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (3, True, False), (2, True, True), (3, False, "one"), (2, True, "one")])
+@pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (3, True, False), (2, True, True), (3, False, "one"), (2, True, "one"),
+                                                        (3, False, "one-dev"), (2, True, "one-dev"), (4, False, "one-dev")])
 def test_library_driven_step_n_ranks_on_one_gpu(orc, world, is_async, pipelined):
     shared = Shared(world)
     out, errs = [None] * world, []

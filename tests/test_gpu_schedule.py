@@ -108,3 +108,45 @@ def test_plan_epoch_wraps():
     for x, y in zip(a[0] + a[1], b[0] + b[1]):
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("early", [1, 0])
+def test_pipelined_sharded_steps_on_device_batches(early):
+    """ps_shard_step's one-model pipeline on device-resident batches (what bench.py --sharded / --gpus N runs): with the next
+    step's plan on side chain 0 while the step trains (early = 1, the default) and with the plan in the step's tail (0) --
+    120 steps each, equal to 120 fused steps bit for bit (the 8-bit plan epoch does not wrap here; the run count's two
+    buffers alternate 120 times)."""
+    import ps_amd
+    from ps_amd import native as N
+    from ps_amd.sharded import NativeWorker
+    F, D, X, fc, V, B, WS = 5, 16, 3, [32, 16, 1], 500, 512, 61
+    rng = np.random.default_rng(21)
+    data = batches(rng, 9, B, F, X, V, WS)
+    res = []
+    N.lib().ps_tune_set(b"plan_early", early)
+    try:
+        for native in (False, True):
+            kv = ps_amd.KVStore(0, SEED)
+            kv.create_embedding([V] * F, D)
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+            bs = [ps_amd.DeviceBatch(kv, E, Xd, Y, W) for E, Xd, Y, W in data]
+            if native:
+                wk = NativeWorker([gm], 1, 0)
+                wk.run(bs, 120)
+                wk.close()
+            else:
+                for i in range(120):
+                    gm.train_async(bs[i % len(bs)])
+            kv.sync()
+            res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)],
+                        kv.get_wide(np.arange(WS)), kv.global_step()))
+            for b in bs:
+                b.close()
+            gm.close(); kv.close()
+    finally:
+        N.lib().ps_tune_set(b"plan_early", 1)
+    a, b = res
+    assert a[3] == b[3] == 120
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2])
