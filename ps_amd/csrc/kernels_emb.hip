@@ -692,17 +692,23 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
         const int grp = lane / a.LPR, part = lane % a.LPR;
         const bool act = grp < G;                               // D = 10: lanes 60..63 idle
         const uint32_t lbase = (uint32_t)(w - 1) * NBW + (uint32_t)(act ? grp : 0);
-        uint32_t ent[SEQ_ILP];
-        Vec<VEC> r[SEQ_ILP];
-        auto load_idx = [&](uint32_t t) {
-            const uint32_t base = s0 + (t % nbatch) * NB + lbase;
+        // TWO register sets: batch j lives in set j & 1, so the rows of two batches are in flight at any time and a batch
+        // has two iterations to arrive.  (One set: every iteration waited a full row latency, ~1.2 us x 24 iterations
+        // for the 2240-entry keys of configs[1] -- which WAS the embedding update: 29 us with the long-key role, 10.5
+        // without, ps_tune_set("seq_ablate", 2).)  No load sits under a condition: past the end the clamped last batch
+        // is fetched and parked into the buffer nobody reads again, so the compiler's wait counts stay exact.
+        uint32_t entA[SEQ_ILP], entB[SEQ_ILP];
+        Vec<VEC> rA[SEQ_ILP], rB[SEQ_ILP];
+        auto load_idx = [&](uint32_t (&ent)[SEQ_ILP], uint32_t t) {
+            const uint32_t tt = t < total ? t : total - 1;
+            const uint32_t base = s0 + (tt % nbatch) * NB + lbase;
 #pragma unroll
             for (int i = 0; i < SEQ_ILP; ++i) {
                 const uint32_t p = base + (uint32_t)i * G;
                 ent[i] = a.sorted_ent[p < e0 ? p : e0 - 1];
             }
         };
-        auto load_rows = [&]() {
+        auto load_rows = [&](Vec<VEC> (&r)[SEQ_ILP], const uint32_t (&ent)[SEQ_ILP]) {
 #pragma unroll
             for (int i = 0; i < SEQ_ILP; ++i) {
                 uint32_t bag = ent[i];
@@ -712,7 +718,7 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
                 r[i] = Vec<VEC>::load(a.delta + (size_t)b * a.ldd + (size_t)f * D + (act ? part : 0) * VEC);
             }
         };
-        auto park = [&](uint32_t t) {
+        auto park = [&](uint32_t t, const Vec<VEC> (&r)[SEQ_ILP]) {
             float *buf = lds + (t & 1u) * SEQ_LDS_FLOATS;
             if (act) {
 #pragma unroll
@@ -721,16 +727,23 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
                     for (int k = 0; k < VEC; ++k) buf[(uint32_t)(part * VEC + k) * LDE + lbase + (uint32_t)i * G] = r[i].get(k);
             }
         };
-        load_idx(0); load_rows();
-        if (total > 1) load_idx(1);
-        park(0);
-        if (total > 1) load_rows();
-        if (total > 2) load_idx(2);
+        load_idx(entA, 0); load_idx(entB, 1);
+        load_rows(rA, entA); load_idx(entA, 2);                 // batch 0; then the indices of batch 2
+        load_rows(rB, entB); load_idx(entB, 3);                 // batch 1; batch 3
+        park(0, rA);
+        load_rows(rA, entA); load_idx(entA, 4);                 // batch 2; batch 4
         __syncthreads();
-        for (uint32_t t = 0; t < total; ++t) {
-            if (t + 1 < total) park(t + 1);                     // rows of batch t+1 (issued one iteration ago)
-            if (t + 2 < total) load_rows();                     // batch t+2, from the indices fetched one iteration ago
-            if (t + 3 < total) load_idx(t + 3);
+        uint32_t t = 0;
+        for (; t + 2 <= total; t += 2) {
+            park(t + 1, rB);                                    // rows of batch t+1 (issued two iterations ago)
+            load_rows(rB, entB); load_idx(entB, t + 5);         // batch t+3 from the indices fetched two iterations ago
+            __syncthreads();
+            park(t + 2, rA);
+            load_rows(rA, entA); load_idx(entA, t + 6);         // batch t+4
+            __syncthreads();
+        }
+        if (t < total) {
+            park(t + 1, rB);
             __syncthreads();
         }
         return;                                                 // (the fold wave's last barrier is this loop's last one)
