@@ -753,6 +753,20 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
     float S[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) S[q] = 0.f;                   // 0 + g_1 = g_1 exactly (put :91)
+    // the key's row, its W and its updater state are fetched NOW, while the loaders fill the first batch: at the end they
+    // were two dependent round trips (row id -> values) on the only serial path of the kernel
+    const uint32_t row = a.sorted_key[s0];
+    float wv0[CPL], s10[CPL], s20[CPL];
+    {
+        const bool upd = a.apply != 0, st = upd && a.upd.kind != PS_UPD_SIMPLE;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int d = lane + 64 * q, dc = d < D ? d : 0;
+            wv0[q] = upd ? a.W[(size_t)row * D + dc] : 0.f;
+            s10[q] = st ? a.state[(size_t)row * 2 * D + dc] : 0.f;
+            s20[q] = st ? a.state[(size_t)row * 2 * D + D + dc] : 0.f;
+        }
+    }
     __syncthreads();
     for (uint32_t t = 0; t < total; ++t) {
         const uint32_t b = t % nbatch;
@@ -784,7 +798,6 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
         __syncthreads();
     }
     // KVStore.sum + update for this key (finish_key's arithmetic, one component per lane)
-    const uint32_t row = a.sorted_key[s0];
     if (a.out_slot) u = a.out_slot[a.sorted_ent[s0]];            // (see the short role)
     const float g0 = __shfl(S[0], 0);                           // FtrlUpdater.java:52 looks at dw[0]
 #pragma unroll
@@ -798,10 +811,10 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
         }
         if (!a.apply) continue;
         float *wp = a.W + (size_t)row * D + d;
-        float wv = *wp;
+        float wv = wv0[q];
         if (a.upd.kind == PS_UPD_SIMPLE) { *wp = (g * -a.upd.eta) + wv; continue; }
         float *sp = a.state + (size_t)row * 2 * D + d;
-        float s1 = sp[0], s2 = sp[D];
+        float s1 = s10[q], s2 = s20[q];
         if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, wv, s1, s2);
         else { if (g0 == 0.f) continue; ftrl_elem(a.upd, g, wv, s1, s2); }
         *wp = wv; sp[0] = s1; sp[D] = s2;
