@@ -51,6 +51,7 @@ struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer 
     float *part; long long part_stride; int ldpart;   // dW partial slabs, one per workgroup
     const int *skip;
     unsigned long long *ts;
+    int prio;                          // raise the waves' priority (the fused step's main chain)
 };
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);   // loss_out NULL: no loss reduction

@@ -38,6 +38,7 @@ struct NtArgs {
     unsigned long long *ts;
     unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (launch_spin_until)
     const unsigned int *wait_flag; unsigned int wait_val;   // workgroup 0 ends only once *wait_flag has reached wait_val
+    int prio;                                               // raise the waves' priority (a main-chain launch of the fused step)
 };
 
 // "This launch does not end before another chain has reached X": the first workgroup, done with its tile, holds its
@@ -78,6 +79,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
     constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
+    // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
+    // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
+    // (Armed per launch by the fused step only: in the sharded step the same priority moved the last dW GEMM under the
+    // embedding backward and gained nothing, 0.198-0.213 against 0.190-0.197 ms.)
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     EndWait end_wait(a.wait_flag, a.wait_val);       // (declared first: runs after the stamp's end)
     StampScope stamp(a.ts);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -395,8 +402,8 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"), g_launch_flag, g_launch_flag_val, g_launch_wait, g_launch_wait_val};
-    g_launch_flag = nullptr; g_launch_wait = nullptr;
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"), g_launch_flag, g_launch_flag_val, g_launch_wait, g_launch_wait_val, g_launch_prio};
+    g_launch_flag = nullptr; g_launch_wait = nullptr; g_launch_prio = 0;
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -437,11 +444,14 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 thread_local hipEvent_t g_launch_stop_event = nullptr;
 thread_local unsigned int *g_launch_flag = nullptr;     // armed like the stop event: the next gemm_nt announces its start there
 thread_local unsigned int g_launch_flag_val = 0;
+thread_local int g_launch_prio = 0;                         // armed: the next gemm_nt's waves run at raised priority
+int g_main_prio = 1;        // ps_tune_set("main_prio", 0): no raised wave priority for the fused step's main-chain kernels
 thread_local const unsigned int *g_launch_wait = nullptr;   // armed: the next gemm_nt's first workgroup ends only once *g_launch_wait reached the value
 thread_local unsigned int g_launch_wait_val = 0;
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
+int g_sort_late = 0;        // ps_tune_set("sort_late", 1): the single-hot field sort behind the first delta GEMM's release instead of the first forward GEMM's
 int g_end_wait = 1;         // ps_tune_set("end_wait", 0): the main chain joins side chain 0 behind a spinner launch again
 int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again

@@ -137,6 +137,9 @@ extern thread_local unsigned int *g_launch_flag;       // armed: the next gemm_n
 extern thread_local unsigned int g_launch_flag_val;
 extern thread_local const unsigned int *g_launch_wait;   // armed: the next gemm_nt does not end before *g_launch_wait reached g_launch_wait_val
 extern thread_local unsigned int g_launch_wait_val;
+extern thread_local int g_launch_prio;                   // armed: the next gemm_nt's waves run at raised priority (s_setprio)
+extern int g_main_prio;
+extern int g_sort_late;
 extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11, g_end_wait, g_radix_scan_free, g_plan_early;
 int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st);
 int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order   // a one-wave kernel that ends when *flag == val

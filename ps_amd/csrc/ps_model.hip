@@ -333,6 +333,7 @@ static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
     if (l > 0) { q.dprev = m->fc[l - 1].dOut; q.ldp = m->fc[l - 1].ldD; q.dprev_cols = p.K; q.mask_cols = p.K; }
     else { q.dprev = m->dx; q.ldp = m->ldx; q.dprev_cols = c.F * c.D; q.mask_cols = c.F * c.D; }
     q.part = b.part; q.part_stride = b.part_stride; q.ldpart = b.ldp; q.skip = nullptr;
+    q.prio = (g_main_prio && !m->sh.active) ? 1 : 0;
 }
 
 // Can the backward of this step release its side chains by device flags (launch_spin_until) instead of events?
@@ -341,6 +342,22 @@ static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
 static bool dev_release(const ps_model *m) {
     const ps_model_config_t &c = m->cfg;
     return g_dev_wait && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1;
+}
+
+// the one-launch field sort of a single-hot batch (keys left in m->keys by the gather) on stream ss
+static int enqueue_field_sort(ps_model *m, hipStream_t ss) {
+    ps_store *s = m->s;
+    const ps_model_config_t &c = m->cfg;
+    Prof pf(m, "emb_sort");
+    if (++m->fs_epoch == 0) ++m->fs_epoch;
+    int64_t span = 1;
+    for (int f = 0; f < c.F; ++f) span = std::max(span, s->emb.row_base[f + 1] - s->emb.row_base[f]);
+    PSCHK(field_sort_segments(m->keys, s->emb.row_base_dev, bits_for(span), m->cur_B, c.F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
+                              m->seg_start, m->seg_id, m->nseg_dev, m->long_list, m->fs_pub, m->fs_epoch, ss));
+    m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
+    m->long_list_valid = true; m->nlong_ptr = m->nseg_dev + 1; m->field_sorted = true;
+    m->side0_pending = true;
+    return PS_OK;
 }
 
 int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
@@ -432,7 +449,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     };
     if (sort_dev) m->field_sorted = true;            // (dev_release() below looks at it before the sort is enqueued)
     else if (train && !m->sh.active) PSCHK(enqueue_sort());
-    bool sort_due = sort_dev;
+    // late: the sort is not released by the first forward GEMM but enqueued by the backward behind the first delta GEMM's
+    // release -- beside the forward GEMMs its 26 workgroups share CUs with fc_fwd1's one-workgroup-per-CU grid
+    const bool sort_late = sort_dev && g_sort_late;
+    m->sort_deferred = false;
+    bool sort_due = sort_dev && !sort_late;
     // sharded worker: the first forward GEMM announces its start too -- everything of this step in front of it (the id and
     // row exchanges, the gather) is then done, which is what the NEXT step's plan waits for on side chain 0
     bool fwd_flag_due = train && m->sh.active && g_dev_wait && !c.use_graph && !m->profile && m->multi_stream;
@@ -448,6 +469,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
         Prof pf(m, names[l]);
         if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; g_launch_flag = m->start_flag + 4; g_launch_flag_val = m->fwd_epoch; }
+        g_launch_prio = (g_main_prio && train && !m->sh.active) ? 1 : 0;
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st));
         if (fwd_flag_due) {
@@ -496,6 +518,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     } else {
         Prof pf(m, "head");
         PSCHK(launch_head(h, nullptr, nullptr, nullptr, 0, st));
+    }
+    if (sort_late) {
+        if (dev_release(m) && m->head_bwd_done && m->side[1] != st) m->sort_deferred = true;     // (enqueue_backward: first release)
+        else { PSCHK(fork(m, st, side_stream(m, 0))); PSCHK(enqueue_field_sort(m, side_stream(m, 0))); }
     }
     m->loss_pending = h.labels != nullptr;
     if (m->loss_pending && !defer_loss) {
@@ -667,6 +693,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
         if (l > 0) {
             Prof pf(m, nd[l]);
+            g_launch_prio = (g_main_prio && !m->sh.active) ? 1 : 0;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
         } else {
@@ -679,6 +706,7 @@ int enqueue_backward(ps_model *m, bool apply) {
                 g_launch_wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
             }
             const bool armed = g_launch_wait != nullptr;
+            g_launch_prio = (g_main_prio && !m->sh.active) ? 1 : 0;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
             s0_joined = armed && g_launch_wait == nullptr;
@@ -691,6 +719,7 @@ int enqueue_backward(ps_model *m, bool apply) {
             PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw));
             if (first_release) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
                 if (sl != sw) PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sl));
+                if (m->sort_deferred) { PSCHK(enqueue_field_sort(m, sl)); m->sort_deferred = false; }
                 PSCHK(small_kernels());
                 first_release = false;
             }

@@ -224,6 +224,8 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "dev_wait") == 0) { g_dev_wait = value; return PS_OK; }
     if (strcmp(knob, "tail_dev") == 0) { g_tail_dev = value; return PS_OK; }
     if (strcmp(knob, "end_wait") == 0) { g_end_wait = value; return PS_OK; }
+    if (strcmp(knob, "main_prio") == 0) { g_main_prio = value; return PS_OK; }
+    if (strcmp(knob, "sort_late") == 0) { g_sort_late = value; return PS_OK; }
     if (strcmp(knob, "plan_early") == 0) { g_plan_early = value; return PS_OK; }
     if (strcmp(knob, "radix_scan_free") == 0) { g_radix_scan_free = value; return PS_OK; }
     if (strcmp(knob, "gemm_8w") == 0) { g_gemm_8w = value; return PS_OK; }

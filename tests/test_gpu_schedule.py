@@ -65,7 +65,8 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
     variants = {"plain events": ({"ext_events": 0}, False), "general sort": ({"field_sort": 0}, False),
                 "dW chain released by event": ({"dev_wait": 0}, False), "dense update on the main chain": ({"tail_dev": 0}, False),
                 "side chain 0 joined behind a spinner": ({"end_wait": 0}, False),
-                "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
+                "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
+                "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
     for name, (knobs, profile) in variants.items():
         got = run(kind, knobs, profile, data, F, D, X, fc, V, B, WS)
