@@ -834,6 +834,8 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
     if (SEQ && (int)blockIdx.x < a.long_blocks) {
+        if (a.ablate & 2) return;                               // measurement: the kernel without its long-key role
+        // (raised wave priority for these workgroups only: measured worse, 0.1515 against 0.1493 ms/step)
         if (a.long_list) {
             // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
             const uint32_t nl = *a.nlong;
@@ -856,6 +858,7 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         long_key_run<VEC, BAG>(a, seq_lds, u, s0, e0);
         return;
     }
+    if (SEQ && (a.ablate & 4)) return;                          // measurement: the kernel without its short-key role
     const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
     const int gpw = 64 / a.LPR;
