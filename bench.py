@@ -389,7 +389,9 @@ def main():
     ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
     args = ap.parse_args()
-    if os.environ.get("PS_TUNE"):           # measurement: ps_tune_set knobs for A/B runs, "knob=value,knob=value"
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("PS_TUNE") and not (args.gpus > 1 or world_env > 1 or args.sharded):     # (sharded: applied after torch is loaded)
+        # measurement: ps_tune_set knobs for A/B runs, "knob=value,knob=value"
         from ps_amd import native as N_
         for kv_ in os.environ["PS_TUNE"].split(","):
             if "=" in kv_:

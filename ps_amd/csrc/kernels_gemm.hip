@@ -82,8 +82,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
     // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
     // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
     // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
-    // (Armed per launch by the fused step only: in the sharded step the same priority moved the last dW GEMM under the
-    // embedding backward and gained nothing, 0.198-0.213 against 0.190-0.197 ms.)
+    // Every GEMM of the step (NT and TN) and the head carry it -- armed per launch by the model, single-hot steps only:
+    // with the NT GEMMs alone 0.1495 ms/step, with all of them 0.1469 (the dW GEMMs no longer fall behind), and the
+    // sharded step settles at 0.189-0.193.
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     EndWait end_wait(a.wait_flag, a.wait_val);       // (declared first: runs after the stamp's end)
     StampScope stamp(a.ts);
@@ -253,6 +254,7 @@ struct TnArgs {
     const int *skip;
     int xcd_swizzle;
     unsigned long long *ts;
+    int prio;        // raise the waves' priority (armed per launch like NtArgs.prio)
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     constexpr int A_F4 = (BKT * BM / 4 + 255) / 256, B_F4 = (BKT * BN / 4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BKT * BM];
     __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
+    if (a.prio) __builtin_amdgcn_s_setprio(3);       // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates)
     StampScope stamp(a.ts);
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -522,7 +525,8 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
         return ps_set_err(PS_E_BAD_ARG, "gemm_tn: leading dims / cols must be multiples of 4");
     if (Kout <= 0 || N <= 0 || nsplit <= 0) return PS_OK;
     const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), 32);
-    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn")};
+    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn"), g_launch_prio};
+    g_launch_prio = 0;
     int cfg = g_gemm_tn_cfg;
     if (cfg == 0) cfg = N <= 32 ? 5 : 2;
     switch (cfg) {

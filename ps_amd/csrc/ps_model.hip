@@ -319,6 +319,11 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // ---------------------------------------------------------------------------
 // the three phases, enqueued on the store's stream
 // ---------------------------------------------------------------------------
+// Raised wave priority for the step's GEMMs and head (s_setprio, kernels_gemm.hip): where the critical path is the FC chain
+// (single-hot: fused and sharded step).  A multi-hot step is bound by its sort chain and the sum of its kernels, and the
+// priority takes from exactly those: 0.387 against 0.382 ms.
+static bool gemm_prio(const ps_model *m) { return g_main_prio && m->cur_offsets == nullptr; }
+
 // FcLayer.backward arguments of the out = 1 layer (layer/FcLayer.java:93-110): delta_prev = W^T delta (outer
 // product) and dW/db (column sums over the batch) in one pass over the layer's input instead of two sliver GEMMs
 static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
@@ -333,7 +338,7 @@ static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
     if (l > 0) { q.dprev = m->fc[l - 1].dOut; q.ldp = m->fc[l - 1].ldD; q.dprev_cols = p.K; q.mask_cols = p.K; }
     else { q.dprev = m->dx; q.ldp = m->ldx; q.dprev_cols = c.F * c.D; q.mask_cols = c.F * c.D; }
     q.part = b.part; q.part_stride = b.part_stride; q.ldpart = b.ldp; q.skip = nullptr;
-    q.prio = (g_main_prio && !m->sh.active) ? 1 : 0;
+    q.prio = gemm_prio(m) ? 1 : 0;
 }
 
 // Can the backward of this step release its side chains by device flags (launch_spin_until) instead of events?
@@ -469,7 +474,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
         Prof pf(m, names[l]);
         if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; g_launch_flag = m->start_flag + 4; g_launch_flag_val = m->fwd_epoch; }
-        g_launch_prio = (g_main_prio && train && !m->sh.active) ? 1 : 0;
+        g_launch_prio = (train && gemm_prio(m)) ? 1 : 0;
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st));
         if (fwd_flag_due) {
@@ -693,7 +698,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
         if (l > 0) {
             Prof pf(m, nd[l]);
-            g_launch_prio = (g_main_prio && !m->sh.active) ? 1 : 0;
+            g_launch_prio = gemm_prio(m) ? 1 : 0;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
         } else {
@@ -706,7 +711,7 @@ int enqueue_backward(ps_model *m, bool apply) {
                 g_launch_wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
             }
             const bool armed = g_launch_wait != nullptr;
-            g_launch_prio = (g_main_prio && !m->sh.active) ? 1 : 0;
+            g_launch_prio = gemm_prio(m) ? 1 : 0;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
             s0_joined = armed && g_launch_wait == nullptr;
@@ -727,6 +732,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
+        g_launch_prio = gemm_prio(m) ? 1 : 0;
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
                              b.nsplit, nullptr, dws));
     }

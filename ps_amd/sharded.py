@@ -547,6 +547,9 @@ def run_bench(args, cfg, synth_batch):
     import torch.distributed as dist
     import ps_amd
 
+    for kv_ in os.environ.get("PS_TUNE", "").split(","):      # measurement knobs (bench.py applies them itself on the fused path)
+        if "=" in kv_:
+            N.lib().ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
