@@ -151,3 +151,41 @@ def test_pipelined_sharded_steps_on_device_batches(early):
     for x, y in zip(a[0] + a[1], b[0] + b[1]):
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[2], b[2])
+
+
+def test_counter_collecting_profiler_guard():
+    """rocprofv3 --pmc runs one kernel at a time in an order of its own; a kernel waiting for another stream's flag then
+    deadlocks (round 2 lost two 600 s PMC passes to it).  libps_amd reads ROCPROF_COUNTER_COLLECTION when it is loaded and
+    uses the event form of every join: a fresh process with the variable set trains the same steps to the same tables."""
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+import ps_amd
+F, D, X, fc, V, B, WS = 6, 16, 5, [64, 32, 1], 3000, 2048, 97
+rng = np.random.default_rng(5)
+kv = ps_amd.KVStore(0, 0x5EED)
+kv.create_embedding([V] * F, D)
+gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+h = hashlib.sha256()
+for _ in range(5):
+    E = np.minimum(rng.zipf(1.2, (B, F)) - 1, V - 1).astype(np.int64)
+    loss = gm.train({"E": E, "X": rng.standard_normal((B, X)).astype(np.float32), "Y": (rng.random(B) < 0.3).astype(np.float32), "W": E %% WS})
+    h.update(np.float32(loss).tobytes())
+for f in range(F):
+    h.update(kv.get_rows(f, np.arange(V)).tobytes())
+for i in range(3):
+    h.update(kv.get("fc%%d.weights" %% i).tobytes())
+print(json.dumps({"digest": h.hexdigest()}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for guard in (False, True):
+        env = dict(os.environ)
+        env.pop("ROCPROF_COUNTER_COLLECTION", None)
+        if guard:
+            env["ROCPROF_COUNTER_COLLECTION"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(json.loads(r.stdout.strip().splitlines()[-1])["digest"])
+    assert out[0] == out[1]
