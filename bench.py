@@ -27,17 +27,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA peak (exact f32; no TF32 on gfx950)
 
-C2 = dict(F=26, V=100000, D=16, X=13, fc=[512, 256, 1], B=4096, wide=100000, zipf=1.05, seed=0x5EED)
+C2 = dict(F=26, V=100000, D=16, X=13, fc=[512, 256, 1], B=4096, wide=100000, zipf=1.05, seed=0x5EED, idgen="zipf_truncated")
 
 
 def synth_batch(cfg, rng, B=None):
-    """ids ~ Zipf(1.05) over V per field, dense ~ N(0,1), labels ~ Bernoulli(0.25),
-    wide ids = id mod wideSize (CTR.java:65, MatrixUtil.hash)."""
+    """ids ~ Zipf(1.05) over V per field (the TRUNCATED law over ranks 1..V, drawn by inverse CDF:
+    ps_amd/synth.py), dense ~ N(0,1), labels ~ Bernoulli(0.25), wide ids = id mod wideSize (CTR.java:65,
+    MatrixUtil.hash).  cfg["idgen"]: "zipf_truncated" (default), "zipf_clamped" (rounds 1-2: unbounded Zipf
+    clamped to V - 1, 55 % of the draws on one row per field), "uniform" (SURVEY 8d's variant)."""
+    from ps_amd import synth
     B = B or cfg["B"]
-    if cfg["zipf"] > 1.0:
-        E = np.minimum(rng.zipf(cfg["zipf"], size=(B, cfg["F"])) - 1, cfg["V"] - 1).astype(np.int64)
-    else:
-        E = rng.integers(0, cfg["V"], size=(B, cfg["F"])).astype(np.int64)     # uniform variant (SURVEY 8d)
+    gen = cfg.get("idgen", "zipf_truncated") if cfg["zipf"] > 1.0 else "uniform"
+    E = synth.draw_ids(rng, cfg["zipf"], cfg["V"], (B, cfg["F"]), gen)
     X = rng.standard_normal((B, cfg["X"])).astype(np.float32)
     Y = (rng.random(B) < 0.25).astype(np.float32)
     return E, X, Y, E % cfg["wide"]
@@ -187,6 +188,8 @@ def run_single(args):
     import ps_amd
     cfg = dict(C2)
     cfg["zipf"] = args.zipf
+    cfg["idgen"] = args.idgen
+    from ps_amd import synth
     rng = np.random.default_rng(cfg["seed"])
     kv = ps_amd.KVStore(0, cfg["seed"])
     kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
@@ -196,11 +199,14 @@ def run_single(args):
     # with a handful of batches it does within ~1500 steps, the loss falls under the reference's stop threshold
     # (model/DNN.java:58-63: loss <= 0.01 -> no backward) and the step would silently get cheaper
     nb = min(4096, max(64, (args.steps + args.warmup + 20) // 8))   # a batch is seen at most ~8 times
-    batches = []
+    batches, stats = [], []
     for _ in range(nb):
         E, X, Y, W = synth_batch(cfg, rng)
         batches.append(ps_amd.DeviceBatch(kv, E, X, Y, W))
-    uniq = sum(len(np.unique(E[:, f])) for f in range(cfg["F"]))
+        if len(stats) < 16:
+            stats.append(synth.id_stats(E))
+    uniq = int(round(np.mean([s_["unique_keys"] for s_ in stats])))      # unique (field, id) keys of a batch, mean of 16
+    hottest = int(max(s_["hottest_run"] for s_ in stats))               # longest run of one key in one field
     nnz = cfg["B"] * cfg["F"]
     for i in range(max(args.warmup, 1)):          # untimed warm-up (module load, caches, clocks)
         gm.train_async(batches[i % nb])
@@ -283,7 +289,10 @@ def run_single(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Wide&Deep synthetic, 26 sparse fields x 100k vocab x 16-dim emb, "
                                "13 dense, FC[512,256,1], batch 4096, Zipf(1.05) ids, Adam + Ftrl(wide), 1 MI355X",
-                   "global_batch": cfg["B"], "parallelism": "single", "resident_inputs": True, "hip_graph": bool(args.graph)},
+                   "global_batch": cfg["B"], "parallelism": "single", "resident_inputs": True, "hip_graph": bool(args.graph),
+                   # "ids ~ Zipf(1.05) over V": the truncated law by inverse CDF (ps_amd/synth.py)
+                   "id_generator": ("uniform" if cfg["zipf"] <= 1.0 else cfg["idgen"]) + ("(alpha=%g, V=%d)" % (cfg["zipf"], cfg["V"])),
+                   "lookups_per_batch": nnz, "unique_keys_per_batch": uniq, "hottest_run": hottest},
         "roofline": roof,
         "roofline_groups": roof_groups,
         # all FC flops of the step / step time / f32 MFMA peak: the matrix cores' utilisation over the WHOLE step
@@ -300,6 +309,32 @@ def run_single(args):
         nthr = min(os.cpu_count() or 1, 64)
         if nthr > 1:
             out["cpu_baseline_threads"] = cpu_baseline_threads(cfg, nthr)
+    if args.clamped and cfg["zipf"] > 1.0 and cfg["idgen"] != "zipf_clamped":
+        # rounds 1-2's id generator (unbounded Zipf clamped to V - 1) on the same model, so the change of workload is visible
+        for b in batches:
+            b.close()
+        batches = []
+        cfg_c = dict(cfg, idgen="zipf_clamped")
+        rng_c = np.random.default_rng(cfg["seed"])
+        st_c = []
+        for _ in range(64):
+            E, X, Y, W = synth_batch(cfg_c, rng_c)
+            batches.append(ps_amd.DeviceBatch(kv, E, X, Y, W))
+            if len(st_c) < 16:
+                st_c.append(synth.id_stats(E))
+        nsteps = min(args.steps, 1000)
+        for i in range(64):
+            gm.train_async(batches[i])
+        gm.sync()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            gm.train_async(batches[i % 64])
+        gm.sync()
+        dtc = time.perf_counter() - t0
+        out["zipf_clamped"] = {"id_generator": "zipf_clamped(alpha=%g, V=%d): min(Zipf - 1, V - 1), rounds 1-2" % (cfg["zipf"], cfg["V"]),
+                               "steps": nsteps, "ms_per_step": 1e3 * dtc / nsteps, "examples_per_s": cfg["B"] * nsteps / dtc,
+                               "unique_keys_per_batch": int(round(np.mean([s_["unique_keys"] for s_ in st_c]))),
+                               "hottest_run": int(max(s_["hottest_run"] for s_ in st_c))}
     if args.gather:
         out["gather_hbm"] = gather_roofline(kv, args)
     if args.multi_hot:
@@ -317,6 +352,7 @@ def multi_hot_step(cfg, steps=60):
     """BASELINE configs[4]'s shape on this GPU (reported beside the headline, not part of `value`): the same model with
     Poisson(30) ids per (sample, field) -- ~3.2 M ids per step -- Zipf(1.05), sum pooling, FTRL on the embedding rows."""
     import ps_amd
+    from ps_amd import synth
     rng = np.random.default_rng(cfg["seed"] + 5)
     B, F, V = cfg["B"], cfg["F"], cfg["V"]
     kv = ps_amd.KVStore(0, cfg["seed"])
@@ -327,7 +363,7 @@ def multi_hot_step(cfg, steps=60):
         lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         nnz = int(offsets[-1]); nnz_max = max(nnz_max, nnz); nnz_sum += nnz
-        ids = np.minimum(rng.zipf(1.05, size=nnz) - 1, V - 1).astype(np.int64)
+        ids = synth.draw_ids(rng, 1.05, V, nnz, cfg.get("idgen", "zipf_truncated"))
         W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)
         bs.append(ps_amd.DeviceBatch(kv, ids, rng.standard_normal((B, cfg["X"])).astype(np.float32),
                                      (rng.random(B) < 0.25).astype(np.float32), W, offsets))
@@ -345,6 +381,7 @@ def multi_hot_step(cfg, steps=60):
         b.close()
     gm.close(); kv.close()
     return {"workload": "configs[4] shape on 1 GPU: bags of Poisson(30) ids per (sample, field), Zipf(1.05), FTRL rows, batch 4096",
+            "id_generator": cfg.get("idgen", "zipf_truncated"),
             "ids_per_step": nnz_sum // 16, "ms_per_step": 1e3 * dt, "examples_per_s": B / dt, "ids_per_s": nnz_sum / 16 / dt,
             "final_loss": loss}
 
@@ -377,6 +414,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--zipf", type=float, default=1.05, help="id distribution exponent; <= 1 means uniform")
+    ap.add_argument("--idgen", default="zipf_truncated", choices=["zipf_truncated", "zipf_clamped"],
+                    help="zipf_truncated = Zipf(alpha) over V by inverse CDF (SURVEY 8d); zipf_clamped = rounds 1-2's min(Zipf - 1, V - 1)")
+    ap.add_argument("--clamped", type=int, default=1, help="also time the rounds 1-2 generator (zipf_clamped) as an extra entry")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="run the sharded (multi-GPU) path even at N=1")
     ap.add_argument("--is-async", type=int, default=0, help="async push (-DisPsAsync=1): no averaging, arrival order")

@@ -21,6 +21,7 @@ CASES = [
     (1024, [1 << 20, 9], "rand"),
     (1500, [300, 70000], "same"),
     (4096, [100000] * 5, "zipf"),
+    (4096, [100000] * 5, "zipf_trunc"),
     (5000, [2000, 100000, 33], "zipf"),
     (8192, [50000, 8], "distinct"),
 ]
@@ -33,8 +34,11 @@ def make_ids(rng, B, vocab, pattern):
             c = np.full(B, V - 1, np.int64)
         elif pattern == "distinct" and V >= B:
             c = rng.permutation(V)[:B].astype(np.int64)
-        elif pattern == "zipf":
+        elif pattern == "zipf":            # rounds 1-2's generator: the unbounded tail piles up on id V - 1
             c = np.minimum(rng.zipf(1.05, B) - 1, V - 1).astype(np.int64)
+        elif pattern == "zipf_trunc":      # Zipf(1.05) over V by inverse CDF
+            from ps_amd import synth
+            c = synth.zipf_truncated(rng, 1.05, V, B)
         else:
             c = rng.integers(0, V, B).astype(np.int64)
         cols.append(c)

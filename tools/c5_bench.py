@@ -16,7 +16,7 @@ for _ in range(4):
     lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     nnz = int(offsets[-1]); nnz_tot += nnz
-    ids = (rng.integers(0, V, size=nnz) if 'uniform' in sys.argv else np.minimum(rng.zipf(1.05, size=nnz) - 1, V - 1)).astype(np.int64)
+    ids = (rng.integers(0, V, size=nnz) if 'uniform' in sys.argv else __import__('ps_amd.synth', fromlist=['x']).draw_ids(rng, 1.05, V, nnz, 'zipf_clamped' if 'clamped' in sys.argv else 'zipf_truncated')).astype(np.int64)
     uniq = len(np.unique(ids + V * (np.repeat(np.arange(B * F), lens) % F)))
     X = rng.standard_normal((B, cfg["X"])).astype(np.float32); Y = (rng.random(B) < 0.25).astype(np.float32)
     W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)

@@ -25,7 +25,7 @@ if os.environ.get("MULTI_HOT"):           # configs[4]'s shape: Poisson(30) ids 
         lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         nnz_max = max(nnz_max, int(offsets[-1]))
-        ids = np.minimum(rng.zipf(1.05, size=int(offsets[-1])) - 1, V - 1).astype(np.int64)
+        ids = __import__('ps_amd.synth', fromlist=['x']).draw_ids(rng, 1.05, V, int(offsets[-1]))
         bs.append(ps_amd.DeviceBatch(kv, ids, rng.standard_normal((B, cfg["X"])).astype(np.float32), (rng.random(B) < 0.25).astype(np.float32),
                                      rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64), offsets))
     gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=B, max_nnz=nnz_max)

@@ -17,7 +17,7 @@ for _ in range(4):
     lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     nnz = int(offsets[-1]); nnz_max = max(nnz_max, nnz)
-    ids = np.minimum(rng.zipf(1.05, size=nnz) - 1, V - 1).astype(np.int64)
+    ids = __import__('ps_amd.synth', fromlist=['x']).draw_ids(rng, 1.05, V, nnz)
     W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)
     bs.append(ps_amd.DeviceBatch(kv, ids, rng.standard_normal((B, cfg["X"])).astype(np.float32),
                                  (rng.random(B) < 0.25).astype(np.float32), W, offsets))
