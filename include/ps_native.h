@@ -144,6 +144,10 @@ int ps_store_advance_global_step(ps_store_t *s, int64_t by);
  * is_async = 1: one updater step per message, in order.  All arithmetic on
  * the device (the kernels of the hot path); the updater of a key is the one
  * ps_store_set_updater resolves for it.  Does not touch globalStep. */
+/* floats a push / upsert of `key` must carry on this shard; PS_MISSING for a key the store does not hold (the facade
+ * validates a BSP push when it arrives, net/PServer.java:164-175, not when the round's last barrier applies it).
+ * ps_store_push_update itself validates EVERY message before it touches the store: a bad one fails the call whole. */
+int ps_store_key_length(const ps_store_t *s, const char *key, int *len_out);
 int ps_store_push_update(ps_store_t *s, int n, const char *const *keys, const float *const *grads,
                          const int *lens, int is_async);
 /* bytes of HBM held by the store */
@@ -501,6 +505,13 @@ int ps_bench_gather_check(ps_store_t *s, int64_t rows, int D, int64_t n, int bag
 /* GEMM micro-benchmark: kind 0 = C[M][N] = A[M][K] * Bt[N][K]^T (FcLayer forward / delta),
  * kind 1 = split-K dW[K][N] = A[M][K]^T * D[M][N].  Average ms per launch (HIP events). */
 int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int nsplit, int iters, double *avg_ms_out);
+/* How this store's models join their streams: 1 = device-side flags (every wait bounded: a waiter that does not see
+ * its flag within the timeout -- ps_tune_set("spin_timeout_ms"), 2000 by default -- is counted, the next call that
+ * waits on the store's stream returns PS_E_STATE and the store switches to events), 0 = events.  The event form is
+ * chosen up front under ROCPROF_COUNTER_COLLECTION, HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, HSA_ENABLE_DEBUG,
+ * GPU_MAX_HW_QUEUES < 4, and while more than one model of this process drives the device.  why: the reason ("" for 1). */
+int ps_store_join_mode(const ps_store_t *s, char *why, int why_cap);
+int64_t ps_store_wait_timeouts(const ps_store_t *s);     /* device-side waits that timed out on this store so far */
 /* tuning knobs for experiments ("gemm_nt_cfg": 0 auto, 1 128x128, 2 64x128, 3 64x64, 4 128x32 tiles) */
 int ps_tune_set(const char *knob, int value);
 /* Run `steps` training steps on `batch` back to back, timed with HIP events

@@ -200,6 +200,12 @@ class KVStore:
     def advance_global_step(self, by=1):
         N.check(N.lib().ps_store_advance_global_step(self.h, by))
 
+    def key_length(self, key):
+        """floats a push of `key` must carry on this shard (raises PsError PS_MISSING for a key the store does not hold)"""
+        n = C.c_int()
+        N.check(N.lib().ps_store_key_length(self.h, key.encode(), C.byref(n)))
+        return n.value
+
     def push_update(self, messages, is_async=False):
         """PServer.push x n + psUpdate (net/PServer.java:164-214) by string key: messages = [(key, gradient), ...] in
         ARRIVAL order.  BSP: every key's pushes summed in arrival order, / count, one updater step; async: one step per

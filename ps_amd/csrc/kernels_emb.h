@@ -23,7 +23,7 @@ struct EmbFwdArgs {
     int LPR, gather_blocks;    // filled by the launcher
     unsigned long long *ts;    // stamp slot (ps_common.h) or nullptr, set by the launcher
 };
-int launch_emb_fwd(EmbFwdArgs a, hipStream_t st);
+int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr);        // lo: stop_event
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st);      // multi-hot: key_out / ent_bag from the ids alone
 
 struct HeadArgs {
@@ -56,7 +56,7 @@ struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer 
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);   // loss_out NULL: no loss reduction
 int launch_loss_reduce(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);
-int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st);
+int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st, LaunchOpts *lo = nullptr);   // lo: stop_event
 int head_last_bwd_fusable(int rows_per_wg);
 
 #define PS_EMB_SEQ_TILE 16             // sequential order: runs above this many entries are "long" (own workgroup)
@@ -83,8 +83,10 @@ struct EmbBwdArgs {
     int LPR;
     unsigned long long *ts;
     unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (set by the launcher)
+    const unsigned int *end_wait; unsigned int end_val; WaitBound bound;   // the last launch's first workgroup ends only once *end_wait reached end_val
 };
-int launch_emb_bwd(EmbBwdArgs a, hipStream_t st);
+int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: flag (the first launch announces its
+                                                                                   // start), wait (the last launch's end wait)
 
 struct WideUpdArgs {
     int64_t rows;
@@ -121,6 +123,11 @@ struct DenseUpdArgs {
     // filling it and applying it are one kernel each instead of two); wide_blocks = 0: none
     WideUpdArgs wide;
     int wide_blocks, tile_blocks;
+    // the fused step's tail: the update starts only once *wait_flag reached wait_val (the embedding update has started =
+    // the last delta GEMM, which reads W_0, has finished) and raises *done_flag = done_val itself when its last
+    // workgroup is through (ps_common.h start_wait / DoneSignal); all NULL otherwise
+    const unsigned int *wait_flag; unsigned int wait_val; WaitBound bound;
+    unsigned int *done_counter, *done_flag; unsigned int done_val;
 };
 int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)

@@ -827,6 +827,7 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
 template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
+    EndWait end_wait(a.end_wait, a.end_val, a.bound);       // (declared first: runs after the stamp's end; every return path)
     // (no raised wave priority here: the dW GEMM and the dense update that run beside this kernel END the step's side
     //  chain -- with this kernel ahead of them the step got longer, 0.1530 against 0.1493 ms)
     StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);
@@ -1063,7 +1064,9 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
 // 5.6 MB of tensors).
 __device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int64_t r);
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
+    DoneSignal done(a.done_counter, a.done_flag, a.done_val);       // (every return path below counts this workgroup)
     StampScope stamp(a.ts);
+    start_wait(a.wait_flag, a.wait_val, a.bound);
     if ((int)blockIdx.x >= a.tile_blocks) {                // the optional wide-table pass of the same launch
         wide_update_body(a.wide, (int64_t)((int)blockIdx.x - a.tile_blocks) * 256 + threadIdx.x);
         return;
@@ -1311,7 +1314,9 @@ int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st) {
     return PS_OK;
 }
 
-int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
+int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo) {
+    if (lo) lo->launched = false;
+    const hipEvent_t stop_ev = lo ? lo->stop_event : nullptr;
     // rows of tables far beyond the 256 MiB Infinity Cache are read once: non-temporal loads (measured on the 256 GB
     // table, tools/gather_nt.py: bags of 32 0.671 -> 0.707 of 8 TB/s, single-hot read+write 0.663 -> 0.694; nt stores: no effect)
     a.nt = a.table_bytes > ((size_t)1 << 30) ? 1 : 0;
@@ -1338,8 +1343,9 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st) {
 #define EMB_FWD_LAUNCH(V)                                                                                          \
     do {                                                                                                           \
         if (multi) { if (slot) EMB_FWD_MH(V, true); else EMB_FWD_MH(V, false); }                                   \
-        else { if (slot) PS_LAUNCH((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, a);                \
-               else PS_LAUNCH((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, a); }                   \
+        else { if (slot) PS_LAUNCH_EV((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a);   \
+               else PS_LAUNCH_EV((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a);        \
+               if (lo) lo->launched = true; }                                                                      \
     } while (0)
     if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0)
         hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);
@@ -1357,7 +1363,9 @@ int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, 
     return PS_OK;
 }
 
-int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
+int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
+    if (lo) lo->launched = false;
+    a.end_wait = lo ? lo->wait : nullptr; a.end_val = lo ? lo->wait_val : 0u; a.bound = wait_bound(werr, 102);
     const int vec = (a.D % 4 == 0) ? 4 : 1;
     a.LPR = a.D / vec;
     if (a.nnz <= 0) return PS_OK;
@@ -1370,8 +1378,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     a.ablate = g_seq_ablate;
     if (!a.seq_order) { a.ts_partials = stamp_next("emb_partials"); if (a.long_runs) a.ts_super = stamp_next("emb_super"); }
     a.ts = stamp_next("emb_bwd_update");
-    a.flag = g_launch_flag; a.flag_val = g_launch_flag_val;      // armed by the caller (ps_common.h): consumed here
-    g_launch_flag = nullptr;
+    a.flag = lo ? lo->flag : nullptr; a.flag_val = lo ? lo->flag_val : 0;      // "this launch has started" (LaunchOpts, ps_common.h)
     // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
     // long runs, a fixed grid walks that list
     a.long_blocks = !a.seq_order ? 0 : a.long_list ? SEQ_LONG_GRID : cdiv(a.nnz, SEQ_TILE);
@@ -1389,6 +1396,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st) {
     else { if (bag) EMB_BWD_LAUNCH(1, true); else EMB_BWD_LAUNCH(1, false); }
 #undef EMB_BWD_LAUNCH
     HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
     return PS_OK;
 }
 
@@ -1424,6 +1432,10 @@ __global__ __launch_bounds__(256) void k_dense_prereduce(float *__restrict__ par
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st) {
     DenseLayer &L = a.L[l];
     if (a.flat_grad || !(L.nsplit > 32 && L.nsplit <= 256)) return PS_OK;
+    // A row window (the keyed push: "fc<i>.weights" / "fc<i>.bias" slabs hold only their own rows behind a shifted base)
+    // is not a full (K+1) x N slab: the fold would read and write outside it, and its butterfly is not the arrival order
+    // KVStore.sum adds in.  k_dense_update walks such slabs itself, in order.
+    if (L.row_cnt > 0) return PS_OK;
     const int64_t elems = (int64_t)(L.K + 1) * L.N;
     hipLaunchKernelGGL(k_dense_prereduce, dim3(cdiv(elems, 4)), dim3(256), 0, st, const_cast<float *>(L.part), L.part_stride, L.ldp, L.N, elems, L.nsplit);
     HIPCHK(hipGetLastError());
@@ -1612,13 +1624,15 @@ int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st) {
 }
 
 // head + the out = 1 layer's backward of the same rows in one launch (no loss reduction: launch_loss_reduce)
-int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st) {
+int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st, LaunchOpts *lo) {
+    if (lo) lo->launched = false;
     if (a.B <= 0 || nsplit <= 0) return PS_OK;
     if (a.chunk > HEAD_ROWS_MAX || !h.labels) return ps_set_err(PS_E_BAD_ARG, "launch_head_last_bwd: %d rows per workgroup / no labels", a.chunk);
     LastBwdArgs q = a;
     q.ts = stamp_next("head_last_bwd");
-    PS_LAUNCH(k_last_bwd<true>, dim3(nsplit), dim3(256), 0, st, q, h);
+    PS_LAUNCH_EV(k_last_bwd<true>, dim3(nsplit), dim3(256), 0, st, lo ? lo->stop_event : nullptr, q, h);
     HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
     return PS_OK;
 }
 int head_last_bwd_fusable(int rows_per_wg) { return rows_per_wg <= HEAD_ROWS_MAX; }

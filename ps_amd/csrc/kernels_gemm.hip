@@ -39,18 +39,7 @@ struct NtArgs {
     unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (launch_spin_until)
     const unsigned int *wait_flag; unsigned int wait_val;   // workgroup 0 ends only once *wait_flag has reached wait_val
     int prio;                                               // raise the waves' priority (a main-chain launch of the fused step)
-};
-
-// "This launch does not end before another chain has reached X": the first workgroup, done with its tile, holds its
-// slot until the flag is there (normally long since) -- the join costs the waiting chain no launch of its own.  Same
-// rule as for the spinners: armed only when the launches that raise the flag were enqueued BEFORE this one.
-struct EndWait {
-    const unsigned int *f; unsigned int v;
-    __device__ __forceinline__ EndWait(const unsigned int *flag, unsigned int val) : f(flag), v(val) {}
-    __device__ __forceinline__ ~EndWait() {
-        if (f && blockIdx.x == 0 && threadIdx.x == 0)
-            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) __builtin_amdgcn_s_sleep(16);
-    }
+    WaitBound bound;                                        // ... or gives up after bound.ticks and reports it in *bound.err
 };
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
@@ -86,7 +75,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
     // with the NT GEMMs alone 0.1495 ms/step, with all of them 0.1469 (the dW GEMMs no longer fall behind), and the
     // sharded step settles at 0.189-0.193.
     if (a.prio) __builtin_amdgcn_s_setprio(3);
-    EndWait end_wait(a.wait_flag, a.wait_val);       // (declared first: runs after the stamp's end)
+    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);       // (declared first: runs after the stamp's end)
     StampScope stamp(a.ts);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
@@ -254,7 +243,8 @@ struct TnArgs {
     const int *skip;
     int xcd_swizzle;
     unsigned long long *ts;
-    int prio;        // raise the waves' priority (armed per launch like NtArgs.prio)
+    int prio;        // raise the waves' priority (per launch like NtArgs.prio)
+    const unsigned int *wait_flag; unsigned int wait_val; WaitBound bound;    // start wait (ps_common.h start_wait)
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
@@ -266,6 +256,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
     if (a.prio) __builtin_amdgcn_s_setprio(3);       // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates)
     StampScope stamp(a.ts);
+    start_wait(a.wait_flag, a.wait_val, a.bound);
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
@@ -397,16 +388,20 @@ int g_gemm_xcd = 1;      // XCD-aware work-group order on/off (for A/B runs)
 int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5 128x32/32
 
 #define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
-    PS_LAUNCH((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64), 0, st, a)
+    PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64), 0, st, stop_ev, a)
 
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
-            const int *skip_flag, hipStream_t st) {
+            const int *skip_flag, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
+    if (lo) lo->launched = false;
     if ((K & 3) || (lda & 3) || (ldb & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_nt: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
     if (M <= 0 || N <= 0) return PS_OK;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"), g_launch_flag, g_launch_flag_val, g_launch_wait, g_launch_wait_val, g_launch_prio};
-    g_launch_flag = nullptr; g_launch_wait = nullptr; g_launch_prio = 0;
+    const LaunchOpts none;
+    const LaunchOpts &o = lo ? *lo : none;
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"),
+             o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100)};
+    const hipEvent_t stop_ev = o.stop_event;
     int cfg = g_gemm_nt_cfg;
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
@@ -441,34 +436,47 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
     return PS_OK;
 }
 
-thread_local hipEvent_t g_launch_stop_event = nullptr;
-thread_local unsigned int *g_launch_flag = nullptr;     // armed like the stop event: the next gemm_nt announces its start there
-thread_local unsigned int g_launch_flag_val = 0;
-thread_local int g_launch_prio = 0;                         // armed: the next gemm_nt's waves run at raised priority
 int g_main_prio = 1;        // ps_tune_set("main_prio", 0): no raised wave priority for the fused step's main-chain kernels
-thread_local const unsigned int *g_launch_wait = nullptr;   // armed: the next gemm_nt's first workgroup ends only once *g_launch_wait reached the value
-thread_local unsigned int g_launch_wait_val = 0;
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
 int g_sort_late = 0;        // ps_tune_set("sort_late", 1): the single-hot field sort behind the first delta GEMM's release instead of the first forward GEMM's
+int g_tn_start_wait = 1;    // ps_tune_set("tn_start_wait", 0): a spinner launch in front of EVERY dW GEMM again
+int g_tail_fused = 1;       // ps_tune_set("tail_fused", 0): the dense update between a spinner and a flag-setter launch, the main chain ends behind a spinner again
 int g_end_wait = 1;         // ps_tune_set("end_wait", 0): the main chain joins side chain 0 behind a spinner launch again
 int g_tail_dev = 1;         // ps_tune_set("tail_dev", 0): dense update last on the main chain again
 int g_dev_wait = 1;         // ps_tune_set("dev_wait", 0): the dW chain waits for the head by event again
-// A profiler that collects hardware counters runs ONE kernel at a time, whichever queue it comes from, in an order of its
-// own: a kernel that waits for a flag raised by a kernel of another stream may then wait for ever.  rocprofv3 --pmc
-// announces itself through ROCPROF_COUNTER_COLLECTION in the child's environment: every device-side wait is then
-// replaced by its event form (the step's results are the same bit for bit, tests/test_gpu_schedule.py).
+// A kernel that waits for a flag raised by a kernel of ANOTHER stream needs the two streams to make progress at the same
+// time.  Environments that run one kernel at a time, whichever queue it comes from, break that: a profiler collecting
+// hardware counters (rocprofv3 --pmc announces itself through ROCPROF_COUNTER_COLLECTION in the child's environment),
+// HIP_LAUNCH_BLOCKING / AMD_SERIALIZE_KERNEL (every launch waits for the one before), a debugger's serialisation
+// (HSA_ENABLE_DEBUG), and a runtime with fewer hardware queues than the step has chains (GPU_MAX_HW_QUEUES < 4: two
+// streams of one model may then share a queue, the waiter in front of its releaser).  There every device-side wait is
+// replaced by its event form when the library is loaded (the step's results are the same bit for bit,
+// tests/test_gpu_schedule.py); anything this list misses ends in a bounded wait's timeout instead of a hang.
+const char *g_dev_wait_off_reason = nullptr;
 namespace {
-const int g_profiler_guard = []() {
-    const char *e = getenv("ROCPROF_COUNTER_COLLECTION");
-    if (e && *e && strcmp(e, "0") != 0 && strcasecmp(e, "false") != 0 && strcasecmp(e, "off") != 0) { g_dev_wait = 0; g_end_wait = 0; }
+bool env_on(const char *name) {
+    const char *e = getenv(name);
+    return e && *e && strcmp(e, "0") != 0 && strcasecmp(e, "false") != 0 && strcasecmp(e, "off") != 0;
+}
+const int g_serial_env_guard = []() {
+    const char *why = nullptr;
+    if (env_on("ROCPROF_COUNTER_COLLECTION")) why = "ROCPROF_COUNTER_COLLECTION";
+    else if (env_on("HIP_LAUNCH_BLOCKING")) why = "HIP_LAUNCH_BLOCKING";
+    else if (env_on("AMD_SERIALIZE_KERNEL")) why = "AMD_SERIALIZE_KERNEL";
+    else if (env_on("HSA_ENABLE_DEBUG")) why = "HSA_ENABLE_DEBUG";
+    else if (const char *q = getenv("GPU_MAX_HW_QUEUES")) { if (*q && atoi(q) < 4) why = "GPU_MAX_HW_QUEUES < 4"; }
+    if (why) { g_dev_wait = 0; g_end_wait = 0; g_dev_wait_off_reason = why; }
     return 0;
 }();
 }  // namespace
+unsigned long long g_spin_timeout_ticks = 200000000ull;      // 2 s of the device's 100 MHz wall clock; ps_tune_set("spin_timeout_ms")
+WaitBound wait_bound(unsigned int *werr, unsigned int code) { return WaitBound{werr, werr ? g_spin_timeout_ticks : 0ull, code}; }
 
 // A stream that reaches a hipStreamWaitEvent before the event has fired resumes 10-20 us after it (the dW chain
 // started 10 us after the head on a good day and 18 on a bad one, which then pushed dW0 under the embedding update:
@@ -477,8 +485,8 @@ const int g_profiler_guard = []() {
 // one-wave spinner in front of its first GEMM, and the main chain's next launch -- which starts only after the head
 // has finished and released its writes -- flips the flag from its first workgroup.
 // (epochs only grow: "reached or passed", wrap-safe, so that a flag already moved on can never strand a waiter)
-__global__ void k_spin_until(const unsigned int *flag, unsigned int val) {
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) __builtin_amdgcn_s_sleep(16);
+__global__ void k_spin_until(const unsigned int *flag, unsigned int val, WaitBound b) {
+    if (threadIdx.x == 0) spin_bounded(flag, val, b);
 }
 __global__ void k_flag_set(unsigned int *flag, unsigned int val) {
     __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -489,8 +497,8 @@ int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
-int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st) {
-    hipLaunchKernelGGL(k_spin_until, dim3(1), dim3(64), 0, st, flag, val);
+int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code) {
+    hipLaunchKernelGGL(k_spin_until, dim3(1), dim3(64), 0, st, flag, val, wait_bound(werr, code));
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -520,13 +528,13 @@ int gemm_tn_choose_split(int Kout, int N, int M) {
 
 int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
-                   const int *skip_flag, hipStream_t st) {
+                   const int *skip_flag, hipStream_t st, const LaunchOpts *lo, unsigned int *werr) {
     if ((lda & 3) || (ldd & 3) || (a_cols & 3) || (d_cols & 3))
         return ps_set_err(PS_E_BAD_ARG, "gemm_tn: leading dims / cols must be multiples of 4");
     if (Kout <= 0 || N <= 0 || nsplit <= 0) return PS_OK;
     const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), 32);
-    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn"), g_launch_prio};
-    g_launch_prio = 0;
+    TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn"), lo ? lo->prio : 0,
+             lo ? lo->wait : nullptr, lo ? lo->wait_val : 0u, wait_bound(werr, 101)};
     int cfg = g_gemm_tn_cfg;
     if (cfg == 0) cfg = N <= 32 ? 5 : 2;
     switch (cfg) {

@@ -122,36 +122,105 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
                         uint32_t *sorted_keys, uint32_t *sorted_ents, uint32_t *seg_start, uint32_t *seg_id,
                         uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st);
 
+// What one launch carries beyond its kernel arguments.  Explicit, per launch: the caller fills a LaunchOpts and hands
+// it to the launcher (rounds 1-2 "armed" thread-local globals that the next launcher of the same host thread consumed).
+//   stop_event  the event another stream will wait on rides on the dispatch packet's own completion signal
+//               (hipExtLaunchKernelGGL) instead of a hipEventRecord behind it (a separate barrier packet: ~3-4 us of the
+//               recording stream before its next kernel starts; tools/gpu_timeline.py)
+//   flag        the launch's first workgroup stores flag_val there when it starts ("everything in front of me on my
+//               stream has finished") for a device-side waiter (launch_spin_until)
+//   wait        the launch's first workgroup ends only once *wait has reached wait_val (a join that costs no launch)
+//   prio        the launch's waves run at raised priority (s_setprio)
+// launched (out): a kernel was launched and took all of the above; false (an empty problem): the caller settles them.
+struct LaunchOpts {
+    hipEvent_t stop_event = nullptr;
+    unsigned int *flag = nullptr; unsigned int flag_val = 0;
+    const unsigned int *wait = nullptr; unsigned int wait_val = 0;
+    int prio = 0;
+    bool launched = false;
+};
+extern int g_main_prio;
+extern int g_sort_late;
+extern int g_tn_start_wait, g_tail_fused;
+extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11, g_end_wait, g_radix_scan_free, g_plan_early;
+// Every device-side wait is BOUNDED: a waiter that has not seen its flag after g_spin_timeout_ticks (10 ns ticks of the
+// device's wall clock; ps_tune_set("spin_timeout_ms")) adds 1 to *werr, stores which wait it was beside it and gives up.
+// The host finds the count at its next wait on the store's stream (store_check_device), returns PS_E_STATE and switches
+// the store to the event form of every join; the step that timed out has run without one of its dependencies.
+extern unsigned long long g_spin_timeout_ticks;
+struct WaitBound { unsigned int *err; unsigned long long ticks; unsigned int code; };
+WaitBound wait_bound(unsigned int *werr, unsigned int code);
+int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code = 0);   // a one-wave kernel that ends when *flag reached val
+int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order
+#define PS_LAUNCH_EV(kernel, grid, block, shmem, st, ev, ...)                                                  \
+    do {                                                                                                       \
+        hipEvent_t se_ = (ev);                                                                                 \
+        if (se_) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, se_, 0, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                  \
+    } while (0)
 // ---------------------------------------------------------------------------
 // GPU-side time stamps (measurement only: ps_tune_set("stamps", 1), tools/gpu_timeline.py).  A stamped kernel takes
 // a slot pointer in its arguments (nullptr when off = one scalar compare per workgroup): slot[0] = start of
 // workgroup 0, slot[1] = latest sampled workgroup end, 10 ns ticks of the device's wall clock.  Unlike a profiler's
 // trace this costs the HOST nothing, so the stream stays as far ahead of the GPU as in a normal run.
 // ---------------------------------------------------------------------------
-// A launch can carry the event another stream will wait on: the dispatch packet's own completion signal, instead of
-// a hipEventRecord behind it (a separate barrier packet: ~3-4 us of the recording stream before its next kernel
-// starts; tools/gpu_timeline.py).  The caller arms g_launch_stop_event, the next PS_LAUNCH of the SAME host thread
-// consumes it (thread-local: several host threads may each drive their own store).
-extern thread_local hipEvent_t g_launch_stop_event;
-extern thread_local unsigned int *g_launch_flag;       // armed: the next gemm_nt stores g_launch_flag_val there when it starts
-extern thread_local unsigned int g_launch_flag_val;
-extern thread_local const unsigned int *g_launch_wait;   // armed: the next gemm_nt does not end before *g_launch_wait reached g_launch_wait_val
-extern thread_local unsigned int g_launch_wait_val;
-extern thread_local int g_launch_prio;                   // armed: the next gemm_nt's waves run at raised priority (s_setprio)
-extern int g_main_prio;
-extern int g_sort_late;
-extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11, g_end_wait, g_radix_scan_free, g_plan_early;
-int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st);
-int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order   // a one-wave kernel that ends when *flag == val
-#define PS_LAUNCH(kernel, grid, block, shmem, st, ...)                                                         \
-    do {                                                                                                       \
-        hipEvent_t se_ = g_launch_stop_event;                                                                  \
-        if (se_) { g_launch_stop_event = nullptr; hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, se_, 0, __VA_ARGS__); } \
-        else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                  \
-    } while (0)
 unsigned long long *stamp_next(const char *name);      // nullptr when stamps are off or the buffer is full
 int stamps_enable(int on);
 #ifdef __HIPCC__
+// ---- device-side waits, all bounded (WaitBound above) ----
+// After bound.ticks of the device's wall clock the waiter counts itself in *bound.err, notes which wait it was, and goes on.
+__device__ __forceinline__ void spin_bounded(const unsigned int *f, unsigned int v, const WaitBound &b) {
+    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) >= 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (b.ticks && (unsigned long long)wall_clock64() - t0 > b.ticks) {
+            if (b.err) { atomicAdd(b.err, 1u); __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            return;
+        }
+    }
+}
+// "This launch does not END before another chain has reached X": the first workgroup, done with its work, holds its
+// slot until the flag is there (normally long since) -- the join costs the waiting chain no launch of its own.  What
+// the other chain wrote is read by the NEXT launch of this stream (its start acquires).
+struct EndWait {
+    const unsigned int *f; unsigned int v; WaitBound b;
+    __device__ __forceinline__ EndWait(const unsigned int *flag, unsigned int val, const WaitBound &bound) : f(flag), v(val), b(bound) {}
+    __device__ __forceinline__ ~EndWait() {
+        if (f && blockIdx.x == 0 && threadIdx.x == 0) spin_bounded(f, v, b);
+    }
+};
+// "This launch does not START its work before X": every workgroup checks the flag when it starts (one load when it is up
+// -- the intended case: the launch sits in order behind a kernel that outlasts X) and then ACQUIRES at agent scope: the
+// data X stands for was written by a kernel of another stream that ended before the flag went up, but this kernel's own
+// start-of-kernel acquire came earlier, and an XCD's L2 may still hold the previous step's lines of those addresses.
+// Call from every thread of the workgroup (a barrier inside).
+__device__ __forceinline__ void start_wait(const unsigned int *f, unsigned int v, const WaitBound &b) {
+    if (!f) return;
+    if (threadIdx.x == 0) spin_bounded(f, v, b);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// "X = this launch has finished", raised by the launch itself: every workgroup releases its writes and counts itself;
+// the last one resets the counter and raises the flag (no flag-setter launch behind the kernel: ~3 us of its stream).
+// RAII so that every return path of the kernel counts; all threads of a workgroup must leave through the same path
+// (a barrier inside).
+struct DoneSignal {
+    unsigned int *counter, *flag; unsigned int val;
+    __device__ __forceinline__ DoneSignal(unsigned int *c, unsigned int *f, unsigned int v) : counter(c), flag(f), val(v) {}
+    __device__ __forceinline__ ~DoneSignal() {
+        if (!flag) return;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+            if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
 struct StampScope {
     unsigned long long *p;
     unsigned int always;            // the first `always` workgroups all report their end (the long-key role of the embedding update)
@@ -175,11 +244,12 @@ enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_MASK_POS = 3 };
 //   EPI_MASK_POS: C = acc * (mask[row][col] > 0 ? 1 : 0) for col < mask_cols, acc otherwise
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
-            const int *skip_flag, hipStream_t st);
+            const int *skip_flag, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);
 // Cpart[z][Kout][ldc] = sum over m in split z of A[m][kout] * D[m][n]  (split-K over M)
 int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
-                   const int *skip_flag, hipStream_t st);
+                   const int *skip_flag, hipStream_t st, const LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: prio, and
+                   // wait = a START wait: no workgroup reads its operands before *wait reached wait_val
 int gemm_tn_choose_split(int Kout, int N, int M);
 extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;

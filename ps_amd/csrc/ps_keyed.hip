@@ -25,6 +25,28 @@ struct DevBuf {            // scratch for one call (the facade is not a hot path
 
 }  // namespace
 
+// The number of floats a push / upsert of `key` must carry on THIS shard (PS_MISSING: a key the store does not hold).
+// The gRPC facade validates a BSP push with it when the push ARRIVES (the reference answers 500 there), not when the
+// round's last barrier applies it.
+extern "C" int ps_store_key_length(const ps_store_t *s, const char *key, int *len_out) {
+    if (!s || !key || !len_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    ParsedKey k;
+    if (!store_parse_key(key, &k)) return ps_set_err(PS_MISSING, "unknown key %s", key);
+    if (k.kind == 0) {
+        if (!s->emb.W || k.idx < 0 || k.idx >= s->emb.F) return ps_set_err(PS_MISSING, "%s: no such field", key);
+        if (store_local_row(s, k.idx, k.id) < 0) return ps_set_err(PS_MISSING, "%s is not held by this shard", key);
+        *len_out = s->emb.D;
+    } else if (k.kind == 1 || k.kind == 2) {
+        if (!s->wide.W) return ps_set_err(PS_MISSING, "no wide table");
+        if (k.kind == 1 && (k.id < 0 || k.id >= s->wide.rows)) return ps_set_err(PS_MISSING, "%s out of range", key);
+        *len_out = 1;
+    } else {
+        if (k.idx < 0 || k.idx >= (int)s->fc.size() || !s->fc[k.idx].present) return ps_set_err(PS_MISSING, "%s absent", key);
+        *len_out = k.kind == 4 ? s->fc[k.idx].N : s->fc[k.idx].K * s->fc[k.idx].N;
+    }
+    return PS_OK;
+}
+
 extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *keys, const float *const *grads, const int *lens,
                                     int is_async) {
     if (!s || n < 0 || (n > 0 && (!keys || !grads || !lens))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
@@ -36,20 +58,49 @@ extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *key
         if (!keys[i] || !grads[i]) return ps_set_err(PS_E_BAD_ARG, "message %d: null key or gradient", i);
         if (!store_parse_key(keys[i], &pk[i])) return ps_set_err(PS_MISSING, "unknown key %s", keys[i]);
     }
-    // ---- embedding rows: one list in arrival order, duplicates = several workers' pushes of one key ----
-    std::vector<uint32_t> rows;
-    std::vector<float> eg;
+    // ---- pass 1: validate EVERY message (kind, length, range, local row) and group the indices; no device work yet, so a
+    // bad message leaves the store untouched (validation and application used to interleave) ----
+    std::vector<uint32_t> rows;                                    // embedding rows: one list in arrival order, duplicates =
+    std::vector<float> eg;                                         // several workers' pushes of one key
+    std::map<int64_t, std::vector<int>> wide;                      // wide keys: ascending key, message order inside
+    std::map<std::pair<int, int>, std::vector<int>> dense;        // (layer, bias) -> messages
     const int D = s->emb.D;
     for (int i = 0; i < n; ++i) {
-        if (pk[i].kind != 0) continue;
-        if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
-        if (lens[i] != D) return ps_set_err(PS_E_BAD_ARG, "%s wants %d floats, got %d", keys[i], D, lens[i]);
-        if (pk[i].idx < 0 || pk[i].idx >= s->emb.F) return ps_set_err(PS_MISSING, "%s: no such field", keys[i]);
-        const int64_t r = store_local_row(s, pk[i].idx, pk[i].id);
-        if (r < 0) return ps_set_err(PS_MISSING, "%s is not held by this shard", keys[i]);
-        rows.push_back((uint32_t)r);
-        eg.insert(eg.end(), grads[i], grads[i] + D);
+        if (lens[i] < 0) return ps_set_err(PS_E_BAD_ARG, "message %d: negative length", i);
+        if (pk[i].kind == 0) {
+            if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
+            if (lens[i] != D) return ps_set_err(PS_E_BAD_ARG, "%s wants %d floats, got %d", keys[i], D, lens[i]);
+            if (pk[i].idx < 0 || pk[i].idx >= s->emb.F) return ps_set_err(PS_MISSING, "%s: no such field", keys[i]);
+            const int64_t r = store_local_row(s, pk[i].idx, pk[i].id);
+            if (r < 0) return ps_set_err(PS_MISSING, "%s is not held by this shard", keys[i]);
+            rows.push_back((uint32_t)r);
+        } else if (pk[i].kind == 1 || pk[i].kind == 2) {
+            if (!s->wide.W) return ps_set_err(PS_MISSING, "no wide table");
+            if (lens[i] != 1) return ps_set_err(PS_E_BAD_ARG, "%s wants 1 float, got %d", keys[i], lens[i]);
+            if (pk[i].kind == 1 && (pk[i].id < 0 || pk[i].id >= s->wide.rows)) return ps_set_err(PS_MISSING, "%s out of range", keys[i]);
+            wide[pk[i].kind == 2 ? s->wide.rows : pk[i].id].push_back(i);
+        } else {
+            const int l = pk[i].idx;
+            if (l < 0 || l >= (int)s->fc.size() || !s->fc[l].present) return ps_set_err(PS_MISSING, "%s absent", keys[i]);
+            const int want = pk[i].kind == 4 ? s->fc[l].N : s->fc[l].K * s->fc[l].N;
+            if (lens[i] != want) return ps_set_err(PS_E_BAD_ARG, "%s wants %d floats, got %d", keys[i], want, lens[i]);
+            dense[{l, pk[i].kind == 4 ? 1 : 0}].push_back(i);
+        }
     }
+    {   // (updaters too: PServer.push answers 500 for an unknown updater before anything is summed)
+        ps_updater_t u;
+        if (!rows.empty()) PSCHK(store_resolve_updater(s, "emF", &u));
+        if (!rows.empty() && !s->emb.state && u.kind != PS_UPD_SIMPLE) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
+        if (!wide.empty()) PSCHK(store_resolve_updater(s, "wide.weights", &u));
+        for (auto &kv : dense) {
+            char name[64];
+            snprintf(name, sizeof name, "fc%d.%s", kv.first.first, kv.first.second ? "bias" : "weights");
+            PSCHK(store_resolve_updater(s, name, &u));
+        }
+    }
+    // ---- pass 2: apply ----
+    for (int i = 0; i < n; ++i)
+        if (pk[i].kind == 0) eg.insert(eg.end(), grads[i], grads[i] + D);
     DevBuf d_rows, d_eg;
     if (!rows.empty()) {
         PSCHK(d_rows.alloc(sizeof(uint32_t) * rows.size()));
@@ -58,15 +109,7 @@ extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *key
         HIPCHK(hipMemcpyAsync(d_eg.p, eg.data(), sizeof(float) * eg.size(), hipMemcpyHostToDevice, st));
         PSCHK(shard_apply_push(s, (const uint32_t *)d_rows.p, (const float *)d_eg.p, (int64_t)rows.size(), nullptr, 0, is_async, false));
     }
-    // ---- wide keys: CSR of pushes per key (std::map: ascending key, message order inside) ----
-    std::map<int64_t, std::vector<int>> wide;
-    for (int i = 0; i < n; ++i) {
-        if (pk[i].kind != 1 && pk[i].kind != 2) continue;
-        if (!s->wide.W) return ps_set_err(PS_MISSING, "no wide table");
-        if (lens[i] != 1) return ps_set_err(PS_E_BAD_ARG, "%s wants 1 float, got %d", keys[i], lens[i]);
-        if (pk[i].kind == 1 && (pk[i].id < 0 || pk[i].id >= s->wide.rows)) return ps_set_err(PS_MISSING, "%s out of range", keys[i]);
-        wide[pk[i].kind == 2 ? s->wide.rows : pk[i].id].push_back(i);
-    }
+    // ---- wide keys: CSR of pushes per key ----
     DevBuf d_wid, d_woff, d_wg;
     if (!wide.empty()) {
         std::vector<int64_t> ids;
@@ -94,15 +137,6 @@ extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *key
         PSCHK(launch_wide_list(a, st));
     }
     // ---- dense tensors: the pushes of one tensor are the slabs of its update ----
-    std::map<std::pair<int, int>, std::vector<int>> dense;        // (layer, bias) -> messages
-    for (int i = 0; i < n; ++i) {
-        if (pk[i].kind != 3 && pk[i].kind != 4) continue;
-        const int l = pk[i].idx;
-        if (l < 0 || l >= (int)s->fc.size() || !s->fc[l].present) return ps_set_err(PS_MISSING, "%s absent", keys[i]);
-        const int want = pk[i].kind == 4 ? s->fc[l].N : s->fc[l].K * s->fc[l].N;
-        if (lens[i] != want) return ps_set_err(PS_E_BAD_ARG, "%s wants %d floats, got %d", keys[i], want, lens[i]);
-        dense[{l, pk[i].kind == 4 ? 1 : 0}].push_back(i);
-    }
     std::vector<DevBuf> slabs(dense.size());
     size_t di = 0;
     for (auto &kv : dense) {

@@ -188,6 +188,10 @@ extern "C" int ps_emb_backward_update(ps_store_t *s, const int64_t *ids_dev, con
         auto fr = [](void *p) { if (p) (void)hipFree(p); };
         sort_ws_free(o.ws);
         fr(o.keys); fr(o.ents); fr(o.ent_bag); fr(o.seg_start); fr(o.seg_id); fr(o.nseg); fr(o.uniq_row); fr(o.partials); fr(o.partials2); fr(o.grads);
+        // (if an allocation below fails the scratch is empty, not dangling: the next call starts over, destroy frees nothing twice)
+        o.keys = o.ents = o.ent_bag = o.seg_start = o.seg_id = o.nseg = o.uniq_row = nullptr;
+        o.partials = o.partials2 = o.grads = nullptr;
+        o.nnz_cap = 0;
         const int64_t cap = nnz + nnz / 4 + 1024;
         PSCHK(sort_ws_alloc(o.ws, cap));
         HIPCHK(hipMalloc((void **)&o.keys, 4 * (size_t)(cap + 1))); HIPCHK(hipMalloc((void **)&o.ents, 4 * (size_t)(cap + 1)));

@@ -50,19 +50,15 @@ int fork(ps_model *m, hipStream_t from, hipStream_t to) {
     return PS_OK;
 }
 int join(ps_model *m, hipStream_t from, hipStream_t to) { return fork(m, from, to); }
-// "the next launch on the main stream carries an event": arm before the launch, then settle(): if the launcher took
-// it (PS_LAUNCH), the event is the kernel's own completion signal; if not, it is recorded the ordinary way.
-hipEvent_t arm_event(ps_model *m) {
+// "this launch on the main stream carries an event": the event goes into the launch's LaunchOpts; settle_event()
+// afterwards: if the launcher took it, the event is the kernel's own completion signal; if not (nothing was launched, or
+// a path that does not carry events), it is recorded the ordinary way.
+hipEvent_t pick_event(ps_model *m) {
     if (m->profile || !m->multi_stream || !g_ext_events || m->cfg.use_graph) return nullptr;      // (stream capture: plain records)
-    hipEvent_t e = m->events[m->next_event++ % m->events.size()];
-    g_launch_stop_event = e;
-    return e;
+    return m->events[m->next_event++ % m->events.size()];
 }
-int settle_event(ps_model *m, hipEvent_t e) {
-    if (e && g_launch_stop_event == e) {        // not consumed by the launch
-        g_launch_stop_event = nullptr;
-        HIPCHK(hipEventRecord(e, m->s->stream));
-    }
+int settle_event(ps_model *m, const LaunchOpts &lo) {
+    if (lo.stop_event && !lo.launched) HIPCHK(hipEventRecord(lo.stop_event, m->s->stream));
     return PS_OK;
 }
 int wait_event(ps_model *m, hipStream_t to, hipEvent_t e) {
@@ -165,7 +161,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * 3 * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
     PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
-    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 8, true));
+    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 16, true));      // [0..7] flags, [8] the dense update's workgroup count
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
@@ -183,6 +179,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     HIPCHK(hipEventCreateWithFlags(&m->s0_ev, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->dw_ev, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->device >= 0 && s->device < PS_MAX_DEVICES) { ++g_models_on_device[s->device]; m->counted = true; }      // (dev_waits_ok)
     *out = m;
     return PS_OK;
 }
@@ -190,6 +187,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
 extern "C" int ps_model_destroy(ps_model_t *m) {
     RtGuard rt_guard;
     if (!m) return PS_OK;
+    if (m->counted) --g_models_on_device[m->s->device];
     (void)hipSetDevice(m->s->device);
     (void)hipStreamSynchronize(m->s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
@@ -240,6 +238,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
     if (need_labels && !b->labels) return ps_set_err(PS_E_BAD_ARG, "batch.labels is NULL");
     if (c.kind == PS_MODEL_WIDEDEEP && !b->wide_ids) return ps_set_err(PS_E_BAD_ARG, "batch.wide_ids is NULL");
     hipStream_t st = m->s->stream;
+    m->dev_ok = dev_waits_ok(m->s);      // one decision per step: device-side flags or events (ps_store.h)
     if (m->side0_pending) {      // a forward without its backward: do not let the next gather race the old sort
         PSCHK(join(m, m->side[0], st));
         m->side0_pending = false;
@@ -346,7 +345,7 @@ static void fill_last_bwd(ps_model *m, LastBwdArgs &q) {
 // see enqueue_backward.
 static bool dev_release(const ps_model *m) {
     const ps_model_config_t &c = m->cfg;
-    return g_dev_wait && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1;
+    return m->dev_ok && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1;
 }
 
 // the one-launch field sort of a single-hot batch (keys left in m->keys by the gather) on stream ss
@@ -400,15 +399,17 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // has finished) flips a flag, the sort sits behind a spinner on side chain 0 -- the gather's launch carries no
     // event (a launch with a stop event starts ~2 us later than a plain one)
     const bool sort_dev = train && !m->sh.active && !m->cur_offsets && g_field_sort && field_sort_fits(B, c.F) && !g_sort_ablate &&
-                          g_dev_wait && !c.use_graph && side_stream(m, 0) != st && !(nfc == 1 && s->fc[0].N == 1);
-    hipEvent_t fwd_ev = (train && !m->sh.active && !keys_early && !sort_dev) ? arm_event(m) : nullptr;
-    { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st)); }
-    PSCHK(settle_event(m, fwd_ev));
+                          m->dev_ok && !c.use_graph && side_stream(m, 0) != st && !(nfc == 1 && s->fc[0].N == 1);
+    LaunchOpts fwd_lo;
+    fwd_lo.stop_event = (train && !m->sh.active && !keys_early && !sort_dev) ? pick_event(m) : nullptr;
+    const hipEvent_t fwd_ev = fwd_lo.stop_event;
+    { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st, &fwd_lo)); }
+    PSCHK(settle_event(m, fwd_lo));
     auto enqueue_sort = [&]() -> int {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
         if (keys_early) {}
-        else if (sort_dev) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss));
+        else if (sort_dev) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss, s->werr(), 4));
         else if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
         static int64_t sort_runs = 0;
@@ -461,7 +462,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     bool sort_due = sort_dev && !sort_late;
     // sharded worker: the first forward GEMM announces its start too -- everything of this step in front of it (the id and
     // row exchanges, the gather) is then done, which is what the NEXT step's plan waits for on side chain 0
-    bool fwd_flag_due = train && m->sh.active && g_dev_wait && !c.use_graph && !m->profile && m->multi_stream;
+    bool fwd_flag_due = train && m->sh.active && m->dev_ok && !c.use_graph && !m->profile && m->multi_stream;
     m->fwd_flag_valid = false;
     // FcLayer.forward x nfc
     for (int l = 0; l < nfc; ++l) {
@@ -473,16 +474,14 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
         if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
         Prof pf(m, names[l]);
-        if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; g_launch_flag = m->start_flag + 4; g_launch_flag_val = m->fwd_epoch; }
-        g_launch_prio = (train && gemm_prio(m)) ? 1 : 0;
+        LaunchOpts lo;
+        if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
+        lo.prio = (train && gemm_prio(m)) ? 1 : 0;
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
-                      nullptr, 0, 0, nullptr, st));
-        if (fwd_flag_due) {
-            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st)); }
-            fwd_flag_due = false; m->fwd_flag_valid = true;
-        }
+                      nullptr, 0, 0, nullptr, st, &lo, s->werr()));
+        if (lo.flag && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st));      // (an empty GEMM)
+        if (fwd_flag_due) { fwd_flag_due = false; m->fwd_flag_valid = true; }
         if (sort_due) {         // the waiter is enqueued after the launch that releases it
-            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st)); }
             PSCHK(enqueue_sort());
             sort_due = false;
         }
@@ -516,9 +515,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         Prof pf(m, "head_last_bwd");
         // (both side chains of the backward are released from the device when they can be -- dev_release() -- and the
         //  head's launch then carries nothing: a launch with a stop event starts ~2 us later than a plain one)
-        m->head_ev = dev_release(m) ? nullptr : arm_event(m);
-        PSCHK(launch_head_last_bwd(h, q, bl.nsplit, st));
-        PSCHK(settle_event(m, m->head_ev));
+        LaunchOpts head_lo;
+        head_lo.stop_event = m->head_ev = dev_release(m) ? nullptr : pick_event(m);
+        PSCHK(launch_head_last_bwd(h, q, bl.nsplit, st, &head_lo));
+        PSCHK(settle_event(m, head_lo));
         m->head_bwd_done = true;
     } else {
         Prof pf(m, "head");
@@ -590,16 +590,18 @@ int enqueue_backward(ps_model *m, bool apply) {
     // (the head's small kernels go behind the same release: on side chain 0 behind their own spinner, or -- multi-hot --
     // at the front of side chain 1)
     // (and not under stream capture: a captured graph needs its side streams joined by events)
-    const bool dev_flags = g_dev_wait && !m->cfg.use_graph;
+    const bool dev_flags = m->dev_ok && !m->cfg.use_graph;
     const bool dev_wait = dev_release(m) && sw != st && m->head_bwd_done;
     if (dev_wait) {}                                              // both chains: spinners behind the first delta GEMM's launch
     else if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
     else PSCHK(fork2(m, st, sw, s0));
     bool first_release = dev_wait;
+    bool sw_gated = false;                    // side chain 1 already sits behind a spinner: later dW GEMMs wait at their own start
     bool s0_joined = false;                   // the last delta GEMM's launch carries the join with side chain 0
     m->head_ev = nullptr;
     bool main_dirty = false;           // a kernel went onto the main chain since the last fork towards sw
     hipEvent_t data_ev = nullptr;      // carried by the last delta GEMM on the main chain, not yet waited on
+    unsigned int *const werr = s->werr();
     // dense tensors: reduce the splits, / B, updater  (KVStore.update for "fc*.weights"/"fc*.bias")
     DenseUpdArgs d;
     memset(&d, 0, sizeof d);
@@ -681,49 +683,54 @@ int enqueue_backward(ps_model *m, bool apply) {
         // measured slower -- 0.180 and 0.195 against 0.170 ms/step; the embedding update took 49 us instead of 30
         // with a GEMM beside it.)
         hipStream_t dws = sw;
+        LaunchOpts lo, tn_lo;
         if (dev_wait) {
             // released from the device: this delta GEMM's first workgroup announces "everything before me on the main
             // chain is done" (delta_l included), dW_l sits behind a spinner on that -- no event anywhere on the chain
             if (++m->start_epoch == 0) ++m->start_epoch;
-            g_launch_flag = m->start_flag; g_launch_flag_val = m->start_epoch;
+            lo.flag = m->start_flag; lo.flag_val = m->start_epoch;
         } else {
             if (main_dirty) {                               // delta_l was just produced on the main chain
                 if (data_ev) PSCHK(wait_event(m, dws, data_ev)); else PSCHK(fork(m, st, dws));
                 main_dirty = false;
             }
-            data_ev = l > 0 ? arm_event(m) : nullptr;  // delta_{l-1}: the next dW GEMM waits for it (nobody after the last)
+            data_ev = l > 0 ? pick_event(m) : nullptr;  // delta_{l-1}: the next dW GEMM waits for it (nobody after the last)
+            lo.stop_event = data_ev;
         }
+        lo.prio = gemm_prio(m) ? 1 : 0;
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
         if (l > 0) {
             Prof pf(m, nd[l]);
-            g_launch_prio = gemm_prio(m) ? 1 : 0;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st));
+                          EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st, &lo, werr));
         } else {
             Prof pf(m, nd[l]);
             // the last launch in front of the embedding update also joins side chain 0 (sort, stop flag, wide update,
             // slab fold -- enqueued behind the FIRST delta GEMM, so before this launch): its first workgroup ends only
             // once that chain's end flag is up, and the main chain needs no spinner launch of its own for it
             if (g_end_wait && dev_flags && s0 != st && !first_release) {
-                g_launch_wait = m->start_flag + (sort_dev_wait ? 1 : 5);          // (multi-hot: the end of the long sort chain)
-                g_launch_wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
+                lo.wait = m->start_flag + (sort_dev_wait ? 1 : 5);          // (multi-hot: the end of the long sort chain)
+                lo.wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
             }
-            const bool armed = g_launch_wait != nullptr;
-            g_launch_prio = gemm_prio(m) ? 1 : 0;
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st));
-            s0_joined = armed && g_launch_wait == nullptr;
-            g_launch_wait = nullptr;
+                          EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st, &lo, werr));
+            s0_joined = lo.wait != nullptr && lo.launched;
         }
-        PSCHK(settle_event(m, data_ev));
+        PSCHK(settle_event(m, lo));
         main_dirty = true;
         if (dev_wait) {             // every waiter is enqueued AFTER the launch that releases it: none can be left spinning
-            if (g_launch_flag) { g_launch_flag = nullptr; PSCHK(launch_flag_set(m->start_flag, m->start_epoch, st)); }   // (an empty GEMM)
-            PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw));
+            if (!lo.launched) PSCHK(launch_flag_set(m->start_flag, m->start_epoch, st));   // (an empty GEMM)
+            // The FIRST dW GEMM of the chain sits behind a one-wave spinner launch (its stream is idle: without it the
+            // GEMM's workgroups would be dispatched at once and hold their CU slots while the forward still runs).  The
+            // later ones are in order behind a GEMM that outlasts their release -- "the next delta GEMM has started" --
+            // so their workgroups check the flag themselves when they start (one load; start_wait in ps_common.h): no
+            // spinner launch between two dW GEMMs (stamps: 7.4 us from the end of dW_1 to the start of dW_0 with it).
+            if (!sw_gated || !g_tn_start_wait) { PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw, werr, 0)); sw_gated = true; }
+            else { tn_lo.wait = m->start_flag; tn_lo.wait_val = m->start_epoch; }
             if (first_release) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
-                if (sl != sw) PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sl));
+                if (sl != sw) PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sl, werr, 10));
                 if (m->sort_deferred) { PSCHK(enqueue_field_sort(m, sl)); m->sort_deferred = false; }
                 PSCHK(small_kernels());
                 first_release = false;
@@ -732,9 +739,9 @@ int enqueue_backward(ps_model *m, bool apply) {
         }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
-        g_launch_prio = gemm_prio(m) ? 1 : 0;
+        tn_lo.prio = gemm_prio(m) ? 1 : 0;
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
-                             b.nsplit, nullptr, dws));
+                             b.nsplit, nullptr, dws, &tn_lo, werr));
     }
     if (first_release) { PSCHK(fork2(m, st, sw, s0)); PSCHK(small_kernels()); first_release = false; }     // (no delta GEMM at all)
     // tail_dev: the dense update goes to the END OF SIDE CHAIN 1 and both of its edges are device-side flags (no event
@@ -744,13 +751,12 @@ int enqueue_backward(ps_model *m, bool apply) {
     // the embedding update instead of after it.
     const bool tail_dev = dev_flags && g_tail_dev && sw != st && !m->profile;
     if (!tail_dev && sw != st) HIPCHK(hipEventRecord(m->dw_ev, sw));      // the last dW GEMM
-    PSCHK(settle_event(m, data_ev));
     // EmbeddingLayer.backward (twice): entries sorted by row (side chain 0, started in forward),
     // per-key run reduce in batch order, fused updater
     const int64_t nnz = m->cur_nnz;
     if (s0 != st && dev_flags && s0_joined) {}           // (the last delta GEMM's launch held the join)
-    else if (sort_dev_wait) PSCHK(launch_spin_until(m->start_flag + 1, m->sort_epoch, st));
-    else if (s0 != st && dev_flags) PSCHK(launch_spin_until(m->start_flag + 5, m->s0_epoch, st));
+    else if (sort_dev_wait) PSCHK(launch_spin_until(m->start_flag + 1, m->sort_epoch, st, werr, 1));
+    else if (s0 != st && dev_flags) PSCHK(launch_spin_until(m->start_flag + 5, m->s0_epoch, st, werr, 5));
     else if (s0 != st) HIPCHK(hipStreamWaitEvent(st, m->s0_ev, 0));  // the sort (forward), the stop flag and the wide update
     if (sl != s0) HIPCHK(hipStreamWaitEvent(st, m->loss_ev, 0));
     m->side0_pending = false;
@@ -771,12 +777,17 @@ int enqueue_backward(ps_model *m, bool apply) {
     PSCHK(store_resolve_updater(s, "emF", &u));
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
-    if (tail_dev) { if (++m->start_epoch == 0) ++m->start_epoch; g_launch_flag = m->start_flag + 2; g_launch_flag_val = m->start_epoch; }
-    { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st)); }
-    if (tail_dev && g_launch_flag) {        // nothing was launched (an empty batch): announce the start ourselves
-        g_launch_flag = nullptr;
+    // tail_dev: the dense update, on side chain 1, starts when the embedding update has STARTED (its first workgroup
+    // raises start_flag[2]) and raises start_flag[3] itself when its last workgroup is through; the embedding update's
+    // first workgroup ENDS only once that flag is up (normally long since): the step's tail is two launches and no
+    // spinner / flag-setter launch on either chain (tail_fused; round 2 had four small launches here).
+    const bool tail_fused = tail_dev && g_tail_fused && nnz > 0;
+    LaunchOpts emb_lo;
+    if (tail_dev) { if (++m->start_epoch == 0) ++m->start_epoch; emb_lo.flag = m->start_flag + 2; emb_lo.flag_val = m->start_epoch; }
+    if (tail_fused) { emb_lo.wait = m->start_flag + 3; emb_lo.wait_val = m->start_epoch; }
+    { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st, &emb_lo, werr)); }
+    if (tail_dev && !emb_lo.launched)       // nothing was launched (an empty batch): announce the start ourselves
         PSCHK(launch_flag_set(m->start_flag + 2, m->start_epoch, st));
-    }
     // The dense update runs LAST ON THE MAIN CHAIN.  A stream that reaches a wait before its event has fired resumes
     // 10-20 us after it (tools/gpu_timeline.py), a wait that is already satisfied costs ~3: on a side chain the update
     // ended within a few microseconds of the embedding update, so the next step's first GEMM -- which must wait for
@@ -793,10 +804,17 @@ int enqueue_backward(ps_model *m, bool apply) {
     }
     if (tail_dev) {
         // (every waiter is enqueued after the launch that releases it)
-        PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw));
+        if (tail_fused && emb_lo.launched) {
+            d.wait_flag = m->start_flag + 2; d.wait_val = m->start_epoch; d.bound = wait_bound(werr, 2);
+            d.done_counter = m->start_flag + 8; d.done_flag = m->start_flag + 3; d.done_val = m->start_epoch;
+            Prof pf(m, "dense_update");
+            PSCHK(launch_dense_update(d, sw));
+            return PS_OK;
+        }
+        PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw, werr, 2));
         { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
         PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
-        PSCHK(launch_spin_until(m->start_flag + 3, m->start_epoch, st));
+        PSCHK(launch_spin_until(m->start_flag + 3, m->start_epoch, st, werr, 3));
         return PS_OK;
     }
     { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }

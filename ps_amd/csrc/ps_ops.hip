@@ -211,6 +211,45 @@ extern "C" int ps_stream_sync(ps_store_t *s, void *hip_stream) {
     return PS_OK;
 }
 
+// How this store's models join their streams right now: 1 = device-side flags (bounded waits), 0 = events; why: the reason
+// for the event form ("" when flags are in use).
+extern const char *g_dev_wait_off_reason;
+extern "C" int ps_store_join_mode(const ps_store_t *s, char *why, int why_cap) {
+    if (!s) return -1;
+    const char *w = "";
+    const bool ok = dev_waits_ok(s);
+    if (!ok) {
+        if (s->dev_wait_off) w = "a device-side wait timed out on this store";
+        else if (!g_dev_wait) w = g_dev_wait_off_reason ? g_dev_wait_off_reason : "dev_wait = 0";
+        else w = "more than one live model on this device in this process";
+    }
+    if (why && why_cap > 0) snprintf(why, (size_t)why_cap, "%s", w);
+    return ok ? 1 : 0;
+}
+extern "C" int64_t ps_store_wait_timeouts(const ps_store_t *s) { return s ? s->wait_timeouts : -1; }
+
+// test hook: a bounded wait on a flag that nobody raises, on the store's stream, then the host-side check -- must come
+// back with PS_E_STATE after the timeout, not hang (tests/test_gpu_schedule.py)
+extern "C" int ps_dbg_stuck_wait(ps_store_t *s, int in_gemm) {
+    if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    unsigned int *flag = nullptr;
+    float *buf = nullptr;
+    { RtGuard g; HIPCHK(hipMalloc((void **)&flag, 64)); HIPCHK(hipMalloc((void **)&buf, sizeof(float) * 3 * 64 * 64)); }
+    HIPCHK(hipMemsetAsync(flag, 0, 64, s->stream));
+    HIPCHK(hipMemsetAsync(buf, 0, sizeof(float) * 3 * 64 * 64, s->stream));
+    int rc = PS_OK;
+    if (in_gemm) {          // the end wait of a GEMM launch (kernels_gemm.hip EndWait)
+        LaunchOpts lo;
+        lo.wait = flag; lo.wait_val = 1;
+        rc = gemm_nt(buf, 64, 64, buf + 64 * 64, 64, 64, buf + 2 * 64 * 64, 64, 64, 64, 64, EPI_NONE, nullptr, 0, 0, nullptr, s->stream, &lo, s->werr());
+    } else rc = launch_spin_until(flag, 1, s->stream, s->werr(), 99);
+    if (rc == PS_OK) rc = store_check_bad_ids(s);
+    (void)hipStreamSynchronize(s->stream);
+    { RtGuard g; (void)hipFree(flag); (void)hipFree(buf); }
+    return rc;
+}
+
 extern "C" int ps_tune_set(const char *knob, int value) {
     if (!knob) return ps_set_err(PS_E_BAD_ARG, "null knob");
     if (strcmp(knob, "gemm_nt_cfg") == 0) { g_gemm_nt_cfg = value; return PS_OK; }
@@ -222,7 +261,10 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "field_sort") == 0) { g_field_sort = value; return PS_OK; }
     if (strcmp(knob, "ext_events") == 0) { g_ext_events = value; return PS_OK; }
     if (strcmp(knob, "dev_wait") == 0) { g_dev_wait = value; return PS_OK; }
+    if (strcmp(knob, "spin_timeout_ms") == 0) { g_spin_timeout_ticks = value > 0 ? (unsigned long long)value * 100000ull : 0ull; return PS_OK; }
     if (strcmp(knob, "tail_dev") == 0) { g_tail_dev = value; return PS_OK; }
+    if (strcmp(knob, "tail_fused") == 0) { g_tail_fused = value; return PS_OK; }
+    if (strcmp(knob, "tn_start_wait") == 0) { g_tn_start_wait = value; return PS_OK; }
     if (strcmp(knob, "end_wait") == 0) { g_end_wait = value; return PS_OK; }
     if (strcmp(knob, "main_prio") == 0) { g_main_prio = value; return PS_OK; }
     if (strcmp(knob, "sort_late") == 0) { g_sort_late = value; return PS_OK; }

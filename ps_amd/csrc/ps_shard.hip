@@ -201,6 +201,7 @@ int ensure_push_ws(ps_store *s, int64_t n) {
     sort_ws_free(s->push_ws);
     fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);
     s->push_keys = s->push_ents = s->push_seg_start = s->push_seg_id = s->push_nseg = nullptr;
+    s->push_cap = 0;            // (a failed allocation below leaves an empty workspace, not a stale capacity)
     const int64_t cap = n + n / 4 + 1024;
     PSCHK(sort_ws_alloc(s->push_ws, cap));
     HIPCHK(hipMalloc((void **)&s->push_keys, sizeof(uint32_t) * (size_t)(cap + 1)));
@@ -288,12 +289,11 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
     ps_store *s = m->s;
     ps_model::Shard &sh = m->sh;
     const int F = m->cfg.F;
-    if (ss != st) {
-        sh.slot_ev = m->events[m->next_event++ % m->events.size()];
-        if (g_ext_events) g_launch_stop_event = sh.slot_ev;
-    }
-    PS_LAUNCH(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, m->keys, nnz, sh.bitmap, sh.word_prefix, sh.slot, stamp_next("plan_slots"));
-    if (ss != st && (g_launch_stop_event == sh.slot_ev || !g_ext_events)) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(sh.slot_ev, ss)); }
+    if (ss != st) sh.slot_ev = m->events[m->next_event++ % m->events.size()];
+    // (the event the forward waits for rides on the slot kernel's launch: no record packet on the side chain)
+    PS_LAUNCH_EV(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, (ss != st && g_ext_events) ? sh.slot_ev : nullptr, m->keys, nnz, sh.bitmap,
+                 sh.word_prefix, sh.slot, stamp_next("plan_slots"));
+    if (ss != st && !g_ext_events) HIPCHK(hipEventRecord(sh.slot_ev, ss));
     HIPCHK(hipGetLastError());
     m->field_sorted = false;
     if (!m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F)) {
@@ -329,7 +329,7 @@ int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st) {
     if (!sh.tail_due) return PS_OK;
     sh.tail_due = false;
     hipStream_t ss = m->side[0];
-    PSCHK(launch_spin_until(m->start_flag + 6, sh.pub_epoch, ss));
+    PSCHK(launch_spin_until(m->start_flag + 6, sh.pub_epoch, ss, m->s->werr(), 6));
     return plan_slots_and_lists(m, nshards, sh.tail_nnz, st, ss);
 }
 
@@ -351,13 +351,13 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     const int F = m->cfg.F;
     const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
     const bool bm = sh.bitmap != nullptr && nnz > 0 && g_plan_sort == 0;
-    early = early && bm && fwd_flag && g_plan_early && g_dev_wait && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback &&
+    early = early && bm && fwd_flag && g_plan_early && m->dev_ok && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback &&
             batch->on_device && !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
     static const bool plan_debug = getenv("PS_PLAN_DEBUG") != nullptr;      // measurement: which way did the plan go
     if (plan_debug) fprintf(stderr, "[plan] early=%d (bitmap %d, fwd flag %d, device batch %d, single-hot %d, field sort fits %d)\n", (int)early, (int)bm,
                             (int)fwd_flag, (int)batch->on_device, (int)!m->cur_offsets, (int)field_sort_fits(m->cur_B, F));
     hipStream_t ps = early ? m->side[0] : st;       // where the id-only kernels go
-    if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps));
+    if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
     m->nseg_cur = early ? (m->nseg_cur == m->nseg_dev ? m->nseg_dev + 4 : m->nseg_dev) : m->nseg_dev;
     if (bm && ++sh.epoch == 0) {          // the byte stamps wrap every 255 plans: start over from a clean map
         HIPCHK(hipMemsetAsync(sh.stamp, 0, (size_t)sh.bm_words * 32, ps));
@@ -377,7 +377,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
             if (++m->start_epoch == 0) ++m->start_epoch;
             sh.plan_epoch = m->start_epoch;
             PSCHK(launch_flag_set(m->start_flag + 7, sh.plan_epoch, ps));
-            PSCHK(launch_spin_until(m->start_flag + 7, sh.plan_epoch, st));      // (enqueued after the launch that releases it)
+            PSCHK(launch_spin_until(m->start_flag + 7, sh.plan_epoch, st, s->werr(), 7));      // (enqueued after the launch that releases it)
             sh.tail_due = true; sh.tail_nnz = nnz;
             return PS_OK;
         }
@@ -385,11 +385,11 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
         // side stream waits for, the slot kernel's launch the one the forward waits for (no record packets on either chain).
         hipStream_t ss = (m->profile || !m->multi_stream) ? st : m->side[0];
         hipEvent_t e1 = nullptr;
-        if (ss != st) { e1 = m->events[m->next_event++ % m->events.size()]; if (g_ext_events) g_launch_stop_event = e1; }
-        PS_LAUNCH(k_plan_emit, dim3(nblk), dim3(256), 0, st, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
-                  sh.owner_start, m->nseg_cur, sh.sbits, nshards, stamp_next("plan_emit"));
+        if (ss != st) e1 = m->events[m->next_event++ % m->events.size()];
+        PS_LAUNCH_EV(k_plan_emit, dim3(nblk), dim3(256), 0, st, g_ext_events ? e1 : nullptr, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix,
+                     sh.send_rows, sh.owner_start, m->nseg_cur, sh.sbits, nshards, stamp_next("plan_emit"));
         if (ss != st) {
-            if (g_launch_stop_event == e1 || !g_ext_events) { g_launch_stop_event = nullptr; HIPCHK(hipEventRecord(e1, st)); }
+            if (!g_ext_events) HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipStreamWaitEvent(ss, e1, 0));
         }
         PSCHK(plan_slots_and_lists(m, nshards, nnz, st, ss));

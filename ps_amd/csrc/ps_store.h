@@ -59,7 +59,10 @@ struct ps_store {
     std::map<std::string, ps_updater_t> updaters;
     int64_t global_step = 0;
     int64_t bytes = 0;
-    int *err_dev = nullptr;     // device-side bad-id counter
+    int *err_dev = nullptr;     // device words: [0] ids outside their table | [1] bounded device-side waits that timed out, [2] which wait
+    unsigned int *werr() const { return reinterpret_cast<unsigned int *>(err_dev) + 1; }
+    bool dev_wait_off = false;  // a device-side wait timed out on this store: every join takes its event form from then on
+    int64_t wait_timeouts = 0;
     // scratch for row get/put
     int64_t *idx_dev = nullptr; float *rowbuf_dev = nullptr; int64_t scratch_rows = 0; int scratch_D = 0;
     // scratch for push application
@@ -89,7 +92,12 @@ int store_resolve_updater(const ps_store *s, const char *key, ps_updater_t *out)
 int64_t store_local_row(const ps_store *s, int field, int64_t id);
 int store_ensure_scratch(ps_store *s, int64_t rows, int D);
 // after a host wait on the store's stream: report (and clear) the device-side count of ids that were outside their table
-int store_check_bad_ids(ps_store *s);
+int store_check_bad_ids(ps_store *s);      // (... and of bounded device-side waits that timed out: PS_E_STATE)
+// may this store's models join their streams by device-side flags?  (g_dev_wait, no timeout so far, one live model on the device)
+#define PS_MAX_DEVICES 64
+#include <atomic>
+extern std::atomic<int> g_models_on_device[PS_MAX_DEVICES];
+bool dev_waits_ok(const ps_store *s);
 
 struct FcBuf {
     float *A = nullptr;  int ldA = 0;     // input activations of layer l: [Bcap][ldA]
@@ -99,6 +107,8 @@ struct FcBuf {
 
 struct ps_model {
     ps_store *s = nullptr;
+    bool counted = false;       // in g_models_on_device
+    bool dev_ok = false;        // this step joins its streams by device-side flags (decided once per step in stage_batch)
     ps_model_config_t cfg;
     int Bcap = 0;
     int64_t nnz_cap = 0;

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "ps_store.h"
 
 // ---------------------------------------------------------------------------
@@ -248,7 +250,7 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
         HIPCHK(hipStreamCreateWithPriority(&s->own_stream, hipStreamNonBlocking, hi));   // main chain: most urgent
     }
     s->stream = s->own_stream;
-    PSCHK(store_dev_alloc(s, (void **)&s->err_dev, sizeof(int), true));
+    PSCHK(store_dev_alloc(s, (void **)&s->err_dev, 4 * sizeof(int), true));      // [0] bad ids | [1] timed-out device waits, [2] which
     ps_updater_t a;
     ps_updater_default_adam(&a);
     s->updaters["default"] = a;
@@ -282,13 +284,34 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     return PS_OK;
 }
 
+// Device-side waits (launch_spin_until, the GEMMs' end wait, the waits folded into the dW GEMM / the dense update) need
+// the streams of ONE model to run concurrently.  Several models driving one device from one process (tests run N ranks
+// as N threads on one GPU) multiply the streams beyond the runtime's hardware queues (GPU_MAX_HW_QUEUES, 4 per
+// priority): streams of different models then share a queue, and a waiter of one model can sit in front of another
+// model's releaser -- the likely cause of round 1's hang in the 4-rank thread test.  With more than one live model on a
+// device every join takes its event form.
+std::atomic<int> g_models_on_device[PS_MAX_DEVICES];
+bool dev_waits_ok(const ps_store *s) {
+    return g_dev_wait && !s->dev_wait_off && s->device >= 0 && s->device < PS_MAX_DEVICES && g_models_on_device[s->device].load() <= 1;
+}
+
 int store_check_bad_ids(ps_store *s) {
-    int err = 0;
-    HIPCHK(hipMemcpyAsync(&err, s->err_dev, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    int err[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(err, s->err_dev, sizeof err, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (err) {
+    if (err[1]) {
+        // a bounded device-side wait gave up: whatever ran behind it ran without one of its dependencies.  From here
+        // on this store's models use the event form of every join (the caller decides what to do with the tables:
+        // the steps since the last successful check are suspect).
+        HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof err, s->stream));
+        s->dev_wait_off = true;
+        s->wait_timeouts += err[1];
+        return ps_set_err(PS_E_STATE, "%d device-side wait(s) timed out after %.0f ms (last: wait %d); the steps since the last check ran without a "
+                          "dependency -- this store now joins its streams by events", err[1], (double)g_spin_timeout_ticks * 1e-5, err[2]);
+    }
+    if (err[0]) {
         HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof(int), s->stream));
-        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err);
+        return ps_set_err(PS_MISSING, "%d ids were outside their table (treated as id 0)", err[0]);
     }
     return PS_OK;
 }

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ps_store_put_wide": (_i, [_vp, _pi64, _i64, _i, _pf]),
     "ps_store_global_step": (_i64, [_vp]),
     "ps_store_advance_global_step": (_i, [_vp, _i64]),
+    "ps_store_key_length": (_i, [_vp, _cp, _pi]),
     "ps_store_push_update": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_pf), _pi, _i]),
     "ps_store_bytes": (_i64, [_vp]),
     "ps_store_sync": (_i, [_vp]),
@@ -155,6 +156,8 @@ SIGNATURES = {
     "ps_bench_gather_check": (_i, [_vp, _i64, _i, _i64, _i, C.c_uint64, _i64, _pi64, _pi64, _pf]),
     "ps_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _pd]),
     "ps_tune_set": (_i, [_cp, _i]),
+    "ps_store_join_mode": (_i, [_vp, _cp, _i]),
+    "ps_store_wait_timeouts": (C.c_int64, [_vp]),
     "ps_model_time_steps": (_i, [_vp, C.POINTER(ps_batch_t), _i, _pd]),
     "ps_model_set_profile": (_i, [_vp, _i]),
     "ps_model_set_profile_filter": (_i, [_vp, _cp]),

@@ -203,6 +203,11 @@ class PsServicer:
                 if req.isAsync:
                     self.store.push_update([(key, g)], is_async=True)       # sum + update at once (:176-184)
                 else:
+                    # validated when it ARRIVES: a bad key or length is this worker's 500, not a failure of the whole
+                    # round inside the last worker's barrier
+                    want = self.store.key_length(key)
+                    if g.size != want:
+                        return GradientMessage(resp=Resp(ec=EC_ERR, em="%s wants %d floats, got %d" % (key, want, g.size)))
                     self.pending.append((key, g))                            # KVStore.sum; applied by psUpdate
             except N.PsError as e:
                 return GradientMessage(resp=Resp(ec=EC_ERR, em=str(e)))

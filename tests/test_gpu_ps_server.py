@@ -180,3 +180,49 @@ def test_push_update_sums_in_arrival_order(shard, orc):
     for g in (e[1], e[0], e[1]):
         wv, M, V = orc.adam_update(wv, g, M, V)
     np.testing.assert_array_equal(kv.get_rows(0, [3])[0], wv)
+
+
+@pytest.mark.parametrize("m", [33, 40, 257])
+def test_push_update_more_than_32_workers(shard, orc, m):
+    """with 32 < m <= 256 pushes of one dense tensor in a BSP round the slab pre-fold ignored the row window
+    of "fc<i>.weights" / "fc<i>.bias" (wrong sums, writes outside the slabs, butterfly instead of arrival order).
+    m pushes of both tensors, order-sensitive values: (..(g0 + g1) + ..) / m in arrival order, one Adam step, and the
+    neighbouring tensor is untouched."""
+    kv, _ = shard
+    import ps_amd
+    kv.set_updater("fc0.weights", ps_amd.AdamUpdater()); kv.set_updater("fc0.bias", ps_amd.AdamUpdater())
+    rng = np.random.default_rng(m)
+    gw = [(rng.standard_normal(6) * 10.0 ** rng.integers(-3, 6)).astype(f32) for _ in range(m)]
+    gb = [(rng.standard_normal(2) * 10.0 ** rng.integers(-3, 6)).astype(f32) for _ in range(m)]
+    w0, b0 = kv.get("fc0.weights"), kv.get("fc0.bias")
+    msgs = []
+    for j in range(m):
+        msgs += [("fc0.weights", gw[j]), ("fc0.bias", gb[j])]
+    kv.push_update(msgs)
+
+    def mean(xs):
+        s = xs[0].copy()
+        for x in xs[1:]:
+            s = (x + s).astype(f32)
+        return (s / f32(len(xs))).astype(f32)
+
+    z = np.zeros
+    np.testing.assert_array_equal(kv.get("fc0.weights"), orc.adam_update(w0, mean(gw), z(6, f32), z(6, f32))[0])
+    np.testing.assert_array_equal(kv.get("fc0.bias"), orc.adam_update(b0, mean(gb), z(2, f32), z(2, f32))[0])
+
+
+def test_push_update_validates_every_message_before_touching_the_store(shard):
+    """one bad message (unknown key, wrong length, row of another shard) fails the call with the store
+    untouched -- not half-updated."""
+    kv, _ = shard
+    import ps_amd
+    from ps_amd import native as N
+    before = (kv.get_rows(0, np.arange(10)), kv.get("fc0.weights"), kv.get_wide(np.arange(7)))
+    good = [("emF0.2.0", np.ones(4, f32)), ("wide.weights.4.0", np.ones(1, f32)), ("fc0.weights", np.ones(6, f32))]
+    for bad in (("fc0.weights", np.ones(5, f32)), ("wide.weights.99.0", np.ones(1, f32)), ("emF0.2.0", np.ones(3, f32)),
+                ("emF9.2.0", np.ones(4, f32)), ("nosuch", np.ones(1, f32))):
+        with pytest.raises(N.PsError):
+            kv.push_update(good + [bad])
+        np.testing.assert_array_equal(kv.get_rows(0, np.arange(10)), before[0])
+        np.testing.assert_array_equal(kv.get("fc0.weights"), before[1])
+        np.testing.assert_array_equal(kv.get_wide(np.arange(7)), before[2])

@@ -10,6 +10,8 @@ leave identical tables:
   * ps_tune_set("dev_wait", 0)                (the dW chain waits for the head by event, not behind a device-side spinner)
   * ps_tune_set("end_wait", 0)                (the main chain joins side chain 0 behind a spinner launch, not inside the last delta GEMM)
   * ps_tune_set("tail_dev", 0)                (the dense update last on the main chain, not beside the embedding update)
+  * ps_tune_set("tail_fused", 0)              (the dense update behind a spinner launch and followed by a flag setter, the main chain ends behind a spinner)
+  * ps_tune_set("tn_start_wait", 0)           (a spinner launch in front of every dW GEMM, not only the first)
   * profile mode                              (everything on ONE stream: the serial order is the definition)
 Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
 consecutive plans must still equal the fused step (the map is re-zeroed when the epoch wraps)."""
@@ -65,6 +67,9 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
     variants = {"plain events": ({"ext_events": 0}, False), "general sort": ({"field_sort": 0}, False),
                 "dW chain released by event": ({"dev_wait": 0}, False), "dense update on the main chain": ({"tail_dev": 0}, False),
                 "side chain 0 joined behind a spinner": ({"end_wait": 0}, False),
+                "dense update between a spinner and a flag setter": ({"tail_fused": 0}, False),
+                "a spinner in front of every dW GEMM": ({"tn_start_wait": 0}, False),
+                "round 2's tail": ({"tail_fused": 0, "tn_start_wait": 0}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
@@ -177,15 +182,74 @@ for f in range(F):
     h.update(kv.get_rows(f, np.arange(V)).tobytes())
 for i in range(3):
     h.update(kv.get("fc%%d.weights" %% i).tobytes())
-print(json.dumps({"digest": h.hexdigest()}))
+import ctypes as C
+why = C.create_string_buffer(256)
+mode = ps_amd.native.lib().ps_store_join_mode(kv.h, why, 256)
+print(json.dumps({"digest": h.hexdigest(), "mode": mode, "why": why.value.decode()}))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for guard in (False, True):
+    guards = [None, "ROCPROF_COUNTER_COLLECTION", "HIP_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL", "GPU_MAX_HW_QUEUES"]
+    for guard in guards:
         env = dict(os.environ)
-        env.pop("ROCPROF_COUNTER_COLLECTION", None)
+        for g in guards[1:]:
+            env.pop(g, None)
         if guard:
-            env["ROCPROF_COUNTER_COLLECTION"] = "1"
+            env[guard] = "2" if guard == "GPU_MAX_HW_QUEUES" else ("3" if guard == "AMD_SERIALIZE_KERNEL" else "1")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-2000:]
-        out.append(json.loads(r.stdout.strip().splitlines()[-1])["digest"])
-    assert out[0] == out[1]
+        rep = json.loads(r.stdout.strip().splitlines()[-1])
+        out.append(rep["digest"])
+        # the serialising environments are recognised when the library is loaded: joins by events, and the reason is reported
+        assert rep["mode"] == (0 if guard else 1), rep
+        assert (guard in rep["why"]) if guard else rep["why"] == "", rep
+    assert all(d == out[0] for d in out[1:])
+
+
+def test_a_wait_that_is_never_released_times_out_with_an_error():
+    """Every device-side wait is bounded (VERDICT r2 next #5): a spinner launch and a GEMM's end wait on a flag nobody
+    raises come back after the timeout with PS_E_STATE -- not a hang -- and the store then joins its streams by events;
+    training on that store still gives the tables of a store that never timed out."""
+    import ctypes as C
+    import time
+    import ps_amd
+    from ps_amd import native as N
+    L = N.lib()
+    L.ps_dbg_stuck_wait.argtypes = [C.c_void_p, C.c_int]
+    L.ps_dbg_stuck_wait.restype = C.c_int
+    F, D, X, fc, V, B, WS = 6, 16, 5, [64, 32, 1], 3000, 1024, 97
+    rng = np.random.default_rng(8)
+    data = batches(rng, 4, B, F, X, V, WS)
+
+    def train(kv):
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+        for E, Xd, Y, W in data:
+            gm.train({"E": E, "X": Xd, "Y": Y, "W": W})
+        r = [kv.get_rows(f, np.arange(V)) for f in range(F)] + [kv.get("fc%d.weights" % i) for i in range(3)]
+        gm.close()
+        return r
+
+    L.ps_tune_set(b"spin_timeout_ms", 150)
+    try:
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        why = C.create_string_buffer(256)
+        assert L.ps_store_join_mode(kv.h, why, 256) == 1 and why.value == b""
+        for in_gemm in (0, 1):
+            t0 = time.perf_counter()
+            rc = L.ps_dbg_stuck_wait(kv.h, in_gemm)
+            dt = time.perf_counter() - t0
+            assert rc == N.PS_E_STATE, (in_gemm, rc, L.ps_last_error())
+            assert b"timed out" in L.ps_last_error()
+            assert 0.1 < dt < 5.0, dt
+        assert L.ps_store_wait_timeouts(kv.h) == 2
+        assert L.ps_store_join_mode(kv.h, why, 256) == 0 and b"timed out" in why.value
+        got = train(kv)
+        kv.close()
+    finally:
+        L.ps_tune_set(b"spin_timeout_ms", 2000)
+    kv2 = ps_amd.KVStore(0, SEED)
+    kv2.create_embedding([V] * F, D)
+    want = train(kv2)
+    kv2.close()
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)

@@ -28,6 +28,11 @@ class DictStore:
     def set_updater(self, group, upd):
         self.updaters[group] = upd
 
+    def key_length(self, key):
+        if key not in self.kv:
+            raise S.N.PsError(S.N.PS_MISSING, "unknown key %s" % key)
+        return self.kv[key].size
+
     def push_update(self, messages, is_async=False):
         self.rounds.append(([k for k, _ in messages], is_async))
 
@@ -108,4 +113,17 @@ def test_async_mode_never_blocks(served):
     assert c.push("emF0.1.0", np.ones(4, f32), "adam@x", is_async=True) == 0
     assert st.rounds == [(["emF0.1.0"], True)]                                              # applied at once
     assert c.barrier() == 200 and c.barrier() == 200 and st.step == 2                       # every barrier: globalStep++
+    c.close()
+
+
+def test_bsp_push_is_validated_when_it_arrives(served):
+    """a bad key or length is answered with ec 500 at push time; the round's other pushes and its barrier are
+    unaffected (the bad message never reaches psUpdate)."""
+    st, target = served(1)
+    c = S.PsClient(target)
+    assert c.push("fc0.weights", np.ones(6, f32), "adam@x") == 0
+    assert c.push("fc0.weights", np.ones(5, f32), "adam@x") == 500          # wrong length
+    assert c.push("nosuch.key", np.ones(1, f32), "adam@x") == 500           # the store does not hold it
+    assert c.barrier() == 200
+    assert st.rounds == [(["fc0.weights"], False)]
     c.close()
