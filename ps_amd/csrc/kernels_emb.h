@@ -123,11 +123,9 @@ struct DenseUpdArgs {
     // filling it and applying it are one kernel each instead of two); wide_blocks = 0: none
     WideUpdArgs wide;
     int wide_blocks, tile_blocks;
-    // the fused step's tail: the update starts only once *wait_flag reached wait_val (the embedding update has started =
-    // the last delta GEMM, which reads W_0, has finished) and raises *done_flag = done_val itself when its last
-    // workgroup is through (ps_common.h start_wait / DoneSignal); all NULL otherwise
+    // the fused step's tail: no workgroup starts before *wait_flag reached wait_val (the embedding update has started =
+    // the last delta GEMM, which reads W_0, has finished; ps_common.h start_wait); NULL otherwise
     const unsigned int *wait_flag; unsigned int wait_val; WaitBound bound;
-    unsigned int *done_counter, *done_flag; unsigned int done_val;
 };
 int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)

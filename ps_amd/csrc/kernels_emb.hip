@@ -1064,7 +1064,6 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
 // 5.6 MB of tensors).
 __device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int64_t r);
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
-    DoneSignal done(a.done_counter, a.done_flag, a.done_val);       // (every return path below counts this workgroup)
     StampScope stamp(a.ts);
     start_wait(a.wait_flag, a.wait_val, a.bound);
     if ((int)blockIdx.x >= a.tile_blocks) {                // the optional wide-table pass of the same launch

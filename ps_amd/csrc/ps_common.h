@@ -169,16 +169,18 @@ int stamps_enable(int on);
 #ifdef __HIPCC__
 // ---- device-side waits, all bounded (WaitBound above) ----
 // After bound.ticks of the device's wall clock the waiter counts itself in *bound.err, notes which wait it was, and goes on.
-__device__ __forceinline__ void spin_bounded(const unsigned int *f, unsigned int v, const WaitBound &b) {
-    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) >= 0) return;
+// Returns whether it had to wait at all.
+__device__ __forceinline__ bool spin_bounded(const unsigned int *f, unsigned int v, const WaitBound &b) {
+    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) >= 0) return false;
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
         __builtin_amdgcn_s_sleep(16);
         if (b.ticks && (unsigned long long)wall_clock64() - t0 > b.ticks) {
             if (b.err) { atomicAdd(b.err, 1u); __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            return;
+            break;
         }
     }
+    return true;
 }
 // "This launch does not END before another chain has reached X": the first workgroup, done with its work, holds its
 // slot until the flag is there (normally long since) -- the join costs the waiting chain no launch of its own.  What
@@ -187,40 +189,23 @@ struct EndWait {
     const unsigned int *f; unsigned int v; WaitBound b;
     __device__ __forceinline__ EndWait(const unsigned int *flag, unsigned int val, const WaitBound &bound) : f(flag), v(val), b(bound) {}
     __device__ __forceinline__ ~EndWait() {
-        if (f && blockIdx.x == 0 && threadIdx.x == 0) spin_bounded(f, v, b);
+        if (f && blockIdx.x == 0 && threadIdx.x == 0) (void)spin_bounded(f, v, b);
     }
 };
-// "This launch does not START its work before X": every workgroup checks the flag when it starts (one load when it is up
-// -- the intended case: the launch sits in order behind a kernel that outlasts X) and then ACQUIRES at agent scope: the
-// data X stands for was written by a kernel of another stream that ended before the flag went up, but this kernel's own
-// start-of-kernel acquire came earlier, and an XCD's L2 may still hold the previous step's lines of those addresses.
-// Call from every thread of the workgroup (a barrier inside).
+// "This launch does not START its work before X": every workgroup checks the flag when it starts.  The intended case is
+// one load: the launch sits in order behind a kernel that outlasts X, so the flag is up -- and then this kernel's own
+// start (which acquires: an XCD's L2 drops its non-coherent lines) came AFTER the data X stands for was released, and
+// nothing else is needed.  A workgroup that really had to wait acquires at agent scope afterwards: X's data was written by
+// a kernel of another stream, and this XCD's L2 may hold older lines of those addresses.  (The fence is a buffer_inv
+// sc1 = an L2 invalidate: paid unconditionally by every workgroup of a 224-workgroup GEMM it cost the step 4 us and
+// slowed every kernel running beside it -- measured, round 3.)  Data nobody reads between this kernel's start and X is
+// all this relies on.  Call from every thread of the workgroup (a barrier inside).
 __device__ __forceinline__ void start_wait(const unsigned int *f, unsigned int v, const WaitBound &b) {
     if (!f) return;
-    if (threadIdx.x == 0) spin_bounded(f, v, b);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int waited = 0;
+    if (threadIdx.x == 0) waited = spin_bounded(f, v, b) ? 1 : 0;
+    if (__syncthreads_or(waited)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-// "X = this launch has finished", raised by the launch itself: every workgroup releases its writes and counts itself;
-// the last one resets the counter and raises the flag (no flag-setter launch behind the kernel: ~3 us of its stream).
-// RAII so that every return path of the kernel counts; all threads of a workgroup must leave through the same path
-// (a barrier inside).
-struct DoneSignal {
-    unsigned int *counter, *flag; unsigned int val;
-    __device__ __forceinline__ DoneSignal(unsigned int *c, unsigned int *f, unsigned int v) : counter(c), flag(f), val(v) {}
-    __device__ __forceinline__ ~DoneSignal() {
-        if (!flag) return;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
-            if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
-                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-};
 struct StampScope {
     unsigned long long *p;
     unsigned int always;            // the first `always` workgroups all report their end (the long-key role of the embedding update)

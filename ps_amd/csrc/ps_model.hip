@@ -778,9 +778,12 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.upd = make_upd_params(u);
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
     // tail_dev: the dense update, on side chain 1, starts when the embedding update has STARTED (its first workgroup
-    // raises start_flag[2]) and raises start_flag[3] itself when its last workgroup is through; the embedding update's
-    // first workgroup ENDS only once that flag is up (normally long since): the step's tail is two launches and no
-    // spinner / flag-setter launch on either chain (tail_fused; round 2 had four small launches here).
+    // raises start_flag[2]; the update's workgroups check that flag themselves, no spinner launch in front of it), a
+    // flag-setter launch behind it raises start_flag[3], and the embedding update's first workgroup ENDS only once that
+    // flag is up (normally long since) -- no spinner launch at the end of the main chain either (tail_fused).  The flag
+    // setter stays a launch: the update's writes (W, Wt of every layer) are released by the END of its kernel, and a
+    // release from inside it would have to write back every XCD's L2 (tried: a per-workgroup agent-scope release made
+    // the update 29 us instead of 7).
     const bool tail_fused = tail_dev && g_tail_fused && nnz > 0;
     LaunchOpts emb_lo;
     if (tail_dev) { if (++m->start_epoch == 0) ++m->start_epoch; emb_lo.flag = m->start_flag + 2; emb_lo.flag_val = m->start_epoch; }
@@ -806,9 +809,8 @@ int enqueue_backward(ps_model *m, bool apply) {
         // (every waiter is enqueued after the launch that releases it)
         if (tail_fused && emb_lo.launched) {
             d.wait_flag = m->start_flag + 2; d.wait_val = m->start_epoch; d.bound = wait_bound(werr, 2);
-            d.done_counter = m->start_flag + 8; d.done_flag = m->start_flag + 3; d.done_val = m->start_epoch;
-            Prof pf(m, "dense_update");
-            PSCHK(launch_dense_update(d, sw));
+            { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
+            PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
             return PS_OK;
         }
         PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw, werr, 2));
