@@ -439,7 +439,7 @@ int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *gr
  * enqueued from C.  The collectives are reached through a table of callbacks:
  * ps_comm_rccl_create fills it with RCCL (ncclSend/ncclRecv groups,
  * ncclAllGather, ncclAllReduce over xGMI; librccl is dlopen'ed on first use;
- * rank 0 makes the 128-byte id with ps_comm_rccl_unique_id and the host
+ * rank 0 makes the ids (3 x 128 bytes) with ps_comm_rccl_unique_id and the host
  * hands it to every rank); a host may plug in its own.  All pointers are
  * device pointers; every callback enqueues on `stream` (hipStream_t).
  * counts are in elements of elem_bytes, ordered by peer rank. */
@@ -451,9 +451,12 @@ typedef struct ps_comm_ops {
                         const int64_t *recv_counts, size_t elem_bytes, void *stream);
     int (*all_reduce_sum_f32)(void *ctx, float *buf, int64_t n, void *stream);
 } ps_comm_ops_t;
-int ps_comm_rccl_unique_id(char *out256);   /* two 128-byte ids: main + prefetch communicator */
-int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id256, ps_comm_ops_t *out);
+int ps_comm_rccl_unique_id(char *out384);   /* three 128-byte ids: the main, the key-list and the all-reduce communicator */
+int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id384, ps_comm_ops_t *out);
 int ps_comm_rccl_destroy(ps_comm_ops_t *ops);
+/* RCCL's own view of a table made by ps_comm_rccl_create: ncclCommCount / ncclCommUserRank of the main communicator
+ * and whether the side communicator exists (what bench.py reports as evidence of the wire a multi-GPU run used). */
+int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int *user_rank, int *has_side);
 /* One-shot wire check (collective: every rank calls it): each callback of the
  * table once on known patterns -- uneven all-to-all-v counts, all-gather slot
  * order, a float all-reduce -- verified on the host.  PS_E_STATE names the

@@ -153,10 +153,10 @@ JNIEXPORT void JNICALL Java_store_NativeKVStore_destroyModel(JNIEnv *, jobject, 
 
 // ---- -Dmode=dist: PSRouterClient / PServer as collectives (one process per GPU) -------------------------------------
 JNIEXPORT jbyteArray JNICALL Java_store_NativeKVStore_commUniqueId(JNIEnv *env, jclass) {
-    char id[256];
+    char id[384];       // three 128-byte communicator ids
     if (fail(env, ps_comm_rccl_unique_id(id))) return nullptr;
-    jbyteArray out = env->NewByteArray(256);
-    if (out) env->SetByteArrayRegion(out, 0, 256, reinterpret_cast<const jbyte *>(id));
+    jbyteArray out = env->NewByteArray(384);
+    if (out) env->SetByteArrayRegion(out, 0, 384, reinterpret_cast<const jbyte *>(id));
     return out;
 }
 JNIEXPORT jlong JNICALL Java_store_NativeKVStore_commCreate(JNIEnv *env, jobject self, jint nranks, jint rank, jbyteArray id) {

@@ -17,13 +17,16 @@ struct EmbFwdArgs {
     uint32_t *key_out;         // [nnz] global row per entry (sort key) or nullptr
     uint32_t *ent_bag;         // [nnz] bag of each entry (multi-hot) or nullptr
     const uint32_t *slot;      // when set: row of entry p is slot[p] (W = pulled-row cache), ids unused
+    const float *W_alt; uint32_t alt_lo, alt_hi;   // slots in [alt_lo, alt_hi) are read from W_alt + slot * D instead (the rows this
+                               // rank owns itself never travel: they stay in the owner-side gather's output)
     int *err;                  // out-of-range id counter
     size_t table_bytes;        // size of W (decides the streaming hints)
     int nt;                    // bit 0: non-temporal row loads, bit 1: non-temporal output stores (set by the launcher)
     int LPR, gather_blocks;    // filled by the launcher
     unsigned long long *ts;    // stamp slot (ps_common.h) or nullptr, set by the launcher
+    const unsigned int *end_wait; unsigned int end_val; WaitBound bound;   // the first workgroup ends only once *end_wait reached end_val
 };
-int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr);        // lo: stop_event
+int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: stop_event, wait (an END wait)
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st);      // multi-hot: key_out / ent_bag from the ids alone
 
 struct HeadArgs {
@@ -179,8 +182,12 @@ struct PushApplyArgs {
     int D, LPR, is_async, npeers;
     uint32_t peer_start[PS_PUSH_MAX_PEERS + 1];   // entry range of every pushing worker
     int64_t n, R;                      // entries, owner-local rows
-    const uint32_t *rows;              // [n] owner-local row of every entry (unique inside one worker's range)
-    const float *grads;                // [n][D]
+    // entry e of worker p = (rows_p[p][e - peer_start[p]], grads_p[p][(e - peer_start[p]) * D ...]): every worker's list
+    // where it lies -- the received id blocks of the exchange, the received gradients, and for this rank's own keys the
+    // buffers they were produced in (nothing of a rank's own traffic is copied)
+    const uint32_t *rows_p[PS_PUSH_MAX_PEERS];    // owner-local row of every entry (unique inside one worker's range)
+    const float *grads_p[PS_PUSH_MAX_PEERS];
+    unsigned int *flag; unsigned int flag_val;    // "this launch has started" (LaunchOpts.flag), or NULL
     uint32_t *mask;                    // [R] bit w set: worker w pushed this row (all zero between steps)
     uint32_t *pos;                     // [npeers][R] entry of worker w's push for the row
     float *W, *state;
@@ -188,4 +195,4 @@ struct PushApplyArgs {
     int *err;
     unsigned long long *ts_mark, *ts_apply;   // stamp slots, set by the launcher
 };
-int launch_push_apply(PushApplyArgs a, hipStream_t st);
+int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo = nullptr);      // lo: flag (the first launch announces its start)

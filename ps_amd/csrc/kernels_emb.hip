@@ -61,6 +61,7 @@ template <> struct Vec<1> {
 #define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
 template <int VEC, bool MULTI, bool SLOT, int MHI>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
+    EndWait end_wait(a.end_wait, a.end_val, a.bound);     // (sharded step: the join with the previous step's replicated update)
     StampScope stamp(a.ts);
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x >= a.gather_blocks) {
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
         if (id < 0 || id >= rn) { if (part == 0) atomicAdd(a.err, 1); id = 0; }
         return rb + id;
     };
+    // sharded worker: the slots of this rank's own keys are read where the owner-side gather left them (EmbFwdArgs.W_alt)
+    auto table_of = [&](int64_t row) -> const float * {
+        return (SLOT && (uint32_t)row - a.alt_lo < a.alt_hi - a.alt_lo) ? a.W_alt : a.W;
+    };
     if (!MULTI) {
         const int64_t bag0 = grp * GATHER_ILP;
         if (bag0 >= nb) return;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
         Vec<VEC> r[GATHER_ILP];
 #pragma unroll
         for (int j = 0; j < GATHER_ILP; ++j) {                                                                       // rcopy (EmbeddingField.java:73)
-            const float *src = a.W + (size_t)rows[j] * a.D + part * VEC;
+            const float *src = table_of(rows[j]) + (size_t)rows[j] * a.D + part * VEC;
             r[j] = (a.nt & 1) ? Vec<VEC>::load_nt(src) : Vec<VEC>::load(src);
         }
 #pragma unroll
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
                 Vec<VEC> r[MH];
 #pragma unroll
                 for (int j = 0; j < MH; ++j) {
-                    const float *src = a.W + (size_t)rows[j] * a.D + part * VEC;
+                    const float *src = table_of(rows[j]) + (size_t)rows[j] * a.D + part * VEC;
                     r[j] = (a.nt & 1) ? Vec<VEC>::load_nt(src) : Vec<VEC>::load(src);
                 }
 #pragma unroll
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
         for (int j = 0; j < GATHER_ILP_MH; ++j) rows[j] = row_of(q + j < p1 ? q + j : p1 - 1, f);
         Vec<VEC> r[GATHER_ILP_MH];
 #pragma unroll
-        for (int j = 0; j < GATHER_ILP_MH; ++j) r[j] = Vec<VEC>::load(a.W + (size_t)rows[j] * a.D + part * VEC);
+        for (int j = 0; j < GATHER_ILP_MH; ++j) r[j] = Vec<VEC>::load(table_of(rows[j]) + (size_t)rows[j] * a.D + part * VEC);
 #pragma unroll
         for (int j = 0; j < GATHER_ILP_MH; ++j) {
             if (q + j < p1) {
@@ -997,18 +1002,21 @@ __device__ __forceinline__ int push_peer_of(const PushApplyArgs &a, uint32_t e) 
 
 __global__ __launch_bounds__(256) void k_push_mark(PushApplyArgs a) {
     StampScope stamp(a.ts_mark);
+    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.n) return;
-    const uint32_t r = a.rows[e];
-    if ((int64_t)r >= a.R) { atomicAdd(a.err, 1); return; }
     const int p = push_peer_of(a, (uint32_t)e);
+    const uint32_t r = a.rows_p[p][e - a.peer_start[p]];
+    if ((int64_t)r >= a.R) { atomicAdd(a.err, 1); return; }
     a.pos[(size_t)p * a.R + r] = (uint32_t)e;
     atomicOr(&a.mask[r], 1u << p);
 }
 
-template <int VEC>
+// ONE: a single pushing worker (its rows are unique): no mark pass, no mask -- every entry is its row's only push
+template <int VEC, bool ONE>
 __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
     StampScope stamp(a.ts_apply);
+    if (ONE && a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
     const int gpw = 64 / a.LPR;
@@ -1016,10 +1024,11 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
     const int64_t e = (gt >> 6) * gpw + lane64 / a.LPR;
     const int part = lane64 % a.LPR;
     if (e >= a.n) return;
-    const uint32_t row = a.rows[e];
-    if ((int64_t)row >= a.R) return;
-    uint32_t m = a.mask[row];
-    if (m == 0u || push_peer_of(a, (uint32_t)e) != __ffs((int)m) - 1) return;     // another worker's entry leads this row
+    const int pe = ONE ? 0 : push_peer_of(a, (uint32_t)e);
+    const uint32_t row = a.rows_p[pe][e - a.peer_start[pe]];
+    if ((int64_t)row >= a.R) { if (ONE && part == 0) atomicAdd(a.err, 1); return; }
+    uint32_t m = ONE ? 1u : a.mask[row];
+    if (m == 0u || pe != __ffs((int)m) - 1) return;     // another worker's entry leads this row
     const int cnt = __popc(m);
     float *wp = a.W + (size_t)row * a.D + part * VEC;
     float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
@@ -1034,14 +1043,14 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
             if (g0 != 0.f) { VFOR(i) ftrl_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
         }
     };
-    Vec<VEC> S = Vec<VEC>::load(a.grads + (size_t)e * a.D + part * VEC);            // the leader's own push comes first
+    Vec<VEC> S = Vec<VEC>::load(a.grads_p[pe] + (size_t)(e - a.peer_start[pe]) * a.D + part * VEC);     // the leader's own push comes first
     if (a.is_async) apply(S);
     m &= m - 1;
     while (m) {
         const int q = __ffs((int)m) - 1;
         m &= m - 1;
         const uint32_t ent = a.pos[(size_t)q * a.R + row];
-        const Vec<VEC> g = Vec<VEC>::load(a.grads + (size_t)ent * a.D + part * VEC);
+        const Vec<VEC> g = Vec<VEC>::load(a.grads_p[q] + (size_t)(ent - a.peer_start[q]) * a.D + part * VEC);
         if (a.is_async) apply(g);
         else { VFOR(i) S.at(i) = g.get(i) + S.at(i); }
     }
@@ -1051,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
     }
     w.store(wp);
     if (a.upd.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
-    if (part == 0) a.mask[row] = 0u;
+    if (!ONE && part == 0) a.mask[row] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -1313,8 +1322,9 @@ int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st) {
     return PS_OK;
 }
 
-int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo) {
+int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
     if (lo) lo->launched = false;
+    a.end_wait = lo ? lo->wait : nullptr; a.end_val = lo ? lo->wait_val : 0u; a.bound = wait_bound(werr, 103);
     const hipEvent_t stop_ev = lo ? lo->stop_event : nullptr;
     // rows of tables far beyond the 256 MiB Infinity Cache are read once: non-temporal loads (measured on the 256 GB
     // table, tools/gather_nt.py: bags of 32 0.671 -> 0.707 of 8 TB/s, single-hot read+write 0.663 -> 0.694; nt stores: no effect)
@@ -1334,24 +1344,24 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo) {
     const int mhi = (multi && 64 % a.LPR == 0) ? (a.LPR <= 4 ? a.LPR : a.LPR == 8 ? 2 : (g_mh_ilp16 > 0 ? g_mh_ilp16 : 1)) : 0;
 #define EMB_FWD_MH(V, S)                                                                                           \
     do {                                                                                                           \
-        if (mhi == 4) hipLaunchKernelGGL((k_emb_fwd<V, true, S, 4>), dim3(grid), dim3(256), 0, st, a);             \
-        else if (mhi == 2) hipLaunchKernelGGL((k_emb_fwd<V, true, S, 2>), dim3(grid), dim3(256), 0, st, a);        \
-        else if (mhi == 1) hipLaunchKernelGGL((k_emb_fwd<V, true, S, 1>), dim3(grid), dim3(256), 0, st, a);        \
-        else hipLaunchKernelGGL((k_emb_fwd<V, true, S, 0>), dim3(grid), dim3(256), 0, st, a);                      \
+        if (mhi == 4) PS_LAUNCH_EV((k_emb_fwd<V, true, S, 4>), dim3(grid), dim3(256), 0, st, stop_ev, a);          \
+        else if (mhi == 2) PS_LAUNCH_EV((k_emb_fwd<V, true, S, 2>), dim3(grid), dim3(256), 0, st, stop_ev, a);     \
+        else if (mhi == 1) PS_LAUNCH_EV((k_emb_fwd<V, true, S, 1>), dim3(grid), dim3(256), 0, st, stop_ev, a);     \
+        else PS_LAUNCH_EV((k_emb_fwd<V, true, S, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a);                   \
     } while (0)
 #define EMB_FWD_LAUNCH(V)                                                                                          \
     do {                                                                                                           \
         if (multi) { if (slot) EMB_FWD_MH(V, true); else EMB_FWD_MH(V, false); }                                   \
         else { if (slot) PS_LAUNCH_EV((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a);   \
-               else PS_LAUNCH_EV((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a);        \
-               if (lo) lo->launched = true; }                                                                      \
+               else PS_LAUNCH_EV((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a); }      \
     } while (0)
-    if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0)
-        hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);
+    if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0 && !stop_ev && !a.end_wait)
+        hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);       // (measurement variant: carries no event / end wait)
     else if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
 #undef EMB_FWD_LAUNCH
 #undef EMB_FWD_MH
     HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
     return PS_OK;
 }
 
@@ -1598,18 +1608,27 @@ int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st) {
     return PS_OK;
 }
 
-int launch_push_apply(PushApplyArgs a, hipStream_t st) {
+int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo) {
+    if (lo) lo->launched = false;
     if (a.n <= 0) return PS_OK;
+    a.flag = lo ? lo->flag : nullptr; a.flag_val = lo ? lo->flag_val : 0u;
     const int vec = a.D % 4 == 0 ? 4 : 1;
     a.LPR = a.D / vec;
     const int gpw = 64 / a.LPR;
     if (gpw < 1) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d needs more than one wave per row", a.D);
-    a.ts_mark = stamp_next("push_mark"); a.ts_apply = stamp_next("push_apply");
-    hipLaunchKernelGGL(k_push_mark, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
     const int g = cdiv((int64_t)cdiv(a.n, gpw) * 64, 256);
-    if (vec == 4) hipLaunchKernelGGL((k_push_apply<4>), dim3(g), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_push_apply<1>), dim3(g), dim3(256), 0, st, a);
+    if (a.npeers == 1) {        // one pushing worker: one launch (its rows are unique, nothing to mark)
+        a.ts_apply = stamp_next("push_apply");
+        if (vec == 4) hipLaunchKernelGGL((k_push_apply<4, true>), dim3(g), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_push_apply<1, true>), dim3(g), dim3(256), 0, st, a);
+    } else {
+        a.ts_mark = stamp_next("push_mark"); a.ts_apply = stamp_next("push_apply");
+        hipLaunchKernelGGL(k_push_mark, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
+        if (vec == 4) hipLaunchKernelGGL((k_push_apply<4, false>), dim3(g), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_push_apply<1, false>), dim3(g), dim3(256), 0, st, a);
+    }
     HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
     return PS_OK;
 }
 

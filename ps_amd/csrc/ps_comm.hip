@@ -44,6 +44,8 @@ struct Rccl {
     int (*Recv)(void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, rcclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*CommCount)(const rcclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const rcclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 } g_rccl;
 
@@ -57,6 +59,7 @@ int rccl_load() {
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+    SYM(CommCount, "ncclCommCount"); SYM(CommUserRank, "ncclCommUserRank");
 #undef SYM
     g_rccl.h = h;
     return PS_OK;
@@ -64,9 +67,17 @@ int rccl_load() {
 
 #define RCCLCHK(x) do { int r__ = (x); if (r__ != 0) return ps_set_err(PS_E_HIP, "%s -> %s", #x, g_rccl.GetErrorString(r__)); } while (0)
 
-// `side` carries the counts all-gather of the NEXT step's prefetch (its own communicator: operations on one
-// communicator are ordered, so sharing it would chain the running step behind the prefetch)
-struct RcclCtx { rcclComm_t comm = nullptr, side = nullptr; int nranks = 1, rank = 0; bool use_side = false; };
+// Three communicators.  `comm` carries what sits on the step's critical chain, on the training stream: the rows of the
+// pull and the gradients of the push.  `side` carries what does not -- the next step's key lists (they read no weight)
+// and the all-reduce of the replicated tensors' gradients -- on a side stream of the model, so that neither queues in
+// front of the push (operations on ONE communicator are ordered).  Every rank issues the operations of a communicator in
+// one fixed order (per step: side = [key lists of t+1, all-reduce of t], comm = [rows of t, gradients of t]); the step code
+// selects the communicator (use_side) before a call.  skip_self: the caller reads this rank's own part where it was
+// produced -- the all-to-all-v then moves nothing for it.
+// `ar` carries only the all-reduce, on side chain 1 (the id exchange runs on side chain 0 right behind the plan's kernels:
+// one communicator per stream, so that no two streams ever drive one communicator).
+struct RcclCtx { rcclComm_t comm = nullptr, side = nullptr, ar = nullptr; int nranks = 1, rank = 0; int which = 0; bool skip_self = false; };
+rcclComm_t pick_comm(RcclCtx *c) { return (c->which == 1 && c->side) ? c->side : (c->which == 2 && c->ar) ? c->ar : c->comm; }
 
 int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
@@ -75,7 +86,7 @@ int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void 
         HIPCHK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
         return PS_OK;
     }
-    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, (c->use_side && c->side) ? c->side : c->comm, st));
+    RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, pick_comm(c), st));
     return PS_OK;
 }
 
@@ -84,18 +95,19 @@ int rccl_all_to_all_v(void *ctx, const void *send, const int64_t *sc, void *recv
     hipStream_t st = (hipStream_t)stream;
     size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
     const bool wire = c->nranks > 1;
+    rcclComm_t cm = pick_comm(c);
     if (wire) RCCLCHK(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
         if (p == c->rank) { self_so = so; self_ro = ro; }
         else {
-            if (sc[p] > 0) RCCLCHK(g_rccl.Send((const char *)send + so * eb, (size_t)sc[p] * eb, RCCL_CHAR, p, c->comm, st));
-            if (rc[p] > 0) RCCLCHK(g_rccl.Recv((char *)recv + ro * eb, (size_t)rc[p] * eb, RCCL_CHAR, p, c->comm, st));
+            if (sc[p] > 0) RCCLCHK(g_rccl.Send((const char *)send + so * eb, (size_t)sc[p] * eb, RCCL_CHAR, p, cm, st));
+            if (rc[p] > 0) RCCLCHK(g_rccl.Recv((char *)recv + ro * eb, (size_t)rc[p] * eb, RCCL_CHAR, p, cm, st));
         }
         so += (size_t)sc[p]; ro += (size_t)rc[p];
     }
     if (wire) RCCLCHK(g_rccl.GroupEnd());
     if (sc[c->rank] != rc[c->rank]) return ps_set_err(PS_E_STATE, "all-to-all-v: self counts differ");
-    if (sc[c->rank] > 0)       // this rank's own keys never touch the wire
+    if (sc[c->rank] > 0 && !c->skip_self)       // this rank's own keys never touch the wire
         HIPCHK(hipMemcpyAsync((char *)recv + self_ro * eb, (const char *)send + self_so * eb, (size_t)sc[c->rank] * eb, hipMemcpyDeviceToDevice, st));
     return PS_OK;
 }
@@ -103,11 +115,7 @@ int rccl_all_to_all_v(void *ctx, const void *send, const int64_t *sc, void *recv
 int rccl_all_reduce(void *ctx, float *buf, int64_t n, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
     if (c->nranks == 1 || n <= 0) return PS_OK;
-    // on the MAIN communicator: ps_shard_step_finish issues it on the main stream behind the gradient all-to-all-v, so
-    // every rank enqueues the collectives of one communicator in one order on one stream.  (Two communicators driven
-    // from two streams at once is a documented NCCL/RCCL deadlock hazard: device launch order across ranks is then not
-    // deterministic.  The side communicator carries only the counts all-gather of an explicitly requested prefetch.)
-    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, c->comm, (hipStream_t)stream));
+    RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, pick_comm(c), (hipStream_t)stream));
     return PS_OK;
 }
 
@@ -126,18 +134,19 @@ int size_once(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
 
 }  // namespace
 
-extern "C" int ps_comm_rccl_unique_id(char *out256) {
-    if (!out256) return ps_set_err(PS_E_BAD_ARG, "null argument");
+extern "C" int ps_comm_rccl_unique_id(char *out384) {
+    if (!out384) return ps_set_err(PS_E_BAD_ARG, "null argument");
     PSCHK(rccl_load());
-    for (int k = 0; k < 2; ++k) {          // two ids: the main communicator and the prefetch one
+    for (int k = 0; k < 3; ++k) {          // three ids: the main communicator, the key-list one, the all-reduce one
         rcclUniqueId id;
         RCCLCHK(g_rccl.GetUniqueId(&id));
-        memcpy(out256 + 128 * k, id.internal, 128);
+        memcpy(out384 + 128 * k, id.internal, 128);
     }
     return PS_OK;
 }
 
-extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id256, ps_comm_ops_t *out) {
+extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id384, ps_comm_ops_t *out) {
+    const char *id256 = id384;
     if (!s || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id256)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(s->device));
     RcclCtx *c = new RcclCtx();
@@ -152,7 +161,12 @@ extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const ch
             memcpy(id.internal, id256 + 128, 128);
             r = g_rccl.CommInitRank(&c->side, nranks, id, rank);
         }
+        if (r == 0) {
+            memcpy(id.internal, id256 + 256, 128);
+            r = g_rccl.CommInitRank(&c->ar, nranks, id, rank);
+        }
         if (r != 0) {
+            if (c->side) (void)g_rccl.CommDestroy(c->side);
             if (c->comm) (void)g_rccl.CommDestroy(c->comm);
             delete c;
             return ps_set_err(PS_E_HIP, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r));
@@ -167,6 +181,7 @@ extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const ch
 extern "C" int ps_comm_rccl_destroy(ps_comm_ops_t *ops) {
     if (!ops || !ops->ctx) return PS_OK;
     RcclCtx *c = (RcclCtx *)ops->ctx;
+    if (c->ar) (void)g_rccl.CommDestroy(c->ar);
     if (c->side) (void)g_rccl.CommDestroy(c->side);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     delete c;
@@ -234,93 +249,178 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
     return rcode;
 }
 
+// RCCL's own view of a communicator made by ps_comm_rccl_create (bench.py prints it: evidence that the wire the step used
+// really spans the ranks): ranks in the main communicator, this rank's index in it, whether the side communicator exists.
+extern "C" int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int *user_rank, int *has_side) {
+    if (!ops || !ops->ctx || ops->all_to_all_v != rccl_all_to_all_v) return ps_set_err(PS_E_BAD_ARG, "not an RCCL communicator table");
+    RcclCtx *c = (RcclCtx *)ops->ctx;
+    int n = c->nranks, r = c->rank;
+    if (c->comm) { RCCLCHK(g_rccl.CommCount(c->comm, &n)); RCCLCHK(g_rccl.CommUserRank(c->comm, &r)); }
+    if (comm_count) *comm_count = n;
+    if (user_rank) *user_rank = r;
+    if (has_side) *has_side = (c->side ? 1 : 0) + (c->ar ? 1 : 0);
+    return PS_OK;
+}
+
 // ---------------------------------------------------------------------------
 // one BSP (or async) step of worker + owner
 // ---------------------------------------------------------------------------
-// Measured on MI355X at N = 1: beginning step t+1 on the prefetch stream while step t trains is SLOWER (0.40 vs
-// 0.33 ms per step) -- the plan is a chain of ~15 tiny kernels, and interleaving them with the training chain
-// delays every launch of the critical path more than the overlap saves; bench.py therefore runs the halves back
-// to back (--overlap 0).  The split stays: it is what a host with longer steps (bigger batches) would use.
+// Round 3.  What one step enqueues, and where (N ranks; `side chain 1` = the model's dW / dense-update stream):
+//
+//   training stream (communicator `comm`)                     side chain 1 (communicator `side`)
+//   -------------------------------------                     ---------------------------------
+//   [host: counts of step t, published during step t-1]
+//   owner gather of the requested rows (PServer.getList)
+//   all-to-all-v rows -> worker cache
+//   forward / backward of step t  .........................   dW GEMMs, flat gradient [fc | wide G | wide C | bias]
+//        (the plan of step t+1 runs on side chain 0 meanwhile)  pack t+1's key lists into per-owner blocks
+//   all-to-all-v per-key gradients (PSClient.push)            all-to-all of the FIXED-SIZE id blocks of step t+1
+//   owner: mean over pushing workers (or async) + updater       + publication of their counts to the host
+//                                                             all-reduce of the flat gradient, replicated update
+//
+// The key lists travel as fixed-size blocks [count | rows | padding] (ps_store.h): no split sizes, so no host wait in
+// front of that exchange, and it carries the counts of the two exchanges that do need them.  Rounds 1-2 all-gathered an
+// N x N count matrix, waited for it on the host and then sent the ids with exact sizes in front of the pull, on the
+// critical chain.  On the critical chain now: two collectives (rows, gradients) and three small kernels per step.
+// A rank's own keys are never copied: the owner-side gather's output, the gradient buffer and the packed id block are
+// read where they are (EmbFwdArgs.W_alt, PushApplyArgs.rows_p / grads_p).
+// Without device-side joins (events only, ps_store_join_mode = 0) or with ps_tune_set("shard_overlap", 0) everything is
+// enqueued on the training stream with the one communicator, in the order of the left column then the right.
+int g_shard_overlap = 1;
 namespace {
-__global__ void k_publish_counts(const uint32_t *__restrict__ src, uint32_t *dst_host, int n, uint32_t *flag_host, uint32_t epoch,
-                                 unsigned int *started, unsigned int started_val, unsigned long long *ts) {
+__global__ __launch_bounds__(256) void k_pack_blocks(const uint32_t *__restrict__ send_rows, const uint32_t *__restrict__ owner_start, int nranks,
+                                                      int64_t blk_words, uint32_t *__restrict__ blk, unsigned long long *ts) {
     StampScope stamp(ts);
-    // "everything in front of this launch on its stream has finished" for a device-side waiter (an early plan's second half)
-    if (started && threadIdx.x == 0) __hip_atomic_store(started, started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst_host[i] = src[i];
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u < nranks) blk[(size_t)u * blk_words] = owner_start[u + 1] - owner_start[u];          // the block's header: its count
+    if (u >= (int64_t)owner_start[nranks]) return;
+    int o = 0;
+    while (o + 1 < nranks && (uint32_t)u >= owner_start[o + 1]) ++o;
+    blk[(size_t)o * blk_words + 1 + ((uint32_t)u - owner_start[o])] = send_rows[u];
+}
+// owner_start[0..n] of this rank's plan and the received blocks' headers -> pinned host memory, then the epoch word
+// (the host spins on it: a copy + event record + event wait woke the host 20-40 us late in some processes, round 2)
+__global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const uint32_t *__restrict__ recv_blk, int nranks, int64_t blk_words,
+                                 uint32_t *host, uint32_t epoch, unsigned long long *ts) {
+    StampScope stamp(ts);
+    for (int i = threadIdx.x; i <= nranks; i += blockDim.x) host[i] = owner_start[i];
+    for (int i = threadIdx.x; i < nranks; i += blockDim.x) host[nranks + 1 + i] = recv_blk[(size_t)i * blk_words];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag_host, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(host + 2 * nranks + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// which: 0 the main communicator, 1 the key-list one, 2 the all-reduce one (RcclCtx)
+void comm_select(const ps_comm_ops_t *comm, int which, bool skip_self) {
+    if (comm->ctx && comm->all_to_all_v == rccl_all_to_all_v) { RcclCtx *c = (RcclCtx *)comm->ctx; c->which = which; c->skip_self = skip_self; }
+}
+bool comm_is_rccl(const ps_comm_ops_t *comm) { return comm->ctx && comm->all_to_all_v == rccl_all_to_all_v; }
 }  // namespace
 
-// begin: everything of a step that reads no weight -- plan, per-owner counts, the all-gather of the counts and
-// their copy to pinned memory -- enqueued without a host wait.  use_side != 0 runs it on the store's prefetch
-// stream (and the prefetch communicator) so it can run beside the previous step's training: call begin for
-// step t+1 (on ANOTHER model of the same store: its own key lists and activations) before finish of step t.
+// begin: everything of a step that reads no weight -- plan, the exchange of the key lists and the publication of the
+// exchange's counts -- enqueued without a host wait.  use_side != 0 runs it on the store's prefetch stream (and the
+// side communicator) so it can run beside the previous step's training: call begin for step t+1 (on ANOTHER model of
+// the same store: its own key lists and activations) before finish of step t.
+static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side, bool inside_finish);
 extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side) {
+    return shard_step_begin(m, batch, comm, use_side, false);
+}
+// inside_finish: called by ps_shard_step_finish_begin between a running step's backward and its push
+static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side, bool inside_finish) {
     RoctxRange roctx_range("ps_shard_step_begin");
     if (!m || !batch || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32)
         return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
     const int nsh = comm->nranks, rank = comm->rank;
-    if (nsh < 1 || rank < 0 || rank >= nsh) return ps_set_err(PS_E_BAD_ARG, "bad communicator");
+    if (nsh < 1 || nsh > PS_PUSH_MAX_PEERS || rank < 0 || rank >= nsh) return ps_set_err(PS_E_BAD_ARG, "bad communicator (1..%d ranks)", PS_PUSH_MAX_PEERS);
     HIPCHK(hipSetDevice(s->device));
     if (use_side && !s->prefetch_stream) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&s->prefetch_stream, hipStreamNonBlocking, hi));
     }
-    hipStream_t st = use_side ? s->prefetch_stream : s->stream;
     ps_model::Shard &sh = m->sh;
     if (!sh.x_ev) {
         HIPCHK(hipEventCreateWithFlags(&sh.x_ev, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sh.done_ev, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sh.flat_ev, hipEventDisableTiming));
     }
+    // overlap mode (decided once per model: every rank must issue a communicator's operations in one order): the key
+    // lists of the next step and the all-reduce go to side chain 1 + the side communicator
+    if (sh.ov_mode < 0) sh.ov_mode = (g_shard_overlap && !use_side && m->multi_stream && !m->cfg.use_graph && dev_waits_ok(s)) ? 1 : 0;
+    const bool ov = sh.ov_mode == 1 && !use_side && !m->profile;
+    // overlap: on side chain 0, in order behind the plan's kernels (which run there while the step trains) -- the counts
+    // reach the host long before the running step's push, and nothing waits across streams for the plan
+    hipStream_t st = use_side ? s->prefetch_stream : ov ? m->side[0] : s->stream;
     // this model's previous step still reads its key lists until its finish has run on the training stream
     if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
-    {   // worst case: all nnz_cap keys of every worker live on this owner
-        const int64_t rmax = m->nnz_cap * (int64_t)nsh, D = m->cfg.D;
-        PSCHK(size_once(s, &sh.x_recv_rows, &sh.x_recv_cap, rmax, sizeof(uint32_t)));
+    if (!sh.blk_words) {
+        // a block holds what one worker can ask one owner for at most: every id of a batch, or every row the owner has
+        int64_t maxrows = 1;
+        for (int o = 0; o < nsh; ++o) {
+            int64_t r = 0;
+            for (int f = 0; f < s->emb.F; ++f)
+                r += s->emb.java_route() ? s->emb.owner_cnt[(size_t)o * s->emb.F + f] : (s->emb.rows[f] > o ? (s->emb.rows[f] - o + nsh - 1) / nsh : 0);
+            maxrows = std::max(maxrows, r);
+        }
+        sh.blk_words = round_up(1 + std::min<int64_t>(m->nnz_cap, maxrows), 64);
+        RtGuard rt_guard;
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipMalloc((void **)&sh.x_send_blk[k], sizeof(uint32_t) * (size_t)sh.blk_words * nsh));
+            HIPCHK(hipMalloc((void **)&sh.x_recv_blk[k], sizeof(uint32_t) * (size_t)sh.blk_words * nsh));
+            HIPCHK(hipMemsetAsync(sh.x_send_blk[k], 0, sizeof(uint32_t) * (size_t)sh.blk_words * nsh, s->stream));
+            HIPCHK(hipMemsetAsync(sh.x_recv_blk[k], 0, sizeof(uint32_t) * (size_t)sh.blk_words * nsh, s->stream));
+            s->bytes += 2 * (int64_t)sizeof(uint32_t) * sh.blk_words * nsh;
+        }
+        HIPCHK(hipHostMalloc((void **)&sh.counts_host, sizeof(uint32_t) * (size_t)(2 * nsh + 2) + 64, hipHostMallocDefault));
+        memset(sh.counts_host, 0, sizeof(uint32_t) * (size_t)(2 * nsh + 2) + 64);
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    {   // the owner side receives at most min(ids of a batch, rows held here) keys from every worker (the worst
+        // case used to be nnz_cap per worker whatever the shard held)
+        const int64_t per_peer = std::min<int64_t>(m->nnz_cap, std::max<int64_t>(s->emb.total_rows, 1)), rmax = per_peer * nsh, D = m->cfg.D;
         PSCHK(size_once(s, &sh.x_rows_out, &sh.x_rows_cap, rmax * D, sizeof(float)));
         PSCHK(size_once(s, &sh.x_recv_grads, &sh.x_grads_cap, rmax * D, sizeof(float)));
         PSCHK(size_once(s, &sh.x_cache, &sh.x_cache_cap, m->nnz_cap * D, sizeof(float)));
+        sh.x_recv_cap = rmax;
         PSCHK(shard_push_reserve(s, nsh));
     }
-    if (comm->ctx && comm->all_gather == rccl_all_gather) ((RcclCtx *)comm->ctx)->use_side = use_side != 0;
-    PSCHK(shard_plan_enqueue(m, batch, nsh, st, false, !use_side));
-    const size_t row = sizeof(uint32_t) * (size_t)(nsh + 1);        // every rank's owner_start[0..nranks]: the host takes the differences
-    if (!sh.matrix_dev) {
-        HIPCHK(hipMalloc((void **)&sh.matrix_dev, row * (size_t)nsh));
-        HIPCHK(hipHostMalloc((void **)&sh.matrix_host, row * (size_t)nsh + 64, hipHostMallocDefault));      // + the epoch word
-        memset(sh.matrix_host, 0, row * (size_t)nsh + 64);
-    }
-    PSCHK(comm->all_gather(comm->ctx, sh.owner_start, sh.matrix_dev, row, st));
-    // The counts go to the host by a KERNEL that writes them into the pinned (host-coherent) matrix and then raises an
-    // epoch word beside it; the host spins on that word.  (hipMemcpyAsync + hipEventRecord + hipEventSynchronize cost a
-    // copy packet and a record packet on the stream, and the host woke up 20-40 us late in some processes: a bimodal
-    // sharded step, 0.217 / 0.24 ms.)
-    if (++sh.x_epoch == 0) ++sh.x_epoch;
-    unsigned int *started = nullptr;
-    if (sh.tail_due) {          // an early plan: its second half waits for this launch's start on side chain 0
-        if (++m->start_epoch == 0) ++m->start_epoch;
-        sh.pub_epoch = m->start_epoch;
-        started = m->start_flag + 6;
-    }
-    hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(256), 0, st, sh.matrix_dev, sh.matrix_host, (int)(nsh * (nsh + 1)),
-                       sh.matrix_host + (size_t)nsh * (nsh + 1), sh.x_epoch, started, sh.pub_epoch, stamp_next("publish_counts"));
+    // (overlap mode without an early plan -- the first step, a store that fell back to events: the plan's kernels go to side
+    //  chain 1 too and are ordered behind the running step's backward, whose lists they overwrite: order_after_main)
+    PSCHK(shard_plan_enqueue(m, batch, nsh, st, false, !use_side, ov));
+    sh.x_set ^= 1;
+    const int set = sh.x_set;
+    hipLaunchKernelGGL(k_pack_blocks, dim3(cdiv(std::max<int64_t>(m->cur_nnz, nsh), 256)), dim3(256), 0, st, sh.send_rows, sh.owner_start, nsh, sh.blk_words,
+                       sh.x_send_blk[set], stamp_next("pack_blocks"));
     HIPCHK(hipGetLastError());
+    {   // the id exchange: fixed size, no host wait
+        std::vector<int64_t> fixed((size_t)nsh, sh.blk_words);
+        comm_select(comm, (use_side || ov) ? 1 : 0, false);
+        int rc = comm->all_to_all_v(comm->ctx, sh.x_send_blk[set], fixed.data(), sh.x_recv_blk[set], fixed.data(), sizeof(uint32_t), st);
+        comm_select(comm, 0, false);
+        PSCHK(rc);
+    }
+    if (++sh.x_epoch == 0) ++sh.x_epoch;
+    hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, st, sh.owner_start, sh.x_recv_blk[set], nsh, sh.blk_words, sh.counts_host, sh.x_epoch,
+                       stamp_next("publish_counts"));
+    HIPCHK(hipGetLastError());
+    if (sh.tail_due) {          // an early plan: its second half (slots, the backward's entry lists) waits on side chain 0 for
+        if (++m->start_epoch == 0) ++m->start_epoch;          // "the running step's backward has finished", raised by that
+        sh.pub_epoch = m->start_epoch;                        // step's push (ps_shard_step_finish_begin)
+        sh.tail_flag_due = inside_finish;
+        // (no running step -- a begin of its own, e.g. the first step of a run on a model that trained before: whatever
+        //  read the lists is in front of this launch on the training stream)
+        if (!inside_finish) PSCHK(launch_flag_set(m->start_flag + 6, sh.pub_epoch, s->stream));
+    }
     PSCHK(shard_plan_enqueue_tail(m, nsh, st));
     if (use_side) HIPCHK(hipEventRecord(sh.x_ev, st));       // (the training stream orders itself behind the prefetch stream)
-    sh.x_begun = true; sh.x_side = use_side != 0;
+    sh.x_begun = true; sh.x_side = use_side != 0; sh.x_ov = ov;
     return PS_OK;
 }
 
-// finish, with the NEXT step's begin slipped in between "gradients ready" and "push": the plan of batch t+1 and its
-// counts all-gather read no weight, so they may run before step t's push and updates -- and when the host then waits
-// for those counts (the step's one host wait) the GPU still has the push, the owner update and the replicated update
-// of step t queued: the host enqueues the start of step t+1 under them instead of in front of an idle GPU.
-// (Measured at N = 1: the host wait + the starved first launches were ~60 us of a 0.285 ms step.)
+// finish, with the NEXT step's begin slipped in between "gradients ready" and "push": the plan of batch t+1 and the
+// exchange of its key lists read no weight, so they are enqueued before step t's push and updates -- when the host
+// then waits for their counts (the step's one host wait) the GPU still has the push, the owner update and the
+// replicated update of step t queued, and the host enqueues the start of step t+1 under them.
 extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, const ps_batch_t *next_batch, float *loss) {
     RoctxRange roctx_range("ps_shard_step_finish");
     if (!m || !comm) return ps_set_err(PS_E_BAD_ARG, "bad argument");
@@ -344,12 +444,12 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         }
     } host_timer(host_timing);
     const double wait_t0 = host_timing ? HostTimer::now() : 0;
-    {   // the step's one host wait: split sizes of every exchange (spin on the epoch word k_publish_counts raises)
-        volatile uint32_t *flag = sh.matrix_host + (size_t)nsh * (nsh + 1);
+    {   // the step's one host wait: the counts of the rows / gradient exchanges (spin on the epoch word k_publish_counts raises)
+        volatile uint32_t *flag = sh.counts_host + 2 * nsh + 1;
         int64_t spins = 0;
         while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != sh.x_epoch) {
             if (++spins > (1ll << 22)) {                 // ~seconds: the kernel never ran -- surface the stream's error instead of hanging
-                HIPCHK(hipStreamSynchronize(sh.x_side ? s->prefetch_stream : st));
+                HIPCHK(hipStreamSynchronize(sh.x_side ? s->prefetch_stream : sh.x_ov ? m->side[0] : st));
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != sh.x_epoch) return ps_set_err(PS_E_STATE, "the counts of the exchange never arrived");
                 break;
             }
@@ -358,39 +458,110 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     }
     if (host_timing) host_timer.wait = HostTimer::now() - wait_t0;
     if (sh.x_side) HIPCHK(hipStreamWaitEvent(st, sh.x_ev, 0));
+    const bool was_side = sh.x_side;
+    m->dev_ok = dev_waits_ok(s);
+    // (overlap: the id blocks arrived on side chain 0.  The host has SEEN the counts the kernel behind that exchange
+    //  published, so the blocks are there -- what the training stream enqueues from here on starts later still)
     sh.x_begun = false; sh.plan_pending = false;
-    const int D = m->cfg.D;
-    std::vector<int64_t> sc((size_t)nsh), rc((size_t)nsh);
-    int64_t U = 0, nrecv = 0;
+    const int D = m->cfg.D, set = sh.x_set;
+    std::vector<int64_t> sc((size_t)nsh), rc((size_t)nsh), scpre((size_t)nsh + 1, 0), rcpre((size_t)nsh + 1, 0);
     for (int o = 0; o < nsh; ++o) {
-        const uint32_t *mine = sh.matrix_host + (size_t)rank * (nsh + 1), *theirs = sh.matrix_host + (size_t)o * (nsh + 1);
-        sc[o] = (int64_t)mine[o + 1] - (int64_t)mine[o];              // what I request from / push to owner o
-        rc[o] = (int64_t)theirs[rank + 1] - (int64_t)theirs[rank];    // what worker o requests from / pushes to me
-        if (sc[o] < 0 || rc[o] < 0) return ps_set_err(PS_E_STATE, "negative key count in the exchange matrix");
-        U += sc[o]; nrecv += rc[o];
+        sc[o] = (int64_t)sh.counts_host[o + 1] - (int64_t)sh.counts_host[o];     // what I request from / push to owner o
+        rc[o] = (int64_t)sh.counts_host[nsh + 1 + o];                             // what worker o requests from / pushes to me
+        if (sc[o] < 0 || rc[o] < 0 || sc[o] >= sh.blk_words || rc[o] >= sh.blk_words) return ps_set_err(PS_E_STATE, "bad key count in the exchange (%lld, %lld)", (long long)sc[o], (long long)rc[o]);
+        scpre[o + 1] = scpre[o] + sc[o]; rcpre[o + 1] = rcpre[o] + rc[o];
     }
+    const int64_t U = scpre[nsh], nrecv = rcpre[nsh];
     sh.U = U;
+    if (sc[rank] != rc[rank]) return ps_set_err(PS_E_STATE, "the exchange's self counts differ");
     if (U > m->nnz_cap || nrecv > sh.x_recv_cap)
         return ps_set_err(PS_E_STATE, "exchange counts (%lld requested, %lld received) exceed the buffers sized at ps_shard_step_begin", (long long)U, (long long)nrecv);
-    // getList: ids out, rows back
-    PSCHK(comm->all_to_all_v(comm->ctx, sh.send_rows, sc.data(), sh.x_recv_rows, rc.data(), sizeof(uint32_t), st));
-    PSCHK(ps_shard_serve_pull(s, sh.x_recv_rows, nrecv, sh.x_rows_out));
-    PSCHK(comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st));
-    // train on the cache
-    PSCHK(ps_shard_forward_backward(m, sh.x_cache, nullptr));
-    // the next step's key lists + counts (same stream, same communicator: every rank issues the same order)
-    if (next_batch) PSCHK(ps_shard_step_begin(m, next_batch, comm, 0));
-    // push: the per-key gradients to their owners, then the dense + wide reduction -- same communicator, same stream,
-    // same order on every rank.  The owner's row update is enqueued between the two: it only needs the all-to-all-v.
-    PSCHK(comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st));
-    if (nsh > 1) PSCHK(comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, st));
-    PSCHK(ps_shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, rc.data(), nsh, is_async));
-    PSCHK(ps_shard_apply_flat(m, nsh));
-    HIPCHK(hipEventRecord(sh.done_ev, st));
-    sh.done_recorded = true;
+    // a rank's own keys are read where they are when the collectives are RCCL's (a plugged-in table copies them like any other)
+    const bool alias = comm_is_rccl(comm);
+    const uint32_t *rows_p[PS_PUSH_MAX_PEERS];
+    const float *grads_p[PS_PUSH_MAX_PEERS];
+    for (int p = 0; p < nsh; ++p) {
+        rows_p[p] = sh.x_recv_blk[set] + (size_t)p * sh.blk_words + 1;
+        grads_p[p] = sh.x_recv_grads + (size_t)rcpre[p] * D;
+    }
+    if (alias) { rows_p[rank] = sh.x_send_blk[set] + (size_t)rank * sh.blk_words + 1; grads_p[rank] = m->grads_out + (size_t)scpre[rank] * D; }
+    // getList: the owner gathers the requested rows, rows back
+    {   // (the gather's launch also holds the join with side chain 0 -- "this step's slots are written" -- for the forward
+        //  behind it: a wait on an event that fired long ago still costs the training stream ~3.5 us, round 2)
+        LaunchOpts lo;
+        if (sh.slot_ev && sh.slot_flag && m->dev_ok) { lo.wait = m->start_flag + 10; lo.wait_val = sh.slot_epoch; }
+        PSCHK(shard_serve_pull_lists(s, rows_p, rc.data(), nsh, sh.x_rows_out, &lo));
+        if (lo.wait && lo.launched) sh.slot_ev = nullptr;        // (else ps_shard_forward_backward waits for the event)
+    }
+    comm_select(comm, 0, alias);
+    int crc = comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st);
+    comm_select(comm, 0, false);
+    PSCHK(crc);
+    // train on the cache (this rank's own rows straight from the gather's output)
+    sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
+    if (alias && sc[rank] > 0) {
+        sh.alt_lo = (uint32_t)scpre[rank]; sh.alt_hi = (uint32_t)scpre[rank + 1];
+        sh.alt_W = reinterpret_cast<const float *>(reinterpret_cast<intptr_t>(sh.x_rows_out) + (intptr_t)sizeof(float) * D * ((intptr_t)rcpre[rank] - (intptr_t)scpre[rank]));
+    }
+    // the previous step's replicated update ran on side chain 1: the gather of this step's forward holds the join when the
+    // update's end raised a device flag (enqueue_forward: EmbFwdArgs.end_wait), else an event
+    if (sh.flat_pending && !(sh.flat_by_flag && m->dev_ok && m->multi_stream && !m->profile)) {
+        HIPCHK(hipStreamWaitEvent(st, sh.flat_ev, 0));
+        sh.flat_pending = false;
+    }
+    {
+        int frc = ps_shard_forward_backward(m, sh.x_cache, nullptr);
+        sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
+        PSCHK(frc);
+    }
+    // the next step's key lists (same order of operations on every rank)
+    if (next_batch) PSCHK(shard_step_begin(m, next_batch, comm, 0, true));
+    const bool ov2 = sh.ov_mode == 1 && !was_side && !m->profile;      // where the replicated tensors' update goes
+    // push: the per-key gradients to their owners
+    comm_select(comm, 0, alias);
+    crc = comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st);
+    comm_select(comm, 0, false);
+    PSCHK(crc);
+    {
+        LaunchOpts lo;
+        if (sh.tail_flag_due) { lo.flag = m->start_flag + 6; lo.flag_val = sh.pub_epoch; }
+        PSCHK(shard_apply_push_lists(s, rows_p, grads_p, rc.data(), nsh, is_async, true, &lo));
+        if (sh.tail_flag_due && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 6, sh.pub_epoch, st));
+        sh.tail_flag_due = false;
+    }
+    // the dense + wide reduction and the replicated update: on side chain 1 + the side communicator (behind the flat
+    // gradient's kernel and the next step's id exchange, beside the push), or in line
+    hipStream_t fs = ov2 ? m->side[1] : st;
+    if (nsh > 1) {
+        comm_select(comm, ov2 ? 2 : 0, false);
+        crc = comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, fs);
+        comm_select(comm, 0, false);
+        PSCHK(crc);
+    }
+    PSCHK(shard_apply_flat(m, nsh, fs));
+    if (ov2) {
+        sh.flat_by_flag = false;
+        if (m->dev_ok && next_batch && !loss) {        // the next step's gather carries the join (EmbFwdArgs.end_wait); the flag from the device
+            if (++m->start_epoch == 0) ++m->start_epoch;
+            sh.flat_epoch = m->start_epoch;
+            PSCHK(launch_flag_set(m->start_flag + 9, sh.flat_epoch, fs));
+            sh.flat_by_flag = true;
+        }
+        HIPCHK(hipEventRecord(sh.flat_ev, fs));
+        sh.flat_pending = true;
+        if (!next_batch || loss) {      // nothing follows that would join: close the step on the training stream
+            HIPCHK(hipStreamWaitEvent(st, sh.flat_ev, 0));
+            sh.flat_pending = false;
+        }
+    }
+    if (was_side) {         // (two-model prefetch: this model's next begin, on the prefetch stream, must not overtake this step)
+        HIPCHK(hipEventRecord(sh.done_ev, st));
+        sh.done_recorded = true;
+    }
     if (loss) {
         HIPCHK(hipMemcpyAsync(loss, m->loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        PSCHK(store_check_bad_ids(s));
     }
     return PS_OK;
 }

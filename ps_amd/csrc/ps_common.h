@@ -141,7 +141,7 @@ struct LaunchOpts {
 };
 extern int g_main_prio;
 extern int g_sort_late;
-extern int g_tn_start_wait, g_tail_fused;
+extern int g_tn_start_wait, g_tail_fused, g_shard_overlap;
 extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11, g_end_wait, g_radix_scan_free, g_plan_early;
 // Every device-side wait is BOUNDED: a waiter that has not seen its flag after g_spin_timeout_ticks (10 ns ticks of the
 // device's wall clock; ps_tune_set("spin_timeout_ms")) adds 1 to *werr, stores which wait it was beside it and gives up.
@@ -176,7 +176,11 @@ __device__ __forceinline__ bool spin_bounded(const unsigned int *f, unsigned int
     while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
         __builtin_amdgcn_s_sleep(16);
         if (b.ticks && (unsigned long long)wall_clock64() - t0 > b.ticks) {
-            if (b.err) { atomicAdd(b.err, 1u); __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (b.err) {
+                atomicAdd(b.err, 1u);
+                __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the last one to give up
+                atomicCAS(b.err + 2, 0u, b.code + 1000u);                                               // the first one (+1000: code 0 is a wait too)
+            }
             break;
         }
     }

@@ -210,6 +210,9 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     if (m->sh.plan_ev) (void)hipEventDestroy(m->sh.plan_ev);
     if (m->sh.owner_start_host) (void)hipHostFree(m->sh.owner_start_host);
     if (m->sh.matrix_host) (void)hipHostFree(m->sh.matrix_host);
+    if (m->sh.counts_host) (void)hipHostFree(m->sh.counts_host);
+    if (m->sh.flat_ev) (void)hipEventDestroy(m->sh.flat_ev);
+    for (int k = 0; k < 2; ++k) { fr(m->sh.x_send_blk[k]); fr(m->sh.x_recv_blk[k]); }
     if (m->sh.x_ev) (void)hipEventDestroy(m->sh.x_ev);
     if (m->sh.done_ev) (void)hipEventDestroy(m->sh.done_ev);
     if (m->sh.ar_ev) (void)hipEventDestroy(m->sh.ar_ev);
@@ -383,6 +386,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // sharded worker: rows come from the cache pulled from their owners (store/KVStore.java:96),
         // keys and the sort were made by ps_shard_plan
         e.W = m->sh.cache; e.slot = m->sh.slot; e.key_out = nullptr; e.ent_bag = nullptr; e.table_bytes = 0;
+        e.W_alt = m->sh.alt_W; e.alt_lo = m->sh.alt_lo; e.alt_hi = m->sh.alt_hi;      // this rank's own rows: never copied (ps_comm.hip)
     }
     // multi-hot: the sort's keys come from the ids alone (k_emb_keys), so the whole sort chain starts BESIDE the gather.
     // (Beside the gather the key kernel takes the gather's ~39 us -- the two share the memory system.  Running it alone
@@ -403,8 +407,17 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     LaunchOpts fwd_lo;
     fwd_lo.stop_event = (train && !m->sh.active && !keys_early && !sort_dev) ? pick_event(m) : nullptr;
     const hipEvent_t fwd_ev = fwd_lo.stop_event;
-    { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st, &fwd_lo)); }
-    PSCHK(settle_event(m, fwd_lo));
+    if (m->sh.active && m->sh.flat_pending && m->sh.flat_by_flag) {
+        // sharded step: the previous step's replicated update (side chain 1) must be done before the first GEMM reads W --
+        // the gather's first workgroup ends only once the update's end flag is up (normally it has been for a while)
+        fwd_lo.wait = m->start_flag + 9; fwd_lo.wait_val = m->sh.flat_epoch;
+    }
+    { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st, &fwd_lo, s->werr())); }
+    if (fwd_lo.wait) {
+        if (!fwd_lo.launched) PSCHK(launch_spin_until(m->start_flag + 9, m->sh.flat_epoch, st, s->werr(), 9));   // (an empty batch)
+        m->sh.flat_pending = false;
+    }
+    if (fwd_lo.stop_event && !fwd_lo.launched) HIPCHK(hipEventRecord(fwd_lo.stop_event, st));
     auto enqueue_sort = [&]() -> int {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
@@ -787,7 +800,10 @@ int enqueue_backward(ps_model *m, bool apply) {
     const bool tail_fused = tail_dev && g_tail_fused && nnz > 0;
     LaunchOpts emb_lo;
     if (tail_dev) { if (++m->start_epoch == 0) ++m->start_epoch; emb_lo.flag = m->start_flag + 2; emb_lo.flag_val = m->start_epoch; }
-    if (tail_fused) { emb_lo.wait = m->start_flag + 3; emb_lo.wait_val = m->start_epoch; }
+    // (sharded step in overlap mode: the flat gradient this launch's companion writes is consumed on side chain 1 itself --
+    //  all-reduce, replicated update -- so the training stream, which goes on to the push, does not wait for it)
+    const bool tail_join = !(m->sh.active && m->sh.ov_mode == 1);
+    if (tail_fused && tail_join) { emb_lo.wait = m->start_flag + 3; emb_lo.wait_val = m->start_epoch; }
     { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st, &emb_lo, werr)); }
     if (tail_dev && !emb_lo.launched)       // nothing was launched (an empty batch): announce the start ourselves
         PSCHK(launch_flag_set(m->start_flag + 2, m->start_epoch, st));
@@ -810,7 +826,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         if (tail_fused && emb_lo.launched) {
             d.wait_flag = m->start_flag + 2; d.wait_val = m->start_epoch; d.bound = wait_bound(werr, 2);
             { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
-            PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
+            if (tail_join) PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
             return PS_OK;
         }
         PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw, werr, 2));

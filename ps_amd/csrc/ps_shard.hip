@@ -176,15 +176,28 @@ __global__ __launch_bounds__(256) void k_plan_slots(const uint32_t *__restrict__
 }
 
 // rows_out[i][:] = W[rows[i]][:]   (PServer.getList: the rows for a key list)
+// The key list arrives grouped by requesting worker, every worker's part where the id exchange left it (PeerLists):
+// entry i of worker p = rows_p[p][i - start[p]].
+struct PeerLists {
+    int npeers;
+    uint32_t start[PS_PUSH_MAX_PEERS + 1];
+    const uint32_t *rows_p[PS_PUSH_MAX_PEERS];
+};
+// end_wait: the first workgroup ends only once *end_wait reached end_val (the sharded step: "the slots of this step's
+// plan are written" -- the gather is the launch in front of the forward, and holds the join with side chain 0 for it)
 template <int VEC>
-__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, const uint32_t *__restrict__ rows, int64_t n,
-                                                     int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err, unsigned long long *ts) {
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, PeerLists pl, int64_t n,
+                                                     int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err, unsigned long long *ts,
+                                                     const unsigned int *end_wait, unsigned int end_val, WaitBound bound) {
+    EndWait end_wait_scope(end_wait, end_val, bound);
     StampScope stamp_scope(ts);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int part = (int)(t % LPR);
     if (i >= n) return;
-    int64_t r = rows[i];
+    int p = 0;
+    while (p + 1 < pl.npeers && (uint32_t)i >= pl.start[p + 1]) ++p;
+    int64_t r = pl.rows_p[p][i - pl.start[p]];
     if (r >= total_rows) { if (part == 0) atomicAdd(err, 1); r = 0; }
     if (VEC == 4) *reinterpret_cast<float4 *>(out + (size_t)i * D + part * 4) = *reinterpret_cast<const float4 *>(W + (size_t)r * D + part * 4);
     else out[(size_t)i * D + part] = W[(size_t)r * D + part];
@@ -289,11 +302,19 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
     ps_store *s = m->s;
     ps_model::Shard &sh = m->sh;
     const int F = m->cfg.F;
-    if (ss != st) sh.slot_ev = m->events[m->next_event++ % m->events.size()];
+    const bool off_main = ss != s->stream;        // (the forward, on the training stream, waits for the slots)
+    if (off_main) sh.slot_ev = m->events[m->next_event++ % m->events.size()];
     // (the event the forward waits for rides on the slot kernel's launch: no record packet on the side chain)
-    PS_LAUNCH_EV(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, (ss != st && g_ext_events) ? sh.slot_ev : nullptr, m->keys, nnz, sh.bitmap,
+    PS_LAUNCH_EV(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, (off_main && g_ext_events) ? sh.slot_ev : nullptr, m->keys, nnz, sh.bitmap,
                  sh.word_prefix, sh.slot, stamp_next("plan_slots"));
-    if (ss != st && !g_ext_events) HIPCHK(hipEventRecord(sh.slot_ev, ss));
+    if (off_main && !g_ext_events) HIPCHK(hipEventRecord(sh.slot_ev, ss));
+    sh.slot_flag = false;
+    if (off_main && m->dev_ok) {       // ... and a device flag: ps_shard_step hangs this join on its owner-side gather's launch
+        if (++m->start_epoch == 0) ++m->start_epoch;
+        sh.slot_epoch = m->start_epoch;
+        PSCHK(launch_flag_set(m->start_flag + 10, sh.slot_epoch, ss));
+        sh.slot_flag = true;
+    }
     HIPCHK(hipGetLastError());
     m->field_sorted = false;
     if (!m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F)) {
@@ -318,7 +339,7 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
         PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->seg_nseg_scratch, ss, m->long_list, PS_EMB_SEQ_TILE));
     }
     m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
-    m->side0_pending = ss != st;
+    m->side0_pending = off_main;
     return PS_OK;
 }
 
@@ -340,7 +361,7 @@ int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st) {
 // trains instead of in its tail; the main stream only parks a spinner on "plan done".  What overwrites lists the
 // running backward still reads (slots, entry lists) is enqueued later by shard_plan_enqueue_tail; the run count is
 // double-buffered (nseg_cur).
-int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early) {
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early, bool order_after_main) {
     ps_store *s = m->s;
     PSCHK(ensure_shard_state(m, nshards));
     ps_model::Shard &sh = m->sh;
@@ -357,6 +378,13 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     if (plan_debug) fprintf(stderr, "[plan] early=%d (bitmap %d, fwd flag %d, device batch %d, single-hot %d, field sort fits %d)\n", (int)early, (int)bm,
                             (int)fwd_flag, (int)batch->on_device, (int)!m->cur_offsets, (int)field_sort_fits(m->cur_B, F));
     hipStream_t ps = early ? m->side[0] : st;       // where the id-only kernels go
+    if (!early && order_after_main && st != s->stream) {
+        // (not early, on another stream than the training stream: the plan overwrites lists the running step's backward
+        //  still reads -- behind everything enqueued on the training stream so far)
+        hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+        HIPCHK(hipEventRecord(e, s->stream));
+        HIPCHK(hipStreamWaitEvent(st, e, 0));
+    }
     if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
     m->nseg_cur = early ? (m->nseg_cur == m->nseg_dev ? m->nseg_dev + 4 : m->nseg_dev) : m->nseg_dev;
     if (bm && ++sh.epoch == 0) {          // the byte stamps wrap every 255 plans: start over from a clean map
@@ -376,8 +404,10 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
             HIPCHK(hipGetLastError());
             if (++m->start_epoch == 0) ++m->start_epoch;
             sh.plan_epoch = m->start_epoch;
-            PSCHK(launch_flag_set(m->start_flag + 7, sh.plan_epoch, ps));
-            PSCHK(launch_spin_until(m->start_flag + 7, sh.plan_epoch, st, s->werr(), 7));      // (enqueued after the launch that releases it)
+            if (st != ps) {         // (the caller continues on another stream: park it behind "plan done")
+                PSCHK(launch_flag_set(m->start_flag + 7, sh.plan_epoch, ps));
+                PSCHK(launch_spin_until(m->start_flag + 7, sh.plan_epoch, st, s->werr(), 7));      // (enqueued after the launch that releases it)
+            }
             sh.tail_due = true; sh.tail_nnz = nnz;
             return PS_OK;
         }
@@ -443,19 +473,38 @@ extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards
     return ps_shard_plan_finish(m, counts_out, send_rows_dev, n_unique);
 }
 
+// PServer.getList for key lists that lie grouped by requesting worker (rows_p[p]: counts[p] owner-local rows)
+int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev, LaunchOpts *lo) {
+    if (lo) lo->launched = false;
+    if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
+    if (npeers < 1 || npeers > PS_PUSH_MAX_PEERS) return ps_set_err(PS_E_BAD_ARG, "1..%d workers", PS_PUSH_MAX_PEERS);
+    PeerLists pl;
+    memset(&pl, 0, sizeof pl);
+    pl.npeers = npeers;
+    int64_t n = 0;
+    for (int p = 0; p < npeers; ++p) { pl.start[p] = (uint32_t)n; pl.rows_p[p] = rows_p[p]; n += counts[p]; }
+    pl.start[npeers] = (uint32_t)n;
+    if (n == 0) return PS_OK;
+    const int D = s->emb.D, vec = D % 4 == 0 ? 4 : 1, LPR = D / vec;
+    const unsigned int *ew = lo ? lo->wait : nullptr;
+    const unsigned int ev = lo ? lo->wait_val : 0u;
+    const WaitBound wb = wait_bound(s->werr(), 104);
+    if (vec == 4)
+        hipLaunchKernelGGL(k_gather_rows<4>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb);
+    else
+        hipLaunchKernelGGL(k_gather_rows<1>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb);
+    HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
+    return PS_OK;
+}
+
 extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int64_t n, float *rows_out_dev) {
     RoctxRange roctx_range("ps_shard_serve_pull");
     if (!s || n < 0 || (n > 0 && (!rows_dev || !rows_out_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (n == 0) return PS_OK;
     HIPCHK(hipSetDevice(s->device));
-    const int D = s->emb.D, vec = D % 4 == 0 ? 4 : 1, LPR = D / vec;
-    if (vec == 4)
-        hipLaunchKernelGGL(k_gather_rows<4>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"));
-    else
-        hipLaunchKernelGGL(k_gather_rows<1>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, rows_dev, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"));
-    HIPCHK(hipGetLastError());
-    return PS_OK;
+    return shard_serve_pull_lists(s, &rows_dev, &n, 1, rows_out_dev, nullptr);
 }
 
 extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, float *loss) {
@@ -489,7 +538,7 @@ extern "C" int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_uniqu
 // the sort-free push's per-row mask and per-worker position tables (allocated once: never between two collectives)
 int shard_push_reserve(ps_store *s, int npeers) {
     const int64_t R = s->emb.total_rows;
-    if (npeers < 1 || npeers > PS_PUSH_MAX_PEERS || (double)npeers * (double)R * 4.0 > 4.0e9) return PS_OK;   // sorted path
+    if (npeers <= 1 || !shard_push_grouped_ok(s, npeers)) return PS_OK;   // one worker: no mask / position tables; else the sorted path
     if (s->push_mask && s->push_pos_peers >= npeers) return PS_OK;
     RtGuard rt_guard;
     hipStream_t st = s->stream;
@@ -510,6 +559,40 @@ extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, cons
     return shard_apply_push(s, rows_dev, grads_dev, n, peer_counts, npeers, is_async, true);
 }
 
+// can the sort-free push (worker-grouped lists, kernels_emb.hip k_push_mark / k_push_apply) serve this store?
+bool shard_push_grouped_ok(const ps_store *s, int npeers) {
+    return npeers >= 1 && npeers <= PS_PUSH_MAX_PEERS && (double)npeers * (double)s->emb.total_rows * 4.0 <= 4.0e9;
+}
+
+// PServer.push + psUpdate for lists that lie grouped by pushing worker, every worker's part where it is (rows_p[p],
+// grads_p[p]: counts[p] entries); lo: the first launch announces its start (LaunchOpts.flag)
+int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
+                           int is_async, bool bump_step, LaunchOpts *lo) {
+    if (lo) lo->launched = false;
+    if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
+    if (!shard_push_grouped_ok(s, npeers)) return ps_set_err(PS_E_UNSUPPORTED, "the sort-free push needs 1..%d workers and a position table under 4 GB", PS_PUSH_MAX_PEERS);
+    ps_updater_t u;
+    PSCHK(store_resolve_updater(s, "emF", &u));
+    PushApplyArgs a;
+    memset(&a, 0, sizeof a);
+    int64_t n = 0;
+    for (int p = 0; p < npeers; ++p) {
+        if (counts[p] < 0) return ps_set_err(PS_E_BAD_ARG, "negative peer count");
+        a.peer_start[p] = (uint32_t)n; a.rows_p[p] = rows_p[p]; a.grads_p[p] = grads_p[p];
+        n += counts[p];
+    }
+    a.peer_start[npeers] = (uint32_t)n;
+    if (n > 0) {
+        if (npeers > 1) PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
+        a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = s->emb.total_rows;
+        a.mask = s->push_mask; a.pos = s->push_pos;
+        a.W = s->emb.W; a.state = s->emb.state; a.upd = make_upd_params(u); a.err = s->err_dev;
+        PSCHK(launch_push_apply(a, s->stream, lo));
+    }
+    if (bump_step) s->global_step++;     // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)
+    return PS_OK;
+}
+
 int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_dev, int64_t n, const int64_t *peer_counts,
                      int npeers, int is_async, bool bump_step) {
     RoctxRange roctx_range("ps_shard_apply_push");
@@ -521,24 +604,18 @@ int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_d
     PSCHK(store_resolve_updater(s, "emF", &u));
     const int64_t R = s->emb.total_rows;
     // worker-grouped lists (what ps_shard_plan + all-to-all-v deliver): no sort, two kernels
-    const bool grouped = peer_counts && npeers >= 1 && npeers <= PS_PUSH_MAX_PEERS && (double)npeers * (double)R * 4.0 <= 4.0e9;
+    const bool grouped = peer_counts && shard_push_grouped_ok(s, npeers);
     if (n > 0 && grouped) {
         int64_t tot = 0;
+        const uint32_t *rp[PS_PUSH_MAX_PEERS];
+        const float *gp[PS_PUSH_MAX_PEERS];
         for (int p = 0; p < npeers; ++p) {
             if (peer_counts[p] < 0) return ps_set_err(PS_E_BAD_ARG, "negative peer count");
+            rp[p] = rows_dev + tot; gp[p] = grads_dev + (size_t)tot * s->emb.D;
             tot += peer_counts[p];
         }
         if (tot != n) return ps_set_err(PS_E_BAD_ARG, "peer counts sum to %lld, n is %lld", (long long)tot, (long long)n);
-        PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
-        PushApplyArgs a;
-        memset(&a, 0, sizeof a);
-        a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = R;
-        uint32_t acc = 0;
-        for (int p = 0; p < npeers; ++p) { a.peer_start[p] = acc; acc += (uint32_t)peer_counts[p]; }
-        a.peer_start[npeers] = acc;
-        a.rows = rows_dev; a.grads = grads_dev; a.mask = s->push_mask; a.pos = s->push_pos;
-        a.W = s->emb.W; a.state = s->emb.state; a.upd = make_upd_params(u); a.err = s->err_dev;
-        PSCHK(launch_push_apply(a, st));
+        return shard_apply_push_lists(s, rp, gp, peer_counts, npeers, is_async, bump_step, nullptr);
     } else if (n > 0) {
         PSCHK(ensure_push_ws(s, n));
         // stable sort by row: within a key the pushes stay in arrival (= source worker) order
@@ -570,8 +647,12 @@ extern "C" int ps_shard_apply_flat(ps_model_t *m, int nworkers) {
     RoctxRange roctx_range("ps_shard_apply_flat");
     if (!m || nworkers < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!m->sh.flat) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
+    HIPCHK(hipSetDevice(m->s->device));
+    return shard_apply_flat(m, nworkers, m->s->stream);
+}
+
+int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st) {
     ps_store *s = m->s;
-    HIPCHK(hipSetDevice(s->device));
     const int nfc = m->cfg.nfc;
     ps_updater_t u;
     DenseUpdArgs d;
@@ -596,6 +677,6 @@ extern "C" int ps_shard_apply_flat(ps_model_t *m, int nworkers) {
         w.upd = make_upd_params(u);
         d.wide_blocks = wide_update_blocks(w);
     }
-    PSCHK(launch_dense_update(d, s->stream));
+    PSCHK(launch_dense_update(d, st));
     return PS_OK;
 }

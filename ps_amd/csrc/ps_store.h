@@ -159,6 +159,7 @@ struct ps_model {
         uint32_t *slot = nullptr;     // [nnz] unique slot of every entry
         uint32_t x_epoch = 0;         // epoch of the last counts publication (host spins on it)
         hipEvent_t slot_ev = nullptr; // set while the slots are being written on a side stream (one of the model's events)
+        bool slot_flag = false; uint32_t slot_epoch = 0;   // ... and start_flag[10] = slot_epoch is raised behind them
         uint32_t *send_rows = nullptr;// [U] owner-local row of every unique key, grouped by owner
         uint32_t *owner_start = nullptr; // [nshards+1] device
         int64_t *lrb_dev = nullptr;   // [nshards][F+1] local row bases of every shard
@@ -171,8 +172,23 @@ struct ps_model {
         uint32_t *owner_start_host = nullptr;   // pinned readback of owner_start
         hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
         bool plan_pending = false;
-        // ps_shard_step (library-driven exchange): counts, the N x N count matrix, exchange buffers
-        uint32_t *matrix_dev = nullptr, *matrix_host = nullptr;      // [nranks][nranks+1]: every rank's owner_start
+        // ps_shard_step (library-driven exchange).  The key lists travel as FIXED-SIZE blocks, one per peer:
+        // [count | count owner-local rows | padding], blk_words words each (1 + the most rows any owner can be asked for), so
+        // the id exchange needs no split sizes -- it is enqueued without a host wait, before the running step's push --
+        // and carries the counts of the two weight-dependent exchanges (rows back, gradients out) with it.  Two sets:
+        // step t+1's lists are exchanged while step t's push still reads its own.
+        int64_t blk_words = 0;
+        uint32_t *x_send_blk[2] = {nullptr, nullptr}, *x_recv_blk[2] = {nullptr, nullptr};    // [nranks][blk_words]
+        int x_set = 0;                                               // the set of the step begun last
+        int ov_mode = -1;                                            // 1: key lists of t+1 and the all-reduce on side chain 1 + the side communicator (decided at the first begin)
+        bool x_ov = false;                                           // the step begun last enqueued its id exchange on side chain 1
+        bool tail_flag_due = false;                                  // the running step's push must raise start_flag[6] = pub_epoch
+        bool flat_by_flag = false;                                   // the replicated update's end also raised start_flag[9] = flat_epoch
+        const float *alt_W = nullptr; uint32_t alt_lo = 0, alt_hi = 0;   // this rank's own rows of the running step (EmbFwdArgs.W_alt)
+        uint32_t *counts_host = nullptr;                             // pinned: [owner_start 0..nranks | received counts 0..nranks-1 | epoch]
+        hipEvent_t flat_ev = nullptr;                                // the replicated tensors' update was enqueued on side chain 1
+        bool flat_pending = false; uint32_t flat_epoch = 0;          // ... and the main chain has not joined it yet
+        uint32_t *matrix_dev = nullptr, *matrix_host = nullptr;      // (rounds 1-2: the N x N count matrix)
         uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;
         float *x_rows_out = nullptr; int64_t x_rows_cap = 0;
         float *x_recv_grads = nullptr; int64_t x_grads_cap = 0;
@@ -215,9 +231,16 @@ struct ps_model {
 
 // shared between ps_model.hip and ps_shard.hip
 int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
-int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early = false);   // ps_shard.hip
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early = false,
+                       bool order_after_main = false);   // ps_shard.hip
+int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st);
 int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st);      // early plans: the slots + the backward's entry lists
 int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
 int enqueue_backward(ps_model *m, bool apply);
 int shard_push_reserve(ps_store *s, int npeers);   // ps_shard.hip
+bool shard_push_grouped_ok(const ps_store *s, int npeers);
+int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
+                           LaunchOpts *lo);       // lo: wait (an END wait of the gather's launch)
+int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
+                           int is_async, bool bump_step, LaunchOpts *lo);
 int finish_step(ps_model *m, float *loss);

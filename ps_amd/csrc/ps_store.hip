@@ -296,7 +296,7 @@ bool dev_waits_ok(const ps_store *s) {
 }
 
 int store_check_bad_ids(ps_store *s) {
-    int err[3] = {0, 0, 0};
+    int err[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(err, s->err_dev, sizeof err, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (err[1]) {
@@ -306,8 +306,8 @@ int store_check_bad_ids(ps_store *s) {
         HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof err, s->stream));
         s->dev_wait_off = true;
         s->wait_timeouts += err[1];
-        return ps_set_err(PS_E_STATE, "%d device-side wait(s) timed out after %.0f ms (last: wait %d); the steps since the last check ran without a "
-                          "dependency -- this store now joins its streams by events", err[1], (double)g_spin_timeout_ticks * 1e-5, err[2]);
+        return ps_set_err(PS_E_STATE, "%d device-side wait(s) timed out after %.0f ms (first: wait %d, last: wait %d); the steps since the last check ran "
+                          "without a dependency -- this store now joins its streams by events", err[1], (double)g_spin_timeout_ticks * 1e-5, err[3] - 1000, err[2]);
     }
     if (err[0]) {
         HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof(int), s->stream));

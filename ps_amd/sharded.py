@@ -467,7 +467,7 @@ class HipBackend:
 # the library-driven step: ONE C call (ps_shard_step) per step, RCCL bound inside libps_amd.so
 # ---------------------------------------------------------------------------
 class NativeWorker:
-    """ps_shard_step over a ps_comm_ops_t.  `ops` None: an RCCL communicator pair is created from `id256`
+    """ps_shard_step over a ps_comm_ops_t.  `ops` None: the RCCL communicators (3) are created from `id256` (384 bytes)
     (made by rank 0 with NativeWorker.unique_id() and handed to every rank by the host).
     `models`: one ps_model, or two on the same store -- then `run` begins step t+1 (its key lists and the
     counts all-gather, on the prefetch stream) before it finishes step t."""
@@ -483,7 +483,7 @@ class NativeWorker:
 
     @staticmethod
     def unique_id():
-        buf = C.create_string_buffer(256)
+        buf = C.create_string_buffer(384)
         N.check(N.lib().ps_comm_rccl_unique_id(buf))
         return buf.raw
 
@@ -570,7 +570,7 @@ def run_bench(args, cfg, synth_batch):
         # torch.distributed only hands the 128-byte RCCL id round and keeps the bench's barriers
         gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
                for _ in range(2 if overlap else 1)]      # two plan contexts: step t+1 begins before step t finishes
-        idt = torch.zeros(256, dtype=torch.uint8, device=dev)
+        idt = torch.zeros(384, dtype=torch.uint8, device=dev)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(NativeWorker.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
