@@ -440,7 +440,12 @@ def main():
     # through C stdio, flushed at exit -- after the JSON): fd 1 is pointed at stderr for the run and the line is
     # written to the real stdout at the end.
     sys.stdout.flush()
-    real_stdout = os.dup(1)
+    if os.environ.get("PS_BENCH_STDOUT_FD"):            # a later stage of a multi-GPU run (ps_amd/sharded.py: the process re-executed itself)
+        real_stdout = int(os.environ["PS_BENCH_STDOUT_FD"])
+    else:
+        real_stdout = os.dup(1)
+        os.set_inheritable(real_stdout, True)           # survives the re-execution of a stage change
+        os.environ["PS_BENCH_STDOUT_FD"] = str(real_stdout)
     os.dup2(2, 1)
 
     def emit(out):

@@ -433,10 +433,9 @@ int ps_shard_grads(ps_model_t *m, float **grads_dev, int64_t *n_unique);
 int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, const float *grads_dev,
                         int64_t n, const int64_t *peer_counts, int npeers, int is_async);
 /* ---- the same exchange driven by the library: ONE call per step ------------
- * ps_shard_step = plan, all-gather of the per-owner key counts (the step's
- * only host wait), all-to-all-v ids / rows / gradients, the dense + wide
- * all-reduce, owner push + updater, replicated update -- everything above,
- * enqueued from C.  The collectives are reached through a table of callbacks:
+ * ps_shard_step = plan, the fixed-size exchange of the key lists with their
+ * counts, all-to-all-v rows / gradients, the dense + wide all-reduce, owner
+ * push + updater, replicated update -- everything above, enqueued from C.  The collectives are reached through a table of callbacks:
  * ps_comm_rccl_create fills it with RCCL (ncclSend/ncclRecv groups,
  * ncclAllGather, ncclAllReduce over xGMI; librccl is dlopen'ed on first use;
  * rank 0 makes the ids (3 x 128 bytes) with ps_comm_rccl_unique_id and the host
@@ -463,18 +462,26 @@ int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int *user_rank,
  * first wrong word.  bench.py runs it before the first timed step. */
 int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm);
 int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);
-/* The step in two halves.  _begin enqueues what reads no weight (plan, counts all-gather) without a host
- * wait; use_side = 1 runs it on the store's prefetch stream so that step t+1 can begin -- on another model of
- * the same store -- before step t finishes.  _finish waits for the counts and enqueues the rest. */
+/* The step in two halves.  _begin enqueues what reads no weight without a host wait: the plan, the exchange of the key
+ * lists -- FIXED-SIZE blocks [count | owner-local rows | padding], one per peer, so the exchange needs no split sizes
+ * and carries the counts of the two exchanges that do (rows back, gradients out) -- and the publication of those
+ * counts to pinned host memory; use_side = 1 runs it on the store's prefetch stream so that step t+1 can begin -- on
+ * another model of the same store -- before step t finishes.  _finish waits for the counts (the step's one host wait)
+ * and enqueues the rest: owner-side gather, rows back, forward / backward, gradients out, owner update, the flat
+ * reduction and the replicated update.  A rank's own keys are read where they are, never copied. */
 int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side);
 int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async, float *loss);
-/* _finish of step t with _begin of step t+1 (next_batch; NULL = plain _finish)
- * issued between "gradients ready" and "push": the next plan reads no
- * weight, so its counts are on their way to the host while the GPU still has
- * step t's push and updates to do -- the host's one wait per step no longer
- * leaves the GPU idle.  Same stream, same communicator, same order on every
- * rank.  One model suffices (the plan only overwrites key lists that step t
- * no longer reads). */
+/* _finish of step t with _begin of step t+1 (next_batch; NULL = plain _finish) issued between "gradients ready"
+ * and "push": the next step's plan runs on a side stream while step t trains, its id blocks are exchanged (own
+ * communicator) right behind it, and its counts are on the host long before step t's push has run -- the host's one
+ * wait per step finds them there.  With device-side joins (ps_store_join_mode = 1) the all-reduce and the replicated
+ * update run on another side stream with a third communicator, beside the push; every rank issues the operations
+ * of each communicator in one fixed order.  ps_tune_set("shard_overlap", 0): everything on the training stream with
+ * one communicator.  One model suffices (the plan only overwrites key lists that step t no longer reads). */
+/* Wire accounting of this model's ps_shard_step calls so far: out[0] steps, [1] id-block bytes sent, [2] row bytes
+ * received, [3] gradient bytes sent, [4] all-reduce payload bytes, [5] unique keys requested, [6] keys served as an
+ * owner, [7] words of one id block (n >= 8). */
+int ps_shard_exchange_stats(const ps_model_t *m, int64_t *out, int n);
 int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *comm, int is_async,
                                const ps_batch_t *next_batch, float *loss);
 

@@ -132,6 +132,11 @@ int size_once(ps_store *s, T **p, int64_t *cap, int64_t need, size_t elem) {
     return PS_OK;
 }
 
+// which: 0 the main communicator, 1 the key-list one, 2 the all-reduce one (RcclCtx)
+void comm_select(const ps_comm_ops_t *comm, int which, bool skip_self) {
+    if (comm->ctx && comm->all_to_all_v == rccl_all_to_all_v) { RcclCtx *c = (RcclCtx *)comm->ctx; c->which = which; c->skip_self = skip_self; }
+}
+bool comm_is_rccl(const ps_comm_ops_t *comm) { return comm->ctx && comm->all_to_all_v == rccl_all_to_all_v; }
 }  // namespace
 
 extern "C" int ps_comm_rccl_unique_id(char *out384) {
@@ -220,6 +225,12 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
     }
     const uint32_t tag = 0xC0DE0000u + (uint32_t)me;
     int rcode = PS_OK;
+    const std::vector<float> red0 = red;
+    // an RCCL table has three communicators (rows + gradients | key lists | all-reduce): every one of them is checked
+    const int ncomm = (comm_is_rccl(comm) && n > 1) ? 3 : 1;
+    for (int which = 0; which < ncomm && rcode == PS_OK; ++which) {
+    red = red0;
+    comm_select(comm, which, false);
     do {
         if (hipMemcpyAsync(dsend, send.data(), 4 * (size_t)ns, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemsetAsync(drecv, 0xFF, 4 * (size_t)nr, st) != hipSuccess ||
@@ -245,6 +256,12 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
             if (n > 1 && red[(size_t)i] != want) rcode = ps_set_err(PS_E_STATE, "selfcheck: all-reduce element %d is %g, expected %g", i, red[(size_t)i], want);
         }
     } while (0);
+    comm_select(comm, 0, false);
+    if (rcode != PS_OK && ncomm > 1) {
+        const std::string msg = ps_last_error();
+        rcode = ps_set_err(rcode, "communicator %d of 3: %s", which, msg.c_str());
+    }
+    }
     { RtGuard rt_guard; fr(); }
     return rcode;
 }
@@ -309,11 +326,6 @@ __global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host + 2 * nranks + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// which: 0 the main communicator, 1 the key-list one, 2 the all-reduce one (RcclCtx)
-void comm_select(const ps_comm_ops_t *comm, int which, bool skip_self) {
-    if (comm->ctx && comm->all_to_all_v == rccl_all_to_all_v) { RcclCtx *c = (RcclCtx *)comm->ctx; c->which = which; c->skip_self = skip_self; }
-}
-bool comm_is_rccl(const ps_comm_ops_t *comm) { return comm->ctx && comm->all_to_all_v == rccl_all_to_all_v; }
 }  // namespace
 
 // begin: everything of a step that reads no weight -- plan, the exchange of the key lists and the publication of the
@@ -476,6 +488,15 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     if (sc[rank] != rc[rank]) return ps_set_err(PS_E_STATE, "the exchange's self counts differ");
     if (U > m->nnz_cap || nrecv > sh.x_recv_cap)
         return ps_set_err(PS_E_STATE, "exchange counts (%lld requested, %lld received) exceed the buffers sized at ps_shard_step_begin", (long long)U, (long long)nrecv);
+    {   // wire accounting (this rank's own part never travels)
+        const int64_t peers = nsh - 1, self = sc[rank];
+        sh.stat[0] += 1;
+        sh.stat[1] += peers * sh.blk_words * (int64_t)sizeof(uint32_t);
+        sh.stat[2] += (U - self) * D * (int64_t)sizeof(float);
+        sh.stat[3] += (U - self) * D * (int64_t)sizeof(float);
+        sh.stat[4] += nsh > 1 ? sh.flat_elems * (int64_t)sizeof(float) : 0;
+        sh.stat[5] += U; sh.stat[6] += nrecv;
+    }
     // a rank's own keys are read where they are when the collectives are RCCL's (a plugged-in table copies them like any other)
     const bool alias = comm_is_rccl(comm);
     const uint32_t *rows_p[PS_PUSH_MAX_PEERS];
@@ -573,4 +594,14 @@ extern "C" int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, in
 extern "C" int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss) {
     PSCHK(ps_shard_step_begin(m, batch, comm, 0));
     return ps_shard_step_finish(m, comm, is_async, loss);
+}
+
+// Wire accounting of this model's ps_shard_step calls so far: out[0] steps, [1] id-block bytes sent, [2] row bytes received,
+// [3] gradient bytes sent, [4] all-reduce payload bytes (per rank, before the algorithm's 2 (N-1) / N), [5] unique keys
+// requested, [6] keys served as an owner, [7] words of one id block.
+extern "C" int ps_shard_exchange_stats(const ps_model_t *m, int64_t *out, int n) {
+    if (!m || !out || n < 8) return ps_set_err(PS_E_BAD_ARG, "bad argument (8 values)");
+    for (int i = 0; i < 7; ++i) out[i] = m->sh.stat[i];
+    out[7] = m->sh.blk_words;
+    return PS_OK;
 }

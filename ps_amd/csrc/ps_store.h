@@ -180,6 +180,9 @@ struct ps_model {
         int64_t blk_words = 0;
         uint32_t *x_send_blk[2] = {nullptr, nullptr}, *x_recv_blk[2] = {nullptr, nullptr};    // [nranks][blk_words]
         int x_set = 0;                                               // the set of the step begun last
+        // what this rank put on / took off the wire so far (ps_shard_exchange_stats): steps, id-block bytes sent, row bytes received,
+        // gradient bytes sent, all-reduce payload bytes, unique keys requested, keys served
+        int64_t stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int ov_mode = -1;                                            // 1: key lists of t+1 and the all-reduce on side chain 1 + the side communicator (decided at the first begin)
         bool x_ov = false;                                           // the step begun last enqueued its id exchange on side chain 1
         bool tail_flag_due = false;                                  // the running step's push must raise start_flag[6] = pub_epoch

@@ -540,34 +540,116 @@ class NativeWorker:
 # ---------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): BASELINE configs[2]
 # ---------------------------------------------------------------------------
+# A multi-GPU run that wedges costs the driver its whole timeout and yields nothing.  The bench therefore runs in STAGES,
+# each more conservative than the one before, and a watchdog thread moves on when a stage makes no progress:
+#   stage 0  the default: device-side joins, key lists + all-reduce on side streams with their own communicators
+#   stage 1  events only (dev_wait = 0, end_wait = 0), everything on the training stream with ONE communicator
+#   stage 2  the torch.distributed wire (ShardedWorker), the library only runs the device-side halves
+# "Moving on" = the process replaces itself (os.execve) with the same command line and PS_BENCH_STAGE + 1: a hung
+# collective or a spinning stream cannot be recovered from inside the process.  Every rank does this on its own
+# watchdog; they meet again in init_process_group on the next stage's rendezvous port.  The stage a line was measured
+# on is in config["stage"], the reason for leaving the earlier ones in config["stage_history"].
+STAGES = ["default (device-side joins, 3 communicators, key lists + all-reduce on side streams)",
+          "events only, one communicator, one stream (dev_wait=0, end_wait=0, shard_overlap=0)",
+          "torch.distributed wire (ShardedWorker)"]
+
+
+class Watchdog:
+    """kick() marks progress; if none for `limit` seconds the process re-executes itself on the next stage."""
+
+    def __init__(self, stage, limit, rank):
+        import threading
+        self.stage, self.limit, self.rank = stage, limit, rank
+        self.last = time.monotonic()
+        self.what = "start"
+        self.off = False
+        self.t = threading.Thread(target=self._run, name="ps-bench-watchdog", daemon=True)
+        self.t.start()
+
+    def kick(self, what, limit=None):
+        self.last = time.monotonic()
+        self.what = what
+        if limit is not None:
+            self.limit = limit
+
+    def stop(self):
+        self.off = True
+
+    def _run(self):
+        while not self.off:
+            time.sleep(0.5)
+            if not self.off and time.monotonic() - self.last > self.limit:
+                next_stage(self.stage, "no progress for %d s in '%s'" % (self.limit, self.what), self.rank)
+
+
+def next_stage(stage, why, rank):
+    import sys
+    hist = os.environ.get("PS_BENCH_STAGE_HISTORY", "")
+    hist = (hist + " | " if hist else "") + "stage %d left: %s" % (stage, why)
+    sys.stderr.write("[bench rank %d] %s\n" % (rank, hist))
+    sys.stderr.flush()
+    if stage + 1 >= len(STAGES):
+        if rank == 0:
+            os.write(int(os.environ.get("PS_BENCH_STDOUT_FD", "1")),
+                     (json.dumps({"metric": "Wide&Deep training examples/sec", "value": None, "unit": "examples/s", "error": hist}) + "\n").encode())
+        os._exit(3)
+    env = dict(os.environ, PS_BENCH_STAGE=str(stage + 1), PS_BENCH_STAGE_HISTORY=hist)
+    os.execve(sys.executable, [sys.executable] + sys.argv, env)
+
+
 def run_bench(args, cfg, synth_batch):
     """One rank per GPU.  Weak scaling: every rank trains its own batch of cfg['B']; `value`
     is the whole-job examples/s over the max-over-ranks time of exactly `steps` steps."""
+    rank = int(os.environ.get("RANK", "0"))
+    stage = int(os.environ.get("PS_BENCH_STAGE", "0"))
+    wd = Watchdog(stage, float(os.environ.get("PS_BENCH_WATCHDOG_S", "240")), rank)     # (first import of torch + RCCL init on a cold box: minutes)
+    try:
+        return _run_bench(args, cfg, synth_batch, stage, wd)
+    except N.PsError as e:
+        if e.code == N.PS_E_STATE and stage + 1 < len(STAGES):       # a bounded device-side wait timed out, the exchange's counts never arrived, ...
+            next_stage(stage, "PsError: %s" % e, rank)
+        raise
+    finally:
+        wd.stop()
+
+
+def _run_bench(args, cfg, synth_batch, stage, wd):
     import torch                     # first: this process must share ONE HIP runtime with libps_amd
     import torch.distributed as dist
     import ps_amd
 
+    L = N.lib()
     for kv_ in os.environ.get("PS_TUNE", "").split(","):      # measurement knobs (bench.py applies them itself on the fused path)
         if "=" in kv_:
-            N.lib().ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
+            L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
+    if stage >= 1:
+        for k in (b"dev_wait", b"end_wait", b"shard_overlap"):
+            L.ps_tune_set(k, 0)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    if stage:       # (the previous stage's process image may have left its rendezvous port bound)
+        base = int(os.environ.get("PS_BENCH_BASE_PORT", os.environ["MASTER_PORT"]))
+        os.environ["PS_BENCH_BASE_PORT"] = str(base)
+        os.environ["MASTER_PORT"] = str(base + 13 * stage)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    wd.kick("init_process_group")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     cfg = dict(cfg)
+    cfg["idgen"] = getattr(args, "idgen", cfg.get("idgen", "zipf_truncated"))
     kv = ps_amd.KVStore(local, cfg["seed"])
     kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"], shard=rank, nshards=world)
     overlap = bool(getattr(args, "overlap", 1))
-    native = bool(getattr(args, "native", 1))
+    native = bool(getattr(args, "native", 1)) and stage < 2
     threaded = False
     wire_check = None
+    rccl = None
     if native:
         # the library drives the exchange (ps_shard_step: one C call per step, RCCL bound inside libps_amd.so);
-        # torch.distributed only hands the 128-byte RCCL id round and keeps the bench's barriers
+        # torch.distributed only hands the RCCL ids round and keeps the bench's barriers
         gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
                for _ in range(2 if overlap else 1)]      # two plan contexts: step t+1 begins before step t finishes
         idt = torch.zeros(384, dtype=torch.uint8, device=dev)
@@ -575,6 +657,7 @@ def run_bench(args, cfg, synth_batch):
             idt.copy_(torch.frombuffer(bytearray(NativeWorker.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         ok = torch.ones(1, dtype=torch.int32, device=dev)
+        wd.kick("ncclCommInitRank x3")
         try:
             if os.environ.get("PS_AMD_FORCE_TORCH_WIRE"):       # exercise the fallback
                 raise RuntimeError("PS_AMD_FORCE_TORCH_WIRE is set")
@@ -587,6 +670,7 @@ def run_bench(args, cfg, synth_batch):
         if int(ok.item()) != 0:
             # the RCCL calls inside libps_amd (ncclSend/Recv groups, all-gather, all-reduce) have never run at N > 1 on
             # the development box (one GPU): verify the wire on known patterns before trusting a single step
+            wd.kick("wire self-check")
             try:
                 worker.selfcheck()
                 wire_check = "ok"
@@ -602,13 +686,24 @@ def run_bench(args, cfg, synth_batch):
                 g.close()
             native = False
         else:
+            # every rank must join its streams the same way (the communicators a step uses depend on it)
+            why = C.create_string_buffer(256)
+            jm = torch.tensor([L.ps_store_join_mode(kv.h, why, 256)], dtype=torch.int32, device=dev)
+            dist.all_reduce(jm, op=dist.ReduceOp.MIN)
+            if int(jm.item()) == 0:
+                for k in (b"dev_wait", b"end_wait", b"shard_overlap"):
+                    L.ps_tune_set(k, 0)
+            cc, ur, hs = C.c_int(), C.c_int(), C.c_int()
+            if world > 1:
+                N.check(L.ps_comm_rccl_info(C.byref(worker.ops), C.byref(cc), C.byref(ur), C.byref(hs)))
+                rccl = {"ncclCommCount": cc.value, "ncclCommUserRank": ur.value, "extra_communicators": hs.value}
             worker_run = lambda n: worker.run(batches, n)                              # noqa: E731
     if not native:
         overlap = bool(getattr(args, "overlap_torch", 0))     # measured: no gain on this wire (host-bound), keep it simple
         gms = [ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
                for _ in range(4 if overlap else 1)]       # plan contexts: steps t+1, t+2 are planned while step t trains and t-1 drains
         torch.cuda.set_stream(torch.cuda.Stream(dev))      # not the legacy null stream (implicit syncs with blocking streams)
-        N.check(N.lib().ps_store_set_stream(kv.h, torch.cuda.current_stream().cuda_stream))
+        N.check(L.ps_store_set_stream(kv.h, torch.cuda.current_stream().cuda_stream))
         comm = TorchComm(dist, torch, dev, overlap=overlap)
         threaded = overlap and bool(getattr(args, "prefetch_thread", 0))
         worker = ShardedWorker(HipBackend(gms, torch, dev), comm, is_async=bool(getattr(args, "is_async", 0)))
@@ -616,11 +711,21 @@ def run_bench(args, cfg, synth_batch):
     rng = np.random.default_rng(cfg["seed"] + 1000 * rank)     # every worker reads its own slice of the data
     nb = 32        # enough distinct samples that the model cannot memorise them within the run (see bench.py)
     batches = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(nb)]
-    # priming (untimed, on top of --warmup): the first few hundred steps run ~30% slower while the caching
-    # allocator, the three communicators and the host settle; keep that out of the timed region
-    worker_run(max(args.warmup, 1) + int(getattr(args, "priming", 300)))
+    # the FIRST steps under the watchdog's short leash: a wedged exchange shows here
+    wd.kick("first 3 steps", float(os.environ.get("PS_BENCH_FIRST_STEPS_S", "60")))
+    if os.environ.get("PS_BENCH_FAKE_HANG") == str(stage):      # (test hook: this stage never gets past its first steps)
+        time.sleep(10 ** 6)
+    worker_run(3)
     kv.sync(); torch.cuda.synchronize()
     dist.barrier()
+    # priming (untimed, on top of --warmup): the first few hundred steps run ~30% slower while the communicators' buffers
+    # and the host's clocks settle; keep that out of the timed region
+    prim = max(args.warmup, 1) + int(getattr(args, "priming", 300))
+    wd.kick("priming", 60 + 0.02 * prim)
+    worker_run(prim)
+    kv.sync(); torch.cuda.synchronize()
+    dist.barrier()
+    wd.kick("timed region", 60 + 0.02 * args.steps)
     t0 = time.perf_counter()
     worker_run(args.steps)
     kv.sync(); torch.cuda.synchronize()
@@ -628,11 +733,23 @@ def run_bench(args, cfg, synth_batch):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    wd.kick("after the timed region", 300)
     loss = worker.step(batches[0], want_loss=True)
+    stats = None
+    if native:
+        st = (C.c_int64 * 8)()
+        N.check(L.ps_shard_exchange_stats(gms[0].h, st, 8))
+        n_st = max(int(st[0]), 1)
+        per = {"id_blocks_sent": st[1] / n_st, "rows_received": st[2] / n_st, "gradients_sent": st[3] / n_st,
+               "allreduce_payload": st[4] / n_st}
+        wire = per["id_blocks_sent"] + per["rows_received"] + per["gradients_sent"] + (2.0 * (world - 1) / world) * per["allreduce_payload"]
+        stats = {"bytes_per_step_per_rank": {k: int(v) for k, v in per.items()},
+                 "wire_bytes_per_step_per_rank": int(wire),
+                 # the step's average: bytes this rank moves over xGMI per step / the step's duration (the links idle most of a step)
+                 "avg_xgmi_GBs_per_rank": wire / (dt / args.steps) / 1e9,
+                 "unique_keys_requested_per_step": st[5] / n_st, "keys_served_per_step": st[6] / n_st, "id_block_words": int(st[7])}
     if os.environ.get("PS_STAMPS") and rank == 0:
         # measurement: the sharded step as the GPU ran it (in-kernel time stamps, tools/gpu_timeline.py's mechanism)
-        import ctypes as C
-        L = N.lib()
         L.ps_tune_set(b"stamps", 1)
         worker_run(200)
         kv.sync()
@@ -660,6 +777,24 @@ def run_bench(args, cfg, synth_batch):
                 groups[k] = (c0 + v[0], m0 + v[1])
             g.set_profile(False)
         phases["kernel_groups_us"] = {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in groups.items()}
+    why = C.create_string_buffer(256)
+    join_mode = L.ps_store_join_mode(kv.h, why, 256)
+    timeouts = int(L.ps_store_wait_timeouts(kv.h))
+    for b in batches:
+        b.close()
+    dist.barrier()
+    if native:
+        worker.close()
+    for g in gms:
+        g.close()
+    kv.close()
+    # the 1-GPU reference values of the same run (rank 0, while the others wait): the fused step bench.py --gpus 1 times,
+    # and the sharded step with a 1-rank communicator -- what the N-GPU value has to be read against
+    n1 = {}
+    if rank == 0 and world > 1 and int(getattr(args, "n1_reference", 1)):
+        wd.kick("1-GPU reference", 300)
+        n1 = n1_reference(cfg, synth_batch, local, min(args.steps, 1000))
+    dist.barrier()
     out = None
     if rank == 0:
         out = {
@@ -669,21 +804,54 @@ def run_bench(args, cfg, synth_batch):
             "config": {"workload": "BASELINE configs[2]: Wide&Deep synthetic (26 x 100k x 16, FC[512,256,1]), batch 4096 per GPU, "
                                    "embedding rows sharded id mod N (PSRouterClient routing -> RCCL all-to-all-v), dense + wide all-reduce, BSP",
                        "global_batch": cfg["B"] * world, "parallelism": "ps-shard%d" % world, "resident_inputs": True,
+                       "id_generator": "%s(alpha=%g, V=%d)" % (cfg.get("idgen", "zipf_truncated"), cfg["zipf"], cfg["V"]),
                        "exchange_driver": "libps_amd (ps_shard_step, RCCL via dlopen)" if native else "torch.distributed",
-                       "rccl_ranks": world, "wire_selfcheck": wire_check,
+                       "stage": stage, "stage_name": STAGES[stage], "stage_history": os.environ.get("PS_BENCH_STAGE_HISTORY", ""),
+                       "world_size": world, "rccl": rccl, "wire_selfcheck": wire_check,
+                       "stream_joins": "device-side flags" if join_mode == 1 else "events (%s)" % why.value.decode(),
+                       "device_wait_timeouts": timeouts,
                        "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
-                       "priming_steps_untimed": int(getattr(args, "priming", 300))},
+                       "priming_steps_untimed": int(getattr(args, "priming", 300)) + 3},
             "final_loss": loss,
         }
+        if stats:
+            out["exchange"] = stats
+        if n1:
+            out.update(n1)
+            if n1.get("n1_fused_ms"):
+                out["scaling_vs_n1_fused"] = out["value"] / (cfg["B"] / (1e-3 * n1["n1_fused_ms"]))
         if phases:
             out["phase_us_serialised"] = phases
-    for b in batches:
-        b.close()
-    dist.barrier()
-    if native:
-        worker.close()
-    for g in gms:
-        g.close()
-    kv.close()
     dist.destroy_process_group()
     return out
+
+
+def n1_reference(cfg, synth_batch, device, steps):
+    """The fused single-GPU step and the sharded step on a 1-rank communicator, same config, same generator, on this GPU."""
+    import ps_amd
+    res = {}
+    rng = np.random.default_rng(cfg["seed"])
+    kv = ps_amd.KVStore(device, cfg["seed"])
+    kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
+    gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+    bs = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(32)]
+    for i in range(100):
+        gm.train_async(bs[i % 32])
+    gm.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        gm.train_async(bs[i % 32])
+    gm.sync()
+    res["n1_fused_ms"] = 1e3 * (time.perf_counter() - t0) / steps
+    wk = NativeWorker([gm], 1, 0)
+    wk.run(bs, 300)
+    kv.sync()
+    t0 = time.perf_counter()
+    wk.run(bs, steps)
+    kv.sync()
+    res["n1_sharded_ms"] = 1e3 * (time.perf_counter() - t0) / steps
+    wk.close()
+    for b in bs:
+        b.close()
+    gm.close(); kv.close()
+    return res
