@@ -15,7 +15,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from test_gpu_parity import RTOL, close, close64, layerwise_f64
+from f64_chain import Chain, bound
+from test_gpu_parity import EPS, RTOL, close, close64, layerwise_f64
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -74,9 +75,26 @@ def test_config1_full_size_step_vs_oracle(orc, idgen):
     pg = gm.p(B).astype(np.float64)
     loss64 = float(np.mean(-Y * np.log(pg) - (1 - Y) * np.log(1 - pg)))
     assert abs(loss_g - loss64) <= RTOL * loss64, (loss_g, loss64)
-    assert abs(loss_g - loss_o) <= 1e-3 * loss_o, (loss_g, loss_o)
+    # ... and against the float64 CHAIN of the same step from the same parameters (tests/f64_chain.py), the oracle's own
+    # distance to it as the yardstick: |gpu - f64| <= 1e-5 |f64| + 4 |oracle - f64|
+    ch = Chain(True, F, D, X, fc, WS)
+    ch.load_fc([kv_before["fc%d.weights" % i] for i in range(3)], [kv_before["fc%d.bias" % i] for i in range(3)])
+    c64 = ch.step(E, Xd, Y, Wd, lambda f, ids: w0[f][np.searchsorted(uniq[f], ids)], update=False)
+    e_loss = bound(loss_g, loss_o, c64["loss"], "loss vs the float64 chain")
+    e_p = bound(gm.p(B), om.p(), c64["P"], "P vs the float64 chain")
     gm.backward()
     layerwise_f64(gm, kv_before, E, Y, F, D, X, fc, True)
+    e_d = [bound(gm.delta(2 + li), om.delta(2 + li)[:, :F * D] * (om.act(0) > 0) if li == 0 else om.delta(2 + li), c64["delta"][li],
+                 "delta into fc%d vs the float64 chain" % li, floor=8 * EPS * c64["mag_delta"][li]) for li in range(3)]
+    e_w = [bound(gm.fc_grad(li), om.grad("fc%d.weights" % li), c64["dW"][li].reshape(-1), "dW%d vs the float64 chain" % li,
+                 floor=8 * EPS * c64["mag_dW"][li].reshape(-1)) for li in range(3)]
+    import json, os
+    try:        # (max |gpu - f64|, max |oracle - f64|) on the record
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/e2e_f64_errors.jsonl", "a") as fjs:
+            fjs.write(json.dumps({"case": "configs[1] full size, %s" % idgen, "loss": e_loss, "P": e_p, "delta": e_d, "dW": e_w}) + "\n")
+    except OSError:
+        pass
     # per-key gradient of every unique key: bit-exact against the oracle's reduction of the GPU's own delta
     dx = gm.delta(2)
     nkeys = 0
@@ -105,12 +123,14 @@ def test_config1_full_size_step_vs_oracle(orc, idgen):
     # rows no sample touched are untouched (lazy Adam)
     cold = np.setdiff1d(np.arange(0, V, 997), uniq[0])
     np.testing.assert_array_equal(kv.get_rows(0, cold), orc.init_rows(SEED, 0, cold, D, orc.xavier_scale(1, D)))
-    # after the step against the oracle's own run (one Adam step moves a weight by <= ~alfa)
+    # after the step: against the float64 chain's updated parameters, the oracle's own distance as the yardstick
+    ch.step(E, Xd, Y, Wd, lambda f, ids: w0[f][np.searchsorted(uniq[f], ids)])       # (same step again, now with its updates)
     for f in range(0, F, 5):
         wo = np.stack([st.get(orc.emb_key(f, float(i))) for i in uniq[f][:400]])
-        assert np.abs(kv.get_rows(f, uniq[f][:400]) - wo).max() <= 2e-5
+        w64 = np.stack([ch.rows[f][int(i)][0] for i in uniq[f][:400]])
+        bound(kv.get_rows(f, uniq[f][:400]), wo, w64, "rows of field %d after the step" % f)
     for li in range(3):
-        assert np.abs(kv.get("fc%d.weights" % li) - st.get("fc%d.weights" % li)).max() <= 2e-5
+        bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after the step" % li)
     gm.close(); kv.close()
 
 
@@ -141,16 +161,20 @@ def test_config0_ctr_shape_b1000_from_libsvm_text(orc, tmp_path):
     gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
     ds = ps_amd.DataSet(kv, str(path), F, X, B, threads=2)
     Eo, Xo, Yo, _ = orc.parse_libsvm(text, F, X)
+    ch = Chain(False, F, D, X, fc)                 # the float64 chain of the same two steps (tests/f64_chain.py)
+    ch.load_fc([kv.get("fc%d.weights" % i) for i in range(3)], [kv.get("fc%d.bias" % i) for i in range(3)])
     for step in range(2):
         b = ds.next()
         assert b is not None
         sl = slice(step * B, (step + 1) * B)
         lo = om.train(Eo[sl].astype(f32), Xo[sl], Yo[sl], None, do_update=False)
         lg = gm.forward(b)
+        c64 = ch.step(Eo[sl].astype(np.int64), Xo[sl], Yo[sl], None, lambda f, ids: kv.get_rows(f, ids))
         if step == 0:
             np.testing.assert_array_equal(gm.act(1), om.act(1))            # parser + gather + concat: bit-exact
-        close(lg, lo, rtol=1e-4, what="loss step %d" % step)     # end to end vs the oracle's own f32 chain (propagated roundoff)
-        close(gm.p(B), om.p(), rtol=1e-4, what="P")
+        # end to end: |gpu - f64| <= 1e-5 |f64| + 4 |oracle - f64| (the oracle's own f32 chain as the yardstick)
+        bound(lg, lo, c64["loss"], "loss step %d" % step)
+        bound(gm.p(B), om.p(), c64["P"], "P step %d" % step)
         kvb = {"fc%d.%s" % (i, k): kv.get("fc%d.%s" % (i, k)) for i in range(3) for k in ("weights", "bias")}
         gm.backward()
         layerwise_f64(gm, kvb, Eo[sl].astype(np.int64), Yo[sl], F, D, X, fc, False)   # every contraction: 1e-5 + f32 floor
@@ -163,7 +187,7 @@ def test_config0_ctr_shape_b1000_from_libsvm_text(orc, tmp_path):
                 np.testing.assert_array_equal(g[i], orc.emb_geff(dx[ks, f * D:(f + 1) * D], orc.GRAD_COMPAT, 0))
         gm.update(); om.apply_update()
         for li in range(3):
-            assert np.abs(kv.get("fc%d.weights" % li) - st.get("fc%d.weights" % li)).max() <= 2e-5 * (step + 1)
+            bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after step %d" % (li, step))
     ds.close(); gm.close(); kv.close()
 
 
