@@ -129,6 +129,7 @@ struct DenseUpdArgs {
     // the fused step's tail: no workgroup starts before *wait_flag reached wait_val (the embedding update has started =
     // the last delta GEMM, which reads W_0, has finished; ps_common.h start_wait); NULL otherwise
     const unsigned int *wait_flag; unsigned int wait_val; WaitBound bound;
+    const unsigned int *wait_flag2; unsigned int wait_val2;     // a second start wait (dw_split: the dW GEMM of the other side chain)
 };
 int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)

@@ -1075,6 +1075,7 @@ __device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     StampScope stamp(a.ts);
     start_wait(a.wait_flag, a.wait_val, a.bound);
+    start_wait(a.wait_flag2, a.wait_val2, a.bound);
     if ((int)blockIdx.x >= a.tile_blocks) {                // the optional wide-table pass of the same launch
         wide_update_body(a.wide, (int64_t)((int)blockIdx.x - a.tile_blocks) * 256 + threadIdx.x);
         return;

@@ -59,9 +59,15 @@ __device__ __forceinline__ float sigmoid_clip_dev(float x) {
 
 // C[M][N] = epi(A[M][K] * Bt[N][K]^T); LDS rows are BKT+4 floats (16-B aligned,
 // conflict-free ds_read_b128 for both BKT=16 (stride 20) and BKT=32 (stride 36)).
-template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
-    constexpr int NTH = WM * WN * 64;                          // 4 waves (the default tiles) or 8
+// KS: split of every K slab over KS groups of waves INSIDE the workgroup (KS = 2: 8 waves on a 64 x 64 tile, each group
+// multiplies half of every slab's k range into its own accumulators; the groups' partial tiles are added through LDS
+// before the epilogue).  The FC shapes give 1-2 workgroups of 4 waves per CU -- one or two waves per SIMD, nothing to
+// hide a barrier or an LDS round trip behind; the in-workgroup split doubles the waves per SIMD at the same tile size,
+// global traffic, LDS footprint and number of output tiles (no extra partial slabs, unlike a split over workgroups).
+template <int WM, int WN, int TM, int TN, int BKT, int KS = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
+    static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
+    constexpr int NTH = WM * WN * 64 * KS;                     // 4 waves (the default tiles) or 8
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LD = BKT + 4;
     constexpr int RF4 = BKT / 4;                               // float4 per tile row
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
     StampScope stamp(a.ts);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) % (WM * WN), kg = (tid >> 6) / (WM * WN);
     const int wm = w / WN, wn = w % WN;
     const int tn = (a.N + BN - 1) / BN;
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
     const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
     auto compute = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < BKT / 8; ++q) {
+        for (int qq = 0; qq < BKT / 8 / KS; ++qq) {
+            const int q = qq + kg * (BKT / 8 / KS);          // this wave group's part of the slab
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -204,6 +211,21 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(NtArgs a) {
         __syncthreads();
     }
     if (kt < nk) compute(0);                                // odd slab count: the last slab sits in buffer 0
+    if (KS > 1) {
+        // the wave groups' partial tiles: group 1 parks its accumulators in LDS (the operand buffers are free now: 16
+        // floats per lane, lane-major per register so that both sides touch consecutive words), group 0 adds them
+        __syncthreads();
+        float *scr = &As[0][0] + w * 16 * 64;               // (2 * BM * LD floats >= WM * WN * 1024)
+        static_assert(KS == 1 || 2 * BM * LD >= WM * WN * 16 * 64, "reduction scratch does not fit the A buffers");
+        if (kg == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (kg != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += scr[r * 64 + lane];
+    }
 
     // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
 #pragma unroll
@@ -248,17 +270,21 @@ struct TnArgs {
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
-template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
+// KS: the batch rows of every slab split over KS groups of waves inside the workgroup (see k_gemm_nt)
+template <int WM, int WN, int TM, int TN, int BKT, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
+    static_assert(WM * WN == 4, "four waves per K group");
+    static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 4 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
+    constexpr int NTH = 256 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_F4 = (BKT * BM / 4 + 255) / 256, B_F4 = (BKT * BN / 4 + 255) / 256;
+    constexpr int A_F4 = (BKT * BM / 4 + NTH - 1) / NTH, B_F4 = (BKT * BN / 4 + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) float As[2][BKT * BM];
     __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
     if (a.prio) __builtin_amdgcn_s_setprio(3);       // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates)
     StampScope stamp(a.ts);
     start_wait(a.wait_flag, a.wait_val, a.bound);
     if (a.skip && *a.skip) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, kg = tid >> 8;
     const int wm = w / WN, wn = w % WN;
     const int tk = (a.Kout + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -275,14 +301,14 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     int ra_r[A_F4], ra_c[A_F4], rb_r[B_F4], rb_c[B_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        const int e = tid + i * 256 < BKT * BM / 4 ? tid + i * 256 : BKT * BM / 4 - 1;
+        const int e = tid + i * NTH < BKT * BM / 4 ? tid + i * NTH : BKT * BM / 4 - 1;
         ra_r[i] = e / (BM / 4);
         const int gc = k0 + (e % (BM / 4)) * 4;
         ra_c[i] = gc < a.a_cols ? gc : a.a_cols - 4;
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-        const int e = tid + i * 256 < BKT * BN / 4 ? tid + i * 256 : BKT * BN / 4 - 1;
+        const int e = tid + i * NTH < BKT * BN / 4 ? tid + i * NTH : BKT * BN / 4 - 1;
         rb_r[i] = e / (BN / 4);
         const int gc = n0 + (e % (BN / 4)) * 4;
         rb_c[i] = gc < a.d_cols ? gc : a.d_cols - 4;
@@ -308,12 +334,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
         const int mb = m_begin + kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             if (e < BKT * BM / 4) *reinterpret_cast<float4 *>(&As[buf][(e / (BM / 4)) * BM + (e % (BM / 4)) * 4]) = masked(ra[i], mb + ra_r[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * NTH;
             if (e < BKT * BN / 4) *reinterpret_cast<float4 *>(&Ds[buf][(e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = masked(rb[i], mb + rb_r[i]);
         }
     };
@@ -331,7 +357,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
     const int kh = lane >> 5;
     auto compute = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < BKT / 2; ++s) {
+        for (int ss = 0; ss < BKT / 2 / KS; ++ss) {
+            const int s = ss + kg * (BKT / 2 / KS);           // this wave group's batch rows of the slab
             float fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = As[buf][(2 * s + kh) * BM + acol + i * 32];
@@ -364,6 +391,19 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs a) {
         __syncthreads();
     }
     if (kt < nk) compute(0);
+    if (KS > 1) {           // the two wave groups' partial tiles, added through LDS (see k_gemm_nt)
+        __syncthreads();
+        float *scr = &As[0][0] + w * 16 * 64;
+        static_assert(KS == 1 || 2 * BKT * BM >= 4 * 16 * 64, "reduction scratch does not fit the A buffers");
+        if (kg == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (kg != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += scr[r * 64 + lane];
+    }
     float *Cz = a.Cpart + (size_t)z * a.part_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -389,6 +429,8 @@ int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5
 
 #define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
     PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64), 0, st, stop_ev, a)
+#define NT_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                            \
+    PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT, KS>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64 * KS), 0, st, stop_ev, a)
 
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
@@ -433,6 +475,9 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 15: NT_LAUNCH(4, 2, 1, 2, 32); break;      // 8 waves: 128 x 128
     case 16: NT_LAUNCH(2, 1, 1, 1, 32); break;      // 2 waves: 64 x 32
     case 17: NT_LAUNCH(1, 2, 1, 1, 32); break;      // 2 waves: 32 x 64
+    case 20: NT_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;   // 8 waves on 64 x 64: two wave groups split every K slab
+    case 21: NT_LAUNCH_KS(2, 2, 1, 1, 64, 2); break;   // ... with 64-wide slabs
+    case 22: NT_LAUNCH_KS(4, 1, 1, 1, 32, 2); break;   // 8 waves on 128 x 32 (narrow N)
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());
@@ -445,6 +490,7 @@ int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles 
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
 int g_sort_late = 0;        // ps_tune_set("sort_late", 1): the single-hot field sort behind the first delta GEMM's release instead of the first forward GEMM's
+int g_dw_split = 0;         // ps_tune_set("dw_split", 1): the first dW GEMM on side chain 0, the others on side chain 1
 int g_tn_start_wait = 1;    // ps_tune_set("tn_start_wait", 0): a spinner launch in front of EVERY dW GEMM again
 int g_tail_fused = 1;       // ps_tune_set("tail_fused", 0): the dense update between a spinner and a flag-setter launch, the main chain ends behind a spinner again
 int g_end_wait = 1;         // ps_tune_set("end_wait", 0): the main chain joins side chain 0 behind a spinner launch again
@@ -525,6 +571,9 @@ int gemm_tn_choose_split(int Kout, int N, int M) {
 #define TN_LAUNCH(WM, WN, TM, TN, BKT)                                                                      \
     hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT>),                                                    \
                        dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256), 0, st, a)
+#define TN_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                               \
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT, KS>),                                                \
+                       dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256 * KS), 0, st, a)
 
 int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
@@ -536,12 +585,17 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn"), lo ? lo->prio : 0,
              lo ? lo->wait : nullptr, lo ? lo->wait_val : 0u, wait_bound(werr, 101)};
     int cfg = g_gemm_tn_cfg;
-    if (cfg == 0) cfg = N <= 32 ? 5 : 2;
+    // 8 waves per 64 x 64 tile, the slab's batch rows split over two wave groups: ~224 workgroups of 4 waves are ONE wave
+    // per SIMD -- nothing hides a barrier or an LDS round trip; alone dW0 27.3 -> 25.3 us, dW1 17.5 -> 16.5, in the step
+    // 0.1437 -> 0.1413 ms (A/B x2, round 3)
+    if (cfg == 0) cfg = N <= 32 ? 5 : 6;
     switch (cfg) {
     case 1: TN_LAUNCH(2, 2, 1, 1, 16); break;
     case 2: TN_LAUNCH(2, 2, 1, 1, 32); break;
     case 3: TN_LAUNCH(2, 2, 2, 2, 16); break;
     case 4: TN_LAUNCH(4, 1, 1, 1, 16); break;
+    case 6: TN_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;    // 8 waves on 64 x 64: two wave groups split every slab's batch rows
+    case 7: TN_LAUNCH_KS(2, 2, 1, 1, 64, 2); break;    // ... with 64-row slabs
     default: TN_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());

@@ -609,6 +609,10 @@ int enqueue_backward(ps_model *m, bool apply) {
     else if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
     else PSCHK(fork2(m, st, sw, s0));
     bool first_release = dev_wait;
+    // (dw_split needs the fused tail: its dense update is what waits for both chains' GEMMs)
+    const bool dw_split = g_dw_split && dev_wait && dev_flags && g_tail_dev && g_tail_fused && sw != st && s0 != st && s0 != sw && sl == s0 &&
+                          !m->profile && m->cur_nnz > 0 && !m->sh.active;
+    bool dw_split_done = false; unsigned int dw_split_epoch = 0;
     bool sw_gated = false;                    // side chain 1 already sits behind a spinner: later dW GEMMs wait at their own start
     bool s0_joined = false;                   // the last delta GEMM's launch carries the join with side chain 0
     m->head_ev = nullptr;
@@ -696,6 +700,12 @@ int enqueue_backward(ps_model *m, bool apply) {
         // measured slower -- 0.180 and 0.195 against 0.170 ms/step; the embedding update took 49 us instead of 30
         // with a GEMM beside it.)
         hipStream_t dws = sw;
+        // dw_split: the FIRST dW GEMM (its delta comes from the head, long before the others') goes to side chain 0, behind
+        // that chain's small kernels, and the later ones to side chain 1 -- the two chains' GEMMs run beside each other
+        // instead of one after the other (side chain 1, dW_1 -> dW_0 -> dense update, had become the step's critical
+        // path).  The dense update then also waits for "side chain 0's dW GEMM is done" (start_flag[11]).
+        const bool split_here = dw_split && first_release && l > 0;
+        if (split_here) dws = s0;
         LaunchOpts lo, tn_lo;
         if (dev_wait) {
             // released from the device: this delta GEMM's first workgroup announces "everything before me on the main
@@ -740,7 +750,8 @@ int enqueue_backward(ps_model *m, bool apply) {
             // later ones are in order behind a GEMM that outlasts their release -- "the next delta GEMM has started" --
             // so their workgroups check the flag themselves when they start (one load; start_wait in ps_common.h): no
             // spinner launch between two dW GEMMs (stamps: 7.4 us from the end of dW_1 to the start of dW_0 with it).
-            if (!sw_gated || !g_tn_start_wait) { PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw, werr, 0)); sw_gated = true; }
+            if (split_here) {}       // (side chain 0 is parked behind its own spinner below)
+            else if (!sw_gated || !g_tn_start_wait) { PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw, werr, 0)); sw_gated = true; }
             else { tn_lo.wait = m->start_flag; tn_lo.wait_val = m->start_epoch; }
             if (first_release) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
                 if (sl != sw) PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sl, werr, 10));
@@ -755,6 +766,12 @@ int enqueue_backward(ps_model *m, bool apply) {
         tn_lo.prio = gemm_prio(m) ? 1 : 0;
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
                              b.nsplit, nullptr, dws, &tn_lo, werr));
+        if (split_here) {
+            if (++m->start_epoch == 0) ++m->start_epoch;
+            dw_split_epoch = m->start_epoch;
+            PSCHK(launch_flag_set(m->start_flag + 11, dw_split_epoch, s0));
+            dw_split_done = true;
+        }
     }
     if (first_release) { PSCHK(fork2(m, st, sw, s0)); PSCHK(small_kernels()); first_release = false; }     // (no delta GEMM at all)
     // tail_dev: the dense update goes to the END OF SIDE CHAIN 1 and both of its edges are device-side flags (no event
@@ -825,6 +842,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         // (every waiter is enqueued after the launch that releases it)
         if (tail_fused && emb_lo.launched) {
             d.wait_flag = m->start_flag + 2; d.wait_val = m->start_epoch; d.bound = wait_bound(werr, 2);
+            if (dw_split_done) { d.wait_flag2 = m->start_flag + 11; d.wait_val2 = dw_split_epoch; }
             { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
             if (tail_join) PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
             return PS_OK;

@@ -54,7 +54,7 @@ def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
         return out
     finally:
         for k in knobs:
-            N.lib().ps_tune_set(k.encode(), 1)
+            N.lib().ps_tune_set(k.encode(), 0 if k == "dw_split" else 1)
 
 
 @pytest.mark.parametrize("kind,F,D,X,fc,V,B", [("dnn", 4, 8, 3, [16, 1], 50, 200), ("widedeep", 6, 16, 5, [64, 32, 1], 3000, 2048),
@@ -70,6 +70,7 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "dense update between a spinner and a flag setter": ({"tail_fused": 0}, False),
                 "a spinner in front of every dW GEMM": ({"tn_start_wait": 0}, False),
                 "round 2's tail": ({"tail_fused": 0, "tn_start_wait": 0}, False),
+                "first dW GEMM on side chain 0": ({"dw_split": 1}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
