@@ -25,6 +25,8 @@ struct EmbFwdArgs {
     int LPR, gather_blocks;    // filled by the launcher
     unsigned long long *ts;    // stamp slot (ps_common.h) or nullptr, set by the launcher
     const unsigned int *end_wait; unsigned int end_val; WaitBound bound;   // the first workgroup ends only once *end_wait reached end_val
+    const unsigned int *start_wait; unsigned int start_val;   // no workgroup starts before *start_wait reached start_val (the previous
+                               // step's dW GEMMs, on a side chain, still read the activations this launch overwrites)
 };
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: stop_event, wait (an END wait)
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st);      // multi-hot: key_out / ent_bag from the ids alone
@@ -130,6 +132,8 @@ struct DenseUpdArgs {
     // the last delta GEMM, which reads W_0, has finished; ps_common.h start_wait); NULL otherwise
     const unsigned int *wait_flag; unsigned int wait_val; WaitBound bound;
     const unsigned int *wait_flag2; unsigned int wait_val2;     // a second start wait (dw_split: the dW GEMM of the other side chain)
+    unsigned int *started_flag; unsigned int started_val;       // raised when the launch starts: everything in front of it on its
+                                                                // stream -- the dW GEMMs -- has finished
 };
 int launch_dense_update(const DenseUpdArgs &a, hipStream_t st);
 int dense_prereduce(DenseUpdArgs &a, int l, hipStream_t st);     // many slabs -> one, in place (launch_dense_update does it otherwise)

@@ -61,8 +61,9 @@ template <> struct Vec<1> {
 #define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
 template <int VEC, bool MULTI, bool SLOT, int MHI>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
-    EndWait end_wait(a.end_wait, a.end_val, a.bound);     // (sharded step: the join with the previous step's replicated update)
+    EndWait end_wait(a.end_wait, a.end_val, a.bound);     // (the join with the previous step's dense / replicated update)
     StampScope stamp(a.ts);
+    start_wait(a.start_wait, a.start_val, a.bound);
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x >= a.gather_blocks) {
         // ConcatLayer.forward (layer/ConcatLayer.java:30-37): dense features behind the embeddings
@@ -1074,6 +1075,7 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
 __device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int64_t r);
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     StampScope stamp(a.ts);
+    if (a.started_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.started_flag, a.started_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     start_wait(a.wait_flag, a.wait_val, a.bound);
     start_wait(a.wait_flag2, a.wait_val2, a.bound);
     if ((int)blockIdx.x >= a.tile_blocks) {                // the optional wide-table pass of the same launch

@@ -115,7 +115,7 @@ int launch_transpose_w(const float *W, float *Wt, int Kpad, int ldw, int N, hipS
 
 extern "C" int ps_store_save(ps_store_t *s, const char *path) {
     if (!s || !path) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     IO io;
     io.s = s; io.write = true;
@@ -162,7 +162,7 @@ extern "C" int ps_store_save(ps_store_t *s, const char *path) {
 
 extern "C" int ps_store_load(ps_store_t *s, const char *path) {
     if (!s || !path) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     IO io;
     io.s = s; io.write = false;

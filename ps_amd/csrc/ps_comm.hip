@@ -153,7 +153,7 @@ extern "C" int ps_comm_rccl_unique_id(char *out384) {
 extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id384, ps_comm_ops_t *out) {
     const char *id256 = id384;
     if (!s || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id256)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     RcclCtx *c = new RcclCtx();
     c->nranks = nranks; c->rank = rank;
     if (nranks > 1) {
@@ -203,7 +203,7 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
     if (!s || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     const int n = comm->nranks, me = comm->rank;
     if (n < 1 || me < 0 || me >= n) return ps_set_err(PS_E_BAD_ARG, "bad communicator");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     // rank r sends (p + 1 + r % 3) words to peer p: word i = r << 20 | p << 10 | i
     std::vector<int64_t> sc((size_t)n), rc((size_t)n);
@@ -344,7 +344,7 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     ps_store *s = m->s;
     const int nsh = comm->nranks, rank = comm->rank;
     if (nsh < 1 || nsh > PS_PUSH_MAX_PEERS || rank < 0 || rank >= nsh) return ps_set_err(PS_E_BAD_ARG, "bad communicator (1..%d ranks)", PS_PUSH_MAX_PEERS);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     if (use_side && !s->prefetch_stream) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -440,7 +440,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     ps_model::Shard &sh = m->sh;
     if (!sh.x_begun) return ps_set_err(PS_E_STATE, "ps_shard_step_begin first");
     const int nsh = comm->nranks, rank = comm->rank;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     // PS_HOST_TIMING=1 (measurement): every 1000 calls, the host time of this call outside / inside the wait for the counts
     static const bool host_timing = getenv("PS_HOST_TIMING") != nullptr;

@@ -110,7 +110,7 @@ extern "C" int ps_auc_compute(ps_store_t *s, const float *p, const float *y, int
                               double *auc, int64_t *pos_num, int64_t *neg_num) {
     if (!s || !auc || n < 0 || (n > 0 && (!p || !y))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (n >= (1ll << 32)) return ps_set_err(PS_E_UNSUPPORTED, "AUC over %lld samples (limit 2^32 - 1)", (long long)n);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     if (n == 0) {       // sampleCount leaves 0/0: the reference's loop adds nothing -> 0.0
         *auc = 0.0;

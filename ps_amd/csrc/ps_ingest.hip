@@ -449,7 +449,7 @@ extern "C" int ps_ingest_create(ps_store_t *s, const ps_ingest_config_t *cfg, ps
     if (!s || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     *out = nullptr;
     PSCHK(check_cfg(cfg));
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     ps_ingest *g = new ps_ingest();
     g->s = s; g->cfg = *cfg;
     const int rc = ingest_alloc(g);

@@ -51,7 +51,7 @@ extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *key
                                     int is_async) {
     if (!s || n < 0 || (n > 0 && (!keys || !grads || !lens))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (n == 0) return PS_OK;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     std::vector<ParsedKey> pk((size_t)n);
     for (int i = 0; i < n; ++i) {

@@ -94,7 +94,7 @@ extern "C" int ps_fc_backward(ps_store_t *s, int layer, int act, const float *x_
     if (ldd != p.ldw) return ps_set_err(PS_E_BAD_ARG, "fc%d wants ldd = %d (out rounded up to 16, padding columns zero)", layer, p.ldw);
     if (act != PS_ACT_NONE && (!y_dev || ldy < p.N)) return ps_set_err(PS_E_BAD_ARG, "act' needs the layer's output y_dev");
     if (dx_dev && (lddx < p.K || (lddx & 3))) return ps_set_err(PS_E_BAD_ARG, "bad lddx %d", lddx);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     // activation.backward in place (:100-102)
     if (act != PS_ACT_NONE) {
@@ -125,7 +125,7 @@ extern "C" int ps_fc_pending_grad(ps_store_t *s, int layer, int bias, float *out
     if (!p.pending || p.pending_cnt == 0) return ps_set_err(PS_MISSING, "fc%d has no pending gradient", layer);
     const int n = bias ? p.N : p.K * p.N;
     if (cap < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipMemcpyAsync(out, p.pending + (bias ? (size_t)p.K * p.N : 0), sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return PS_OK;
@@ -134,7 +134,7 @@ extern "C" int ps_fc_pending_grad(ps_store_t *s, int layer, int bias, float *out
 extern "C" int ps_dense_update(ps_store_t *s, int layer) {
     RoctxRange roctx_range("ps_dense_update");
     if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     int done = 0;
     for (int l = 0; l < (int)s->fc.size(); ++l) {
         if (layer >= 0 && l != layer) continue;
@@ -178,7 +178,7 @@ extern "C" int ps_emb_backward_update(ps_store_t *s, const int64_t *ids_dev, con
     if (apply && !e.state && u.kind != PS_UPD_SIMPLE)
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
     if (nnz == 0) return PS_OK;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     ps_store::OpScratch &o = s->ops;
     const int ldm = (int)round_up(C, 16);
@@ -233,7 +233,7 @@ extern "C" int ps_emb_last_grads(ps_store_t *s, int64_t *rows_out, float *grads_
     if (!s || !n_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     ps_store::OpScratch &o = s->ops;
     if (!o.nseg || o.last_nnz <= 0) return ps_set_err(PS_MISSING, "no ps_emb_backward_update yet");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     uint32_t nseg = 0;
     HIPCHK(hipMemcpyAsync(&nseg, o.nseg, 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));

@@ -94,7 +94,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     if (cfg->fc_dims[cfg->nfc - 1] != 1) return ps_set_err(PS_E_UNSUPPORTED, "the last FcLayer must have 1 output (CrossEntropy is binary)");
     if (!s->emb.W) return ps_set_err(PS_E_STATE, "create the embedding tables first (ps_store_create_embedding)");
     if (s->emb.F != cfg->F || s->emb.D != cfg->D) return ps_set_err(PS_E_BAD_ARG, "store embedding is %dx%d, model wants %dx%d", s->emb.F, s->emb.D, cfg->F, cfg->D);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     if (cfg->kind == PS_MODEL_WIDEDEEP) {
         if (cfg->wide_size <= 0) return ps_set_err(PS_E_BAD_ARG, "WideDeep needs wide_size");
         if (!s->wide.W) PSCHK(ps_store_create_wide(s, cfg->wide_size));
@@ -178,6 +178,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     HIPCHK(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->s0_ev, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->dw_ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->tail_ev, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->device >= 0 && s->device < PS_MAX_DEVICES) { ++g_models_on_device[s->device]; m->counted = true; }      // (dev_waits_ok)
     *out = m;
@@ -189,6 +190,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     if (!m) return PS_OK;
     if (m->counted) --g_models_on_device[m->s->device];
     (void)hipSetDevice(m->s->device);
+    (void)store_settle(m->s);            // (its flag lives in this model's memory)
     (void)hipStreamSynchronize(m->s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -197,6 +199,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
     if (m->s0_ev) (void)hipEventDestroy(m->s0_ev);
     if (m->dw_ev) (void)hipEventDestroy(m->dw_ev);
+    if (m->tail_ev) (void)hipEventDestroy(m->tail_ev);
     if (m->hstage.copy_stream) {
         (void)hipStreamSynchronize(m->hstage.copy_stream);
         for (int k = 0; k < 2; ++k) {
@@ -407,13 +410,27 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     LaunchOpts fwd_lo;
     fwd_lo.stop_event = (train && !m->sh.active && !keys_early && !sort_dev) ? pick_event(m) : nullptr;
     const hipEvent_t fwd_ev = fwd_lo.stop_event;
+    if (!m->sh.active && s->pending_ev) {
+        // the previous fused step's dense update (side chain 1 of the model that ran it) may still be running: this
+        // launch's first workgroup ends only once the update's end flag is up -- the gather runs beside the update's
+        // tail, the first GEMM (which reads W) starts behind both.  Without device-side joins: the event.
+        if (m->dev_ok && s->pending_flag && s->pending_start && !m->profile) {
+            fwd_lo.wait = s->pending_flag; fwd_lo.wait_val = s->pending_val;
+            // ... and no workgroup of it STARTS before that update has started: the dW GEMMs in front of the update (side
+            // chain 1) read the activations of the previous step, which this launch overwrites
+            e.start_wait = s->pending_start; e.start_val = s->pending_val;
+        } else PSCHK(store_settle(s));
+    } else if (m->sh.active) PSCHK(store_settle(s));
     if (m->sh.active && m->sh.flat_pending && m->sh.flat_by_flag) {
         // sharded step: the previous step's replicated update (side chain 1) must be done before the first GEMM reads W --
         // the gather's first workgroup ends only once the update's end flag is up (normally it has been for a while)
         fwd_lo.wait = m->start_flag + 9; fwd_lo.wait_val = m->sh.flat_epoch;
     }
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st, &fwd_lo, s->werr())); }
-    if (fwd_lo.wait) {
+    if (fwd_lo.wait && !m->sh.active) {          // (the fused step's deferred join)
+        if (!fwd_lo.launched) PSCHK(store_settle(s));
+        s->pending_ev = nullptr; s->pending_flag = nullptr;
+    } else if (fwd_lo.wait) {
         if (!fwd_lo.launched) PSCHK(launch_spin_until(m->start_flag + 9, m->sh.flat_epoch, st, s->werr(), 9));   // (an empty batch)
         m->sh.flat_pending = false;
     }
@@ -820,7 +837,10 @@ int enqueue_backward(ps_model *m, bool apply) {
     // (sharded step in overlap mode: the flat gradient this launch's companion writes is consumed on side chain 1 itself --
     //  all-reduce, replicated update -- so the training stream, which goes on to the push, does not wait for it)
     const bool tail_join = !(m->sh.active && m->sh.ov_mode == 1);
-    if (tail_fused && tail_join) { emb_lo.wait = m->start_flag + 3; emb_lo.wait_val = m->start_epoch; }
+    // tail_defer (fused step): the join with the dense update is not held by this launch either -- it is handed to
+    // whatever uses the store's stream next (ps_store.h pending_ev): the next step's gather runs beside the update's tail
+    const bool tail_defer = tail_fused && tail_join && g_tail_defer && !m->sh.active && apply;
+    if (tail_fused && tail_join && !tail_defer) { emb_lo.wait = m->start_flag + 3; emb_lo.wait_val = m->start_epoch; }
     { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st, &emb_lo, werr)); }
     if (tail_dev && !emb_lo.launched)       // nothing was launched (an empty batch): announce the start ourselves
         PSCHK(launch_flag_set(m->start_flag + 2, m->start_epoch, st));
@@ -843,8 +863,14 @@ int enqueue_backward(ps_model *m, bool apply) {
         if (tail_fused && emb_lo.launched) {
             d.wait_flag = m->start_flag + 2; d.wait_val = m->start_epoch; d.bound = wait_bound(werr, 2);
             if (dw_split_done) { d.wait_flag2 = m->start_flag + 11; d.wait_val2 = dw_split_epoch; }
+            if (tail_defer) { d.started_flag = m->start_flag + 12; d.started_val = m->start_epoch; }
             { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
             if (tail_join) PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
+            if (tail_defer) {
+                HIPCHK(hipEventRecord(m->tail_ev, sw));
+                s->pending_ev = m->tail_ev; s->pending_flag = m->start_flag + 3; s->pending_val = m->start_epoch;
+                s->pending_start = m->start_flag + 12;
+            }
             return PS_OK;
         }
         PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw, werr, 2));
@@ -976,7 +1002,7 @@ extern "C" int ps_model_backward(ps_model_t *m) {
     RoctxRange roctx_range("ps_model_backward");
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     if (!m->fwd_done) return ps_set_err(PS_E_STATE, "backward before forward");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     PSCHK(enqueue_backward(m, false));
     m->bwd_done = true;
     return PS_OK;
@@ -986,7 +1012,7 @@ extern "C" int ps_model_update(ps_model_t *m) {
     RoctxRange roctx_range("ps_model_update");
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
     if (!m->bwd_done) return ps_set_err(PS_E_STATE, "update before backward");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     PSCHK(enqueue_update(m));
     m->s->global_step++;
     m->bwd_done = false;
@@ -996,7 +1022,7 @@ extern "C" int ps_model_update(ps_model_t *m) {
 extern "C" int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p_out) {
     RoctxRange roctx_range("ps_model_predict");
     if (!m || !p_out || !batch) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     ps_batch_t b = *batch;
     b.labels = nullptr;
     PSCHK(stage_batch(m, &b, false));
@@ -1009,14 +1035,14 @@ extern "C" int ps_model_predict(ps_model_t *m, const ps_batch_t *batch, float *p
 
 extern "C" int ps_model_sync(ps_model_t *m) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     HIPCHK(hipStreamSynchronize(m->s->stream));
     return store_check_bad_ids(m->s);       // ps_model_train(loss = NULL) never waits: out-of-range ids surface here
 }
 
 extern "C" int ps_model_last_loss(ps_model_t *m, float *loss) {
     if (!m || !loss) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     return finish_step(m, loss);
 }
 
@@ -1036,7 +1062,7 @@ static int copy_out_2d(ps_model *m, const float *src, int ld, int rows, int cols
 
 extern "C" int ps_model_get_act(ps_model_t *m, int layer, float *out, int64_t cap, int *rows, int *cols) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     const ps_model_config_t &c = m->cfg;
     const int B = m->cur_B;
     if (layer == 0) return copy_out_2d(m, m->fc[0].A, m->fc[0].ldA, B, c.F * c.D, out, cap, rows, cols);
@@ -1049,7 +1075,7 @@ extern "C" int ps_model_get_act(ps_model_t *m, int layer, float *out, int64_t ca
 
 extern "C" int ps_model_get_delta(ps_model_t *m, int layer, float *out, int64_t cap, int *rows, int *cols) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     const ps_model_config_t &c = m->cfg;
     const int B = m->cur_B, l = layer - 2;
     if (l < 0 || l >= c.nfc) return ps_set_err(PS_E_BAD_ARG, "no such layer %d", layer);
@@ -1060,7 +1086,7 @@ extern "C" int ps_model_get_delta(ps_model_t *m, int layer, float *out, int64_t 
 extern "C" int ps_model_get_p(ps_model_t *m, float *out, int cap) {
     if (!m || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     if (cap < m->cur_B) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     HIPCHK(hipMemcpyAsync(out, m->P, sizeof(float) * m->cur_B, hipMemcpyDeviceToHost, m->s->stream));
     HIPCHK(hipStreamSynchronize(m->s->stream));
     return PS_OK;
@@ -1070,7 +1096,7 @@ extern "C" int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out
                                       int64_t cap_rows, int64_t *n_out) {
     if (!m || !n_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     ps_store *s = m->s;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     uint32_t nseg = 0;
     HIPCHK(hipMemcpyAsync(&nseg, m->nseg_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1104,7 +1130,7 @@ extern "C" int ps_model_get_fc_grad(ps_model_t *m, int layer, int bias, float *o
     if (!m || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     ps_store *s = m->s;
     if (layer < 0 || layer >= m->cfg.nfc) return ps_set_err(PS_E_BAD_ARG, "no such layer");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     int64_t off = 0;
     for (int l = 0; l < layer; ++l) off += (int64_t)(s->fc[l].K + 1) * s->fc[l].N;
@@ -1136,7 +1162,7 @@ static int prof_collect(ps_model *m) {
 
 extern "C" int ps_model_set_profile(ps_model_t *m, int enabled) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     PSCHK(prof_collect(m));
     if (enabled) m->prof_acc.clear();
     m->profile = enabled != 0;
@@ -1146,7 +1172,7 @@ extern "C" int ps_model_set_profile(ps_model_t *m, int enabled) {
 
 extern "C" int ps_model_set_profile_filter(ps_model_t *m, const char *group) {
     if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     PSCHK(prof_collect(m));
     m->prof_acc.clear();
     m->prof_filter = group ? group : "";
@@ -1156,7 +1182,7 @@ extern "C" int ps_model_set_profile_filter(ps_model_t *m, const char *group) {
 
 extern "C" int ps_model_profile_report(ps_model_t *m, char *report, int cap) {
     if (!m || !report || cap <= 0) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     PSCHK(prof_collect(m));
     std::string out;
     char line[160];
@@ -1171,7 +1197,7 @@ extern "C" int ps_model_profile_report(ps_model_t *m, char *report, int cap) {
 extern "C" int ps_model_time_steps(ps_model_t *m, const ps_batch_t *batch, int steps, double *ms_out) {
     if (!m || !batch || !ms_out || steps <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_store *s = m->s;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));

@@ -9,7 +9,7 @@
 extern "C" int ps_dev_alloc(ps_store_t *s, size_t bytes, void **out_dev) {
     RtGuard rt_guard;
     if (!s || !out_dev) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipMalloc(out_dev, bytes ? bytes : 16));
     HIPCHK(hipMemsetAsync(*out_dev, 0, bytes ? bytes : 16, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -18,28 +18,28 @@ extern "C" int ps_dev_alloc(ps_store_t *s, size_t bytes, void **out_dev) {
 extern "C" int ps_dev_free(ps_store_t *s, void *p) {
     RtGuard rt_guard;
     if (!s) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (p) HIPCHK(hipFree(p));
     return PS_OK;
 }
 extern "C" int ps_dev_upload(ps_store_t *s, void *dst, const void *src, size_t bytes) {
     if (!s || !dst || !src) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return PS_OK;
 }
 extern "C" int ps_dev_download(ps_store_t *s, void *dst, const void *src, size_t bytes) {
     if (!s || !dst || !src) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return PS_OK;
 }
 extern "C" int ps_store_sync(ps_store_t *s) {
     if (!s) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     return store_check_bad_ids(s);
 }
@@ -50,7 +50,7 @@ extern "C" int ps_emb_forward(ps_store_t *s, const int64_t *ids_dev, const int64
     if (!s || !ids_dev || !out_dev || B <= 0) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (ld < s->emb.F * s->emb.D || (s->emb.D % 4 == 0 && (ld & 3))) return ps_set_err(PS_E_BAD_ARG, "bad ld %d", ld);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     EmbFwdArgs e;
     memset(&e, 0, sizeof e);
     e.W = s->emb.W; e.row_base = s->emb.row_base_dev; e.ids = ids_dev; e.offsets = offsets_dev;
@@ -68,7 +68,7 @@ extern "C" int ps_fc_forward(ps_store_t *s, int layer, int act, const float *x_d
     FcParams &p = s->fc[layer];
     if (ldx != p.Kpad) return ps_set_err(PS_E_BAD_ARG, "fc%d wants ldx = %d (in+1 rounded up to 16, ones column at %d)", layer, p.Kpad, p.K);
     if (ldy < p.N) return ps_set_err(PS_E_BAD_ARG, "ldy %d < out %d", ldy, p.N);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     const int epi = act == PS_ACT_RELU ? EPI_RELU : act == PS_ACT_SIGMOID ? EPI_SIGMOID : EPI_NONE;
     return gemm_nt(x_dev, ldx, B, p.Wt, p.Kpad, p.N, y_dev, ldy, B, p.N, p.Kpad, epi, nullptr, 0, 0, nullptr, s->stream);
 }
@@ -152,7 +152,7 @@ extern "C" int ps_bench_gather(ps_store_t *s, int64_t rows, int D, int64_t n, in
                                double *avg_ms_out, double *bytes_read_out, double *bytes_written_out) {
     if (!s || rows <= 0 || D <= 0 || (D & 3) || n <= 0 || n > 0x7fffffff || bag <= 0 || iters <= 0 || !avg_ms_out)
         return ps_set_err(PS_E_BAD_ARG, "bad argument (D must be a multiple of 4)");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     GatherRun g;
     PSCHK(g.setup(s, rows, D, n, bag, seed));
     hipStream_t st = g.st;
@@ -179,7 +179,7 @@ extern "C" int ps_bench_gather_check(ps_store_t *s, int64_t rows, int D, int64_t
     if (!s || rows <= 0 || D <= 0 || (D & 3) || n <= 0 || n > 0x7fffffff || bag <= 0 || n_sample <= 0 || n_sample > n ||
         !bag_index_out || !ids_out || !out_rows)
         return ps_set_err(PS_E_BAD_ARG, "bad argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     GatherRun g;
     PSCHK(g.setup(s, rows, D, n, bag, seed));
     hipStream_t st = g.st;
@@ -206,7 +206,7 @@ extern "C" int ps_bench_gather_check(ps_store_t *s, int64_t rows, int D, int64_t
 // and stage through the host: the callbacks' `stream` argument is the stream their inputs were produced on.
 extern "C" int ps_stream_sync(ps_store_t *s, void *hip_stream) {
     if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : s->stream));
     return PS_OK;
 }
@@ -232,7 +232,7 @@ extern "C" int64_t ps_store_wait_timeouts(const ps_store_t *s) { return s ? s->w
 // back with PS_E_STATE after the timeout, not hang (tests/test_gpu_schedule.py)
 extern "C" int ps_dbg_stuck_wait(ps_store_t *s, int in_gemm) {
     if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     unsigned int *flag = nullptr;
     float *buf = nullptr;
     { RtGuard g; HIPCHK(hipMalloc((void **)&flag, 64)); HIPCHK(hipMalloc((void **)&buf, sizeof(float) * 3 * 64 * 64)); }
@@ -266,6 +266,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "tail_fused") == 0) { g_tail_fused = value; return PS_OK; }
     if (strcmp(knob, "tn_start_wait") == 0) { g_tn_start_wait = value; return PS_OK; }
     if (strcmp(knob, "dw_split") == 0) { g_dw_split = value; return PS_OK; }
+    if (strcmp(knob, "tail_defer") == 0) { g_tail_defer = value; return PS_OK; }
     if (strcmp(knob, "end_wait") == 0) { g_end_wait = value; return PS_OK; }
     if (strcmp(knob, "main_prio") == 0) { g_main_prio = value; return PS_OK; }
     if (strcmp(knob, "sort_late") == 0) { g_sort_late = value; return PS_OK; }
@@ -286,7 +287,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
 
 extern "C" int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int nsplit, int iters, double *avg_ms_out) {
     if (!s || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !avg_ms_out) return ps_set_err(PS_E_BAD_ARG, "bad argument");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     const int Kp = (int)round_up(K, 16), Np = (int)round_up(N, 16);
     float *A = nullptr, *B = nullptr, *Cc = nullptr;

@@ -288,7 +288,7 @@ extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
     // Adopt the host framework's stream (e.g. torch.cuda.current_stream().cuda_stream) so the
     // kernels here and the RCCL collectives the host enqueues are ordered without host syncs.
     if (!s) return ps_set_err(PS_E_BAD_ARG, "store is NULL");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->stream = (hipStream_t)hip_stream;      // the store's own stream is simply left idle
     return PS_OK;
@@ -448,7 +448,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
 extern "C" int ps_shard_plan_launch(ps_model_t *m, const ps_batch_t *batch, int nshards, void *hip_stream) {
     RoctxRange roctx_range("ps_shard_plan_launch");
     if (!m || !batch || nshards < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     return shard_plan_enqueue(m, batch, nshards, hip_stream ? (hipStream_t)hip_stream : m->s->stream, true);
 }
 
@@ -456,7 +456,7 @@ extern "C" int ps_shard_plan_finish(ps_model_t *m, int64_t *counts_out, uint32_t
     if (!m || !counts_out) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     ps_model::Shard &sh = m->sh;
     if (!sh.plan_pending) return ps_set_err(PS_E_STATE, "ps_shard_plan_launch first");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     HIPCHK(hipEventSynchronize(sh.plan_ev));
     sh.plan_pending = false;
     for (int o = 0; o < sh.nshards; ++o) counts_out[o] = (int64_t)sh.owner_start_host[o + 1] - (int64_t)sh.owner_start_host[o];
@@ -503,7 +503,7 @@ extern "C" int ps_shard_serve_pull(ps_store_t *s, const uint32_t *rows_dev, int6
     if (!s || n < 0 || (n > 0 && (!rows_dev || !rows_out_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (n == 0) return PS_OK;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     return shard_serve_pull_lists(s, &rows_dev, &n, 1, rows_out_dev, nullptr);
 }
 
@@ -514,7 +514,7 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     ps_store *s = m->s;
     if (m->cfg.kind == PS_MODEL_WIDEDEEP && m->cfg.wide_grad_mode != PS_GRAD_COMPAT)
         return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is single-GPU only (the sharded push carries the compat G/C pair)");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     m->sh.active = true;
     m->sh.cache = cache_dev;
     if (m->sh.slot_ev) { HIPCHK(hipStreamWaitEvent(s->stream, m->sh.slot_ev, 0)); m->sh.slot_ev = nullptr; }   // the plan's slots (side stream)
@@ -598,7 +598,7 @@ int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_d
     RoctxRange roctx_range("ps_shard_apply_push");
     if (!s || n < 0 || (n > 0 && (!rows_dev || !grads_dev))) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     hipStream_t st = s->stream;
     ps_updater_t u;
     PSCHK(store_resolve_updater(s, "emF", &u));
@@ -647,7 +647,7 @@ extern "C" int ps_shard_apply_flat(ps_model_t *m, int nworkers) {
     RoctxRange roctx_range("ps_shard_apply_flat");
     if (!m || nworkers < 1) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!m->sh.flat) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
-    HIPCHK(hipSetDevice(m->s->device));
+    PSCHK(store_enter(m->s));
     return shard_apply_flat(m, nworkers, m->s->stream);
 }
 

@@ -61,6 +61,12 @@ struct ps_store {
     int64_t bytes = 0;
     int *err_dev = nullptr;     // device words: [0] ids outside their table | [1] bounded device-side waits that timed out, [2] which wait
     unsigned int *werr() const { return reinterpret_cast<unsigned int *>(err_dev) + 1; }
+    // The fused step's LAST join -- its dense update, on a side chain, is done -- is not paid at the end of the step but by
+    // whatever touches the store's stream next: the next training step hangs it on its gather's launch (device flag: the
+    // gather and the update's tail run beside each other), every other entry point waits for the event first (store_enter).
+    hipEvent_t pending_ev = nullptr; const unsigned int *pending_flag = nullptr; unsigned int pending_val = 0;
+    const unsigned int *pending_start = nullptr;    // "the update has STARTED" (same value): its chain's dW GEMMs, which read the
+                                                    // activations the next gather overwrites, are done
     bool dev_wait_off = false;  // a device-side wait timed out on this store: every join takes its event form from then on
     int64_t wait_timeouts = 0;
     // scratch for row get/put
@@ -93,6 +99,9 @@ int64_t store_local_row(const ps_store *s, int field, int64_t id);
 int store_ensure_scratch(ps_store *s, int64_t rows, int D);
 // after a host wait on the store's stream: report (and clear) the device-side count of ids that were outside their table
 int store_check_bad_ids(ps_store *s);      // (... and of bounded device-side waits that timed out: PS_E_STATE)
+// every entry point that enqueues on (or waits for) the store's stream: hipSetDevice + the pending join of the last fused step
+int store_enter(ps_store *s);
+int store_settle(ps_store *s);             // the pending join alone (an event wait on the store's stream)
 // may this store's models join their streams by device-side flags?  (g_dev_wait, no timeout so far, one live model on the device)
 #define PS_MAX_DEVICES 64
 #include <atomic>
@@ -223,7 +232,7 @@ struct ps_model {
     HeadArgs head_args;           // the head of the last forward (the loss reduction may be launched by the backward)
     bool head_bwd_done = false;   // the head's launch also did the out = 1 layer's backward
     bool loss_pending = false;    // loss / gbar / stop flag not reduced yet
-    hipEvent_t loss_ev = nullptr, s0_ev = nullptr, dw_ev = nullptr;
+    hipEvent_t loss_ev = nullptr, s0_ev = nullptr, dw_ev = nullptr, tail_ev = nullptr;
     unsigned int sort_epoch = 0, fwd_epoch = 0, s0_epoch = 0;
     unsigned int *start_flag = nullptr, start_epoch = 0;      // device word + host epoch of the spinner in front of the dW chain
     hipEvent_t head_ev = nullptr;                             // carried by the head's launch (one of `events`), consumed by the backward

@@ -262,6 +262,7 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     RtGuard rt_guard;
     if (!s) return PS_OK;
     (void)hipSetDevice(s->device);
+    (void)store_settle(s);
     (void)hipStreamSynchronize(s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(s->emb.W); fr(s->emb.state); fr(s->emb.row_base_dev);
@@ -293,6 +294,19 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
 std::atomic<int> g_models_on_device[PS_MAX_DEVICES];
 bool dev_waits_ok(const ps_store *s) {
     return g_dev_wait && !s->dev_wait_off && s->device >= 0 && s->device < PS_MAX_DEVICES && g_models_on_device[s->device].load() <= 1;
+}
+
+int store_settle(ps_store *s) {
+    if (s->pending_ev) {
+        hipEvent_t e = s->pending_ev;
+        s->pending_ev = nullptr; s->pending_flag = nullptr; s->pending_start = nullptr;
+        HIPCHK(hipStreamWaitEvent(s->stream, e, 0));
+    }
+    return PS_OK;
+}
+int store_enter(ps_store *s) {
+    HIPCHK(hipSetDevice(s->device));
+    return store_settle(s);
 }
 
 int store_check_bad_ids(ps_store *s) {
@@ -361,7 +375,7 @@ extern "C" int ps_store_create_embedding(ps_store_t *s, int F, const int64_t *ro
     }
     if ((D % 4 == 0 && D > 256) || (D % 4 != 0 && D > 64)) return ps_set_err(PS_E_UNSUPPORTED, "embedding dim %d too wide for one wave per row", D);
     if (state_slots != 0 && state_slots != 2) return ps_set_err(PS_E_BAD_ARG, "state_slots must be 0 or 2");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     EmbTables &e = s->emb;
     e.F = F; e.D = D; e.state_slots = state_slots; e.shard = shard; e.nshards = nshards; e.route_mode = route_mode;
     e.rows.assign(rows, rows + F);
@@ -431,7 +445,7 @@ extern "C" int ps_store_create_embedding(ps_store_t *s, int F, const int64_t *ro
 extern "C" int ps_store_create_wide(ps_store_t *s, int64_t wide_size) {
     if (!s || wide_size <= 0) return ps_set_err(PS_E_BAD_ARG, "bad wide size");
     if (s->wide.W) return ps_set_err(PS_E_STATE, "wide table already exists");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     WideTable &w = s->wide;
     w.rows = wide_size;
     // layer/LRLayer.java:37-52: weights and bias start at zero
@@ -452,7 +466,7 @@ extern "C" int ps_store_create_wide(ps_store_t *s, int64_t wide_size) {
 
 extern "C" int ps_store_create_fc(ps_store_t *s, int layer, int in_dims, int out_dims) {
     if (!s || layer < 0 || layer >= 8 || in_dims <= 0 || out_dims <= 0) return ps_set_err(PS_E_BAD_ARG, "bad fc layer");
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     if ((int)s->fc.size() <= layer) s->fc.resize(layer + 1);
     FcParams &f = s->fc[layer];
     if (f.present) {
@@ -504,7 +518,7 @@ static int rows_io(ps_store *s, float *table, int64_t row_stride, int64_t col_of
                    const std::vector<int64_t> &lrows, float *host, int to_table) {
     const int64_t n = (int64_t)lrows.size();
     if (n == 0) return PS_OK;
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     PSCHK(store_ensure_scratch(s, n, D));
     HIPCHK(hipMemcpyAsync(s->idx_dev, lrows.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, s->stream));
     if (to_table) HIPCHK(hipMemcpyAsync(s->rowbuf_dev, host, sizeof(float) * n * D, hipMemcpyHostToDevice, s->stream));
@@ -591,7 +605,7 @@ static int fc_io(ps_store *s, int layer, int bias, float *host, int cap, int *le
     const int n = bias ? f.N : f.K * f.N;
     if (len) *len = n;
     if (cap < n) return ps_set_err(PS_E_BAD_ARG, "buffer too small: %d < %d", cap, n);
-    HIPCHK(hipSetDevice(s->device));
+    PSCHK(store_enter(s));
     const int krows = bias ? 1 : f.K;
     float *src = f.W + (bias ? (size_t)f.K * f.ldw : 0);
     if (!to_dev) {
@@ -630,7 +644,7 @@ extern "C" int ps_store_get(ps_store_t *s, const char *key, float *out, int cap,
         if (!s->wide.W) return ps_set_err(PS_MISSING, "no wide table");
         if (len) *len = 1;
         if (cap < 1) return ps_set_err(PS_E_BAD_ARG, "buffer too small");
-        HIPCHK(hipSetDevice(s->device));
+        PSCHK(store_enter(s));
         HIPCHK(hipMemcpyAsync(out, s->wide.bias, sizeof(float), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         return PS_OK;
@@ -654,7 +668,7 @@ extern "C" int ps_store_put(ps_store_t *s, const char *key, const float *val, in
         return ps_store_put_wide(s, &k.id, 1, 0, val);
     case 2:
         if (!s->wide.W) return ps_set_err(PS_MISSING, "no wide table");
-        HIPCHK(hipSetDevice(s->device));
+        PSCHK(store_enter(s));
         HIPCHK(hipMemcpyAsync(s->wide.bias, val, sizeof(float), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         return PS_OK;

@@ -22,6 +22,11 @@ _ORDER = ["test_gpu_operators", "test_gpu_parity", "test_gpu_configs", "test_gpu
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     faulthandler.enable()
+    if os.environ.get("PS_TUNE"):       # measurement / debugging: ps_tune_set knobs for the whole session, "knob=value,knob=value"
+        from ps_amd import native as N
+        for kv_ in os.environ["PS_TUNE"].split(","):
+            if "=" in kv_:
+                N.lib().ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -12,6 +12,8 @@ leave identical tables:
   * ps_tune_set("tail_dev", 0)                (the dense update last on the main chain, not beside the embedding update)
   * ps_tune_set("tail_fused", 0)              (the dense update behind a spinner launch and followed by a flag setter, the main chain ends behind a spinner)
   * ps_tune_set("tn_start_wait", 0)           (a spinner launch in front of every dW GEMM, not only the first)
+  * ps_tune_set("tail_defer", 0)              (the step ends behind its dense update; default: the NEXT use of the store's stream pays the join)
+  * ps_tune_set("dw_split", 1)                (the first dW GEMM on side chain 0 -- measured slower, off)
   * profile mode                              (everything on ONE stream: the serial order is the definition)
 Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
 consecutive plans must still equal the fused step (the map is re-zeroed when the epoch wraps)."""
@@ -71,6 +73,7 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "a spinner in front of every dW GEMM": ({"tn_start_wait": 0}, False),
                 "round 2's tail": ({"tail_fused": 0, "tn_start_wait": 0}, False),
                 "first dW GEMM on side chain 0": ({"dw_split": 1}, False),
+                "the embedding update holds the join with the dense update": ({"tail_defer": 0}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
