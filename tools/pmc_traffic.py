@@ -17,8 +17,10 @@ import sys
 root, tag = sys.argv[1], sys.argv[2]
 # (kernel name prefix, grid size) -> group, for F=26 D=16 X=13 FC[512,256,1] B=4096 (64x64 tiles, 256 threads)
 GROUPS = {
-    ("k_gemm_tn", 57344): "fc_bwd_dw0",       # 7 x 8 tiles x 4 batch splits
+    ("k_gemm_tn", 57344): "fc_bwd_dw0",       # 7 x 8 tiles x 4 batch splits (4-wave workgroups, rounds 1-2)
     ("k_gemm_tn", 64512): "fc_bwd_dw1",       # 9 x 4 tiles x 7 batch splits
+    ("k_gemm_tn", 114688): "fc_bwd_dw0",      # ... 8-wave workgroups (round 3: two wave groups split every slab)
+    ("k_gemm_tn", 129024): "fc_bwd_dw1",
     ("k_gemm_nt", 114688): "fc_bwd_data0",    # 64 x 7 tiles
     ("k_gemm_nt", 65536): "fc_fwd1",          # 64 x 4 tiles
     ("k_gemm_nt", 131072): "fc_fwd0|fc_bwd_data1",   # 64 x 8 tiles each (same grid: averaged)
