@@ -70,10 +70,14 @@ JNIEXPORT void JNICALL Java_store_NativeKVStore_destroy(JNIEnv *, jclass, jlong 
 // ---- store.KVStore: get / put / rows / updaters / globalStep ---------------------------------------------------------
 JNIEXPORT jfloatArray JNICALL Java_store_NativeKVStore_get(JNIEnv *env, jobject self, jstring key) {
     Utf k(env, key);
-    std::vector<float> buf(1 << 22);
-    int len = 0;
-    const int rc = ps_store_get(S(env, self), k.c, buf.data(), (int)buf.size(), &len);
+    int want = 0;                                         // the key's own length (a row: D floats; a tensor: in x out) -- no 16 MB scratch per call
+    int rc = ps_store_key_length(S(env, self), k.c, &want);
     if (rc == PS_MISSING) return nullptr;                 // KVStore.get: null when absent (store/KVStore.java:129-134)
+    if (fail(env, rc)) return nullptr;
+    std::vector<float> buf((size_t)(want > 0 ? want : 1));
+    int len = 0;
+    rc = ps_store_get(S(env, self), k.c, buf.data(), (int)buf.size(), &len);
+    if (rc == PS_MISSING) return nullptr;
     if (fail(env, rc)) return nullptr;
     return to_java(env, buf.data(), len);
 }

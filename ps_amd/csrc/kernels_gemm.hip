@@ -257,6 +257,124 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction with the operand tiles DMA'd global -> LDS (global_load_lds_dwordx4 on gfx950: 16 bytes per lane
+// straight into LDS, no VGPR round trip, no ds_write): the k_gemm_nt above stages every slab through registers (4 float4
+// loads + 4 ds_write_b128 per thread and slab, two register sets in flight) and measures ~71 % of the f32 MFMA rate in
+// its steady state against ~87 % with the global loads ablated.  Here a slab is 2 + 2 load instructions per wave and
+// nothing else; three LDS stages keep two slabs in flight.
+//   LDS image of a 64 x 32 operand tile: 512 chunks of 16 bytes.  A wave-level load writes 64 consecutive chunks (the
+//   hardware adds lane * 16 to a wave-uniform base), so the image is "as loaded": chunk slot s holds row s / 8, and the
+//   row's k-chunk c sits at position c ^ (row & 7) -- each lane simply FETCHES the global chunk that belongs in its
+//   slot.  The XOR spreads the 8 rows that 8 consecutive lanes of a fragment read (same c, rows r .. r + 7) over the 8
+//   bank groups: ds_read_b128 without conflicts, no padding (which contiguous 16-byte lane writes could not produce).
+// K needs K % 4 == 0 (as above); a tail slab shorter than 32 loads and multiplies only its valid chunks.
+template <int NST>
+__global__ __launch_bounds__(256) void k_gemm_nt_lds(NtArgs a) {
+    static_assert(NST == 3, "three LDS stages (two slabs in flight)");
+    constexpr int BM = 64, BN = 64, BKT = 32;
+    // one object per stage: the compiler's wait-count pass then knows that a DMA into stage i cannot alias a ds_read of
+    // stage j (through one array with a runtime stage index it waits for EVERY outstanding DMA before every LDS read)
+    __shared__ __attribute__((aligned(16))) float As0[BM * BKT], As1[BM * BKT], As2[BM * BKT];
+    __shared__ __attribute__((aligned(16))) float Bs0[BN * BKT], Bs1[BN * BKT], Bs2[BN * BKT];
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);
+    StampScope stamp(a.ts);
+    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.skip && *a.skip) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int tn = (a.N + BN - 1) / BN;
+    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;
+    const int nk = (a.K + BKT - 1) / BKT;
+    // this thread's two chunk slots per operand: slot = (i * 4 + w) * 64 + lane -> (row, k-chunk)
+    const float *pa[2], *pb[2];
+    int kc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = (i * 4 + w) * 64 + lane, row = slot >> 3;
+        kc[i] = ((slot & 7) ^ (row & 7)) * 4;               // first k of the chunk that belongs in this slot
+        int ra = m0 + row; ra = ra < a.a_rows ? ra : a.a_rows - 1;      // (rows beyond the operand: clamped, never stored)
+        int rb = n0 + row; rb = rb < a.b_rows ? rb : a.b_rows - 1;
+        pa[i] = a.A + (size_t)ra * a.lda + kc[i];
+        pb[i] = a.Bt + (size_t)rb * a.ldb + kc[i];
+    }
+    // K % 32 == 0 or 16 (the launcher's condition: K % 16 == 0): a half slab at the end loads and multiplies chunks 0-3 only
+    const int kfull = a.K / BKT, half = (a.K % BKT) ? 1 : 0;
+    auto issue = [&](float *Ast, float *Bst, int kt) {      // (every instruction has active lanes: the waits count instructions)
+        const int k0 = kt * BKT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (kt < kfull || kc[i] < 16) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[i] + k0),
+                                                 (__attribute__((address_space(3))) void *)(Ast + (i * 4 + w) * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k0),
+                                                 (__attribute__((address_space(3))) void *)(Bst + (i * 4 + w) * 256), 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = lane >> 5;
+    const int aoff = arow * BKT, boff = brow * BKT, ax = arow & 7, bx = brow & 7;
+    auto mult = [&](const float *Ast, const float *Bst, int q) {
+        const int c = 2 * q + kh;
+        const float4 fa = *reinterpret_cast<const float4 *>(Ast + aoff + ((c ^ ax) << 2));
+        const float4 fb = *reinterpret_cast<const float4 *>(Bst + boff + ((c ^ bx) << 2));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    };
+    const int nkt = kfull + half;
+    // One pipeline step: slab kt (in stage S) has landed once at most the 4 load instructions of slab kt + 1 are
+    // outstanding (a wave's loads retire in order); the barrier (no fence: the DMA waits are explicit) says every wave's
+    // part of slab kt is in LDS and every wave is past slab kt - 1, whose stage the next DMA overwrites.
+#define LDS_STEP(S_A, S_B, N_A, N_B)                                                                                   \
+    {                                                                                                                  \
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        if (kt + 2 < nkt) issue(N_A, N_B, kt + 2);                                                                     \
+        if (kt < kfull) { mult(S_A, S_B, 0); mult(S_A, S_B, 1); mult(S_A, S_B, 2); mult(S_A, S_B, 3); }                \
+        else { mult(S_A, S_B, 0); mult(S_A, S_B, 1); }                                                                 \
+        ++kt;                                                                                                          \
+    }
+    issue(As0, Bs0, 0);
+    if (nkt > 1) issue(As1, Bs1, 1);
+    int kt = 0;
+    while (kt < nkt) {
+        LDS_STEP(As0, Bs0, As2, Bs2)
+        if (kt >= nkt) break;
+        LDS_STEP(As1, Bs1, As0, Bs0)
+        if (kt >= nkt) break;
+        LDS_STEP(As2, Bs2, As1, Bs1)
+    }
+#undef LDS_STEP
+    // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+    const int col = n0 + wn * 32 + (lane & 31);
+    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    float mk[16];
+    if (a.epi == EPI_MASK_POS) {
+        const int mc = col < a.mask_cols ? col : a.mask_cols - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            mk[r] = a.mask[(size_t)(row < a.M ? row : a.M - 1) * a.ldmask + mc];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float v = acc[r];
+        if (a.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
+        else if (a.epi == EPI_SIGMOID) v = sigmoid_clip_dev(v);
+        else if (a.epi == EPI_MASK_POS) v *= (col >= a.mask_cols || mk[r] > 0.f) ? 1.f : 0.f;
+        if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
+    }
+}
+
 struct TnArgs {
     const float *A; int lda; int a_cols;
     const float *D; int ldd; int d_cols;
@@ -445,6 +563,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
              o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100)};
     const hipEvent_t stop_ev = o.stop_event;
     int cfg = g_gemm_nt_cfg;
+    if (cfg == 30 && (K & 15)) cfg = 0;       // the LDS-DMA kernel multiplies whole or half slabs
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
         // (measured best on MI355X for M=4096, N in 256..512, K in 256..528); narrow N: 128x32.
@@ -478,6 +597,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 20: NT_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;   // 8 waves on 64 x 64: two wave groups split every K slab
     case 21: NT_LAUNCH_KS(2, 2, 1, 1, 64, 2); break;   // ... with 64-wide slabs
     case 22: NT_LAUNCH_KS(4, 1, 1, 1, 32, 2); break;   // 8 waves on 128 x 32 (narrow N)
+    case 30: PS_LAUNCH_EV((k_gemm_nt_lds<3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;   // operands DMA'd global -> LDS, 3 stages
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());

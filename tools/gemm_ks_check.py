@@ -22,7 +22,7 @@ def run(knobs, shape):
     return out
 for shape in [(26, 16, 13, [512, 256, 1], 1000, 4096, 97), (5, 8, 3, [40, 24, 1], 50, 333, 11), (3, 4, 2, [5, 3, 1], 7, 6, 5)]:
     ref = run({}, shape)
-    for knobs in ({"gemm_nt_cfg": 20}, {"gemm_nt_cfg": 21}, {"gemm_tn_cfg": 6}, {"gemm_tn_cfg": 7}, {"gemm_nt_cfg": 20, "gemm_tn_cfg": 6}):
+    for knobs in ({"gemm_nt_cfg": 20}, {"gemm_nt_cfg": 21}, {"gemm_nt_cfg": 30}, {"gemm_tn_cfg": 2}, {"gemm_tn_cfg": 7}, {"gemm_nt_cfg": 30, "gemm_tn_cfg": 6}):
         got = run(knobs, shape)
         dl = max(abs(a - b) / abs(b) for a, b in zip(got[0], ref[0]))
         dw = max(np.abs(a - b).max() for a, b in zip(got[1], ref[1]))
