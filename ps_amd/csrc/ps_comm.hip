@@ -2,21 +2,22 @@
 //
 // ps_amd/sharded.py drives the same device-side halves through torch.distributed; measured on MI355X that
 // wire is host-bound (five Python-level collectives, two host round trips for split sizes, ~45 ctypes
-// launches: ~0.5 ms per step for ~0.3 ms of GPU work).  Here the whole step of net/PSRouterClient.java:60-151
-// + net/PServer.java:102-283 is enqueued by ps_shard_step with ONE host wait (the N x N matrix of key counts):
+// launches: ~0.4 ms per step for ~0.16 ms of GPU work).  Here the whole step of net/PSRouterClient.java:60-151
+// + net/PServer.java:102-283 is enqueued by ps_shard_step with ONE host wait (the counts of the two
+// weight-dependent exchanges, which arrive with the NEXT step's key lists long before they are needed):
 //
-//   plan (sort/unique by owner)            ps_shard_plan_launch
-//   all-gather of the per-owner counts     -> every rank learns what it sends AND what it receives
-//   all-to-all-v row ids                   PSRouterClient.getList fan-out
+//   plan (unique keys by owner)            ps_shard_plan_launch, packed into one fixed-size block per owner
+//   all-to-all of the id blocks            PSRouterClient.getList fan-out; no split sizes; carries the counts
 //   owner gather + all-to-all-v rows back  PServer.getList -> worker cache
 //   forward / backward on the cache        Model.train
-//   all-reduce of [fc | wide G | wide C | wide.bias]
 //   all-to-all-v per-key gradients         PSClient.push
-//   owner: mean over pushing workers (or async) + updater; replicated tensors: identical update
+//   owner: mean over pushing workers (or async) + updater
+//   all-reduce of [fc | wide G | wide C | wide.bias]; replicated tensors: identical update
 //
 // The collectives go through a small table of callbacks (ps_comm_ops_t): the product implementation is RCCL
-// (ncclSend/ncclRecv groups, ncclAllGather, ncclAllReduce over xGMI), loaded with dlopen so that single-GPU
-// use never maps the 570 MB library; tests plug in an in-process implementation to run N ranks on one GPU.
+// (ncclSend/ncclRecv groups, ncclAllGather, ncclAllReduce over xGMI; three communicators, see RcclCtx), loaded
+// with dlopen so that single-GPU use never maps the 570 MB library; tests plug in their own (N rank threads in
+// one process, N rank processes over gloo) to run N ranks on one GPU.
 #include <dlfcn.h>
 #include <string.h>
 
