@@ -158,7 +158,7 @@ def run_processes(world, is_async, device_batches):
     return out
 
 
-@pytest.mark.parametrize("world,is_async,device_batches", [(2, False, True), (3, True, True), (4, False, True), (2, False, False)])
+@pytest.mark.parametrize("world,is_async,device_batches", [(2, False, True), (3, True, True), (4, False, True), (2, False, False), (8, False, True)])
 def test_one_process_per_rank_on_one_gpu(orc, world, is_async, device_batches):
     out = run_processes(world, is_async, device_batches)
     emb, fcW, fcb, ww, wb = expected(world, is_async)
