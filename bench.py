@@ -98,6 +98,8 @@ def group_algorithmic(cfg, name, nnz, uniq):
         return "hbm", 13.0 * cfg["wide"]
     if name == "loss_reduce":
         return "hbm", 8.0 * B
+    if name == "fc_fwd01":                                        # the first two forward GEMMs in one launch (k_fc_fwd_pair)
+        return "mfma", 2.0 * B * (dims[0] * dims[1] + dims[1] * dims[2])
     for l in range(len(cfg["fc"])):
         if name == "fc_fwd%d" % l:
             return "mfma", 2.0 * B * dims[l] * dims[l + 1]
@@ -110,6 +112,8 @@ def group_algorithmic(cfg, name, nnz, uniq):
 
 def kernel_of_group(name):
     """The device function a kernel group of the step launches (names as in rocprofv3's kernel stats)."""
+    if name == "fc_fwd01" or name == "fc_fwd_pair":
+        return "k_fc_fwd_pair"
     if name.startswith("fc_fwd") or name.startswith("fc_bwd_data"):
         return "k_gemm_nt"
     if name.startswith("fc_bwd_dw"):

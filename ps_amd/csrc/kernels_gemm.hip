@@ -64,32 +64,18 @@ __device__ __forceinline__ float sigmoid_clip_dev(float x) {
 // before the epilogue).  The FC shapes give 1-2 workgroups of 4 waves per CU -- one or two waves per SIMD, nothing to
 // hide a barrier or an LDS round trip behind; the in-workgroup split doubles the waves per SIMD at the same tile size,
 // global traffic, LDS footprint and number of output tiles (no extra partial slabs, unlike a split over workgroups).
-template <int WM, int WN, int TM, int TN, int BKT, int KS = 1>
-__global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
-    static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
-    constexpr int NTH = WM * WN * 64 * KS;                     // 4 waves (the default tiles) or 8
+// One output tile of C = epi(A * Bt^T): everything of k_gemm_nt behind the choice of the tile (m0, n0).  As / Bs: the
+// workgroup's double-buffered operand tiles.  Shared by k_gemm_nt and k_fc_fwd_pair.
+template <int WM, int WN, int TM, int TN, int BKT, int KS>
+__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0,
+                                             float (&As)[2][WM * TM * 32 * (BKT + 4)], float (&Bs)[2][WN * TN * 32 * (BKT + 4)]) {
+    constexpr int NTH = WM * WN * 64 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LD = BKT + 4;
     constexpr int RF4 = BKT / 4;                               // float4 per tile row
     constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
-    // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
-    // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
-    // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
-    // Every GEMM of the step (NT and TN) and the head carry it -- armed per launch by the model, single-hot steps only:
-    // with the NT GEMMs alone 0.1495 ms/step, with all of them 0.1469 (the dW GEMMs no longer fall behind), and the
-    // sharded step settles at 0.189-0.193.
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);       // (declared first: runs after the stamp's end)
-    StampScope stamp(a.ts);
-    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) % (WM * WN), kg = (tid >> 6) / (WM * WN);
     const int wm = w / WN, wn = w % WN;
-    const int tn = (a.N + BN - 1) / BN;
-    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;     // consecutive ids: the N tiles of one M tile
     const int nk = (a.K + BKT - 1) / BKT;
 
     // TWO register sets: slab t+2 is already in flight while slab t is multiplied and slab t+1
@@ -255,6 +241,94 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
                 if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
             }
         }
+}
+
+template <int WM, int WN, int TM, int TN, int BKT, int KS = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
+    static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;       // (4 waves -- the default tiles -- or 8)
+    constexpr int LD = BKT + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
+    // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
+    // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
+    // Every GEMM of the step (NT and TN) and the head carry it -- armed per launch by the model, single-hot steps only:
+    // with the NT GEMMs alone 0.1495 ms/step, with all of them 0.1469 (the dW GEMMs no longer fall behind), and the
+    // sharded step settles at 0.189-0.193.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);       // (declared first: runs after the stamp's end)
+    StampScope stamp(a.ts);
+    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.skip && *a.skip) return;
+    const int tn = (a.N + BN - 1) / BN;
+    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    gemm_nt_tile<WM, WN, TM, TN, BKT, KS>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two consecutive FcLayer.forward GEMMs in ONE launch (layer/FcLayer.java:74-91 twice): Y1 = relu(A0 W0'), Y2 = relu(Y1 W1').
+// The FC chain is local to a panel of 64 batch rows -- a tile of Y2 needs the whole row panel of Y1 and nothing else -- so
+// the second GEMM's tiles need not wait for the first GEMM to END, only for their own panel.  One launch of
+// tiles(Y1) + tiles(Y2) workgroups: a phase-2 workgroup waits (bounded) until its panel's phase-1 tiles have counted
+// themselves in, then runs the same tile code on the second problem.  Saves a launch boundary (~3.5 us on the training
+// stream) and overlaps the first GEMM's tail with the second's ramp.
+//   Coherence.  Each XCD has its own L2, not coherent with the others' for ordinary memory inside a kernel (DESIGN.md
+//   4.1.1): a hand-over through memory needs an L2 write-back + invalidate -- unless producer and consumer share the L2.
+//   MI355X deals the workgroups of a launch round-robin over the 8 XCDs (tools/ubench/xcc_probe.hip: XCC_ID == blockIdx % 8
+//   for a launch alone on the chip; inside the step the rotation starts where the previous launch left off, so it is
+//   (blockIdx + s) % 8 with one s per launch): workgroups with the same blockIdx % 8 share an XCD, and panel p's tiles of
+//   BOTH phases are given to class p % 8.  The producer's stores (write-through L1) are in that XCD's L2 when its counter
+//   increment is issued (s_waitcnt vmcnt(0) + barrier first), the consumer's loads miss its L1 (invalidated at kernel
+//   start, and nobody read those lines since) and hit the same L2.  Every workgroup checks that its class agrees on one
+//   XCC_ID for the launch and reports a disagreement (the host then stops using this kernel).
+//   Progress.  Workgroups are dispatched in blockIdx order and every phase-1 workgroup has a smaller index than every
+//   phase-2 one: a waiting consumer can only wait for workgroups that are already running or done.
+struct PairArgs {
+    NtArgs p1, p2;
+    int mt, tn1, tn2, lp_max;          // row panels, N tiles of each problem, panels per XCD (ceil(mt / 8))
+    unsigned int *ctr;                 // [mt] tiles of phase 1 finished per panel, ever (never reset)
+    unsigned int target;               // value ctr[p] reaches when this launch's phase 1 of panel p is complete
+    unsigned int *xcc_err;             // counts workgroups that found a workgroup of their class (blockIdx % 8) on another XCD
+    unsigned int *xcc_tag; unsigned int epoch;      // [8] per class: (epoch << 4) | XCC id of this launch
+};
+template <int WM, int WN, int TM, int TN, int BKT>
+__global__ __launch_bounds__(WM * WN * 64) void k_fc_fwd_pair(PairArgs q) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BKT + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    if (q.p1.prio) __builtin_amdgcn_s_setprio(3);
+    StampScope stamp(q.p1.ts);
+    if (q.p1.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(q.p1.flag, q.p1.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q.p1.skip && *q.p1.skip) return;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (threadIdx.x == 0) {
+        // same blockIdx % 8 => same XCD, within this launch (the dispatcher's round robin carries over from launch to launch,
+        // so WHICH XCD class x lands on differs per launch; that every workgroup of a class shares one is what is needed):
+        // the class's tag = (launch epoch, XCC id); whoever finds this epoch's tag with another id reports it
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned int mine = (q.epoch << 4) | (xcc & 0xFu);
+        const unsigned int old = atomicMax(q.xcc_tag + x, mine);
+        if ((old >> 4) == q.epoch && old != mine) atomicAdd(q.xcc_err, 1u);
+    }
+    const int n1 = q.lp_max * q.tn1;
+    if (j < n1) {                                            // ---- phase 1: a tile of Y1
+        const int p = (j / q.tn1) * 8 + x, nt = j % q.tn1;
+        if (p >= q.mt) return;
+        gemm_nt_tile<WM, WN, TM, TN, BKT, 1>(q.p1, p * BM, nt * BN, As, Bs);
+        __syncthreads();                                     // every wave's stores have been acknowledged by the L2 (vmcnt(0) + barrier)
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(q.ctr + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int j2 = j - n1;                                   // ---- phase 2: a tile of Y2, once its panel of Y1 is complete
+    const int p = (j2 / q.tn2) * 8 + x, nt = j2 % q.tn2;
+    if (p >= q.mt) return;
+    if (q.p1.ablate & 8) return;                             // (measurement only)
+    if (threadIdx.x == 0 && !(q.p1.ablate & 16)) (void)spin_bounded(q.ctr + p, q.target, q.p2.bound);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (an L1 invalidate: cheap; the L2 is the producers' own)
+    gemm_nt_tile<WM, WN, TM, TN, BKT, 1>(q.p2, p * BM, nt * BN, As, Bs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -600,6 +674,50 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 30: PS_LAUNCH_EV((k_gemm_nt_lds<3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;   // operands DMA'd global -> LDS, 3 stages
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
+    HIPCHK(hipGetLastError());
+    if (lo) lo->launched = true;
+    return PS_OK;
+}
+
+// FcLayer.forward of two consecutive relu layers in one launch (k_fc_fwd_pair).  Y1 = relu(A W1t^T) [M][N1] with leading
+// dimension ldy1 (the second layer's input incl. its ones column and padding, untouched), Y2 = relu(Y1 W2t^T).  K2 = the
+// second problem's K (Y1's padded width).  ctr: [ceil(M / 64) + 8] device words owned by the caller, zero at first use;
+// *epoch: the caller's launch count for those counters.  Returns PS_E_UNSUPPORTED when the shapes do not fit (the caller
+// then launches the two GEMMs one after the other).
+// MEASURED SLOWER, off by default (round 3): the paired launch takes 48 us where the two launches take 20.4 + 3.5 + 13.7.  Its
+// ablations say why, and correct an earlier reading of these GEMMs: with the second phase switched off the first alone takes
+// 28.5 us inside this launch, and with the wait removed -- both problems' 768 workgroups running fully concurrently, three per
+// CU -- the two GEMMs together take 38.5 us: no better than one after the other.  At 64 x 64 tiles these kernels are bound by
+// their steady-state THROUGHPUT (~0.5 of the f32 MFMA rate whatever the concurrency), not by launch boundaries; overlapping
+// them buys nothing, and the resident waiting workgroups cost the side chains their CU slots (the field sort started 50 us late).
+int g_fwd_pair = 0;         // ps_tune_set("fwd_pair", 1): the first two forward GEMMs in one launch (k_fc_fwd_pair)
+int gemm_nt_fwd_pair_ok(int M, int N1, int N2, int K1, int K2) {
+    if (!g_fwd_pair || g_gemm_nt_cfg != 0) return 0;
+    if (M <= 0 || N1 <= 32 || N2 <= 32 || (K1 & 3) || (K2 & 3)) return 0;
+    auto tiles = [&](int n) { return (long long)cdiv(M, 64) * cdiv(n, 64); };
+    if (tiles(N1) >= 2048 || tiles(N2) >= 2048) return 0;       // (those shapes take the 64 x 128 tiles)
+    return 1;
+}
+int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int ldb1, int N1, float *Y1, int ldy1, int K1,
+                     const float *W2t, int ldb2, int N2, float *Y2, int ldy2, int K2, int M, unsigned int *ctr, unsigned int *epoch,
+                     unsigned int *xcc_err, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
+    if (lo) lo->launched = false;
+    if (!gemm_nt_fwd_pair_ok(M, N1, N2, K1, K2)) return ps_set_err(PS_E_UNSUPPORTED, "gemm_nt_fwd_pair: shapes");
+    const LaunchOpts none;
+    const LaunchOpts &o = lo ? *lo : none;
+    PairArgs q;
+    memset(&q, 0, sizeof q);
+    q.p1 = NtArgs{A, lda, a_rows, W1t, ldb1, N1, Y1, ldy1, M, N1, K1, EPI_RELU, nullptr, 0, 0, nullptr, 0, g_gemm_ablate, stamp_next("fc_fwd_pair"),
+                  o.flag, o.flag_val, nullptr, 0u, o.prio, wait_bound(werr, 105)};
+    q.p2 = NtArgs{Y1, ldy1, M, W2t, ldb2, N2, Y2, ldy2, M, N2, K2, EPI_RELU, nullptr, 0, 0, nullptr, 0, 0, nullptr,
+                  nullptr, 0u, nullptr, 0u, o.prio, wait_bound(werr, 105)};
+    q.mt = cdiv(M, 64); q.tn1 = cdiv(N1, 64); q.tn2 = cdiv(N2, 64); q.lp_max = cdiv(q.mt, 8);
+    q.ctr = ctr;
+    *epoch += 1;
+    q.target = *epoch * (unsigned int)q.tn1;
+    q.xcc_err = xcc_err; q.xcc_tag = ctr + q.mt; q.epoch = *epoch & 0x0FFFFFFFu;      // (the 8 words behind the panel counters)
+    const int grid = 8 * q.lp_max * (q.tn1 + q.tn2);
+    PS_LAUNCH_EV((k_fc_fwd_pair<2, 2, 1, 1, 32>), dim3(grid), dim3(256), 0, st, o.stop_event, q);
     HIPCHK(hipGetLastError());
     if (lo) lo->launched = true;
     return PS_OK;

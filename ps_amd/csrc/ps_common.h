@@ -240,6 +240,12 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
                    const int *skip_flag, hipStream_t st, const LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: prio, and
                    // wait = a START wait: no workgroup reads its operands before *wait reached wait_val
 int gemm_tn_choose_split(int Kout, int N, int M);
+// two consecutive relu FcLayer.forward GEMMs in one launch (kernels_gemm.hip k_fc_fwd_pair); _ok: do the shapes fit
+int gemm_nt_fwd_pair_ok(int M, int N1, int N2, int K1, int K2);
+int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int ldb1, int N1, float *Y1, int ldy1, int K1,
+                     const float *W2t, int ldb2, int N2, float *Y2, int ldy2, int K2, int M, unsigned int *ctr, unsigned int *epoch,
+                     unsigned int *xcc_err, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);
+extern int g_fwd_pair;
 extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate;

@@ -161,7 +161,8 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * 3 * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
     PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
-    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 16, true));      // [0..7] flags, [8] the dense update's workgroup count
+    PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 16, true));
+    PSCHK(model_alloc(m, (void **)&m->pair_ctr, sizeof(unsigned int) * (size_t)(cdiv(B, 64) + 8), true));       // k_fc_fwd_pair: tiles done per row panel      // [0..7] flags, [8] the dense update's workgroup count
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->uniq_cnt, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->partials, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
@@ -226,7 +227,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
     sort_ws_free(m->ws); sort_ws_free(m->wws);
     fr(m->wkeys); fr(m->wents); fr(m->wseg_start); fr(m->wseg_id); fr(m->wnseg);
-    fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub); fr(m->start_flag);
+    fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub); fr(m->start_flag); fr(m->pair_ctr);
     fr(m->seg_nseg_scratch); fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
     fr(m->partials); fr(m->partials2); fr(m->grads_out); fr(m->dense_grad_flat);
     delete m;
@@ -503,10 +504,21 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         if (l == nfc - 1) epi = c.kind == PS_MODEL_WIDEDEEP ? EPI_NONE : EPI_SIGMOID;   // FcLayer.java:58-62, WideDeepNN.java:128
         static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
         if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
-        Prof pf(m, names[l]);
+        // two consecutive hidden (relu) layers: ONE launch, the second layer's tiles start as their row panel of the first
+        // layer's output completes (kernels_gemm.hip k_fc_fwd_pair)
+        const bool pair = l + 2 < nfc && !s->fwd_pair_off && m->pair_ctr &&
+                          gemm_nt_fwd_pair_ok(B, p.N, s->fc[l + 1].N, p.Kpad, s->fc[l + 1].Kpad);
+        Prof pf(m, pair ? (l == 0 ? "fc_fwd01" : "fc_fwd_pair") : names[l]);
         LaunchOpts lo;
         if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
         lo.prio = (train && gemm_prio(m)) ? 1 : 0;
+        if (pair) {
+            FcParams &p2 = s->fc[l + 1];
+            float *out2 = l + 2 < nfc ? m->fc[l + 2].A : m->out_last;
+            const int ldo2 = l + 2 < nfc ? m->fc[l + 2].ldA : m->ld_last;
+            PSCHK(gemm_nt_fwd_pair(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, p.Kpad, p2.Wt, p2.Kpad, p2.N, out2, ldo2, p2.Kpad, B,
+                                   m->pair_ctr, &m->pair_epoch, reinterpret_cast<unsigned int *>(s->err_dev) + 4, st, &lo, s->werr()));
+        } else
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st, &lo, s->werr()));
         if (lo.flag && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st));      // (an empty GEMM)
@@ -515,6 +527,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
             PSCHK(enqueue_sort());
             sort_due = false;
         }
+        if (pair) ++l;          // (layer l + 1 went with this launch)
     }
     // LRLayer.forward + AddLayer.forward + loss
     HeadArgs h;

@@ -266,6 +266,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "tail_fused") == 0) { g_tail_fused = value; return PS_OK; }
     if (strcmp(knob, "tn_start_wait") == 0) { g_tn_start_wait = value; return PS_OK; }
     if (strcmp(knob, "dw_split") == 0) { g_dw_split = value; return PS_OK; }
+    if (strcmp(knob, "fwd_pair") == 0) { g_fwd_pair = value; return PS_OK; }
     if (strcmp(knob, "tail_defer") == 0) { g_tail_defer = value; return PS_OK; }
     if (strcmp(knob, "end_wait") == 0) { g_end_wait = value; return PS_OK; }
     if (strcmp(knob, "main_prio") == 0) { g_main_prio = value; return PS_OK; }

@@ -67,6 +67,7 @@ struct ps_store {
     hipEvent_t pending_ev = nullptr; const unsigned int *pending_flag = nullptr; unsigned int pending_val = 0;
     const unsigned int *pending_start = nullptr;    // "the update has STARTED" (same value): its chain's dW GEMMs, which read the
                                                     // activations the next gather overwrites, are done
+    bool fwd_pair_off = false;  // a workgroup of k_fc_fwd_pair was not on XCD blockIdx % 8: the two forward GEMMs are launched separately
     bool dev_wait_off = false;  // a device-side wait timed out on this store: every join takes its event form from then on
     int64_t wait_timeouts = 0;
     // scratch for row get/put
@@ -117,6 +118,7 @@ struct FcBuf {
 struct ps_model {
     ps_store *s = nullptr;
     bool counted = false;       // in g_models_on_device
+    unsigned int *pair_ctr = nullptr, pair_epoch = 0;      // k_fc_fwd_pair: per-row-panel tile counters (never reset) and their launch count
     bool dev_ok = false;        // this step joins its streams by device-side flags (decided once per step in stage_batch)
     ps_model_config_t cfg;
     int Bcap = 0;

@@ -250,7 +250,7 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
         HIPCHK(hipStreamCreateWithPriority(&s->own_stream, hipStreamNonBlocking, hi));   // main chain: most urgent
     }
     s->stream = s->own_stream;
-    PSCHK(store_dev_alloc(s, (void **)&s->err_dev, 4 * sizeof(int), true));      // [0] bad ids | [1] timed-out device waits, [2] which
+    PSCHK(store_dev_alloc(s, (void **)&s->err_dev, 8 * sizeof(int), true));      // [0] bad ids | [1] timed-out device waits, [2] last, [3] first | [4] XCD mismatches
     ps_updater_t a;
     ps_updater_default_adam(&a);
     s->updaters["default"] = a;
@@ -310,7 +310,7 @@ int store_enter(ps_store *s) {
 }
 
 int store_check_bad_ids(ps_store *s) {
-    int err[4] = {0, 0, 0, 0};
+    int err[5] = {0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(err, s->err_dev, sizeof err, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (err[1]) {
@@ -322,6 +322,14 @@ int store_check_bad_ids(ps_store *s) {
         s->wait_timeouts += err[1];
         return ps_set_err(PS_E_STATE, "%d device-side wait(s) timed out after %.0f ms (first: wait %d, last: wait %d); the steps since the last check ran "
                           "without a dependency -- this store now joins its streams by events", err[1], (double)g_spin_timeout_ticks * 1e-5, err[3] - 1000, err[2]);
+    }
+    if (err[4]) {
+        // k_fc_fwd_pair hands a row panel from one workgroup to another through the L2 of "their" XCD, which it takes to be
+        // blockIdx % 8: that did not hold, so the second layer may have read stale rows.  Never again on this store.
+        HIPCHK(hipMemsetAsync(s->err_dev + 4, 0, sizeof(int), s->stream));
+        s->fwd_pair_off = true;
+        return ps_set_err(PS_E_STATE, "%d workgroups of the paired forward GEMM did not run on XCD (blockIdx %% 8): the steps since the last check are "
+                          "suspect; the forward GEMMs are launched one by one from now on", err[4]);
     }
     if (err[0]) {
         HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof(int), s->stream));

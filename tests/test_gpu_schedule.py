@@ -56,7 +56,7 @@ def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
         return out
     finally:
         for k in knobs:
-            N.lib().ps_tune_set(k.encode(), 0 if k == "dw_split" else 1)
+            N.lib().ps_tune_set(k.encode(), 0 if k in ("dw_split", "fwd_pair") else 1)
 
 
 @pytest.mark.parametrize("kind,F,D,X,fc,V,B", [("dnn", 4, 8, 3, [16, 1], 50, 200), ("widedeep", 6, 16, 5, [64, 32, 1], 3000, 2048),
@@ -73,6 +73,7 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "a spinner in front of every dW GEMM": ({"tn_start_wait": 0}, False),
                 "round 2's tail": ({"tail_fused": 0, "tn_start_wait": 0}, False),
                 "first dW GEMM on side chain 0": ({"dw_split": 1}, False),
+                "first two forward GEMMs in one launch": ({"fwd_pair": 1}, False),
                 "the embedding update holds the join with the dense update": ({"tail_defer": 0}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),

@@ -24,6 +24,7 @@ GROUPS = {
     ("k_gemm_nt", 114688): "fc_bwd_data0",    # 64 x 7 tiles
     ("k_gemm_nt", 65536): "fc_fwd1",          # 64 x 4 tiles
     ("k_gemm_nt", 131072): "fc_fwd0|fc_bwd_data1",   # 64 x 8 tiles each (same grid: averaged)
+    ("k_fc_fwd_pair", None): "fc_fwd01",      # round 3: the first two forward GEMMs in one launch
     ("k_emb_fwd", 159744): "emb_fwd",
     ("k_emb_fwd", 16777216): "gather_c4_single_hot",
     ("k_emb_fwd", 2097152): "gather_c4_bags32",
