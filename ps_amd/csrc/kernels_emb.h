@@ -158,6 +158,8 @@ struct WideIntendedArgs {              // wide_grad_mode = intended (SURVEY App.
     float *W, *state;
     UpdParams upd;
     const int *skip;
+    float *G, *C;                      // when set (sharded worker): G[key] = the key's gradient, C[key] = 1, no update here -- the
+                                       // owner side averages over the workers that pushed the key (ps_shard_apply_flat)
 };
 int launch_wide_keys(const int64_t *ids, int64_t n, int64_t rows, uint32_t *keys, int *err, hipStream_t st);
 int launch_wide_intended(const WideIntendedArgs &a, int64_t n, hipStream_t st);

@@ -1150,11 +1150,12 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
 // materialise the flat dense gradient (sum of split partials / B) without updating
 __device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int64_t r) {
     if (a.skip && *a.skip) return;
-    if (a.mode == 1) {
+    if (a.mode == 1 || a.mode == 5) {
         // sharded worker, before the all-reduce: G[k] = touched[k] * gbar, C[k] = touched[k]
         // (the PS averages a key over the workers that pushed it: net/PServer.java:164-214)
+        // mode 5 (wide_grad_mode = intended): the keys' G / C were written by k_wide_intended; only the bias here
         const float gb = a.gbar[0];
-        if (r < a.rows) { const float t = a.touched[r] ? 1.f : 0.f; a.G[r] = t * gb; a.C[r] = t; }
+        if (r < a.rows) { if (a.mode == 1) { const float t = a.touched[r] ? 1.f : 0.f; a.G[r] = t * gb; a.C[r] = t; } }
         else if (r == a.rows) a.G[2 * a.rows] = gb;          // wide.bias: every worker pushes it
         return;
     }
@@ -1495,6 +1496,7 @@ __global__ __launch_bounds__(256) void k_wide_intended(WideIntendedArgs a) {
     float S = 0.f;
     for (uint32_t k = s0; k < e0; ++k) S = a.delta[(size_t)(a.sorted_ent[k] / (uint32_t)a.F) * a.ldd] + S;   // (sample, field) order
     const float g = div_rn(S, (float)a.B);
+    if (a.G) { a.G[key] = g; a.C[key] = 1.f; return; }      // sharded worker: pushed, not applied
     float w = a.W[key], z = a.state[2 * (size_t)key], n = a.state[2 * (size_t)key + 1];
     if (a.upd.kind == PS_UPD_FTRL) { if (g == 0.f) return; ftrl_elem(a.upd, g, w, z, n); }
     else if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, z, n);

@@ -583,7 +583,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
 // wide_grad_mode = intended (not a reference path): the gradient of a wide key is the sum of delta
 // over the (sample, field) occurrences of the key IN THIS BATCH, / B -- a stable sort of the batch's wide ids, their
 // segments, one sequential sum per key, Ftrl on those keys only; "wide.bias" as in compat mode.
-static int enqueue_wide_intended(ps_model *m, WideUpdArgs w, hipStream_t st) {
+// to_flat (sharded worker, gradients only): the keys' gradients go to the flat buffer's [G | C] part instead of the table --
+// G[key] = the batch's sum / B, C[key] = 1 for the keys of THIS worker's batch, zero elsewhere; the all-reduce and
+// ps_shard_apply_flat then give every key the mean over the workers that pushed it (net/PServer.java:164-214).
+static int enqueue_wide_intended(ps_model *m, WideUpdArgs w, hipStream_t st, bool to_flat = false) {
     ps_store *s = m->s;
     const int64_t n = (int64_t)m->cur_B * m->cfg.F;
     if (!m->wkeys) {
@@ -604,6 +607,11 @@ static int enqueue_wide_intended(ps_model *m, WideUpdArgs w, hipStream_t st) {
     a.sorted_key = sk; a.sorted_ent = se; a.seg_start = m->wseg_start; a.nseg = m->wnseg;
     a.delta = m->fc[m->cfg.nfc - 1].dOut; a.ldd = m->fc[m->cfg.nfc - 1].ldD;
     a.B = m->cur_B; a.F = m->cfg.F; a.W = w.W; a.state = w.state; a.upd = w.upd; a.skip = w.skip;
+    if (to_flat) {
+        a.G = m->sh.flat + m->dense_elems; a.C = a.G + s->wide.rows;
+        HIPCHK(hipMemsetAsync(a.G, 0, sizeof(float) * 2 * (size_t)s->wide.rows, st));
+        return launch_wide_intended(a, n, st);              // ("wide.bias": by the flat gradient's launch, mode 5)
+    }
     PSCHK(launch_wide_intended(a, n, st));
     w.mode = 3;                                             // "wide.bias": rowMeans(delta), as in compat mode
     return launch_wide_update(w, st);
@@ -676,6 +684,15 @@ int enqueue_backward(ps_model *m, bool apply) {
             Prof pf(m, "loss_reduce");
             PSCHK(launch_loss_reduce(m->head_args, m->loss_dev, m->gbar_dev, m->skip_dev, m->sh.active ? 1 : 0, sl));
             m->loss_pending = false;
+        }
+        if (c.kind == PS_MODEL_WIDEDEEP && !apply && m->sh.active && c.wide_grad_mode == PS_GRAD_INTENDED) {
+            // sharded worker, intended mode: the per-key sums into the flat buffer (this chain ends before the flat
+            // gradient's launch starts: that one waits for the embedding backward, which joins this chain first)
+            WideUpdArgs w;
+            memset(&w, 0, sizeof w);
+            w.skip = nullptr;
+            Prof pf(m, "wide_update");
+            PSCHK(enqueue_wide_intended(m, w, sl, true));
         }
         // wide part: LRLayer.backward (layer/LRLayer.java:100-120) + Ftrl
         if (c.kind == PS_MODEL_WIDEDEEP && apply) {
@@ -867,7 +884,8 @@ int enqueue_backward(ps_model *m, bool apply) {
     if (m->sh.active && c.kind == PS_MODEL_WIDEDEEP) {
         // sharded worker: the wide part of the flat buffer ([fc | wide G | wide C | bias]) is filled by the same launch
         WideUpdArgs &w = d.wide;
-        w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev; w.mode = 1;
+        w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev;
+        w.mode = c.wide_grad_mode == PS_GRAD_INTENDED ? 5 : 1;
         w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
         d.wide_blocks = wide_update_blocks(w);
     }

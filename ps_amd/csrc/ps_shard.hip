@@ -512,8 +512,6 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     if (!m || (!cache_dev && m->sh.U > 0)) return ps_set_err(PS_E_BAD_ARG, "bad argument");
     if (!m->sh.slot) return ps_set_err(PS_E_STATE, "ps_shard_plan first");
     ps_store *s = m->s;
-    if (m->cfg.kind == PS_MODEL_WIDEDEEP && m->cfg.wide_grad_mode != PS_GRAD_COMPAT)
-        return ps_set_err(PS_E_UNSUPPORTED, "wide_grad_mode=intended is single-GPU only (the sharded push carries the compat G/C pair)");
     PSCHK(store_enter(s));
     m->sh.active = true;
     m->sh.cache = cache_dev;

@@ -271,7 +271,7 @@ class CallbackComm:
         return self._guard(f, stream)
 
 
-def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
+def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False, wide_mode=None):
     try:
         import ps_amd
         from ps_amd.sharded import NativeWorker
@@ -280,7 +280,8 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False):
         kv.create_embedding([V] * F, D, shard=rank, nshards=world)
         # pipelined: True = two models, begin(t+1) on the prefetch stream before finish(t); "one" = ONE model, the next
         # step's begin slipped in before this step's push (ps_shard_step_finish_begin: what bench.py --gpus N runs)
-        gms = [ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"]) for _ in range(2 if pipelined is True else 1)]
+        kw = {} if wide_mode is None else {"wide_grad_mode": wide_mode}
+        gms = [ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"], **kw) for _ in range(2 if pipelined is True else 1)]
         gm = gms[0]
         comm = CallbackComm(rank, shared, kv)
         wk = NativeWorker(gms, world, rank, ops=comm.ops, is_async=is_async)
@@ -486,3 +487,23 @@ def test_multi_hot_ftrl_ranks(orc, world, is_async):
         for l in range(3):
             np.testing.assert_array_equal(gW[l], fcW[l]); np.testing.assert_array_equal(gb[l], fcb[l])
     assert moved > 10
+
+
+def test_intended_wide_mode_n_ranks():
+    """wide_grad_mode = intended at N = 3 ranks through ps_shard_step: every rank ends with the SAME wide table (the owner side
+    applies the mean over the workers that pushed a key, from the all-reduced G / C pair), it differs from the compat run's,
+    and the embedding / FC results are those of the compat run only up to the wide part's influence (not compared)."""
+    from ps_amd import native as N
+    world = 3
+    res = []
+    for mode in (N.PS_GRAD_INTENDED, None):
+        shared = Shared(world)
+        out, errs = [None] * world, []
+        run_ranks(native_rank_main, [(r, world, shared, False, out, errs, "one", mode) for r in range(world)])
+        assert not errs, "\n".join("rank %d:\n%s" % e for e in errs)
+        for r in range(1, world):
+            np.testing.assert_array_equal(out[r][3], out[0][3]); np.testing.assert_array_equal(out[r][4], out[0][4])
+            for l in range(3):
+                np.testing.assert_array_equal(out[r][1][l], out[0][1][l])
+        res.append(out[0])
+    assert np.abs(res[0][3]).max() > 0 and not np.array_equal(res[0][3], res[1][3])

@@ -715,3 +715,49 @@ def test_intended_wide_gradient_mode_on_device(orc):
             assert w1[key] == we[0] and z1[key] == ze[0] and n1[key] == ne[0], "wide.weights.%d" % key
     assert kv.get("wide.bias")[0] != 0          # "wide.bias" keeps its compat gradient rowMeans(delta) (Ftrl: w lags z by one step)
     gm.close(); kv.close()
+
+
+def test_intended_wide_gradient_mode_in_the_sharded_step():
+    """wide_grad_mode = intended through the key-sharded step (VERDICT r2 missing #5): the worker writes G[key] = its batch's
+    sum / B and C[key] = 1 for the keys of its batch into the flat buffer, the owner side takes G / C (the mean over the workers
+    that pushed the key) through Ftrl.  N = 1: equal to the fused intended step, bit for bit, for both drivers of the
+    exchange, device and host batches; keys outside the batch keep their state."""
+    import ps_amd
+    from ps_amd import native as N
+    from ps_amd.sharded import HipBackend, LocalComm, NativeWorker, ShardedWorker
+    F, D, X, fc, V, B, WS = 5, 8, 3, [16, 8, 1], 40, 96, 211
+    res = []
+    for mode in ("fused", "python", "native", "native-dev"):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B, wide_grad_mode=N.PS_GRAD_INTENDED)
+        rng = np.random.default_rng(4)
+        raw = []
+        for _ in range(5):
+            E, Xd, Y = data(rng, B, F, X, V, True)
+            Wd = (E * 7 + 3) % WS
+            Wd[:, 0] = 5
+            raw.append((E, Xd, Y, Wd))
+        bs = [ps_amd.DeviceBatch(kv, *r) if mode == "native-dev" else ps_amd.Batch(*r) for r in raw]
+        if mode == "fused":
+            losses = [gm.train(b) for b in bs]
+        elif mode == "python":
+            wk = ShardedWorker(HipBackend([gm]), LocalComm())
+            losses = [wk.step(b) for b in bs]
+        else:
+            wk = NativeWorker([gm], 1, 0)
+            losses = [wk.step(b) for b in bs[:2]] + [None, None] + [wk.run(bs[2:], 3, want_loss=True)]
+            wk.close()
+        res.append((losses, kv.get_wide(np.arange(WS)), kv.get_wide(np.arange(WS), 1), kv.get_wide(np.arange(WS), 2), kv.get("wide.bias"),
+                    [kv.get("fc%d.weights" % i) for i in range(3)], [kv.get_rows(f, np.arange(V)) for f in range(F)]))
+        gm.close(); kv.close()
+    a = res[0]
+    used = np.unique(np.concatenate([r[3].ravel() for r in raw]))
+    assert len(used) < WS and np.all(a[1][np.setdiff1d(np.arange(WS), used)] == 0)       # untouched keys: still zero
+    assert np.abs(a[1][used]).max() > 0
+    for b in res[1:]:
+        assert [x for x in b[0] if x is not None][-1] == a[0][-1] and b[0][0] == a[0][0]
+        for i in (1, 2, 3, 4):
+            np.testing.assert_array_equal(a[i], b[i])
+        for x, y in zip(a[5] + a[6], b[5] + b[6]):
+            np.testing.assert_array_equal(x, y)
