@@ -828,51 +828,9 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
     }
 }
 
-// SEQ: the reference's summation order for every key.  Blocks [0, a.long_blocks) are the long-key waves above,
-// the rest handle one key per lane group as before and leave keys above PS_EMB_CHUNK to them.
+// the short-key role of k_emb_reduce_update for ONE key (run u of the sorted entries), by the LPR lanes of a lane group
 template <int VEC, bool BAG, bool SEQ>
-__global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
-    EndWait end_wait(a.end_wait, a.end_val, a.bound);       // (declared first: runs after the stamp's end; every return path)
-    // (no raised wave priority here: the dW GEMM and the dense update that run beside this kernel END the step's side
-    //  chain -- with this kernel ahead of them the step got longer, 0.1530 against 0.1493 ms)
-    StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);
-    if (SEQ && a.flag && blockIdx.x == 0 && threadIdx.x == 0)         // (chunked order: k_emb_partials is the first launch)
-        __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.skip && *a.skip) return;
-    if (SEQ && (int)blockIdx.x < a.long_blocks) {
-        if (a.ablate & 2) return;                               // measurement: the kernel without its long-key role
-        // (raised wave priority for these workgroups only: measured worse, 0.1515 against 0.1493 ms/step)
-        if (a.long_list) {
-            // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
-            const uint32_t nl = *a.nlong;
-            for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.long_blocks) {
-                const uint32_t *ll = a.long_list + 3 * (size_t)i;        // (run id, first entry, end): one load level
-                long_key_run<VEC, BAG>(a, seq_lds, ll[0], ll[1], ll[2]);
-                __syncthreads();                               // the next run reuses the LDS buffers
-            }
-            return;
-        }
-        // no list: the workgroup of the SEQ_TILE-entry tile in which a long run starts owns it
-        const uint32_t CH = SEQ_TILE;
-        const int64_t c = blockIdx.x;
-        if (c * CH >= a.nnz) return;
-        const uint32_t t0 = (uint32_t)(c * CH);
-        const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
-        const uint32_t u = a.seg_id[t1];
-        const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
-        if (s0 < t0 || e0 - s0 <= CH) return;                  // the run starts in an earlier tile, or is a short key (block-uniform)
-        long_key_run<VEC, BAG>(a, seq_lds, u, s0, e0);
-        return;
-    }
-    if (SEQ && (a.ablate & 4)) return;                          // measurement: the kernel without its short-key role
-    const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
-    const int lane64 = (int)(gt & 63);
-    const int gpw = 64 / a.LPR;
-    if (lane64 / a.LPR >= gpw) return;
-    const int64_t u = (gt >> 6) * gpw + lane64 / a.LPR;
-    const int part = lane64 % a.LPR;
-    if (u >= (int64_t)*a.nseg) return;
+__device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_t u, const int part) {
     const uint32_t CH = PS_EMB_CHUNK;
     const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
     const uint32_t n = e0 - s0;
@@ -936,6 +894,58 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     const uint32_t uo = a.out_slot ? a.out_slot[a.sorted_ent[s0]] : (uint32_t)u;
     finish_key<VEC>(a, uo, row, n, S, part);
 }
+
+// SEQ: the reference's summation order for every key.  Blocks [0, a.long_blocks) are the long-key waves above,
+// the rest handle one key per lane group as before and leave keys above PS_EMB_CHUNK to them.
+template <int VEC, bool BAG, bool SEQ>
+__global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
+    EndWait end_wait(a.end_wait, a.end_val, a.bound);       // (declared first: runs after the stamp's end; every return path)
+    // (no raised wave priority here: the dW GEMM and the dense update that run beside this kernel END the step's side
+    //  chain -- with this kernel ahead of them the step got longer, 0.1530 against 0.1493 ms)
+    StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);
+    if (SEQ && a.flag && blockIdx.x == 0 && threadIdx.x == 0)         // (chunked order: k_emb_partials is the first launch)
+        __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.skip && *a.skip) return;
+    if (SEQ && (int)blockIdx.x < a.long_blocks) {
+        if (a.ablate & 2) return;                               // measurement: the kernel without its long-key role
+        // (raised wave priority for these workgroups only: measured worse, 0.1515 against 0.1493 ms/step)
+        if (a.long_list) {
+            // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
+            const uint32_t nl = *a.nlong;
+            for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.long_blocks) {
+                const uint32_t *ll = a.long_list + 3 * (size_t)i;        // (run id, first entry, end): one load level
+                long_key_run<VEC, BAG>(a, seq_lds, ll[0], ll[1], ll[2]);
+                __syncthreads();                               // the next run reuses the LDS buffers
+            }
+            return;
+        }
+        // no list: the workgroup of the SEQ_TILE-entry tile in which a long run starts owns it
+        const uint32_t CH = SEQ_TILE;
+        const int64_t c = blockIdx.x;
+        if (c * CH >= a.nnz) return;
+        const uint32_t t0 = (uint32_t)(c * CH);
+        const uint32_t t1 = (uint32_t)((int64_t)t0 + CH < a.nnz ? t0 + CH : a.nnz) - 1;
+        const uint32_t u = a.seg_id[t1];
+        const uint32_t s0 = a.seg_start[u], e0 = a.seg_start[u + 1];
+        if (s0 < t0 || e0 - s0 <= CH) return;                  // the run starts in an earlier tile, or is a short key (block-uniform)
+        long_key_run<VEC, BAG>(a, seq_lds, u, s0, e0);
+        return;
+    }
+    if (SEQ && (a.ablate & 4)) return;                          // measurement: the kernel without its short-key role
+    // One lane group per key, GRID-STRIDE: the launcher cannot know the number of unique keys (it lives on the device) and
+    // used to size the grid for the worst case, one key per entry -- at a multi-hot batch 50 k workgroups of which 40 k
+    // found nothing to do; dispatching them was a sixth of the kernel.  Now a bounded grid walks the keys.
+    const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
+    const int lane64 = (int)(gt & 63);
+    const int gpw = 64 / a.LPR;
+    if (lane64 / a.LPR >= gpw) return;
+    const int part = lane64 % a.LPR;
+    const int64_t nseg = (int64_t)*a.nseg;
+    const int64_t stride = (int64_t)a.short_blocks * 4 * gpw;      // lane groups in the short-key role's grid
+    for (int64_t u = (gt >> 6) * gpw + lane64 / a.LPR; u < nseg; u += stride) reduce_one_key<VEC, BAG, SEQ>(a, u, part);
+}
+
 
 // ---------------------------------------------------------------------------
 // PS owner side: apply a list of pushed (row, gradient) pairs
@@ -1238,6 +1248,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_emb_short_grid = 4096;    // ps_tune_set("emb_short_grid", workgroups): grid of the embedding update's one-key-per-lane-group role
 int g_seq_ablate = 0;    // measurement only (results wrong): 1 = the fold wave skips its LDS reads + adds, 2 = the loaders skip their global loads
 
 // The LDS-staged form of the single-hot gather that BASELINE.json's north_star names ("coalesced CSR gather with
@@ -1395,15 +1406,17 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
     // long runs, a fixed grid walks that list
     a.long_blocks = !a.seq_order ? 0 : a.long_list ? SEQ_LONG_GRID : cdiv(a.nnz, SEQ_TILE);
+    // the short-key role: enough workgroups to fill the chip a few times over, never more than one lane group per entry
+    a.short_blocks = gr < g_emb_short_grid ? gr : g_emb_short_grid;
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
         if (a.seq_order) {                                                                     \
-            hipLaunchKernelGGL((k_emb_reduce_update<V, BG, true>), dim3(a.long_blocks + gr), dim3(256), 0, st, a); \
+            hipLaunchKernelGGL((k_emb_reduce_update<V, BG, true>), dim3(a.long_blocks + a.short_blocks), dim3(256), 0, st, a); \
             break;                                                                             \
         }                                                                                      \
         hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gp), dim3(256), 0, st, a);            \
         if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gp), dim3(256), 0, st, a);  \
-        hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(gr), dim3(256), 0, st, a); \
+        hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(a.short_blocks), dim3(256), 0, st, a); \
     } while (0)
     if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }
     else { if (bag) EMB_BWD_LAUNCH(1, true); else EMB_BWD_LAUNCH(1, false); }

@@ -361,7 +361,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(NtArgs a) {
     const int tn = (a.N + BN - 1) / BN;
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;
-    const int nk = (a.K + BKT - 1) / BKT;
     // this thread's two chunk slots per operand: slot = (i * 4 + w) * 64 + lane -> (row, k-chunk)
     const float *pa[2], *pb[2];
     int kc[2];

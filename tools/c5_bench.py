@@ -6,6 +6,9 @@ import numpy as np
 import ps_amd
 from bench import C2
 
+from ps_amd import native as N_
+for kv_ in os.environ.get("PS_TUNE", "").split(","):
+    if "=" in kv_: N_.lib().ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
 cfg = dict(C2); B, F, V = cfg["B"], cfg["F"], cfg["V"]
 rng = np.random.default_rng(5)
 kv = ps_amd.KVStore(0, cfg["seed"]); kv.create_embedding([V] * F, cfg["D"])
