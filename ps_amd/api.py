@@ -112,6 +112,10 @@ class KVStore:
     def _adopt(self, obj):
         import weakref
         self._dependents.append(weakref.ref(obj))
+        # a model's native handle, shared with the model: when both are collected together (a reference cycle, interpreter
+        # exit) the weak reference above is already dead, and the model must still be destroyed BEFORE its store
+        if hasattr(obj, "_hcell"):
+            self._model_cells = getattr(self, "_model_cells", []) + [obj._hcell]
 
     @classmethod
     def ins(cls, device=0, seed=0):
@@ -126,6 +130,11 @@ class KVStore:
                 if obj is not None:
                     obj.close()
             self._dependents = []
+            for cell in getattr(self, "_model_cells", []):
+                if cell[0]:
+                    N.lib().ps_model_destroy(cell[0])
+                    cell[0] = None
+            self._model_cells = []
             N.lib().ps_store_destroy(self.h)
             self.h = None
 
@@ -312,14 +321,20 @@ class _Model:
         self.F, self.D, self.X, self.fc_dims = F, D, X, list(fc_dims)
         h = C.c_void_p()
         N.check(N.lib().ps_model_create(store.h, C.byref(cfg), C.byref(h)))
-        self.h = h
+        self._hcell = [h]               # (self.h reads it: the store destroys its models' handles through this cell too)
         store._adopt(self)
         self._updater = {"default": AdamUpdater()}
 
     def close(self):
-        if getattr(self, "h", None):
-            N.lib().ps_model_destroy(self.h)
-            self.h = None
+        cell = getattr(self, "_hcell", None)
+        if cell and cell[0]:
+            N.lib().ps_model_destroy(cell[0])
+            cell[0] = None
+
+    @property
+    def h(self):
+        cell = self.__dict__.get("_hcell")
+        return cell[0] if cell else None
 
     def __del__(self):
         try:

@@ -64,6 +64,18 @@ int launch_loss_reduce(const HeadArgs &a, float *loss_out, float *gbar_out, int 
 int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st, LaunchOpts *lo = nullptr);   // lo: stop_event
 int head_last_bwd_fusable(int rows_per_wg);
 
+// The updater of an embedding row.  KVStore.update(Map) resolves an updater per KEY (exact key, then any map key that is
+// a prefix, then "default": store/KVStore.java:240-252), so "emF3." may name another updater than "emF" does.  The store
+// resolves one updater per FIELD (store_fill_field_upd); when they are all the same -- the common case -- ngroups is 1 and
+// a kernel uses its `upd` argument with no lookup at all.  Otherwise a row's field (from row_base) picks `upd` (group 0)
+// or alt[group - 1].
+#define PS_EMB_UPD_GROUPS 4
+struct FieldUpd {
+    const int64_t *row_base;           // [F + 1] first local row of every field (device)
+    int F, ngroups;
+    unsigned char grp[64];             // field -> group
+    UpdParams alt[PS_EMB_UPD_GROUPS - 1];
+};
 #define PS_EMB_SEQ_TILE 16             // sequential order: runs above this many entries are "long" (own workgroup)
 struct EmbBwdArgs {
     int64_t nnz;
@@ -83,6 +95,7 @@ struct EmbBwdArgs {
     int ablate;                        // measurement only (g_seq_ablate)
     float *W, *state;                  // [rows][D], [rows][2][D]
     UpdParams upd;
+    FieldUpd fu;
     float *grads_out; uint32_t *uniq_row; uint32_t *uniq_cnt;   // [nseg][D], [nseg], [nseg]
     const int *skip;
     int LPR;
@@ -179,6 +192,7 @@ struct RowsApplyArgs {
     const float *grads;                // [n][D], indexed by sorted_ent
     float *W, *state;
     UpdParams upd;
+    FieldUpd fu;
     const int *skip;
     int LPR;
 };
@@ -199,7 +213,9 @@ struct PushApplyArgs {
     uint32_t *pos;                     // [npeers][R] entry of worker w's push for the row
     float *W, *state;
     UpdParams upd;
+    FieldUpd fu;
     int *err;
     unsigned long long *ts_mark, *ts_apply;   // stamp slots, set by the launcher
+                     // set by the launcher: the mark pass ran in an earlier launch of this push (another updater's)
 };
 int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo = nullptr);      // lo: flag (the first launch announces its start)

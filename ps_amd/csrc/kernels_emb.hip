@@ -537,6 +537,14 @@ __device__ __forceinline__ Vec<VEC> small_key(const EmbBwdArgs &a, uint32_t s0, 
     return S;
 }
 
+// the updater of `row` when the fields' updaters differ (FieldUpd, kernels_emb.h); callers test fu.ngroups > 1 first
+template <class ARGS>
+__device__ __forceinline__ UpdParams row_upd(const ARGS &a, uint32_t row) {
+    int f = 0;
+    while (f + 1 < a.fu.F && (int64_t)row >= a.fu.row_base[f + 1]) ++f;
+    const int g = a.fu.grp[f];
+    return g ? a.fu.alt[g - 1] : a.upd;
+}
 template <int VEC, bool BAG>
 __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
     StampScope stamp(a.ts_partials);
@@ -627,31 +635,36 @@ __global__ __launch_bounds__(256) void k_emb_super(EmbBwdArgs a) {
 // hand it out (split form / sharded push) and/or run the updater on the row in place.  Called by the LPR lanes
 // of the key's lane group (all of them: the Ftrl skip test shuffles element 0 from part 0).
 template <int VEC>
+__device__ __forceinline__ void update_key(const EmbBwdArgs &a, const UpdParams &upd, uint32_t row, Vec<VEC> &S, int part) {
+    float *wp = a.W + (size_t)row * a.D + part * VEC;
+    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
+    Vec<VEC> w = Vec<VEC>::load(wp);
+    if (upd.kind == PS_UPD_SIMPLE) {
+        VFOR(i) w.at(i) = (S.get(i) * -upd.eta) + w.get(i);      // update/SimpleUpdater.java:20-22
+        w.store(wp);
+        return;
+    }
+    Vec<VEC> s1 = Vec<VEC>::load(sp), s2 = Vec<VEC>::load(sp + a.D);
+    if (upd.kind == PS_UPD_ADAM) {
+        VFOR(i) adam_elem(upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+    } else {
+        // FtrlUpdater.java:52: skip the whole key when dw[0] == 0; element 0 lives in part 0
+        const int lane = threadIdx.x & 63;
+        const float g0 = __shfl(S.get(0), lane - part);
+        if (g0 == 0.f) return;
+        VFOR(i) ftrl_elem(upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+    }
+    w.store(wp); s1.store(sp); s2.store(sp + a.D);
+}
+template <int VEC>
 __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint32_t row, uint32_t n, Vec<VEC> &S, int part) {
     if (a.grads_out) {
         S.store(a.grads_out + (size_t)u * a.D + part * VEC);
         if (part == 0) { a.uniq_row[u] = row; if (a.uniq_cnt) a.uniq_cnt[u] = n; }
     }
     if (!a.apply) return;
-    float *wp = a.W + (size_t)row * a.D + part * VEC;
-    float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
-    Vec<VEC> w = Vec<VEC>::load(wp);
-    if (a.upd.kind == PS_UPD_SIMPLE) {
-        VFOR(i) w.at(i) = (S.get(i) * -a.upd.eta) + w.get(i);      // update/SimpleUpdater.java:20-22
-        w.store(wp);
-        return;
-    }
-    Vec<VEC> s1 = Vec<VEC>::load(sp), s2 = Vec<VEC>::load(sp + a.D);
-    if (a.upd.kind == PS_UPD_ADAM) {
-        VFOR(i) adam_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
-    } else {
-        // FtrlUpdater.java:52: skip the whole key when dw[0] == 0; element 0 lives in part 0
-        const int lane = threadIdx.x & 63;
-        const float g0 = __shfl(S.get(0), lane - part);
-        if (g0 == 0.f) return;
-        VFOR(i) ftrl_elem(a.upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
-    }
-    w.store(wp); s1.store(sp); s2.store(sp + a.D);
+    if (a.fu.ngroups > 1) update_key<VEC>(a, row_upd(a, row), row, S, part);      // (a lane group's lanes share the row)
+    else update_key<VEC>(a, a.upd, row, S, part);
 }
 
 // The REFERENCE order for a key seen n > PS_EMB_CHUNK times (layer/EmbeddingField.java:86-104: one addi per sample,
@@ -764,8 +777,10 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
     // were two dependent round trips (row id -> values) on the only serial path of the kernel
     const uint32_t row = a.sorted_key[s0];
     float wv0[CPL], s10[CPL], s20[CPL];
+    UpdParams U = a.upd;
+    if (a.fu.ngroups > 1) U = row_upd(a, row);
     {
-        const bool upd = a.apply != 0, st = upd && a.upd.kind != PS_UPD_SIMPLE;
+        const bool upd = a.apply != 0, st = upd && U.kind != PS_UPD_SIMPLE;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int d = lane + 64 * q, dc = d < D ? d : 0;
@@ -819,11 +834,11 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
         if (!a.apply) continue;
         float *wp = a.W + (size_t)row * D + d;
         float wv = wv0[q];
-        if (a.upd.kind == PS_UPD_SIMPLE) { *wp = (g * -a.upd.eta) + wv; continue; }
+        if (U.kind == PS_UPD_SIMPLE) { *wp = (g * -U.eta) + wv; continue; }
         float *sp = a.state + (size_t)row * 2 * D + d;
         float s1 = s10[q], s2 = s20[q];
-        if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, wv, s1, s2);
-        else { if (g0 == 0.f) continue; ftrl_elem(a.upd, g, wv, s1, s2); }
+        if (U.kind == PS_UPD_ADAM) adam_elem(U, g, wv, s1, s2);
+        else { if (g0 == 0.f) continue; ftrl_elem(U, g, wv, s1, s2); }
         *wp = wv; sp[0] = s1; sp[D] = s2;
     }
 }
@@ -967,18 +982,20 @@ __global__ __launch_bounds__(256) void k_rows_apply(RowsApplyArgs a) {
     uint32_t s0 = (uint32_t)u, e0 = (uint32_t)u + 1;
     if (!IDENT) { s0 = a.seg_start[u]; e0 = a.seg_start[u + 1]; }
     const uint32_t row = a.sorted_key[s0];
+    UpdParams U = a.upd;
+    if (a.fu.ngroups > 1) U = row_upd(a, row);
     auto ent = [&](uint32_t k) -> size_t { return IDENT ? (size_t)k : (size_t)a.sorted_ent[k]; };
     float *wp = a.W + (size_t)row * a.D + part * VEC;
     float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
     Vec<VEC> w = Vec<VEC>::load(wp), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
-    if (a.upd.kind != PS_UPD_SIMPLE) { s1 = Vec<VEC>::load(sp); s2 = Vec<VEC>::load(sp + a.D); }
+    if (U.kind != PS_UPD_SIMPLE) { s1 = Vec<VEC>::load(sp); s2 = Vec<VEC>::load(sp + a.D); }
     const int lane = threadIdx.x & 63;
     auto apply = [&](const Vec<VEC> &g) {
-        if (a.upd.kind == PS_UPD_ADAM) { VFOR(i) adam_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
-        else if (a.upd.kind == PS_UPD_SIMPLE) { VFOR(i) w.at(i) = (g.get(i) * -a.upd.eta) + w.get(i); }
+        if (U.kind == PS_UPD_ADAM) { VFOR(i) adam_elem(U, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+        else if (U.kind == PS_UPD_SIMPLE) { VFOR(i) w.at(i) = (g.get(i) * -U.eta) + w.get(i); }
         else {
             const float g0 = __shfl(g.get(0), lane - part);
-            if (g0 != 0.f) { VFOR(i) ftrl_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+            if (g0 != 0.f) { VFOR(i) ftrl_elem(U, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
         }
     };
     if (a.is_async) {
@@ -994,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_rows_apply(RowsApplyArgs a) {
         apply(S);
     }
     w.store(wp);
-    if (a.upd.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
+    if (U.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
 }
 
 // ---------------------------------------------------------------------------
@@ -1037,6 +1054,8 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
     if (e >= a.n) return;
     const int pe = ONE ? 0 : push_peer_of(a, (uint32_t)e);
     const uint32_t row = a.rows_p[pe][e - a.peer_start[pe]];
+    UpdParams U = a.upd;
+    if (a.fu.ngroups > 1) U = row_upd(a, row);
     if ((int64_t)row >= a.R) { if (ONE && part == 0) atomicAdd(a.err, 1); return; }
     uint32_t m = ONE ? 1u : a.mask[row];
     if (m == 0u || pe != __ffs((int)m) - 1) return;     // another worker's entry leads this row
@@ -1044,14 +1063,14 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
     float *wp = a.W + (size_t)row * a.D + part * VEC;
     float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
     Vec<VEC> w = Vec<VEC>::load(wp), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
-    if (a.upd.kind != PS_UPD_SIMPLE) { s1 = Vec<VEC>::load(sp); s2 = Vec<VEC>::load(sp + a.D); }
+    if (U.kind != PS_UPD_SIMPLE) { s1 = Vec<VEC>::load(sp); s2 = Vec<VEC>::load(sp + a.D); }
     const int lane = threadIdx.x & 63;
     auto apply = [&](const Vec<VEC> &g) {
-        if (a.upd.kind == PS_UPD_ADAM) { VFOR(i) adam_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
-        else if (a.upd.kind == PS_UPD_SIMPLE) { VFOR(i) w.at(i) = (g.get(i) * -a.upd.eta) + w.get(i); }
+        if (U.kind == PS_UPD_ADAM) { VFOR(i) adam_elem(U, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+        else if (U.kind == PS_UPD_SIMPLE) { VFOR(i) w.at(i) = (g.get(i) * -U.eta) + w.get(i); }
         else {
             const float g0 = __shfl(g.get(0), lane - part);
-            if (g0 != 0.f) { VFOR(i) ftrl_elem(a.upd, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
+            if (g0 != 0.f) { VFOR(i) ftrl_elem(U, g.get(i), w.at(i), s1.at(i), s2.at(i)); }
         }
     };
     Vec<VEC> S = Vec<VEC>::load(a.grads_p[pe] + (size_t)(e - a.peer_start[pe]) * a.D + part * VEC);     // the leader's own push comes first
@@ -1070,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
         apply(S);
     }
     w.store(wp);
-    if (a.upd.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
+    if (U.kind != PS_UPD_SIMPLE) { s1.store(sp); s2.store(sp + a.D); }
     if (!ONE && part == 0) a.mask[row] = 0u;
 }
 
@@ -1248,6 +1267,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_seq_long_grid = 0;        // ps_tune_set("seq_long_grid", workgroups): long-key workgroups of the sequential order (0: SEQ_LONG_GRID)
 int g_emb_short_grid = 4096;    // ps_tune_set("emb_short_grid", workgroups): grid of the embedding update's one-key-per-lane-group role
 int g_seq_ablate = 0;    // measurement only (results wrong): 1 = the fold wave skips its LDS reads + adds, 2 = the loaders skip their global loads
 
@@ -1405,7 +1425,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     a.flag = lo ? lo->flag : nullptr; a.flag_val = lo ? lo->flag_val : 0;      // "this launch has started" (LaunchOpts, ps_common.h)
     // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
     // long runs, a fixed grid walks that list
-    a.long_blocks = !a.seq_order ? 0 : a.long_list ? SEQ_LONG_GRID : cdiv(a.nnz, SEQ_TILE);
+    a.long_blocks = !a.seq_order ? 0 : a.long_list ? (g_seq_long_grid > 0 ? g_seq_long_grid : SEQ_LONG_GRID) : cdiv(a.nnz, SEQ_TILE);
     // the short-key role: enough workgroups to fill the chip a few times over, never more than one lane group per entry
     a.short_blocks = gr < g_emb_short_grid ? gr : g_emb_short_grid;
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \

@@ -248,6 +248,6 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
 extern int g_fwd_pair;
 extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
-extern int g_seq_ablate, g_emb_short_grid;
+extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

@@ -89,8 +89,11 @@ extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *key
     }
     {   // (updaters too: PServer.push answers 500 for an unknown updater before anything is summed)
         ps_updater_t u;
-        if (!rows.empty()) PSCHK(store_resolve_updater(s, "emF", &u));
-        if (!rows.empty() && !s->emb.state && u.kind != PS_UPD_SIMPLE) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
+        UpdParams eu;
+        FieldUpd efu;
+        bool stateful = false;
+        if (!rows.empty()) PSCHK(store_fill_field_upd(s, &eu, &efu, &stateful));
+        if (!rows.empty() && !s->emb.state && stateful) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
         if (!wide.empty()) PSCHK(store_resolve_updater(s, "wide.weights", &u));
         for (auto &kv : dense) {
             char name[64];

@@ -173,9 +173,11 @@ extern "C" int ps_emb_backward_update(ps_store_t *s, const int64_t *ids_dev, con
     if (grad_mode != PS_GRAD_COMPAT && grad_mode != PS_GRAD_INTENDED) return ps_set_err(PS_E_BAD_ARG, "bad grad_mode");
     if (sum_order < PS_SUM_AUTO || sum_order > PS_SUM_CHUNKED) return ps_set_err(PS_E_BAD_ARG, "bad sum_order");
     if (e.nshards > 1) return ps_set_err(PS_E_UNSUPPORTED, "a sharded store takes its gradients through ps_shard_apply_push");
-    ps_updater_t u;
-    PSCHK(store_resolve_updater(s, "emF", &u));
-    if (apply && !e.state && u.kind != PS_UPD_SIMPLE)
+    UpdParams emb_upd;
+    FieldUpd emb_fu;
+    bool stateful = false;
+    PSCHK(store_fill_field_upd(s, &emb_upd, &emb_fu, &stateful));
+    if (apply && !e.state && stateful)
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
     if (nnz == 0) return PS_OK;
     PSCHK(store_enter(s));
@@ -220,7 +222,7 @@ extern "C" int ps_emb_backward_update(ps_store_t *s, const int64_t *ids_dev, con
     g.delta = o.masked; g.ldd = ldm; g.partials = o.partials; g.partials2 = o.partials2; g.W = e.W; g.state = e.state;
     g.long_runs = 1;
     g.seq_order = (sum_order == PS_SUM_SEQUENTIAL || (sum_order == PS_SUM_AUTO && !offsets_dev)) ? 1 : 0;
-    g.upd = make_upd_params(u);
+    g.upd = emb_upd; g.fu = emb_fu;
     g.grads_out = o.grads; g.uniq_row = o.uniq_row; g.uniq_cnt = nullptr; g.skip = nullptr;
     PSCHK(launch_emb_bwd(g, st));
     o.last_nnz = nnz;

@@ -624,8 +624,11 @@ int enqueue_backward(ps_model *m, bool apply) {
     const int B = m->cur_B, nfc = c.nfc;
     const int *skip = m->skip_dev;
     ps_updater_t u;
-    PSCHK(store_resolve_updater(s, "emF", &u));
-    if (apply && !s->emb.state && u.kind != PS_UPD_SIMPLE)       // before anything is enqueued
+    UpdParams emb_upd;
+    FieldUpd emb_fu;
+    bool emb_stateful = false;
+    PSCHK(store_fill_field_upd(s, &emb_upd, &emb_fu, &emb_stateful));
+    if (apply && !s->emb.state && emb_stateful)                  // before anything is enqueued
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
     // Main chain: delta GEMMs, embedding update, dense update (last: nothing crosses a stream at the step boundary).
     // Side chain 1: every dW GEMM as soon as its delta exists.  Side chain 0 (the sort ran there during the forward):
@@ -851,8 +854,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.long_runs = (m->cur_offsets != nullptr || (int64_t)B > (int64_t)PS_EMB_CHUNK * PS_EMB_SUPER_MIN) ? 1 : 0;
     // the reference's own summation order wherever the reference's input domain reaches (single-hot: n <= B)
     g.seq_order = (c.emb_sum_order == PS_SUM_SEQUENTIAL || (c.emb_sum_order == PS_SUM_AUTO && m->cur_offsets == nullptr)) ? 1 : 0;
-    PSCHK(store_resolve_updater(s, "emF", &u));
-    g.upd = make_upd_params(u);
+    g.upd = emb_upd; g.fu = emb_fu;
     g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
     // tail_dev: the dense update, on side chain 1, starts when the embedding update has STARTED (its first workgroup
     // raises start_flag[2]; the update's workgroups check that flag themselves, no spinner launch in front of it), a
@@ -921,8 +923,11 @@ static int enqueue_update(ps_model *m) {
     hipStream_t st = s->stream;
     const int nfc = c.nfc;
     ps_updater_t u;
-    PSCHK(store_resolve_updater(s, "emF", &u));
-    if (!s->emb.state && u.kind != PS_UPD_SIMPLE)                 // before anything is enqueued
+    UpdParams emb_upd;
+    FieldUpd emb_fu;
+    bool emb_stateful = false;
+    PSCHK(store_fill_field_upd(s, &emb_upd, &emb_fu, &emb_stateful));
+    if (!s->emb.state && emb_stateful)                            // before anything is enqueued
         return ps_set_err(PS_E_STATE, "the embedding table was created weights-only (state_slots = 0): Adam / Ftrl cannot train it");
     DenseUpdArgs d;
     memset(&d, 0, sizeof d);
@@ -955,8 +960,7 @@ static int enqueue_update(ps_model *m) {
         r.D = c.D; r.is_async = 0; r.identity = 1;
         r.sorted_key = m->uniq_row; r.nseg = m->nseg_dev; r.grads = m->grads_out;
         r.W = s->emb.W; r.state = s->emb.state; r.skip = m->skip_dev;
-        PSCHK(store_resolve_updater(s, "emF", &u));
-        r.upd = make_upd_params(u);
+        r.upd = emb_upd; r.fu = emb_fu;
         PSCHK(launch_rows_apply(r, m->cur_nnz, st));
     }
     return PS_OK;

@@ -280,6 +280,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "gemm_ablate") == 0) { g_gemm_ablate = value; return PS_OK; }
     if (strcmp(knob, "mh_ilp16") == 0) { g_mh_ilp16 = value; return PS_OK; }
     if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }
+    if (strcmp(knob, "seq_long_grid") == 0) { g_seq_long_grid = value; return PS_OK; }
     if (strcmp(knob, "emb_short_grid") == 0) { g_emb_short_grid = value > 0 ? value : 4096; return PS_OK; }
     if (strcmp(knob, "gather_nt") == 0) { g_gather_nt = value; return PS_OK; }
     if (strcmp(knob, "gather_lds") == 0) { g_gather_lds = value; return PS_OK; }

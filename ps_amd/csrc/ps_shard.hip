@@ -569,10 +569,9 @@ int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const flo
     if (lo) lo->launched = false;
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
     if (!shard_push_grouped_ok(s, npeers)) return ps_set_err(PS_E_UNSUPPORTED, "the sort-free push needs 1..%d workers and a position table under 4 GB", PS_PUSH_MAX_PEERS);
-    ps_updater_t u;
-    PSCHK(store_resolve_updater(s, "emF", &u));
     PushApplyArgs a;
     memset(&a, 0, sizeof a);
+    PSCHK(store_fill_field_upd(s, &a.upd, &a.fu));
     int64_t n = 0;
     for (int p = 0; p < npeers; ++p) {
         if (counts[p] < 0) return ps_set_err(PS_E_BAD_ARG, "negative peer count");
@@ -584,7 +583,7 @@ int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const flo
         if (npeers > 1) PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
         a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = s->emb.total_rows;
         a.mask = s->push_mask; a.pos = s->push_pos;
-        a.W = s->emb.W; a.state = s->emb.state; a.upd = make_upd_params(u); a.err = s->err_dev;
+        a.W = s->emb.W; a.state = s->emb.state; a.err = s->err_dev;
         PSCHK(launch_push_apply(a, s->stream, lo));
     }
     if (bump_step) s->global_step++;     // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)
@@ -598,8 +597,6 @@ int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_d
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
     PSCHK(store_enter(s));
     hipStream_t st = s->stream;
-    ps_updater_t u;
-    PSCHK(store_resolve_updater(s, "emF", &u));
     const int64_t R = s->emb.total_rows;
     // worker-grouped lists (what ps_shard_plan + all-to-all-v deliver): no sort, two kernels
     const bool grouped = peer_counts && shard_push_grouped_ok(s, npeers);
@@ -626,7 +623,7 @@ int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_d
         r.D = s->emb.D; r.is_async = is_async ? 1 : 0; r.identity = 0;
         r.sorted_key = sk; r.sorted_ent = se; r.seg_start = s->push_seg_start; r.nseg = s->push_nseg;
         r.grads = grads_dev; r.W = s->emb.W; r.state = s->emb.state;
-        r.upd = make_upd_params(u);
+        PSCHK(store_fill_field_upd(s, &r.upd, &r.fu));
         PSCHK(launch_rows_apply(r, n, st));
     }
     if (bump_step) s->global_step++;     // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)

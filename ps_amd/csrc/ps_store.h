@@ -95,6 +95,12 @@ int shard_apply_push(ps_store *s, const uint32_t *rows_dev, const float *grads_d
                      int npeers, int is_async, bool bump_step);
 // updater resolution as KVStore.update(Map): exact key, then prefix, then "default"
 int store_resolve_updater(const ps_store *s, const char *key, ps_updater_t *out);
+// The embedding rows' updaters, resolved per FIELD (probe "emF<f>." through store_resolve_updater, i.e. exact key, prefix,
+// default like KVStore.update(Map), store/KVStore.java:240-252): group 0 -> *upd, the others -> fu->alt; fu->ngroups == 1
+// (and no lookup in the kernels) when every field resolves to the same updater.  *stateful: any group other than Simple.
+// An updater key naming single rows ("emF3.17") cannot be honoured per field, more than PS_EMB_UPD_GROUPS distinct
+// updaters neither: PS_E_UNSUPPORTED.
+int store_fill_field_upd(const ps_store *s, UpdParams *upd, FieldUpd *fu, bool *stateful = nullptr);
 // local global row of (field, id) on this shard, or -1 when not held here
 int64_t store_local_row(const ps_store *s, int field, int64_t id);
 int store_ensure_scratch(ps_store *s, int64_t rows, int D);

@@ -365,6 +365,51 @@ int store_resolve_updater(const ps_store *s, const char *key, ps_updater_t *out)
     return PS_OK;
 }
 
+int store_fill_field_upd(const ps_store *s, UpdParams *upd, FieldUpd *fu, bool *stateful) {
+    memset(fu, 0, sizeof *fu);
+    fu->row_base = s->emb.row_base_dev; fu->F = s->emb.F; fu->ngroups = 1;
+    const int F = s->emb.F;
+    bool field_level = false;
+    for (auto &kv : s->updaters) {
+        const std::string &k = kv.first;
+        if (k.compare(0, 3, "emF") != 0 || k.size() == 3) continue;
+        const size_t dot = k.find('.');
+        if (dot != std::string::npos && dot + 1 < k.size())
+            return ps_set_err(PS_E_UNSUPPORTED, "updater key %s names single embedding rows: updaters are resolved per field (\"emF<f>.\")", k.c_str());
+        field_level = true;
+    }
+    ps_updater_t u0;
+    if (!field_level || F <= 0) {          // one updater for every row: the "emF" prefix (or "default")
+        PSCHK(store_resolve_updater(s, "emF", &u0));
+        *upd = make_upd_params(u0);
+        if (stateful) *stateful = u0.kind != PS_UPD_SIMPLE;
+        return PS_OK;
+    }
+    if (F > 64) return ps_set_err(PS_E_UNSUPPORTED, "per-field updaters need F <= 64 (F = %d)", F);
+    ps_updater_t groups[PS_EMB_UPD_GROUPS];
+    int ng = 0;
+    bool st = false;
+    for (int f = 0; f < F; ++f) {
+        char probe[32];
+        snprintf(probe, sizeof probe, "emF%d.", f);
+        ps_updater_t u;
+        PSCHK(store_resolve_updater(s, probe, &u));
+        st = st || u.kind != PS_UPD_SIMPLE;
+        int g = 0;
+        while (g < ng && memcmp(&groups[g], &u, sizeof u) != 0) ++g;
+        if (g == ng) {
+            if (ng == PS_EMB_UPD_GROUPS) return ps_set_err(PS_E_UNSUPPORTED, "more than %d distinct embedding updaters", PS_EMB_UPD_GROUPS);
+            groups[ng++] = u;
+        }
+        fu->grp[f] = (unsigned char)g;
+    }
+    *upd = make_upd_params(groups[0]);
+    for (int g = 1; g < ng; ++g) fu->alt[g - 1] = make_upd_params(groups[g]);
+    fu->ngroups = ng;
+    if (stateful) *stateful = st;
+    return PS_OK;
+}
+
 static int64_t local_count(int64_t rows, int shard, int nshards) {
     return rows > shard ? (rows - shard + nshards - 1) / nshards : 0;
 }

@@ -283,6 +283,70 @@ def test_ftrl_rows_bit_exact(orc):
     gm.close(); kv.close()
 
 
+def _expect_row(orc, kind, w, g, s1, s2):
+    if kind == "ftrl":
+        return orc.ftrl_update(w, g, s1, s2)[:3]
+    if kind == "adam2":
+        return orc.adam_update(w, g, s1, s2, alfa=0.02, beta1=0.8)
+    if kind == "simple":
+        return (np.asarray(g, f32) * f32(-0.05) + np.asarray(w, f32)).astype(f32), s1, s2
+    return orc.adam_update(w, g, s1, s2)
+
+
+@pytest.mark.parametrize("form", ["fused", "split", "keyed"])
+def test_per_field_updaters_bit_exact(orc, form):
+    """KVStore.update(Map) picks the updater per KEY: exact key, then a map key that is a prefix, then "default"
+    (store/KVStore.java:240-252).  "emF1." -> Ftrl, "emF2" -> another Adam, "emF3." -> Simple, fields 0 and 4 fall through
+    to "default": every field's rows move by ITS updater, bit for bit -- in the fused step (short keys and the long-key
+    role: V is small, so the hottest key's run is far above 16), the split form (k_rows_apply) and the keyed push."""
+    import ps_amd
+    F, D, X, fc, V, B = 5, 8, 1, [8, 1], 7, 192
+    kinds = ["adam", "ftrl", "adam2", "simple", "adam"]
+    rng = np.random.default_rng(21)
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([V] * F, D)
+    kv.set_updater("emF1.", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))
+    kv.set_updater("emF2", ps_amd.AdamUpdater(0.02, 0.8))
+    kv.set_updater("emF3.", ps_amd.SimpleUpdater(0.05))
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    for step in range(3):
+        E, Xd, Y = data(rng, B, F, X, V)
+        uniq = [np.unique(E[:, f]) for f in range(F)]
+        before = [[kv.get_rows(f, uniq[f], k) for k in range(3)] for f in range(F)]
+        if form == "fused":
+            gm.train({"E": E, "X": Xd, "Y": Y})
+            grads = [gm.emb_grads(f) for f in range(F)]
+        elif form == "split":
+            gm.forward({"E": E, "X": Xd, "Y": Y}); gm.backward()
+            grads = [gm.emb_grads(f) for f in range(F)]
+            gm.update()
+        else:
+            grads = [(uniq[f], rng.standard_normal((len(uniq[f]), D)).astype(f32)) for f in range(F)]
+            kv.push_update([("emF%d.%d" % (f, int(i)), grads[f][1][k]) for f in range(F) for k, i in enumerate(grads[f][0])])
+        for f in range(F):
+            ids, g = grads[f]
+            np.testing.assert_array_equal(ids, uniq[f])
+            after = [kv.get_rows(f, ids, k) for k in range(3)]
+            for i in range(len(ids)):
+                exp = _expect_row(orc, kinds[f], before[f][0][i], g[i], before[f][1][i], before[f][2][i])
+                for k in range(3):
+                    np.testing.assert_array_equal(after[k][i], np.asarray(exp[k], f32).ravel(), err_msg="field %d id %d slot %d step %d" % (f, ids[i], k, step))
+    gm.close(); kv.close()
+
+
+def test_single_row_updater_keys_are_refused(orc):
+    """an updater map key that names ONE embedding row cannot be honoured by the per-field resolution: said, not ignored"""
+    import ps_amd
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([6, 6], 4)
+    kv.set_updater("emF1.3", ps_amd.FtrlUpdater())
+    gm = ps_amd.DNN.buildModel(2, 4, 1, [4, 1], store=kv, max_batch=8)
+    with pytest.raises(ps_amd.native.PsError) as ei:
+        gm.train({"E": np.zeros((8, 2), np.int64), "X": np.zeros((8, 1), f32), "Y": np.ones(8, f32)})
+    assert ei.value.code == ps_amd.native.PS_E_UNSUPPORTED
+    gm.close(); kv.close()
+
+
 def test_loss_slim_stops_backward(orc):
     """model/DNN.java:58-63: loss <= 0.01 (or NaN) returns before backward: nothing is updated."""
     import ps_amd
@@ -490,11 +554,12 @@ def test_against_committed_golden(name):
     gm.close(); kv.close()
 
 
-@pytest.mark.parametrize("is_async", [0, 1])
-def test_owner_push_from_many_workers(orc, is_async):
+@pytest.mark.parametrize("is_async,per_field", [(0, False), (1, False), (0, True), (1, True)])
+def test_owner_push_from_many_workers(orc, is_async, per_field):
     """PServer.push + psUpdate on one owner receiving the lists of 5 workers (net/PServer.java:164-214):
     the sort-free path (worker-grouped lists) == the stable-sort path == the oracle's arithmetic
-    (BSP: mean over the pushing workers in worker order; async: one Adam step per push in worker order)."""
+    (BSP: mean over the pushing workers in worker order; async: one Adam step per push in worker order).
+    per_field: the rows of field 1 are under "emF1." -> Ftrl, the others under "default" (store/KVStore.java:240-252)."""
     import ctypes as C
     import ps_amd
     from ps_amd import native as N
@@ -514,6 +579,8 @@ def test_owner_push_from_many_workers(orc, is_async):
     for grouped in (True, False):
         kv = ps_amd.KVStore(0, SEED)
         kv.create_embedding([V] * F, D)
+        if per_field:
+            kv.set_updater("emF1.", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))
         w0 = np.concatenate([kv.get_rows(f, np.arange(V)) for f in range(F)])
         L = N.lib()
         dr, dg = C.c_void_p(), C.c_void_p()
@@ -531,17 +598,23 @@ def test_owner_push_from_many_workers(orc, is_async):
         np.testing.assert_array_equal(a, b)
     # the oracle's arithmetic
     W, M, Vv = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
+
+    def upd(r, g):
+        if per_field and V <= r < 2 * V:
+            W[r], M[r], Vv[r] = orc.ftrl_update(W[r], g, M[r], Vv[r])[:3]
+        else:
+            W[r], M[r], Vv[r] = orc.adam_update(W[r], g, M[r], Vv[r])
     for rep in range(2):
         for r in np.unique(rows):
             gs = grads[rows == r]                        # worker order
             if is_async:
                 for g in gs:
-                    W[r], M[r], Vv[r] = orc.adam_update(W[r], g, M[r], Vv[r])
+                    upd(r, g)
             else:
                 S = gs[0].copy()
                 for g in gs[1:]:
                     S = (g + S).astype(f32)
-                W[r], M[r], Vv[r] = orc.adam_update(W[r], (S / f32(len(gs))).astype(f32), M[r], Vv[r])
+                upd(r, (S / f32(len(gs))).astype(f32))
     np.testing.assert_array_equal(out[0][0], W); np.testing.assert_array_equal(out[0][1], M); np.testing.assert_array_equal(out[0][2], Vv)
 
 
