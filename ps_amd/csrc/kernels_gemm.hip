@@ -20,6 +20,8 @@
 #include <string.h>
 #include <strings.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -66,9 +68,33 @@ __device__ __forceinline__ float sigmoid_clip_dev(float x) {
 // global traffic, LDS footprint and number of output tiles (no extra partial slabs, unlike a split over workgroups).
 // One output tile of C = epi(A * Bt^T): everything of k_gemm_nt behind the choice of the tile (m0, n0).  As / Bs: the
 // workgroup's double-buffered operand tiles.  Shared by k_gemm_nt and k_fc_fwd_pair.
-template <int WM, int WN, int TM, int TN, int BKT, int KS>
-__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0,
-                                             float (&As)[2][WM * TM * 32 * (BKT + 4)], float (&Bs)[2][WN * TN * 32 * (BKT + 4)]) {
+// PS_GEMM_ABLATE (a MEASUREMENT build, tools/gemm_ablate_build.sh; results are garbage): what one part of a slab costs.
+//   1 B fragments not read from LDS    2 no LDS reads at all    4 no MFMAs    8 no barriers in the loop
+//   16 no global loads in the loop     32 no LDS writes in the loop
+#ifndef PS_GEMM_ABLATE
+#define PS_GEMM_ABLATE 0
+#endif
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// PIPE = 1: the slab loop software-pipelined INSIDE the wave (round 3; tools/gemm_ablate_build.sh priced the parts of a
+// slab: MFMAs alone 96 % of the f32 MFMA rate, with the fragment reads from LDS 70 % -- hipcc issued each group's
+// ds_read_b128 right in front of the MFMAs that use them, behind the previous group's dependent MFMA chain, so every group
+// exposed an LDS round trip, and the LDS write of the next slab, the barrier and the first fragment read stood in a row at
+// every slab boundary).  Now:
+//   * the fragments of group g + 1 are read while group g's MFMAs run (two named fragment sets);
+//   * THREE LDS buffers: slab kt + 2 is written during slab kt (its rows arrived in registers two slabs ago) -- the write's
+//     latency hides behind MFMAs, and the first fragments of slab kt + 1 (written and made visible one barrier earlier) are
+//     read BEFORE the barrier that ends slab kt: no LDS latency at the slab boundary at all;
+//   * the masks / LDS writes / next global loads are dealt out one chunk per MFMA of the first group, so the VALU work sits
+//     in the shadow of a running MFMA instead of between two groups.
+// Same products in the same order per accumulator as PIPE = 0: bit-identical results.
+template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0>
+__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs) {
+    constexpr int ASZ = WM * TM * 32 * (BKT + 4), BSZ = WN * TN * 32 * (BKT + 4);      // floats per LDS buffer
     constexpr int NTH = WM * WN * 64 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LD = BKT + 4;
@@ -117,6 +143,8 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         for (int i = 0; i < B_F4; ++i) { const int c = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (c < a.K ? c : a.K - 4)); }
     };
     auto masked = [&](float4 v, int c) -> float4 {
+        if (PS_GEMM_ABLATE & 256) return make_float4(1.f, 2.f, 3.f, 4.f);      // (the LDS writes carry constants: no wait for the loads, no VALU)
+        if (PS_GEMM_ABLATE & 128) return v;                                     // (no masking VALU)
         const int m = c < a.K ? -1 : 0;
         v.x = __int_as_float(__float_as_int(v.x) & m); v.y = __int_as_float(__float_as_int(v.y) & m);
         v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
@@ -128,13 +156,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * NTH;
             if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                *reinterpret_cast<float4 *>(&As[buf][(e / RF4) * LD + (e % RF4) * 4]) = masked(ra[i], k0 + ca[i]);
+                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + (e % RF4) * 4) = masked(ra[i], k0 + ca[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * NTH;
             if ((BN * RF4) % NTH == 0 || e < BN * RF4)
-                *reinterpret_cast<float4 *>(&Bs[buf][(e / RF4) * LD + (e % RF4) * 4]) = masked(rb[i], k0 + cb[i]);
+                *reinterpret_cast<float4 *>(Bs + buf * BSZ + (e / RF4) * LD + (e % RF4) * 4) = masked(rb[i], k0 + cb[i]);
         }
     };
 
@@ -154,11 +182,22 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             const int q = qq + kg * (BKT / 8 / KS);          // this wave group's part of the slab
             float4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4 *>(&As[buf][arow + i * 32 * LD + q * 8]);
+            for (int i = 0; i < TM; ++i) {
+                if (PS_GEMM_ABLATE & 2) fa[i] = make_float4((float)q, (float)lane, 1.f, (float)buf);
+                else fa[i] = *reinterpret_cast<const float4 *>(As + buf * ASZ + arow + i * 32 * LD + q * 8);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][brow + j * 32 * LD + q * 8]);
+            for (int j = 0; j < TN; ++j) {
+                if (PS_GEMM_ABLATE & 3) fb[j] = fa[0];
+                else fb[j] = *reinterpret_cast<const float4 *>(Bs + buf * BSZ + brow + j * 32 * LD + q * 8);
+            }
+            if (PS_GEMM_ABLATE & 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fa[i].x), "v"(fa[i].w), "v"(fb[j].x), "v"(fb[j].w));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -173,35 +212,188 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     // The loop body has NO conditional around a load or an LDS write: a slab index past the end loads from clamped
     // (valid) addresses and writes zeros to the LDS buffer nobody reads again.  With conditionals hipcc's wait-count
     // pass merges the two paths conservatively and waits for EVERY outstanding load before the next one is issued.
-    gload(0, ra0, rb0);
-    gload(1, ra1, rb1);
-    swrite(0, 0, ra0, rb0);
-    __syncthreads();
-    // sched_barrier: the loads of slab t+2 are issued BEFORE the MFMAs of slab t and the LDS write of slab t+1
-    // comes AFTER them (left alone, hipcc's scheduler sinks the loads behind the LDS write: ~6 MFMAs of lookahead)
-    int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {
-        // even slab kt: in LDS buffer 0; set 1 holds slab kt+1; set 0 is free for slab kt+2
-        gload(kt + 2, ra0, rb0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0);
-        __builtin_amdgcn_sched_barrier(0);
-        swrite(1, kt + 1, ra1, rb1);
+    if constexpr (PIPE == 0) {
+        gload(0, ra0, rb0);
+        gload(1, ra1, rb1);
+        swrite(0, 0, ra0, rb0);
         __syncthreads();
-        // odd slab kt+1: in LDS buffer 1; set 0 holds slab kt+2; set 1 is free for slab kt+3
-        gload(kt + 3, ra1, rb1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
-        __builtin_amdgcn_sched_barrier(0);
-        swrite(0, kt + 2, ra0, rb0);
-        __syncthreads();
+        // sched_barrier: the loads of slab t+2 are issued BEFORE the MFMAs of slab t and the LDS write of slab t+1
+        // comes AFTER them (left alone, hipcc's scheduler sinks the loads behind the LDS write: ~6 MFMAs of lookahead)
+        int kt = 0;
+        for (; kt + 2 <= nk; kt += 2) {
+            // even slab kt: in LDS buffer 0; set 1 holds slab kt+1; set 0 is free for slab kt+2
+            if (!(PS_GEMM_ABLATE & 16)) gload(kt + 2, ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(PS_GEMM_ABLATE & 32)) swrite(1, kt + 1, ra1, rb1);
+            if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+            // odd slab kt+1: in LDS buffer 1; set 0 holds slab kt+2; set 1 is free for slab kt+3
+            if (!(PS_GEMM_ABLATE & 16)) gload(kt + 3, ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(PS_GEMM_ABLATE & 32)) swrite(0, kt + 2, ra0, rb0);
+            if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+        }
+        if (kt < nk) compute(0);                                // odd slab count: the last slab sits in buffer 0
+    } else {
+        constexpr int NG = BKT / 8 / KS;                    // fragment groups per slab and wave
+        constexpr int MF = TM * TN * 4;                     // MFMAs per group
+        constexpr int NCH = A_F4 + B_F4;                    // operand chunks (float4) per thread and slab
+        float4 FA[PIPE == 2 ? 4 : 2][TM], FB[PIPE == 2 ? 4 : 2][TN];          // fragment sets (indexed by compile-time constants only: registers)
+        // chunk c of a slab: c < A_F4 -> A chunk c, else B chunk c - A_F4
+        auto gload1 = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int c) {
+            const int k0 = kt2 * BKT;
+            if (c < A_F4) { const int cc = k0 + ca[c]; ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4)); }
+            else { const int i = c - A_F4; const int cc = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (cc < a.K ? cc : a.K - 4)); }
+        };
+        auto swrite1 = [&](int oa, int ob, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4], int c) {
+            const int k0 = kt2 * BKT;
+            if (c < A_F4) {
+                const int e = tid + c * NTH;
+                if ((BM * RF4) % NTH == 0 || e < BM * RF4)
+                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + (e % RF4) * 4) = masked(ra[c], k0 + ca[c]);
+            } else {
+                const int i = c - A_F4, e = tid + i * NTH;
+                if ((BN * RF4) % NTH == 0 || e < BN * RF4)
+                    *reinterpret_cast<float4 *>(Bs + ob + (e / RF4) * LD + (e % RF4) * 4) = masked(rb[i], k0 + cb[i]);
+            }
+        };
+        auto fread = [&](float4 (&fa)[TM], float4 (&fb)[TN], int oa, int ob, int g) {
+            const int q = g + kg * NG;
+            if (PS_GEMM_ABLATE & 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = make_float4((float)q, (float)lane, 1.f, (float)oa);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = fa[0];
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(As + oa + arow + i * 32 * LD + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = (PS_GEMM_ABLATE & 1) ? fa[0] : *reinterpret_cast<const float4 *>(Bs + ob + brow + j * 32 * LD + q * 8);
+        };
+        // MFMA m of a group: k component m / (TM * TN) of tile m % (TM * TN) -- consecutive MFMAs go to different
+        // accumulators where there are several; per accumulator the k order is that of PIPE = 0
+        auto fmfma = [&](const float4 (&fa)[TM], const float4 (&fb)[TN], auto mc) {
+            constexpr int m = decltype(mc)::value, c = m / (TM * TN), t = m % (TM * TN), i = t / TN, j = t % TN;
+            float x = c == 0 ? fa[i].x : c == 1 ? fa[i].y : c == 2 ? fa[i].z : fa[i].w;
+            float y = c == 0 ? fb[j].x : c == 1 ? fb[j].y : c == 2 ? fb[j].z : fb[j].w;
+            if (PS_GEMM_ABLATE & 64) {      // the reads happen, the MFMAs do not depend on them (consumed once per group, below)
+                if (c == 3) asm volatile("" ::"v"(fa[i].x), "v"(fa[i].w), "v"(fb[j].x), "v"(fb[j].w));
+                x = (float)lane; y = 1.f;
+            }
+            if (PS_GEMM_ABLATE & 4) { asm volatile("" ::"v"(x), "v"(y)); return; }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i][j], 0, 0, 0);
+        };
+        // One slab (in the LDS buffer at o_cur), first fragment set P0 already read.  FULL: the slab's part in the pipeline too
+        // (slab kt + 2 from register set r to the buffer at o_wr, slab kt + 4 into r, first fragments of slab kt + 1 from o_nxt).
+        // program order is the schedule: neither the IR passes (memory clobber) nor the machine scheduler (sched_barrier) may
+        // move anything across
+#define PS_ORDER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        // LOOK = PIPE: how many groups ahead the fragments are read (1: two fragment sets; 2: four -- the LDS queue behind the
+        // writes of eight waves can be deeper than one group's 256 MFMA cycles)
+        // PIPE = 3: THREE register sets of operand chunks in flight (the rows of slab kt + 5 are requested while slab kt is
+        // multiplied: three slab times of load latency covered instead of two) and everything static: the loop is unrolled
+        // by 3, register set and LDS buffer of a slab are both (slab % 3)
+        constexpr int LOOK = PIPE == 2 ? 2 : 1, NS = 2 * LOOK, GS = PIPE == 3 ? 3 : 2;
+        static_assert(NG >= LOOK && (2 * NG) % NS == 0, "fragment sets must be back at set 0 after two slabs");
+        auto slab = [&](auto p0c, auto fullc, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int kt2, int oca, int ocb, int ona, int onb, int owa, int owb) {
+            constexpr int P0 = decltype(p0c)::value;
+            constexpr bool FULL = decltype(fullc)::value;
+            static_for<NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, P = (P0 + g) % NS, PN = (P0 + g + LOOK) % NS;
+                PS_ORDER();
+                if constexpr (g + LOOK < NG) fread(FA[PN], FB[PN], oca, ocb, g + LOOK);
+                else if constexpr (FULL) fread(FA[PN], FB[PN], ona, onb, g + LOOK - NG);
+                PS_ORDER();
+                static_for<MF>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    fmfma(FA[P], FB[P], mc);
+                    if constexpr (FULL) {
+                        // this MFMA's share of the chunks: dealt out over ALL MFMAs of the slab (LDS writes run at ~75 B/clk per CU,
+                        // tools/ubench/lds_write.hip, a third of the read rate: the four waves' writes of a whole slab in one burst
+                        // are 220 cycles of LDS time in front of the fragment reads queued behind them -- with the reads alone, or
+                        // the writes alone, the loop runs at 94 % of the MFMA rate, with both in bursts at 74 %)
+                        constexpr int mm = g * MF + m, T = NG * MF, c0 = (mm * NCH + T - 1) / T, c1 = ((mm + 1) * NCH + T - 1) / T;    // (behind the FIRST MFMA of a stretch)
+                        if constexpr (c1 > c0) {
+                            PS_ORDER();
+                            static_for<c1 - c0>([&](auto cc) {
+                                constexpr int c = c0 + decltype(cc)::value;
+                                if (!(PS_GEMM_ABLATE & 32)) swrite1(owa, owb, kt2 + 2, ra, rb, c);
+                                if (!(PS_GEMM_ABLATE & 16)) gload1(kt2 + 2 + GS, ra, rb, c);
+                            });
+                            PS_ORDER();
+                        }
+                    }
+                });
+            });
+            PS_ORDER();     // (the slab's last MFMAs are issued BEFORE the barrier: its wait for the prefetched fragments hides behind them)
+        };
+#undef PS_ORDER
+        constexpr auto I0 = std::integral_constant<int, 0>{};
+        constexpr auto I1 = std::integral_constant<int, NG % NS>{};
+        constexpr auto YES = std::integral_constant<bool, true>{};
+        constexpr auto NO = std::integral_constant<bool, false>{};
+        if constexpr (PIPE == 3) {
+            static_assert(NG % 2 == 0, "PIPE = 3: an even number of fragment groups per slab (the fragment sets start every slab at set 0)");
+            float4 ra2[A_F4], rb2[B_F4];
+            gload(0, ra0, rb0);
+            gload(1, ra1, rb1);
+            gload(2, ra2, rb2);
+            swrite(0, 0, ra0, rb0);
+            gload(3, ra0, rb0);
+            swrite(1, 1, ra1, rb1);
+            gload(4, ra1, rb1);
+            __syncthreads();
+            fread(FA[0], FB[0], 0, 0, 0);
+            constexpr int A0 = 0, A1 = ASZ, A2 = 2 * ASZ, B0 = 0, B1 = BSZ, B2 = 2 * BSZ;
+            int kt = 0;
+            for (; kt + 3 <= nk; kt += 3) {
+                slab(I0, YES, ra2, rb2, kt, A0, B0, A1, B1, A2, B2);
+                if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+                slab(I0, YES, ra0, rb0, kt + 1, A1, B1, A2, B2, A0, B0);
+                if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+                slab(I0, YES, ra1, rb1, kt + 2, A2, B2, A0, B0, A1, B1);
+                if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+            }
+            if (nk - kt == 2) {
+                slab(I0, YES, ra2, rb2, kt, A0, B0, A1, B1, A2, B2);
+                __syncthreads();
+                slab(I0, NO, ra0, rb0, kt + 1, A1, B1, A2, B2, A0, B0);
+            } else if (nk - kt == 1) {
+                slab(I0, NO, ra2, rb2, kt, A0, B0, A1, B1, A2, B2);
+            }
+        } else {
+            gload(0, ra0, rb0);
+            gload(1, ra1, rb1);
+            swrite(0, 0, ra0, rb0);
+            gload(2, ra0, rb0);
+            swrite(1, 1, ra1, rb1);
+            gload(3, ra1, rb1);
+            __syncthreads();
+            fread(FA[0], FB[0], 0, 0, 0);
+            if constexpr (LOOK == 2) fread(FA[1], FB[1], 0, 0, 1);
+            int oca = 0, ocb = 0, ona = ASZ, onb = BSZ, owa = 2 * ASZ, owb = 2 * BSZ;
+            auto rotate = [&]() { const int ta = oca, tb = ocb; oca = ona; ocb = onb; ona = owa; onb = owb; owa = ta; owb = tb; };
+            int kt = 0;
+            for (; kt + 2 <= nk; kt += 2) {
+                slab(I0, YES, ra0, rb0, kt, oca, ocb, ona, onb, owa, owb);
+                if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+                rotate();
+                slab(I1, YES, ra1, rb1, kt + 1, oca, ocb, ona, onb, owa, owb);
+                if (!(PS_GEMM_ABLATE & 8)) __syncthreads();
+                rotate();
+            }
+            if (kt < nk) slab(I0, NO, ra0, rb0, kt, oca, ocb, ona, onb, owa, owb);    // odd slab count (the sets are back at parity 0)
+        }
     }
-    if (kt < nk) compute(0);                                // odd slab count: the last slab sits in buffer 0
     if (KS > 1) {
         // the wave groups' partial tiles: group 1 parks its accumulators in LDS (the operand buffers are free now: 16
         // floats per lane, lane-major per register so that both sides touch consecutive words), group 0 adds them
         __syncthreads();
-        float *scr = &As[0][0] + w * 16 * 64;               // (2 * BM * LD floats >= WM * WN * 1024)
+        float *scr = As + w * 16 * 64;                      // (2 * BM * LD floats >= WM * WN * 1024)
         static_assert(KS == 1 || 2 * BM * LD >= WM * WN * 16 * 64, "reduction scratch does not fit the A buffers");
         if (kg == 1) {
 #pragma unroll
@@ -243,13 +435,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         }
 }
 
-template <int WM, int WN, int TM, int TN, int BKT, int KS = 1>
+template <int WM, int WN, int TM, int TN, int BKT, int KS = 1, int PIPE = 0>
 __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;       // (4 waves -- the default tiles -- or 8)
     constexpr int LD = BKT + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    __shared__ __attribute__((aligned(16))) float As[(PIPE ? 3 : 2) * BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[(PIPE ? 3 : 2) * BN * LD];
     // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
     // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
     // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
@@ -263,7 +455,188 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     if (a.skip && *a.skip) return;
     const int tn = (a.N + BN - 1) / BN;
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    gemm_nt_tile<WM, WN, TM, TN, BKT, KS>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
+    gemm_nt_tile<WM, WN, TM, TN, BKT, KS, PIPE>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction on v_mfma_f32_16x16x4_f32 (round 3).  What the ablation builds showed about the 32x32x2 loop above:
+// MFMAs alone run at 96 % of the f32 MFMA rate; the fragment reads from LDS cost 23 % of it EVEN WHEN NO MFMA DEPENDS ON
+// THEM (PS_GEMM_ABLATE=64: same time as the full loop) and although LDS itself is at an eighth of its bandwidth
+// (tools/ubench/lds_read.hip: 256 B/clk for this pattern) -- every ds_read_b128 takes ~40 cycles out of the matrix pipe.
+// A 32x32x2 MFMA writes 16 result registers in its 64 cycles: back-to-back MFMAs keep the register file's write side busy
+// all the time, and every LDS return (4 registers) has to take its slots from them.  The 16x16x4 instruction has the same
+// rate (2048 flops in 32 cycles) and the same LDS volume per flop on a 2 x 2 block of accumulators, but writes HALF the
+// result registers per flop (4 per 2048 flops).  Tiles, LDS image, global traffic, pipeline: as gemm_nt_tile<PIPE = 1>.
+//   fragments: lane l reads the float4 at (row l % 16, k = 4 (l / 16) ..+3) of a 16-row block: MFMA c of a 16-wide k chunk
+//   multiplies component c, i.e. k = 4 (l / 16) + c from lane group l / 16 -- any fixed bijection of k serves both operands;
+//   result block: register r of lane l = C[4 (l / 16) + r][l % 16].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int WM, int WN, int TM, int TN, int BKT>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt16(NtArgs a) {
+    constexpr int NTH = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BKT + 4, ASZ = BM * LD, BSZ = BN * LD;
+    constexpr int RF4 = BKT / 4;
+    constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH, NCH = A_F4 + B_F4;
+    constexpr int RA = 2 * TM, RB = 2 * TN;                    // 16-row blocks per wave
+    constexpr int NG = BKT / 16, MF = RA * RB * 4;             // k chunks per slab, MFMAs per chunk
+    __shared__ __attribute__((aligned(16))) float As[3 * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[3 * BSZ];
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);
+    StampScope stamp(a.ts);
+    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.skip && *a.skip) return;
+    const int tn = (a.N + BN - 1) / BN;
+    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int nk = (a.K + BKT - 1) / BKT;
+
+    float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];       // two register sets of operand chunks in flight (see gemm_nt_tile)
+    const float *pa[A_F4], *pb[B_F4];
+    int ca[A_F4], cb[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int e = tid + i * NTH;
+        int r = m0 + (e / RF4 < BM ? e / RF4 : BM - 1);
+        r = r < a.a_rows ? r : a.a_rows - 1;
+        ca[i] = (e % RF4) * 4;
+        pa[i] = a.A + (size_t)r * a.lda;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int e = tid + i * NTH;
+        int r = n0 + (e / RF4 < BN ? e / RF4 : BN - 1);
+        r = r < a.b_rows ? r : a.b_rows - 1;
+        cb[i] = (e % RF4) * 4;
+        pb[i] = a.Bt + (size_t)r * a.ldb;
+    }
+    auto masked = [&](float4 v, int c) -> float4 {
+        const int m = c < a.K ? -1 : 0;
+        v.x = __int_as_float(__float_as_int(v.x) & m); v.y = __int_as_float(__float_as_int(v.y) & m);
+        v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
+        return v;
+    };
+    auto gload1 = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int c) {
+        const int k0 = kt2 * BKT;
+        if (c < A_F4) { const int cc = k0 + ca[c]; ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4)); }
+        else { const int i = c - A_F4; const int cc = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (cc < a.K ? cc : a.K - 4)); }
+    };
+    auto swrite1 = [&](int oa, int ob, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4], int c) {
+        const int k0 = kt2 * BKT;
+        if (c < A_F4) {
+            const int e = tid + c * NTH;
+            if ((BM * RF4) % NTH == 0 || e < BM * RF4)
+                *reinterpret_cast<float4 *>(__builtin_assume_aligned(As + oa + (e / RF4) * LD + (e % RF4) * 4, 16)) = masked(ra[c], k0 + ca[c]);
+        } else {
+            const int i = c - A_F4, e = tid + i * NTH;
+            if ((BN * RF4) % NTH == 0 || e < BN * RF4)
+                *reinterpret_cast<float4 *>(__builtin_assume_aligned(Bs + ob + (e / RF4) * LD + (e % RF4) * 4, 16)) = masked(rb[i], k0 + cb[i]);
+        }
+    };
+    f32x4 acc[RA][RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const int arow = (wm * TM * 32 + (lane & 15)) * LD + (lane >> 4) * 4;
+    const int brow = (wn * TN * 32 + (lane & 15)) * LD + (lane >> 4) * 4;
+    float4 fa0[RA], fb0[RB], fa1[RA], fb1[RB];
+    auto fread = [&](float4 (&fa)[RA], float4 (&fb)[RB], int oa, int ob, int g) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) fa[i] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(As + oa + arow + i * 16 * LD + g * 16, 16));
+#pragma unroll
+        for (int j = 0; j < RB; ++j) fb[j] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(Bs + ob + brow + j * 16 * LD + g * 16, 16));
+    };
+    auto fmfma = [&](const float4 (&fa)[RA], const float4 (&fb)[RB], auto mc) {
+        constexpr int m = decltype(mc)::value, c = m / (RA * RB), t = m % (RA * RB), i = t / RB, j = t % RB;
+        const float x = c == 0 ? fa[i].x : c == 1 ? fa[i].y : c == 2 ? fa[i].z : fa[i].w;
+        const float y = c == 0 ? fb[j].x : c == 1 ? fb[j].y : c == 2 ? fb[j].z : fb[j].w;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[i][j], 0, 0, 0);
+    };
+#define PS_ORDER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    auto slab = [&](auto p0c, auto fullc, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int kt2, int oca, int ocb, int ona, int onb, int owa, int owb) {
+        constexpr int P0 = decltype(p0c)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, P = (P0 + g) & 1;
+            PS_ORDER();
+            if constexpr (g + 1 < NG) { if constexpr (P == 0) fread(fa1, fb1, oca, ocb, g + 1); else fread(fa0, fb0, oca, ocb, g + 1); }
+            else if constexpr (FULL) { if constexpr (P == 0) fread(fa1, fb1, ona, onb, 0); else fread(fa0, fb0, ona, onb, 0); }
+            PS_ORDER();
+            static_for<MF>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (P == 0) fmfma(fa0, fb0, mc); else fmfma(fa1, fb1, mc);
+                if constexpr (FULL && g == 0) {
+                    constexpr int c0 = m * NCH / MF, c1 = (m + 1) * NCH / MF;
+                    if constexpr (c1 > c0) {
+                        PS_ORDER();
+                        static_for<c1 - c0>([&](auto cc) {
+                            constexpr int c = c0 + decltype(cc)::value;
+                            swrite1(owa, owb, kt2 + 2, ra, rb, c);
+                            gload1(kt2 + 4, ra, rb, c);
+                        });
+                        PS_ORDER();
+                    }
+                }
+            });
+        });
+        PS_ORDER();
+    };
+#undef PS_ORDER
+    constexpr auto I0 = std::integral_constant<int, 0>{};
+    constexpr auto I1 = std::integral_constant<int, NG & 1>{};
+    constexpr auto YES = std::integral_constant<bool, true>{};
+    constexpr auto NO = std::integral_constant<bool, false>{};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) gload1(0, ra0, rb0, c);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) gload1(1, ra1, rb1, c);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { swrite1(0, 0, 0, ra0, rb0, c); gload1(2, ra0, rb0, c); }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { swrite1(ASZ, BSZ, 1, ra1, rb1, c); gload1(3, ra1, rb1, c); }
+    __syncthreads();
+    fread(fa0, fb0, 0, 0, 0);
+    int oca = 0, ocb = 0, ona = ASZ, onb = BSZ, owa = 2 * ASZ, owb = 2 * BSZ;
+    auto rotate = [&]() { const int ta = oca, tb = ocb; oca = ona; ocb = onb; ona = owa; onb = owb; owa = ta; owb = tb; };
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        slab(I0, YES, ra0, rb0, kt, oca, ocb, ona, onb, owa, owb);
+        __syncthreads();
+        rotate();
+        slab(I1, YES, ra1, rb1, kt + 1, oca, ocb, ona, onb, owa, owb);
+        __syncthreads();
+        rotate();
+    }
+    if (kt < nk) slab(I0, NO, ra0, rb0, kt, oca, ocb, ona, onb, owa, owb);
+
+    // epilogue: block (i, j), register r of lane l -> row 16 i + 4 (l / 16) + r, column 16 j + l % 16
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 16 + (lane & 15);
+            const int rbase = m0 + wm * TM * 32 + i * 16 + 4 * (lane >> 4);
+            float mk[4];
+            if (a.epi == EPI_MASK_POS) {                    // (loads up front from clamped addresses, see k_gemm_nt)
+                const int mc = col < a.mask_cols ? col : a.mask_cols - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[r] = a.mask[(size_t)(rbase + r < a.M ? rbase + r : a.M - 1) * a.ldmask + mc];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + r;
+                float v = acc[i][j][r];
+                if (a.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
+                else if (a.epi == EPI_SIGMOID) v = sigmoid_clip_dev(v);
+                else if (a.epi == EPI_MASK_POS) v *= (col >= a.mask_cols || mk[r] > 0.f) ? 1.f : 0.f;
+                if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -295,23 +668,27 @@ struct PairArgs {
 template <int WM, int WN, int TM, int TN, int BKT>
 __global__ __launch_bounds__(WM * WN * 64) void k_fc_fwd_pair(PairArgs q) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BKT + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LD];
     if (q.p1.prio) __builtin_amdgcn_s_setprio(3);
     StampScope stamp(q.p1.ts);
     if (q.p1.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(q.p1.flag, q.p1.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (q.p1.skip && *q.p1.skip) return;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    if (threadIdx.x == 0) {
-        // same blockIdx % 8 => same XCD, within this launch (the dispatcher's round robin carries over from launch to launch,
-        // so WHICH XCD class x lands on differs per launch; that every workgroup of a class shares one is what is needed):
-        // the class's tag = (launch epoch, XCC id); whoever finds this epoch's tag with another id reports it
+    // same blockIdx % 8 => same XCD, within this launch (the dispatcher's round robin carries over from launch to launch,
+    // so WHICH XCD class x lands on differs per launch; that every workgroup of a class shares one is what is needed):
+    // the class's tag = (launch epoch, XCC id); whoever finds this epoch's tag with another id reports it.  Checked when
+    // the workgroup's tile is DONE: a returning atomic on one of 8 words from ~100 workgroups each is a queue of ~100
+    // memory-side round trips, and in front of the tile every workgroup's first barrier stood behind it (the pair took
+    // 48 us; phase 1 alone 28.5 against the plain launch's 20.4).
+    auto xcc_check = [&]() {
+        if (threadIdx.x != 0) return;
         unsigned int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         const unsigned int mine = (q.epoch << 4) | (xcc & 0xFu);
         const unsigned int old = atomicMax(q.xcc_tag + x, mine);
         if ((old >> 4) == q.epoch && old != mine) atomicAdd(q.xcc_err, 1u);
-    }
+    };
     const int n1 = q.lp_max * q.tn1;
     if (j < n1) {                                            // ---- phase 1: a tile of Y1
         const int p = (j / q.tn1) * 8 + x, nt = j % q.tn1;
@@ -319,6 +696,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_fc_fwd_pair(PairArgs q) {
         gemm_nt_tile<WM, WN, TM, TN, BKT, 1>(q.p1, p * BM, nt * BN, As, Bs);
         __syncthreads();                                     // every wave's stores have been acknowledged by the L2 (vmcnt(0) + barrier)
         if (threadIdx.x == 0) __hip_atomic_fetch_add(q.ctr + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xcc_check();
         return;
     }
     const int j2 = j - n1;                                   // ---- phase 2: a tile of Y2, once its panel of Y1 is complete
@@ -329,6 +707,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_fc_fwd_pair(PairArgs q) {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (an L1 invalidate: cheap; the L2 is the producers' own)
     gemm_nt_tile<WM, WN, TM, TN, BKT, 1>(q.p2, p * BM, nt * BN, As, Bs);
+    xcc_check();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -471,7 +850,11 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
     constexpr int A_F4 = (BKT * BM / 4 + NTH - 1) / NTH, B_F4 = (BKT * BN / 4 + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) float As[2][BKT * BM];
     __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
-    if (a.prio) __builtin_amdgcn_s_setprio(3);       // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates)
+    // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates; prio 2 / 3: one or
+    // two levels below the delta GEMMs of the main chain -- ps_tune_set("tn_prio"))
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(3);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(1);
     StampScope stamp(a.ts);
     start_wait(a.wait_flag, a.wait_val, a.bound);
     if (a.skip && *a.skip) return;
@@ -620,6 +1003,10 @@ int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5
 
 #define NT_LAUNCH(WM, WN, TM, TN, BKT)                                                                   \
     PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64), 0, st, stop_ev, a)
+#define NT_LAUNCH_P(WM, WN, TM, TN, BKT, KS)                                                             \
+    PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT, KS, 1>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64 * KS), 0, st, stop_ev, a)
+#define NT_LAUNCH_P2(WM, WN, TM, TN, BKT, KS)                                                            \
+    PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT, KS, 2>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64 * KS), 0, st, stop_ev, a)
 #define NT_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                            \
     PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT, KS>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64 * KS), 0, st, stop_ev, a)
 
@@ -645,10 +1032,13 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
         // twice the waves (global traffic per flop -25%); measured alone (tools/gemm_sweep2.py, M = 4096):
         // fwd0 22.7 -> 21.1 us, delta1 14.8 -> 14.0, delta0 (224 workgroups) 23.9 -> 23.1; N = 256 (128 workgroups) 15.4 -> 23.3.
         // In the step the difference disappears (0.1613 vs 0.1614 ms, six runs each): off by default.
+        // gemm_pipe: the software-pipelined slab loop (3: three register sets, the default; 0: round 2's loop);
+        // gemm_ks: the in-workgroup K split where 64 x 64 tiles give at most ~one workgroup per CU
         if (N <= 32) cfg = 8;
         else if (tiles(64, 128) >= 2048) cfg = 6;
-        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = 13;
-        else cfg = 5;
+        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = g_gemm_pipe == 3 ? 113 : g_gemm_pipe ? 53 : 13;
+        else if (g_gemm_ks && tiles(64, 64) <= 320 && K % 16 == 0) cfg = g_gemm_pipe == 3 ? 120 : g_gemm_pipe ? 60 : 20;
+        else cfg = g_gemm_pipe == 3 ? 105 : g_gemm_pipe ? 45 : 5;
     }
     switch (cfg) {
     case 1: NT_LAUNCH(2, 2, 2, 2, 16); break;
@@ -670,6 +1060,26 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 20: NT_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;   // 8 waves on 64 x 64: two wave groups split every K slab
     case 21: NT_LAUNCH_KS(2, 2, 1, 1, 64, 2); break;   // ... with 64-wide slabs
     case 22: NT_LAUNCH_KS(4, 1, 1, 1, 32, 2); break;   // 8 waves on 128 x 32 (narrow N)
+    // software-pipelined slab loop (PIPE = 1), same tiles as 5 / 6 / 7 / 13 / 20 / 8
+    case 45: NT_LAUNCH_P(2, 2, 1, 1, 32, 1); break;
+    case 46: NT_LAUNCH_P(2, 2, 1, 2, 32, 1); break;
+    case 47: NT_LAUNCH_P(2, 2, 2, 2, 32, 1); break;
+    case 48: NT_LAUNCH_P(4, 1, 1, 1, 32, 1); break;
+    case 53: NT_LAUNCH_P(4, 2, 1, 1, 32, 1); break;
+    case 60: NT_LAUNCH_P(2, 2, 1, 1, 32, 2); break;
+    // ... fragments read two groups ahead (PIPE = 2)
+    case 105: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;      // PIPE = 3
+    case 113: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 32, 1, 3>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
+    case 120: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 2, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
+    case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
+    case 86: NT_LAUNCH_P2(2, 2, 1, 2, 32, 1); break;
+    case 93: NT_LAUNCH_P2(4, 2, 1, 1, 32, 1); break;
+    case 90: NT_LAUNCH_P2(2, 2, 1, 1, 32, 2); break;
+    // ... on 16x16x4 MFMAs (k_gemm_nt16): 64x64, 64x128, 128x128, 128x64 (8 waves)
+    case 65: PS_LAUNCH_EV((k_gemm_nt16<2, 2, 1, 1, 32>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;
+    case 66: PS_LAUNCH_EV((k_gemm_nt16<2, 2, 1, 2, 32>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;
+    case 67: PS_LAUNCH_EV((k_gemm_nt16<2, 2, 2, 2, 32>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;
+    case 73: PS_LAUNCH_EV((k_gemm_nt16<4, 2, 1, 1, 32>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 30: PS_LAUNCH_EV((k_gemm_nt_lds<3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;   // operands DMA'd global -> LDS, 3 stages
     default: NT_LAUNCH(4, 1, 1, 1, 32); break;
     }
@@ -722,7 +1132,10 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
     return PS_OK;
 }
 
+int g_tn_prio = 1;          // ps_tune_set("tn_prio", 0 / 2 / 3): the dW GEMMs' wave priority: none / one / two levels under the main chain's; +8: dW_0 only
 int g_main_prio = 1;        // ps_tune_set("main_prio", 0): no raised wave priority for the fused step's main-chain kernels
+int g_gemm_pipe = 3;        // ps_tune_set("gemm_pipe", 0 / 1): round 2's slab loop / the pipelined one with two register sets
+int g_gemm_ks = 0;          // ps_tune_set("gemm_ks", 1): 8 waves (K split inside the workgroup) on shapes with <= ~one 64 x 64 tile per CU
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again

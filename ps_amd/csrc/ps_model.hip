@@ -813,7 +813,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch
-        tn_lo.prio = gemm_prio(m) ? 1 : 0;
+        tn_lo.prio = gemm_prio(m) ? (((g_tn_prio & 8) && l > 0) ? 1 : (g_tn_prio & 7)) : 0;
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
                              b.nsplit, nullptr, dws, &tn_lo, werr));
         if (split_here) {

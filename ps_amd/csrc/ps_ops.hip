@@ -270,6 +270,9 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "tail_defer") == 0) { g_tail_defer = value; return PS_OK; }
     if (strcmp(knob, "end_wait") == 0) { g_end_wait = value; return PS_OK; }
     if (strcmp(knob, "main_prio") == 0) { g_main_prio = value; return PS_OK; }
+    if (strcmp(knob, "gemm_pipe") == 0) { g_gemm_pipe = value; return PS_OK; }
+    if (strcmp(knob, "gemm_ks") == 0) { g_gemm_ks = value; return PS_OK; }
+    if (strcmp(knob, "tn_prio") == 0) { g_tn_prio = value; return PS_OK; }
     if (strcmp(knob, "sort_late") == 0) { g_sort_late = value; return PS_OK; }
     if (strcmp(knob, "plan_early") == 0) { g_plan_early = value; return PS_OK; }
     if (strcmp(knob, "shard_overlap") == 0) { g_shard_overlap = value; return PS_OK; }
