@@ -841,15 +841,18 @@ struct TnArgs {
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
 // KS: the batch rows of every slab split over KS groups of waves inside the workgroup (see k_gemm_nt)
-template <int WM, int WN, int TM, int TN, int BKT, int KS = 1>
+// PIPE = 3: the slab loop software-pipelined like gemm_nt_tile<PIPE = 3> (fragments of the next four batch-row pairs read
+// while the current four are multiplied, three LDS buffers and three register sets, one operand chunk's LDS write + next
+// global load per stretch of MFMAs); same products in the same order per accumulator: bit-identical results.
+template <int WM, int WN, int TM, int TN, int BKT, int KS = 1, int PIPE = 0>
 __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
     static_assert(WM * WN == 4, "four waves per K group");
     static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 4 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
     constexpr int NTH = 256 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = (BKT * BM / 4 + NTH - 1) / NTH, B_F4 = (BKT * BN / 4 + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) float As[2][BKT * BM];
-    __shared__ __attribute__((aligned(16))) float Ds[2][BKT * BN];
+    __shared__ __attribute__((aligned(16))) float As[PIPE ? 3 : 2][BKT * BM];
+    __shared__ __attribute__((aligned(16))) float Ds[PIPE ? 3 : 2][BKT * BN];
     // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates; prio 2 / 3: one or
     // two levels below the delta GEMMs of the main chain -- ps_tune_set("tn_prio"))
     if (a.prio == 1) __builtin_amdgcn_s_setprio(3);
@@ -945,26 +948,126 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     };
-    gload(0, ra0, rb0);                                     // (no conditionals around loads / LDS writes: see k_gemm_nt)
-    gload(1, ra1, rb1);
-    swrite(0, 0, ra0, rb0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {
-        gload(kt + 2, ra0, rb0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0);
-        __builtin_amdgcn_sched_barrier(0);
-        swrite(1, kt + 1, ra1, rb1);
+    if constexpr (PIPE == 0) {
+        gload(0, ra0, rb0);                                     // (no conditionals around loads / LDS writes: see k_gemm_nt)
+        gload(1, ra1, rb1);
+        swrite(0, 0, ra0, rb0);
         __syncthreads();
-        gload(kt + 3, ra1, rb1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
-        __builtin_amdgcn_sched_barrier(0);
-        swrite(0, kt + 2, ra0, rb0);
+        int kt = 0;
+        for (; kt + 2 <= nk; kt += 2) {
+            gload(kt + 2, ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            swrite(1, kt + 1, ra1, rb1);
+            __syncthreads();
+            gload(kt + 3, ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            swrite(0, kt + 2, ra0, rb0);
+            __syncthreads();
+        }
+        if (kt < nk) compute(0);
+    } else {
+        constexpr int SPW = BKT / 2 / KS;                   // batch-row pairs (MFMA k steps) per wave and slab
+        constexpr int GM = SPW >= 4 ? 4 : SPW;              // ... per fragment group
+        constexpr int NG = SPW / GM, MF = GM * TM * TN, NCH = A_F4 + B_F4;
+        static_assert(SPW % GM == 0 && NG % 2 == 0, "an even number of fragment groups per slab");
+        float4 ra2[A_F4], rb2[B_F4];
+        float FA[2][GM][TM], FB[2][GM][TN];
+        auto gload1 = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int c) {
+            const int mb = m_begin + kt2 * BKT;
+            if (c < A_F4) ra[c] = ld4(a.A, a.lda, mb + ra_r[c], ra_c[c]);
+            else rb[c - A_F4] = ld4(a.D, a.ldd, mb + rb_r[c - A_F4], rb_c[c - A_F4]);
+        };
+        auto swrite1 = [&](int buf, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4], int c) {
+            const int mb = m_begin + kt2 * BKT;
+            if (c < A_F4) {
+                const int e = tid + c * NTH;
+                if (e < BKT * BM / 4) *reinterpret_cast<float4 *>(&As[buf][(e / (BM / 4)) * BM + (e % (BM / 4)) * 4]) = masked(ra[c], mb + ra_r[c]);
+            } else {
+                const int i = c - A_F4, e = tid + i * NTH;
+                if (e < BKT * BN / 4) *reinterpret_cast<float4 *>(&Ds[buf][(e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = masked(rb[i], mb + rb_r[i]);
+            }
+        };
+        auto fread = [&](float (&fa)[GM][TM], float (&fb)[GM][TN], int buf, int g) {
+#pragma unroll
+            for (int t = 0; t < GM; ++t) {
+                const int sidx = g * GM + t + kg * SPW;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[t][i] = As[buf][(2 * sidx + kh) * BM + acol + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[t][j] = Ds[buf][(2 * sidx + kh) * BN + bcol + j * 32];
+            }
+        };
+        auto fmfma = [&](const float (&fa)[GM][TM], const float (&fb)[GM][TN], auto mc) {
+            constexpr int m = decltype(mc)::value, t = m / (TM * TN), q = m % (TM * TN), i = q / TN, j = q % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][i], fb[t][j], acc[i][j], 0, 0, 0);
+        };
+#define PS_ORDER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        // one slab (LDS buffer cur); FULL: slab kt + 2 from register set r to buffer wr, slab kt + 5 into r, the first fragments of
+        // slab kt + 1 from buffer nxt
+        auto slab = [&](auto fullc, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int kt2, auto curc, auto nxtc, auto wrc) {
+            constexpr bool FULL = decltype(fullc)::value;
+            constexpr int cur = decltype(curc)::value, nxt = decltype(nxtc)::value, wr = decltype(wrc)::value;
+            static_for<NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, P = g & 1;
+                PS_ORDER();
+                if constexpr (g + 1 < NG) fread(FA[P ^ 1], FB[P ^ 1], cur, g + 1);
+                else if constexpr (FULL) fread(FA[P ^ 1], FB[P ^ 1], nxt, 0);
+                PS_ORDER();
+                static_for<MF>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    fmfma(FA[P], FB[P], mc);
+                    if constexpr (FULL) {
+                        constexpr int mm = g * MF + m, T = NG * MF, c0 = (mm * NCH + T - 1) / T, c1 = ((mm + 1) * NCH + T - 1) / T;
+                        if constexpr (c1 > c0) {
+                            PS_ORDER();
+                            static_for<c1 - c0>([&](auto cc) {
+                                constexpr int c = c0 + decltype(cc)::value;
+                                swrite1(wr, kt2 + 2, ra, rb, c);
+                                gload1(kt2 + 5, ra, rb, c);
+                            });
+                            PS_ORDER();
+                        }
+                    }
+                });
+            });
+            PS_ORDER();
+        };
+#undef PS_ORDER
+        constexpr auto YES = std::integral_constant<bool, true>{};
+        constexpr auto NO = std::integral_constant<bool, false>{};
+        constexpr auto B0 = std::integral_constant<int, 0>{};
+        constexpr auto B1 = std::integral_constant<int, 1>{};
+        constexpr auto B2 = std::integral_constant<int, 2>{};
+        gload(0, ra0, rb0);
+        gload(1, ra1, rb1);
+        gload(2, ra2, rb2);
+        swrite(0, 0, ra0, rb0);
+        gload(3, ra0, rb0);
+        swrite(1, 1, ra1, rb1);
+        gload(4, ra1, rb1);
         __syncthreads();
+        fread(FA[0], FB[0], 0, 0);
+        int kt = 0;
+        for (; kt + 3 <= nk; kt += 3) {
+            slab(YES, ra2, rb2, kt, B0, B1, B2);
+            __syncthreads();
+            slab(YES, ra0, rb0, kt + 1, B1, B2, B0);
+            __syncthreads();
+            slab(YES, ra1, rb1, kt + 2, B2, B0, B1);
+            __syncthreads();
+        }
+        if (nk - kt == 2) {
+            slab(YES, ra2, rb2, kt, B0, B1, B2);
+            __syncthreads();
+            slab(NO, ra0, rb0, kt + 1, B1, B2, B0);
+        } else if (nk - kt == 1) {
+            slab(NO, ra2, rb2, kt, B0, B1, B2);
+        }
     }
-    if (kt < nk) compute(0);
     if (KS > 1) {           // the two wave groups' partial tiles, added through LDS (see k_gemm_nt)
         __syncthreads();
         float *scr = &As[0][0] + w * 16 * 64;
@@ -1222,6 +1325,9 @@ int gemm_tn_choose_split(int Kout, int N, int M) {
 #define TN_LAUNCH(WM, WN, TM, TN, BKT)                                                                      \
     hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT>),                                                    \
                        dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256), 0, st, a)
+#define TN_LAUNCH_P(WM, WN, TM, TN, BKT, KS)                                                                \
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT, KS, 3>),                                             \
+                       dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256 * KS), 0, st, a)
 #define TN_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                               \
     hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT, KS>),                                                \
                        dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256 * KS), 0, st, a)
@@ -1247,6 +1353,9 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     case 4: TN_LAUNCH(4, 1, 1, 1, 16); break;
     case 6: TN_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;    // 8 waves on 64 x 64: two wave groups split every slab's batch rows
     case 7: TN_LAUNCH_KS(2, 2, 1, 1, 64, 2); break;    // ... with 64-row slabs
+    case 12: TN_LAUNCH_P(2, 2, 1, 1, 32, 1); break;    // software-pipelined slab loop (PIPE = 3), 4 waves
+    case 16: TN_LAUNCH_P(2, 2, 1, 1, 32, 2); break;    // ... 8 waves (K split)
+    case 17: TN_LAUNCH_P(2, 2, 1, 1, 64, 2); break;    // ... 64-row slabs
     default: TN_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());

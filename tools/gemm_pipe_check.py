@@ -6,9 +6,10 @@ import numpy as np
 import ps_amd
 from ps_amd import native as N
 L = N.lib()
-def run(cfg, shape):
+def run(cfg, shape, tn=0):
     F, D, X, fc, V, B, WS = shape
     L.ps_tune_set(b"gemm_nt_cfg", cfg)
+    L.ps_tune_set(b"gemm_tn_cfg", tn)
     rng = np.random.default_rng(5)
     kv = ps_amd.KVStore(0, 0x5EED); kv.create_embedding([V] * F, D)
     gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
@@ -19,6 +20,7 @@ def run(cfg, shape):
     out = (losses, [kv.get("fc%d.weights" % i) for i in range(len(fc))], kv.get_rows(0, np.arange(V)))
     gm.close(); kv.close()
     L.ps_tune_set(b"gemm_nt_cfg", 0)
+    L.ps_tune_set(b"gemm_tn_cfg", 0)
     return out
 bad = 0
 for shape in [(26, 16, 13, [512, 256, 1], 1000, 4096, 97), (5, 8, 3, [40, 24, 1], 50, 333, 11), (3, 4, 2, [5, 3, 1], 7, 6, 5), (9, 8, 1, [130, 70, 1], 40, 1000, 13), (2, 4, 0, [8, 1], 9, 70, 3)]:
@@ -27,6 +29,11 @@ for shape in [(26, 16, 13, [512, 256, 1], 1000, 4096, 97), (5, 8, 3, [40, 24, 1]
         same = ref[0] == got[0] and all(np.array_equal(a, b) for a, b in zip(ref[1], got[1])) and np.array_equal(ref[2], got[2])
         bad += not same
         print(shape[:5], "cfg %d vs %d:" % (base, pipe), "bit-identical" if same else "MISMATCH  losses %r vs %r" % (ref[0], got[0]))
+    for base, pipe in ((2, 12), (6, 16), (7, 17)):          # k_gemm_tn's pipelined loop
+        ref, got = run(0, shape, base), run(0, shape, pipe)
+        same = ref[0] == got[0] and all(np.array_equal(a, b) for a, b in zip(ref[1], got[1])) and np.array_equal(ref[2], got[2])
+        bad += not same
+        print(shape[:5], "tn cfg %d vs %d:" % (base, pipe), "bit-identical" if same else "MISMATCH  losses %r vs %r" % (ref[0], got[0]))
 # k_gemm_nt16 (16x16x4 MFMAs): another summation grouping inside the instruction, so float32 roundoff apart, not bit-equal
 for shape in [(26, 16, 13, [512, 256, 1], 1000, 4096, 97), (5, 8, 3, [40, 24, 1], 50, 333, 11), (3, 4, 2, [5, 3, 1], 7, 6, 5), (9, 8, 1, [130, 70, 1], 40, 1000, 13), (2, 4, 0, [8, 1], 9, 70, 3)]:
     ref = run(5, shape)
