@@ -638,6 +638,17 @@ template <int VEC>
 __device__ __forceinline__ void update_key(const EmbBwdArgs &a, const UpdParams &upd, uint32_t row, Vec<VEC> &S, int part) {
     float *wp = a.W + (size_t)row * a.D + part * VEC;
     float *sp = a.state + (size_t)row * 2 * a.D + part * VEC;
+    if (upd.kind == PS_UPD_FTRL) {
+        // FtrlUpdater.java:64-74 computes w from the OLD z, n: the row's weights are written, never read (a sixth of the
+        // bytes of a key); :52 skips the whole key when dw[0] == 0 (element 0 lives in part 0)
+        Vec<VEC> w = Vec<VEC>::zero(), s1 = Vec<VEC>::load(sp), s2 = Vec<VEC>::load(sp + a.D);
+        const int lane = threadIdx.x & 63;
+        const float g0 = __shfl(S.get(0), lane - part);
+        if (g0 == 0.f) return;
+        VFOR(i) ftrl_elem(upd, S.get(i), w.at(i), s1.at(i), s2.at(i));
+        w.store(wp); s1.store(sp); s2.store(sp + a.D);
+        return;
+    }
     Vec<VEC> w = Vec<VEC>::load(wp);
     if (upd.kind == PS_UPD_SIMPLE) {
         VFOR(i) w.at(i) = (S.get(i) * -upd.eta) + w.get(i);      // update/SimpleUpdater.java:20-22
@@ -784,7 +795,7 @@ __device__ __forceinline__ void long_key_run(const EmbBwdArgs &a, float *lds /* 
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int d = lane + 64 * q, dc = d < D ? d : 0;
-            wv0[q] = upd ? a.W[(size_t)row * D + dc] : 0.f;
+            wv0[q] = (upd && U.kind != PS_UPD_FTRL) ? a.W[(size_t)row * D + dc] : 0.f;     // (Ftrl writes w, never reads it)
             s10[q] = st ? a.state[(size_t)row * 2 * D + dc] : 0.f;
             s20[q] = st ? a.state[(size_t)row * 2 * D + D + dc] : 0.f;
         }
