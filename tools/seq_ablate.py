@@ -6,7 +6,7 @@ import ps_amd
 from ps_amd import native as N
 from bench import C2, synth_batch
 cfg = dict(C2)
-for abl in (0, 1, 2, 3):
+for abl in (0, 1, 2, 4, 6):
     N.lib().ps_tune_set(b"seq_ablate", abl)
     kv = ps_amd.KVStore(0, cfg["seed"]); kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
     gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
