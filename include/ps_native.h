@@ -111,9 +111,12 @@ int ps_store_create_wide(ps_store_t *s, int64_t wide_size);
  * init +-U(0, 4*sqrt(6)/sqrt(in+out)) / (in+1)  (layer/FcLayer.java:34-50). */
 int ps_store_create_fc(ps_store_t *s, int layer, int in_dims, int out_dims);
 
-/* "default" / "wide.weights" / "wide.bias" / "emF" ... -> updater
+/* "default" / "wide.weights" / "wide.bias" / "emF" / "emF3." ... -> updater
  * (the Map<String,Updater> of model/DNN.java:33, looked up exact-key, then
- * prefix, then "default": store/KVStore.java:242-252). */
+ * prefix, then "default": store/KVStore.java:242-252).  Embedding rows
+ * resolve per FIELD (the lookup of "emF<f>."): up to 4 distinct updaters
+ * over the fields of a table group; a key that names one row ("emF1.3")
+ * makes every update of embedding rows fail with PS_E_UNSUPPORTED. */
 int ps_store_set_updater(ps_store_t *s, const char *key_or_prefix, const ps_updater_t *u);
 
 /* KVStore.get(key) / put(key,val) by reference-style string key:

@@ -297,7 +297,11 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         // PIPE = 3: THREE register sets of operand chunks in flight (the rows of slab kt + 5 are requested while slab kt is
         // multiplied: three slab times of load latency covered instead of two) and everything static: the loop is unrolled
         // by 3, register set and LDS buffer of a slab are both (slab % 3)
+        // PIPE = 4: the pipeline inside a slab only, on TWO LDS buffers (37 KB per 64 x 64 workgroup instead of 55): slab kt + 1 is
+        // written during slab kt, the first fragments of a slab are read behind the barrier (one exposed LDS round trip per slab)
         constexpr int LOOK = PIPE == 2 ? 2 : 1, NS = 2 * LOOK, GS = PIPE == 3 ? 3 : 2;
+        constexpr bool CROSS = PIPE != 4;                   // fragments of the next slab are read across the barrier
+        constexpr int WAHEAD = CROSS ? 2 : 1;               // the slab written while slab kt is multiplied
         static_assert(NG >= LOOK && (2 * NG) % NS == 0, "fragment sets must be back at set 0 after two slabs");
         auto slab = [&](auto p0c, auto fullc, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int kt2, int oca, int ocb, int ona, int onb, int owa, int owb) {
             constexpr int P0 = decltype(p0c)::value;
@@ -305,8 +309,9 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             static_for<NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, P = (P0 + g) % NS, PN = (P0 + g + LOOK) % NS;
                 PS_ORDER();
+                if constexpr (!CROSS && g == 0) fread(FA[P], FB[P], oca, ocb, 0);
                 if constexpr (g + LOOK < NG) fread(FA[PN], FB[PN], oca, ocb, g + LOOK);
-                else if constexpr (FULL) fread(FA[PN], FB[PN], ona, onb, g + LOOK - NG);
+                else if constexpr (FULL && CROSS) fread(FA[PN], FB[PN], ona, onb, g + LOOK - NG);
                 PS_ORDER();
                 static_for<MF>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
@@ -321,8 +326,8 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
                             PS_ORDER();
                             static_for<c1 - c0>([&](auto cc) {
                                 constexpr int c = c0 + decltype(cc)::value;
-                                if (!(PS_GEMM_ABLATE & 32)) swrite1(owa, owb, kt2 + 2, ra, rb, c);
-                                if (!(PS_GEMM_ABLATE & 16)) gload1(kt2 + 2 + GS, ra, rb, c);
+                                if (!(PS_GEMM_ABLATE & 32)) swrite1(owa, owb, kt2 + WAHEAD, ra, rb, c);
+                                if (!(PS_GEMM_ABLATE & 16)) gload1(kt2 + WAHEAD + GS, ra, rb, c);
                             });
                             PS_ORDER();
                         }
@@ -336,7 +341,21 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         constexpr auto I1 = std::integral_constant<int, NG % NS>{};
         constexpr auto YES = std::integral_constant<bool, true>{};
         constexpr auto NO = std::integral_constant<bool, false>{};
-        if constexpr (PIPE == 3) {
+        if constexpr (PIPE == 4) {
+            gload(0, ra0, rb0);
+            gload(1, ra1, rb1);
+            swrite(0, 0, ra0, rb0);
+            gload(2, ra0, rb0);
+            __syncthreads();
+            int kt = 0;
+            for (; kt + 2 <= nk; kt += 2) {
+                slab(I0, YES, ra1, rb1, kt, 0, 0, 0, 0, ASZ, BSZ);
+                __syncthreads();
+                slab(I1, YES, ra0, rb0, kt + 1, ASZ, BSZ, 0, 0, 0, 0);
+                __syncthreads();
+            }
+            if (kt < nk) slab(I0, NO, ra1, rb1, kt, 0, 0, 0, 0, ASZ, BSZ);
+        } else if constexpr (PIPE == 3) {
             static_assert(NG % 2 == 0, "PIPE = 3: an even number of fragment groups per slab (the fragment sets start every slab at set 0)");
             float4 ra2[A_F4], rb2[B_F4];
             gload(0, ra0, rb0);
@@ -440,8 +459,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;       // (4 waves -- the default tiles -- or 8)
     constexpr int LD = BKT + 4;
-    __shared__ __attribute__((aligned(16))) float As[(PIPE ? 3 : 2) * BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[(PIPE ? 3 : 2) * BN * LD];
+    __shared__ __attribute__((aligned(16))) float As[((PIPE && PIPE != 4) ? 3 : 2) * BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[((PIPE && PIPE != 4) ? 3 : 2) * BN * LD];
     // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
     // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
     // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
@@ -851,8 +870,8 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
     constexpr int NTH = 256 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_F4 = (BKT * BM / 4 + NTH - 1) / NTH, B_F4 = (BKT * BN / 4 + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) float As[PIPE ? 3 : 2][BKT * BM];
-    __shared__ __attribute__((aligned(16))) float Ds[PIPE ? 3 : 2][BKT * BN];
+    __shared__ __attribute__((aligned(16))) float As[PIPE == 3 ? 3 : 2][BKT * BM];
+    __shared__ __attribute__((aligned(16))) float Ds[PIPE == 3 ? 3 : 2][BKT * BN];
     // (see k_gemm_nt: every GEMM of the fused step ahead of the sort, the small kernels and the updates; prio 2 / 3: one or
     // two levels below the delta GEMMs of the main chain -- ps_tune_set("tn_prio"))
     if (a.prio == 1) __builtin_amdgcn_s_setprio(3);
@@ -1014,8 +1033,9 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
             static_for<NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, P = g & 1;
                 PS_ORDER();
+                if constexpr (PIPE == 4 && g == 0) fread(FA[0], FB[0], cur, 0);      // (two LDS buffers: a slab's first fragments behind the barrier)
                 if constexpr (g + 1 < NG) fread(FA[P ^ 1], FB[P ^ 1], cur, g + 1);
-                else if constexpr (FULL) fread(FA[P ^ 1], FB[P ^ 1], nxt, 0);
+                else if constexpr (FULL && PIPE == 3) fread(FA[P ^ 1], FB[P ^ 1], nxt, 0);
                 PS_ORDER();
                 static_for<MF>([&](auto mc) {
                     constexpr int m = decltype(mc)::value;
@@ -1026,8 +1046,8 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
                             PS_ORDER();
                             static_for<c1 - c0>([&](auto cc) {
                                 constexpr int c = c0 + decltype(cc)::value;
-                                swrite1(wr, kt2 + 2, ra, rb, c);
-                                gload1(kt2 + 5, ra, rb, c);
+                                swrite1(wr, kt2 + (PIPE == 3 ? 2 : 1), ra, rb, c);
+                                gload1(kt2 + (PIPE == 3 ? 5 : 3), ra, rb, c);
                             });
                             PS_ORDER();
                         }
@@ -1042,6 +1062,21 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
         constexpr auto B0 = std::integral_constant<int, 0>{};
         constexpr auto B1 = std::integral_constant<int, 1>{};
         constexpr auto B2 = std::integral_constant<int, 2>{};
+        if constexpr (PIPE == 4) {
+            gload(0, ra0, rb0);
+            gload(1, ra1, rb1);
+            swrite(0, 0, ra0, rb0);
+            gload(2, ra0, rb0);
+            __syncthreads();
+            int kt = 0;
+            for (; kt + 2 <= nk; kt += 2) {
+                slab(YES, ra1, rb1, kt, B0, B1, B1);
+                __syncthreads();
+                slab(YES, ra0, rb0, kt + 1, B1, B0, B0);
+                __syncthreads();
+            }
+            if (kt < nk) slab(NO, ra1, rb1, kt, B0, B1, B1);
+        } else {
         gload(0, ra0, rb0);
         gload(1, ra1, rb1);
         gload(2, ra2, rb2);
@@ -1066,6 +1101,7 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
             slab(NO, ra0, rb0, kt + 1, B1, B2, B0);
         } else if (nk - kt == 1) {
             slab(NO, ra2, rb2, kt, B0, B1, B2);
+        }
         }
     }
     if (KS > 1) {           // the two wave groups' partial tiles, added through LDS (see k_gemm_nt)
@@ -1139,9 +1175,9 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
         // gemm_ks: the in-workgroup K split where 64 x 64 tiles give at most ~one workgroup per CU
         if (N <= 32) cfg = 8;
         else if (tiles(64, 128) >= 2048) cfg = 6;
-        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = g_gemm_pipe == 3 ? 113 : g_gemm_pipe ? 53 : 13;
+        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = g_gemm_pipe == 4 ? 133 : g_gemm_pipe == 3 ? 113 : g_gemm_pipe ? 53 : 13;
         else if (g_gemm_ks && tiles(64, 64) <= 320 && K % 16 == 0) cfg = g_gemm_pipe == 3 ? 120 : g_gemm_pipe ? 60 : 20;
-        else cfg = g_gemm_pipe == 3 ? 105 : g_gemm_pipe ? 45 : 5;
+        else cfg = g_gemm_pipe == 4 ? 125 : g_gemm_pipe == 3 ? 105 : g_gemm_pipe ? 45 : 5;
     }
     switch (cfg) {
     case 1: NT_LAUNCH(2, 2, 2, 2, 16); break;
@@ -1174,6 +1210,8 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 105: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;      // PIPE = 3
     case 113: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 32, 1, 3>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 120: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 2, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
+    case 125: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;      // PIPE = 4
+    case 133: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 32, 1, 4>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
     case 86: NT_LAUNCH_P2(2, 2, 1, 2, 32, 1); break;
     case 93: NT_LAUNCH_P2(4, 2, 1, 1, 32, 1); break;
@@ -1235,9 +1273,10 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
     return PS_OK;
 }
 
+int g_dw_late = 0;         // ps_tune_set("dw_late", 1): the first dW GEMM starts with the NEXT delta GEMM (the first delta GEMM runs alone)
 int g_tn_prio = 1;          // ps_tune_set("tn_prio", 0 / 2 / 3): the dW GEMMs' wave priority: none / one / two levels under the main chain's; +8: dW_0 only
 int g_main_prio = 1;        // ps_tune_set("main_prio", 0): no raised wave priority for the fused step's main-chain kernels
-int g_gemm_pipe = 3;        // ps_tune_set("gemm_pipe", 0 / 1): round 2's slab loop / the pipelined one with two register sets
+int g_gemm_pipe = 4;        // ps_tune_set("gemm_pipe", 0 / 1 / 3): round 2's slab loop / pipelined across the barrier on three LDS buffers with two / three register sets; 4 (default): pipelined inside the slab, two LDS buffers
 int g_gemm_ks = 0;          // ps_tune_set("gemm_ks", 1): 8 waves (K split inside the workgroup) on shapes with <= ~one 64 x 64 tile per CU
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
@@ -1328,6 +1367,9 @@ int gemm_tn_choose_split(int Kout, int N, int M) {
 #define TN_LAUNCH_P(WM, WN, TM, TN, BKT, KS)                                                                \
     hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT, KS, 3>),                                             \
                        dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256 * KS), 0, st, a)
+#define TN_LAUNCH_P4(WM, WN, TM, TN, BKT, KS)                                                               \
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT, KS, 4>),                                             \
+                       dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256 * KS), 0, st, a)
 #define TN_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                               \
     hipLaunchKernelGGL((k_gemm_tn<WM, WN, TM, TN, BKT, KS>),                                                \
                        dim3(cdiv(Kout, WM * TM * 32) * cdiv(N, WN * TN * 32) * nsplit), dim3(256 * KS), 0, st, a)
@@ -1356,6 +1398,9 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     case 12: TN_LAUNCH_P(2, 2, 1, 1, 32, 1); break;    // software-pipelined slab loop (PIPE = 3), 4 waves
     case 16: TN_LAUNCH_P(2, 2, 1, 1, 32, 2); break;    // ... 8 waves (K split)
     case 17: TN_LAUNCH_P(2, 2, 1, 1, 64, 2); break;    // ... 64-row slabs
+    case 22: TN_LAUNCH_P4(2, 2, 1, 1, 32, 1); break;   // pipelined inside the slab, two LDS buffers (PIPE = 4), 4 waves
+    case 26: TN_LAUNCH_P4(2, 2, 1, 1, 32, 2); break;   // ... 8 waves (K split)
+    case 27: TN_LAUNCH_P4(2, 2, 1, 1, 64, 2); break;   // ... 64-row slabs
     default: TN_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());

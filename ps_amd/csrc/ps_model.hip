@@ -654,6 +654,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     const bool dw_split = g_dw_split && dev_wait && dev_flags && g_tail_dev && g_tail_fused && sw != st && s0 != st && s0 != sw && sl == s0 &&
                           !m->profile && m->cur_nnz > 0 && !m->sh.active;
     bool dw_split_done = false; unsigned int dw_split_epoch = 0;
+    int deferred_l = -1;                      // dw_late: the dW GEMM held back for the next release
     bool sw_gated = false;                    // side chain 1 already sits behind a spinner: later dW GEMMs wait at their own start
     bool s0_joined = false;                   // the last delta GEMM's launch carries the join with side chain 0
     m->head_ev = nullptr;
@@ -756,6 +757,10 @@ int enqueue_backward(ps_model *m, bool apply) {
         // path).  The dense update then also waits for "side chain 0's dW GEMM is done" (start_flag[11]).
         const bool split_here = dw_split && first_release && l > 0;
         if (split_here) dws = s0;
+        // dw_late: the FIRST dW GEMM is held back until the NEXT delta GEMM starts (one spinner for both dW GEMMs, on that
+        // launch's epoch): the first delta GEMM of the critical chain runs alone instead of sharing the matrix pipes with a
+        // dW GEMM that has 20 us of slack on its side chain
+        const bool defer_this = g_dw_late && dev_wait && !dw_split && sl != sw && l > 0 && first_release;
         LaunchOpts lo, tn_lo;
         if (dev_wait) {
             // released from the device: this delta GEMM's first workgroup announces "everything before me on the main
@@ -801,6 +806,7 @@ int enqueue_backward(ps_model *m, bool apply) {
             // so their workgroups check the flag themselves when they start (one load; start_wait in ps_common.h): no
             // spinner launch between two dW GEMMs (stamps: 7.4 us from the end of dW_1 to the start of dW_0 with it).
             if (split_here) {}       // (side chain 0 is parked behind its own spinner below)
+            else if (defer_this) {}  // (released together with the next one)
             else if (!sw_gated || !g_tn_start_wait) { PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw, werr, 0)); sw_gated = true; }
             else { tn_lo.wait = m->start_flag; tn_lo.wait_val = m->start_epoch; }
             if (first_release) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
@@ -810,6 +816,17 @@ int enqueue_backward(ps_model *m, bool apply) {
                 first_release = false;
             }
             main_dirty = false;
+        }
+        if (defer_this) { deferred_l = l; continue; }
+        if (deferred_l >= 0) {
+            FcParams &dp = s->fc[deferred_l];
+            FcBuf &db = m->fc[deferred_l];
+            LaunchOpts dlo;
+            dlo.prio = gemm_prio(m) ? (g_tn_prio & 7) : 0;
+            Prof pfd(m, nw[deferred_l]);
+            PSCHK(gemm_tn_splitk(db.A, db.ldA, db.ldA, db.dOut, db.ldD, db.ldD, db.part, db.ldp, db.part_stride, dp.K + 1, dp.N, B,
+                                 db.nsplit, nullptr, dws, &dlo, werr));
+            deferred_l = -1;
         }
         Prof pf2(m, nw[l]);
         // dW (+ db through the ones column), split over the batch

@@ -14,6 +14,8 @@ leave identical tables:
   * ps_tune_set("tn_start_wait", 0)           (a spinner launch in front of every dW GEMM, not only the first)
   * ps_tune_set("tail_defer", 0)              (the step ends behind its dense update; default: the NEXT use of the store's stream pays the join)
   * ps_tune_set("dw_split", 1)                (the first dW GEMM on side chain 0 -- measured slower, off)
+  * ps_tune_set("dw_late", 1)                 (the first dW GEMM released with the next delta GEMM)
+  * ps_tune_set("gemm_pipe", 0) / gemm_8w   (other slab loops / tiles of the SAME contraction order: k_gemm_nt / k_gemm_tn)
   * profile mode                              (everything on ONE stream: the serial order is the definition)
 Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
 consecutive plans must still equal the fused step (the map is re-zeroed when the epoch wraps)."""
@@ -31,6 +33,9 @@ def batches(rng, n, B, F, X, V, WS):
         E = np.minimum(rng.zipf(1.2, (B, F)) - 1, V - 1).astype(np.int64)
         out.append((E, rng.standard_normal((B, X)).astype(f32), (rng.random(B) < 0.3).astype(f32), E % WS))
     return out
+
+
+DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "dw_late": 0, "gemm_pipe": 4, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
 
 
 def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
@@ -56,7 +61,7 @@ def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
         return out
     finally:
         for k in knobs:
-            N.lib().ps_tune_set(k.encode(), 0 if k in ("dw_split", "fwd_pair") else 1)
+            N.lib().ps_tune_set(k.encode(), DEFAULTS.get(k, 1))
 
 
 @pytest.mark.parametrize("kind,F,D,X,fc,V,B", [("dnn", 4, 8, 3, [16, 1], 50, 200), ("widedeep", 6, 16, 5, [64, 32, 1], 3000, 2048),
@@ -74,6 +79,9 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "round 2's tail": ({"tail_fused": 0, "tn_start_wait": 0}, False),
                 "first dW GEMM on side chain 0": ({"dw_split": 1}, False),
                 "first two forward GEMMs in one launch": ({"fwd_pair": 1}, False),
+                "first dW GEMM held back to the next delta GEMM": ({"dw_late": 1}, False),
+                "round 2's GEMM slab loop": ({"gemm_pipe": 0}, False),
+                "8-wave 128 x 64 tiles": ({"gemm_8w": 1}, False),
                 "the embedding update holds the join with the dense update": ({"tail_defer": 0}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
@@ -87,6 +95,30 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                     np.testing.assert_array_equal(x, y, err_msg=name)
             else:
                 np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+@pytest.mark.parametrize("knob,plain,piped", [("gemm_nt_cfg", 5, 45), ("gemm_nt_cfg", 5, 85), ("gemm_nt_cfg", 5, 105), ("gemm_nt_cfg", 6, 46),
+                                              ("gemm_nt_cfg", 7, 47), ("gemm_nt_cfg", 8, 48), ("gemm_nt_cfg", 13, 113), ("gemm_nt_cfg", 20, 120), ("gemm_nt_cfg", 5, 125), ("gemm_nt_cfg", 13, 133),
+                                              ("gemm_tn_cfg", 2, 12), ("gemm_tn_cfg", 6, 16), ("gemm_tn_cfg", 7, 17),
+                                              ("gemm_tn_cfg", 2, 22), ("gemm_tn_cfg", 6, 26), ("gemm_tn_cfg", 7, 27)])
+def test_pipelined_gemm_loops_are_bit_identical(knob, plain, piped):
+    """The software-pipelined slab loops of k_gemm_nt / k_gemm_tn (fragment prefetch, three LDS buffers and register sets,
+    LDS writes dealt out over the slab) multiply the same products in the same order per accumulator as the plain loop on the
+    same tiles: six training steps leave identical tables, on shapes with ragged M, N and K."""
+    for kind, F, D, X, fc, V, B in (("widedeep", 6, 16, 5, [64, 32, 1], 3000, 2048), ("dnn", 9, 8, 1, [130, 70, 1], 40, 1000),
+                                    ("dnn", 3, 4, 2, [5, 3, 1], 7, 6)):
+        rng = np.random.default_rng(F * 100 + B)
+        WS = 97
+        data = batches(rng, 6, B, F, X, V, WS)
+        ref = run(kind, {knob: plain}, False, data, F, D, X, fc, V, B, WS)
+        got = run(kind, {knob: piped}, False, data, F, D, X, fc, V, B, WS)
+        assert got[0] == ref[0], "%s %d vs %d: losses %s vs %s" % (knob, plain, piped, got[0], ref[0])
+        for a, b in zip(ref[1:], got[1:]):
+            if isinstance(a, list):
+                for x, y in zip(a, b):
+                    np.testing.assert_array_equal(x, y)
+            else:
+                np.testing.assert_array_equal(a, b)
 
 
 def test_plan_epoch_wraps():

@@ -24,7 +24,7 @@ def run(cfg, shape, tn=0):
     return out
 bad = 0
 for shape in [(26, 16, 13, [512, 256, 1], 1000, 4096, 97), (5, 8, 3, [40, 24, 1], 50, 333, 11), (3, 4, 2, [5, 3, 1], 7, 6, 5), (9, 8, 1, [130, 70, 1], 40, 1000, 13), (2, 4, 0, [8, 1], 9, 70, 3)]:
-    for base, pipe in ((5, 45), (6, 46), (7, 47), (8, 48), (13, 53), (20, 60), (5, 85), (6, 86), (13, 93), (20, 90), (5, 105), (13, 113), (20, 120)):
+    for base, pipe in ((5, 45), (6, 46), (7, 47), (8, 48), (13, 53), (20, 60), (5, 85), (6, 86), (13, 93), (20, 90), (5, 105), (13, 113), (20, 120), (5, 125), (13, 133)):
         ref, got = run(base, shape), run(pipe, shape)
         same = ref[0] == got[0] and all(np.array_equal(a, b) for a, b in zip(ref[1], got[1])) and np.array_equal(ref[2], got[2])
         bad += not same
