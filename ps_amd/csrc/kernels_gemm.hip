@@ -1175,9 +1175,9 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
         // gemm_ks: the in-workgroup K split where 64 x 64 tiles give at most ~one workgroup per CU
         if (N <= 32) cfg = 8;
         else if (tiles(64, 128) >= 2048) cfg = 6;
-        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = g_gemm_pipe == 4 ? 133 : g_gemm_pipe == 3 ? 113 : g_gemm_pipe ? 53 : 13;
+        else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = g_gemm_pipe == 5 ? 143 : g_gemm_pipe == 4 ? 133 : g_gemm_pipe == 3 ? 113 : g_gemm_pipe ? 53 : 13;
         else if (g_gemm_ks && tiles(64, 64) <= 320 && K % 16 == 0) cfg = g_gemm_pipe == 3 ? 120 : g_gemm_pipe ? 60 : 20;
-        else cfg = g_gemm_pipe == 4 ? 125 : g_gemm_pipe == 3 ? 105 : g_gemm_pipe ? 45 : 5;
+        else cfg = g_gemm_pipe == 5 ? 140 : g_gemm_pipe == 4 ? 125 : g_gemm_pipe == 3 ? 105 : g_gemm_pipe ? 45 : 5;
     }
     switch (cfg) {
     case 1: NT_LAUNCH(2, 2, 2, 2, 16); break;
@@ -1212,6 +1212,11 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 120: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 2, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 125: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;      // PIPE = 4
     case 133: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 32, 1, 4>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
+    case 140: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 16-wide slabs: 30 KB / 20 KB of LDS
+    case 141: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;
+    case 143: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;    // 8 waves, 128 x 64: 46 KB
+    case 144: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;    // 64 x 128
+    case 142: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 64, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 64-wide slabs: 70 KB
     case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
     case 86: NT_LAUNCH_P2(2, 2, 1, 2, 32, 1); break;
     case 93: NT_LAUNCH_P2(4, 2, 1, 1, 32, 1); break;
@@ -1276,7 +1281,7 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
 int g_dw_late = 0;         // ps_tune_set("dw_late", 1): the first dW GEMM starts with the NEXT delta GEMM (the first delta GEMM runs alone)
 int g_tn_prio = 1;          // ps_tune_set("tn_prio", 0 / 2 / 3): the dW GEMMs' wave priority: none / one / two levels under the main chain's; +8: dW_0 only
 int g_main_prio = 1;        // ps_tune_set("main_prio", 0): no raised wave priority for the fused step's main-chain kernels
-int g_gemm_pipe = 4;        // ps_tune_set("gemm_pipe", 0 / 1 / 3): round 2's slab loop / pipelined across the barrier on three LDS buffers with two / three register sets; 4 (default): pipelined inside the slab, two LDS buffers
+int g_gemm_pipe = 5;        // ps_tune_set("gemm_pipe", ...): 0 round 2's slab loop; 1 / 3 pipelined across the barrier on three LDS buffers with two / three register sets (32-wide slabs, 55 KB); 4 pipelined inside the slab, two buffers (37 KB); 5 (default): as 3 on 16-wide slabs (30 KB)
 int g_gemm_ks = 0;          // ps_tune_set("gemm_ks", 1): 8 waves (K split inside the workgroup) on shapes with <= ~one 64 x 64 tile per CU
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again

@@ -35,7 +35,7 @@ def batches(rng, n, B, F, X, V, WS):
     return out
 
 
-DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "dw_late": 0, "gemm_pipe": 4, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
+DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "dw_late": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
 
 
 def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
@@ -98,7 +98,7 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
 
 
 @pytest.mark.parametrize("knob,plain,piped", [("gemm_nt_cfg", 5, 45), ("gemm_nt_cfg", 5, 85), ("gemm_nt_cfg", 5, 105), ("gemm_nt_cfg", 6, 46),
-                                              ("gemm_nt_cfg", 7, 47), ("gemm_nt_cfg", 8, 48), ("gemm_nt_cfg", 13, 113), ("gemm_nt_cfg", 20, 120), ("gemm_nt_cfg", 5, 125), ("gemm_nt_cfg", 13, 133),
+                                              ("gemm_nt_cfg", 7, 47), ("gemm_nt_cfg", 8, 48), ("gemm_nt_cfg", 13, 113), ("gemm_nt_cfg", 20, 120), ("gemm_nt_cfg", 5, 125), ("gemm_nt_cfg", 13, 133), ("gemm_nt_cfg", 3, 140), ("gemm_nt_cfg", 3, 141),
                                               ("gemm_tn_cfg", 2, 12), ("gemm_tn_cfg", 6, 16), ("gemm_tn_cfg", 7, 17),
                                               ("gemm_tn_cfg", 2, 22), ("gemm_tn_cfg", 6, 26), ("gemm_tn_cfg", 7, 27)])
 def test_pipelined_gemm_loops_are_bit_identical(knob, plain, piped):
