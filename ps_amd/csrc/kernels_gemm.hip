@@ -1216,6 +1216,8 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 141: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;
     case 143: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;    // 8 waves, 128 x 64: 46 KB
     case 144: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;    // 64 x 128
+    case 145: PS_LAUNCH_EV((k_gemm_nt<2, 1, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 32)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 64 x 32
+    case 146: PS_LAUNCH_EV((k_gemm_nt<1, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 32) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 32 x 64
     case 142: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 64, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 64-wide slabs: 70 KB
     case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
     case 86: NT_LAUNCH_P2(2, 2, 1, 2, 32, 1); break;
