@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
         if (kt < nk) compute(0);
     } else {
         constexpr int SPW = BKT / 2 / KS;                   // batch-row pairs (MFMA k steps) per wave and slab
-        constexpr int GM = SPW >= 4 ? 4 : SPW;              // ... per fragment group
+        constexpr int GM = SPW % 8 == 0 ? 4 : SPW % 4 == 0 ? 2 : 1;      // ... per fragment group (an even number of groups per slab)
         constexpr int NG = SPW / GM, MF = GM * TM * TN, NCH = A_F4 + B_F4;
         static_assert(SPW % GM == 0 && NG % 2 == 0, "an even number of fragment groups per slab");
         float4 ra2[A_F4], rb2[B_F4];
@@ -1408,6 +1408,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     case 22: TN_LAUNCH_P4(2, 2, 1, 1, 32, 1); break;   // pipelined inside the slab, two LDS buffers (PIPE = 4), 4 waves
     case 26: TN_LAUNCH_P4(2, 2, 1, 1, 32, 2); break;   // ... 8 waves (K split)
     case 27: TN_LAUNCH_P4(2, 2, 1, 1, 64, 2); break;   // ... 64-row slabs
+    case 32: TN_LAUNCH_P(2, 2, 1, 1, 16, 1); break;    // PIPE = 3 on 16-row slabs (24 KB of LDS), 4 waves
     default: TN_LAUNCH(4, 1, 1, 1, 32); break;
     }
     HIPCHK(hipGetLastError());
