@@ -375,10 +375,12 @@ def test_predict_matches_forward(orc):
     gm.close(); kv.close()
 
 
-def test_sharded_path_n1_equals_fused_step(orc):
+@pytest.mark.parametrize("per_field", [False, True])
+def test_sharded_path_n1_equals_fused_step(orc, per_field):
     """The PS exchange with one shard (every collective the identity) is the fused step, bit for bit:
     pull -> train on the cached rows -> push -> owner mean over 1 worker -> updater; dense/wide g/1.
-    Also with two plan contexts (two models on one store) and step t+1 prepared before step t finishes."""
+    Also with two plan contexts (two models on one store) and step t+1 prepared before step t finishes.
+    per_field: "emF1." -> Ftrl, "emF3" -> another Adam (the owner-side push resolves the updater per field like the fused step)."""
     import ps_amd
     from ps_amd.sharded import HipBackend, LocalComm, ShardedWorker
     F, D, X, fc, V, B, WS = 5, 8, 3, [16, 8, 1], 40, 96, 31
@@ -386,6 +388,9 @@ def test_sharded_path_n1_equals_fused_step(orc):
     for nctx in (0, 1, 2, 3):
         kv = ps_amd.KVStore(0, SEED)
         kv.create_embedding([V] * F, D)
+        if per_field:
+            kv.set_updater("emF1.", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))
+            kv.set_updater("emF3", ps_amd.AdamUpdater(0.02, 0.8))
         gms = [ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B) for _ in range(max(nctx, 1))]
         worker = ShardedWorker(HipBackend(gms), LocalComm())
         rng = np.random.default_rng(4)
