@@ -116,7 +116,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     // write: the slab-(t+2) loads just issued were waited for as well, i.e. the second register set bought nothing
     // (measured: 42..53 % of the f32 MFMA peak on the FC shapes whatever the tile shape).
     const float *pa[A_F4], *pb[B_F4];
-    int ca[A_F4], cb[B_F4];
+    int ca[A_F4], cb[B_F4], ar[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
         const int e = tid + i * NTH;
@@ -124,6 +124,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         r = r < a.a_rows ? r : a.a_rows - 1;
         ca[i] = (e % RF4) * 4;
         pa[i] = a.A + (size_t)r * a.lda;
+        ar[i] = r;
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
@@ -133,12 +134,26 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         cb[i] = (e % RF4) * 4;
         pb[i] = a.Bt + (size_t)r * a.ldb;
     }
+    // PS_GEMM_ABLATE & 512 (measurement): the A chunk of (row r, slab kt) comes from a pseudo-random 64-byte row of a big table
+    // (a.mask, a.ldmask rows of 16 floats; half of the draws from a 4096-row hot set) -- what fusing the embedding gather into
+    // the first FC GEMM's A-operand load would do to its loop
+    auto emu_src = [&](int r, int kt2, int chunk) -> const float * {
+        unsigned h = (unsigned)r * 2654435761u + (unsigned)kt2 * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        unsigned idx = h % (unsigned)a.ldmask;
+        if (h & 0x10000u) idx &= 4095u;
+        return a.mask + (size_t)idx * 16 + (chunk & 12);
+    };
     // (the mask is applied when the registers go to LDS, a slab or two later: touching the loaded value in gload
     // would put the wait for it right behind the load)
     auto gload = [&](int kt, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
         const int k0 = kt * BKT;
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) { const int c = k0 + ca[i]; ra[i] = *reinterpret_cast<const float4 *>(pa[i] + (c < a.K ? c : a.K - 4)); }
+        for (int i = 0; i < A_F4; ++i) {
+            const int c = k0 + ca[i];
+            if (PS_GEMM_ABLATE & 512) ra[i] = *reinterpret_cast<const float4 *>(emu_src(ar[i], kt, ca[i]));
+            else ra[i] = *reinterpret_cast<const float4 *>(pa[i] + (c < a.K ? c : a.K - 4));
+        }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) { const int c = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (c < a.K ? c : a.K - 4)); }
     };
@@ -245,7 +260,11 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         // chunk c of a slab: c < A_F4 -> A chunk c, else B chunk c - A_F4
         auto gload1 = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int c) {
             const int k0 = kt2 * BKT;
-            if (c < A_F4) { const int cc = k0 + ca[c]; ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4)); }
+            if (c < A_F4) {
+                const int cc = k0 + ca[c];
+                if (PS_GEMM_ABLATE & 512) ra[c] = *reinterpret_cast<const float4 *>(emu_src(ar[c], kt2, ca[c]));
+                else ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4));
+            }
             else { const int i = c - A_F4; const int cc = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (cc < a.K ? cc : a.K - 4)); }
         };
         auto swrite1 = [&](int oa, int ob, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4], int c) {

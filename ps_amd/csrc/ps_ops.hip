@@ -305,12 +305,19 @@ extern "C" int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int n
     (void)ea;
     PSCHK(launch_fill(A, (int64_t)M * Kp, 0.5f, st));
     PSCHK(launch_fill(B, kind == 0 ? (int64_t)N * Kp : (int64_t)M * Np, 0.25f, st));
+    // PS_GEMM_GATHER_EMU=<rows> (with a PS_GEMM_ABLATE & 512 build): a table of that many 64-byte rows for the emulated gather
+    float *emu = nullptr;
+    int emu_rows = 0;
+    if (const char *e = getenv("PS_GEMM_GATHER_EMU")) {
+        emu_rows = atoi(e);
+        if (emu_rows > 0) { HIPCHK(hipMalloc((void **)&emu, sizeof(float) * 16 * (size_t)emu_rows)); PSCHK(launch_fill(emu, (int64_t)emu_rows * 16, 0.5f, st)); }
+    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     int rc = PS_OK;
     for (int it = -2; it < iters && rc == PS_OK; ++it) {
         if (it == 0) HIPCHK(hipEventRecord(e0, st));
-        if (kind == 0) rc = gemm_nt(A, Kp, M, B, Kp, N, Cc, Np, M, N, Kp, EPI_RELU, nullptr, 0, 0, nullptr, st);
+        if (kind == 0) rc = gemm_nt(A, Kp, M, B, Kp, N, Cc, Np, M, N, Kp, EPI_RELU, emu, emu_rows, 0, nullptr, st);
         else rc = gemm_tn_splitk(A, Kp, Kp, B, Np, Np, Cc, Np, (int64_t)Kp * Np, K, N, M, nsplit, nullptr, st);
     }
     HIPCHK(hipEventRecord(e1, st));
@@ -320,6 +327,7 @@ extern "C" int ps_bench_gemm(ps_store_t *s, int kind, int M, int N, int K, int n
     *avg_ms_out = ms / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(A); (void)hipFree(B); (void)hipFree(Cc);
+    if (emu) (void)hipFree(emu);
     return rc;
 }
 
