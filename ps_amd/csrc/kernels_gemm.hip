@@ -42,9 +42,6 @@ struct NtArgs {
     const unsigned int *wait_flag; unsigned int wait_val;   // workgroup 0 ends only once *wait_flag has reached wait_val
     int prio;                                               // raise the waves' priority (a main-chain launch of the fused step)
     WaitBound bound;                                        // ... or gives up after bound.ticks and reports it in *bound.err
-    const unsigned int *sw_flag[2]; unsigned int sw_val[2]; // every workgroup waits for these when it starts (LaunchOpts.swait)
-    const int64_t *g_ids; const int64_t *g_row_base; const float *g_W; int g_F;      // gathered A operand (LaunchOpts.g_*)
-    const float *g_X; int g_nx;
 };
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
@@ -95,9 +92,8 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 //   * the masks / LDS writes / next global loads are dealt out one chunk per MFMA of the first group, so the VALU work sits
 //     in the shadow of a running MFMA instead of between two groups.
 // Same products in the same order per accumulator as PIPE = 0: bit-identical results.
-template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0, int GATHER = 0>
-__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs, uint32_t *const Ks = nullptr) {
-    static_assert(!GATHER || (PIPE == 3 && BKT == 16), "the gathered A operand: 16-wide slabs (one embedding row of D = 16 per slab), PIPE = 3");
+template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0>
+__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs) {
     constexpr int ASZ = WM * TM * 32 * (BKT + 4), BSZ = WN * TN * 32 * (BKT + 4);      // floats per LDS buffer
     constexpr int NTH = WM * WN * 64 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -120,9 +116,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     // write: the slab-(t+2) loads just issued were waited for as well, i.e. the second register set bought nothing
     // (measured: 42..53 % of the f32 MFMA peak on the FC shapes whatever the tile shape).
     const float *pa[A_F4], *pb[B_F4];
-    int ca[A_F4], cb[B_F4], ar[A_F4], atr[A_F4], xo[A_F4];
-    int xs1[GATHER ? A_F4 : 1], xs2[GATHER ? A_F4 : 1], xvm[GATHER ? A_F4 : 1][4];      // (gathered operand: the dense slab's shift and masks)
-    float xon[GATHER ? A_F4 : 1][4];
+    int ca[A_F4], cb[B_F4], ar[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
         const int e = tid + i * NTH;
@@ -131,17 +125,6 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         ca[i] = (e % RF4) * 4;
         pa[i] = a.A + (size_t)r * a.lda;
         ar[i] = r;
-        atr[i] = e / RF4 < BM ? e / RF4 : BM - 1;
-        xo[i] = GATHER ? (ca[i] + 4 <= a.g_nx ? ca[i] : (a.g_nx >= 4 ? a.g_nx - 4 : 0)) : 0;
-        if (GATHER) {
-            const int sh = (ca[i] - xo[i]) & 3;               // (0 when the whole chunk lies past the features: its masks are all "not a feature")
-            xs1[i] = (sh & 1) ? -1 : 0; xs2[i] = (sh & 2) ? -1 : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xvm[i][j] = ca[i] + j < a.g_nx ? -1 : 0;
-                xon[i][j] = ca[i] + j == a.g_nx ? 1.f : 0.f;
-            }
-        }
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
@@ -280,20 +263,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             if (c < A_F4) {
                 const int cc = k0 + ca[c];
                 if (PS_GEMM_ABLATE & 512) ra[c] = *reinterpret_cast<const float4 *>(emu_src(ar[c], kt2, ca[c]));
-                else if constexpr (GATHER) {
-                    // slab kt2 < g_F of tile row r: the embedding row of field kt2 (its key sits in LDS since the prologue);
-                    // later slabs (dense features, ones column, padding): the activation buffer as usual.  ONE load either
-                    // way (a select of the address, no branch around a load)
-                    const int fk = kt2 < a.g_F ? kt2 : a.g_F - 1;
-                    const float *gs = a.g_W + (size_t)Ks[atr[c] * 32 + fk] * 16 + ca[c];
-                    // the dense slab: four of the row's features from an offset that keeps the load inside the row (xo: per thread,
-                    // fixed); the chunk is put together from them, the ones column and zeros when it goes to LDS (swrite1)
-                    const float *xs = a.g_X + (size_t)ar[c] * a.g_nx + xo[c];
-                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                    const f4u v = *reinterpret_cast<const f4u *>(kt2 < a.g_F ? gs : xs);
-                    ra[c] = make_float4(v.x, v.y, v.z, v.w);
-                    (void)cc;
-                } else ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4));
+                else ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4));
             }
             else { const int i = c - A_F4; const int cc = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (cc < a.K ? cc : a.K - 4)); }
         };
@@ -301,25 +271,8 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             const int k0 = kt2 * BKT;
             if (c < A_F4) {
                 const int e = tid + c * NTH;
-                float4 v = masked(ra[c], k0 + ca[c]);
-                if constexpr (GATHER) {
-                    // BRANCH-FREE (bit selects; a branch between the loads makes hipcc wait for every load in flight at the next
-                    // wait: measured 41.7 us for this launch instead of 21).  Gathered slab: EmbeddingLayer's Relu
-                    // (layer/EmbeddingLayer.java:53).  Dense slab (ConcatLayer.forward): column q + j = feature q + j | 1 (the bias
-                    // column) | 0 -- the four loaded features shifted down by q - xo (two conditional shifts), then the per-thread
-                    // masks.  Slabs past the end of K: zeros (nobody reads them).
-                    auto bsel = [](int m, float x, float y) -> float { return __int_as_float((__float_as_int(x) & m) | (__float_as_int(y) & ~m)); };
-                    const float l0 = ra[c].x, l1 = ra[c].y, l2 = ra[c].z, l3 = ra[c].w;
-                    const float s0 = bsel(xs1[c], l1, l0), s1 = bsel(xs1[c], l2, l1), s2 = bsel(xs1[c], l3, l2), s3 = l3;
-                    const float t0 = bsel(xs2[c], s2, s0), t1 = bsel(xs2[c], s3, s1);
-                    const float x0 = bsel(xvm[c][0], t0, xon[c][0]), x1 = bsel(xvm[c][1], t1, xon[c][1]);
-                    const float x2 = bsel(xvm[c][2], s2, xon[c][2]), x3 = bsel(xvm[c][3], s3, xon[c][3]);
-                    const int gm = kt2 < a.g_F ? -1 : 0, pm = kt2 > a.g_F ? -1 : 0;
-                    v.x = bsel(gm, fmaxf(l0, 0.f), bsel(pm, 0.f, x0)); v.y = bsel(gm, fmaxf(l1, 0.f), bsel(pm, 0.f, x1));
-                    v.z = bsel(gm, fmaxf(l2, 0.f), bsel(pm, 0.f, x2)); v.w = bsel(gm, fmaxf(l3, 0.f), bsel(pm, 0.f, x3));
-                }
                 if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + (e % RF4) * 4) = v;
+                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + (e % RF4) * 4) = masked(ra[c], k0 + ca[c]);
             } else {
                 const int i = c - A_F4, e = tid + i * NTH;
                 if ((BN * RF4) % NTH == 0 || e < BN * RF4)
@@ -424,42 +377,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         } else if constexpr (PIPE == 3) {
             static_assert(NG % 2 == 0, "PIPE = 3: an even number of fragment groups per slab (the fragment sets start every slab at set 0)");
             float4 ra2[A_F4], rb2[B_F4];
-            if constexpr (GATHER) {
-                // keys of this row panel: row_base[f] + id, clamped like the gather kernel (which counts the bad ids: it still
-                // runs, beside this launch, to leave the activations for the backward)
-                // (thread -> field tid % 32 of rows tid / 32 + (NTH / 32) k: one round trip for all of a thread's ids -- a loop over
-                //  "next entry" paid one per entry, 10 us in front of the first slab)
-                static_assert(NTH % 32 == 0 && (BM * 32) % NTH == 0, "key table: 32 fields per row");
-                constexpr int KPT = BM * 32 / NTH;
-                const int F = a.g_F, f = tid & 31, fc = f < F ? f : F - 1;
-                const int64_t rb = a.g_row_base[fc], rn = a.g_row_base[fc + 1] - rb;
-                int64_t idv[KPT];
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) {
-                    const int r = (tid >> 5) + (NTH / 32) * k;
-                    const int row = m0 + r < a.a_rows ? m0 + r : a.a_rows - 1;
-                    idv[k] = a.g_ids[(size_t)row * F + fc];
-                }
-#pragma unroll
-                for (int k = 0; k < KPT; ++k) {
-                    const int r = (tid >> 5) + (NTH / 32) * k;
-                    int64_t id = idv[k];
-                    if (id < 0 || id >= rn) id = 0;
-                    Ks[r * 32 + f] = (uint32_t)(rb + id);
-                }
-                __syncthreads();
-            }
-            auto gload_all = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) { static_for<NCH>([&](auto cc) { gload1(kt2, ra, rb, decltype(cc)::value); }); };
-            auto swrite_all = [&](int oa, int ob, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
-                static_for<NCH>([&](auto cc) { swrite1(oa, ob, kt2, ra, rb, decltype(cc)::value); });
-            };
-            gload_all(0, ra0, rb0);
-            gload_all(1, ra1, rb1);
-            gload_all(2, ra2, rb2);
-            swrite_all(0, 0, 0, ra0, rb0);
-            gload_all(3, ra0, rb0);
-            swrite_all(ASZ, BSZ, 1, ra1, rb1);
-            gload_all(4, ra1, rb1);
+            gload(0, ra0, rb0);
+            gload(1, ra1, rb1);
+            gload(2, ra2, rb2);
+            swrite(0, 0, ra0, rb0);
+            gload(3, ra0, rb0);
+            swrite(1, 1, ra1, rb1);
+            gload(4, ra1, rb1);
             __syncthreads();
             fread(FA[0], FB[0], 0, 0, 0);
             constexpr int A0 = 0, A1 = ASZ, A2 = 2 * ASZ, B0 = 0, B1 = BSZ, B2 = 2 * BSZ;
@@ -549,14 +473,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         }
 }
 
-template <int WM, int WN, int TM, int TN, int BKT, int KS = 1, int PIPE = 0, int GATHER = 0>
+template <int WM, int WN, int TM, int TN, int BKT, int KS = 1, int PIPE = 0>
 __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;       // (4 waves -- the default tiles -- or 8)
     constexpr int LD = BKT + 4;
     __shared__ __attribute__((aligned(16))) float As[((PIPE && PIPE != 4) ? 3 : 2) * BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[((PIPE && PIPE != 4) ? 3 : 2) * BN * LD];
-    __shared__ uint32_t Ks[GATHER ? BM * 32 : 1];            // (gathered A operand: the row panel's keys, up to 32 fields)
     // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
     // HIP stream priorities changed nothing on this runtime; the wave priority does: with it fc_fwd1 (one workgroup per
     // CU, 26 of them beside a sort workgroup) takes 13.8 us instead of 16.3 and the last delta GEMM 25.2 instead of 29.5.
@@ -566,14 +489,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     EndWait end_wait(a.wait_flag, a.wait_val, a.bound);       // (declared first: runs after the stamp's end)
     StampScope stamp(a.ts);
-    // (start waits in front of the start flag: whoever this launch's start releases may rely on what it waited for)
-    start_wait(a.sw_flag[0], a.sw_val[0], a.bound);
-    start_wait(a.sw_flag[1], a.sw_val[1], a.bound);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
     const int tn = (a.N + BN - 1) / BN;
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    gemm_nt_tile<WM, WN, TM, TN, BKT, KS, PIPE, GATHER>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs, Ks);     // consecutive ids: the N tiles of one M tile
+    gemm_nt_tile<WM, WN, TM, TN, BKT, KS, PIPE>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1248,13 +1168,6 @@ int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5
 #define NT_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                            \
     PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT, KS>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64 * KS), 0, st, stop_ev, a)
 
-int g_fwd_gather = 0;       // ps_tune_set("fwd_gather", 1): EmbeddingLayer.forward inside the first FcLayer.forward's operand load (ps_model.hip)
-// the first FC GEMM can gather its embedding slabs itself: D = 16 (a 16-wide slab is one row), the default 64 x 64 tiles
-int gemm_nt_gather_ok(int M, int N, int K, int F) {
-    if (g_gemm_nt_cfg != 0 || g_gemm_pipe != 5 || g_gemm_8w) return 0;
-    if (F < 1 || F > 32 || K != 16 * (F + 1) || N <= 32) return 0;
-    return (long long)cdiv(M, 64) * cdiv(N, 128) < 2048 ? 1 : 0;
-}
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
             const int *skip_flag, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
@@ -1265,17 +1178,10 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     const LaunchOpts none;
     const LaunchOpts &o = lo ? *lo : none;
     NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"),
-             o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100),
-             {o.swait[0], o.swait[1]}, {o.swait_val[0], o.swait_val[1]}, o.g_ids, o.g_row_base, o.g_W, o.g_F, o.g_X, o.g_nx};
+             o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100)};
     const hipEvent_t stop_ev = o.stop_event;
     int cfg = g_gemm_nt_cfg;
     if (cfg == 30 && (K & 15)) cfg = 0;       // the LDS-DMA kernel multiplies whole or half slabs
-    // start waits and the gathered operand live in k_gemm_nt only (not in the LDS-DMA / 16x16x4 measurement kernels)
-    if ((o.swait[0] || o.swait[1]) && (cfg == 30 || (cfg >= 65 && cfg <= 73))) cfg = 0;
-    if (o.g_W) {
-        if (!gemm_nt_gather_ok(M, N, K, o.g_F) || !o.g_ids || !o.g_row_base) return ps_set_err(PS_E_BAD_ARG, "gemm_nt: gathered operand on an unsupported shape");
-        cfg = 150;
-    }
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
         // (measured best on MI355X for M=4096, N in 256..512, K in 256..528); narrow N: 128x32.
@@ -1331,7 +1237,6 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 144: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;    // 64 x 128
     case 145: PS_LAUNCH_EV((k_gemm_nt<2, 1, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 32)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 64 x 32
     case 146: PS_LAUNCH_EV((k_gemm_nt<1, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 32) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 32 x 64
-    case 150: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 3, 1>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;  // gathered A operand
     case 142: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 64, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 64-wide slabs: 70 KB
     case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
     case 86: NT_LAUNCH_P2(2, 2, 1, 2, 32, 1); break;

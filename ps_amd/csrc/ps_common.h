@@ -138,15 +138,8 @@ struct LaunchOpts {
     const unsigned int *wait = nullptr; unsigned int wait_val = 0;
     int prio = 0;
     bool launched = false;
-    // (k_gemm_nt only) every workgroup waits for these flags when it STARTS (start_wait: free when they are up already)
-    const unsigned int *swait[2] = {nullptr, nullptr}; unsigned int swait_val[2] = {0, 0};
-    // (k_gemm_nt only) the A operand is GATHERED: slab f < g_F of row b = relu(g_W[row_base[f] + ids[b][f]]) (D = 16: a 16-wide slab
-    // is one embedding row), slab g_F = (the row's g_nx dense features, 1, 0, ...) -- EmbeddingLayer.forward + ConcatLayer.forward
-    // inside the first FcLayer.forward's operand load (fwd_gather, ps_model.hip); the activation buffer is not read at all
-    const int64_t *g_ids = nullptr; const int64_t *g_row_base = nullptr; const float *g_W = nullptr; int g_F = 0;
-    const float *g_X = nullptr; int g_nx = 0;
 };
-extern int g_main_prio, g_fwd_gather;
+extern int g_main_prio;
 extern int g_sort_late;
 extern int g_tn_prio, g_gemm_pipe, g_gemm_ks, g_dw_late;
 extern int g_tn_start_wait, g_tail_fused, g_shard_overlap, g_dw_split, g_tail_defer;
@@ -239,7 +232,6 @@ struct StampScope {
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_MASK_POS = 3 };
 // C[M][N] = epi( A[M][K] * Bt[N][K]^T )   (both operands K-contiguous)
 //   EPI_MASK_POS: C = acc * (mask[row][col] > 0 ? 1 : 0) for col < mask_cols, acc otherwise
-int gemm_nt_gather_ok(int M, int N, int K, int F);
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
             const int *skip_flag, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);

@@ -408,34 +408,9 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // event (a launch with a stop event starts ~2 us later than a plain one)
     const bool sort_dev = train && !m->sh.active && !m->cur_offsets && g_field_sort && field_sort_fits(B, c.F) && !g_sort_ablate &&
                           m->dev_ok && !c.use_graph && side_stream(m, 0) != st && !(nfc == 1 && s->fc[0].N == 1);
-    // fwd_gather: EmbeddingLayer.forward + ConcatLayer.forward inside the first FC GEMM's operand load (kernels_gemm.hip, GATHER): the
-    // main chain loses the gather launch and its boundary; the gather kernel itself still runs -- on side chain 0, released like
-    // the field sort by the first GEMM's start, in front of that sort (it leaves the sort's keys and the activations the BACKWARD
-    // reads: the last delta GEMM start-waits for start_flag[13], raised behind it).  Needs the device-released backward (the dW
-    // GEMM that reads the activations is released by that delta GEMM's start), D = 16 and the dense features + bias column in
-    // exactly one 16-wide slab.
-    const bool fuse = g_fwd_gather && sort_dev && !g_sort_late && dev_release(m) && c.D == 16 && c.X >= 4 && c.X <= 15 && m->cur_dense &&
-                      !(s->fc[0].N == 1) && s->fc[0].Kpad == 16 * (c.F + 1) && gemm_nt_gather_ok(B, s->fc[0].N, s->fc[0].Kpad, c.F) &&
-                      !(nfc > 2 && !s->fwd_pair_off && m->pair_ctr && gemm_nt_fwd_pair_ok(B, s->fc[0].N, s->fc[1].N, s->fc[0].Kpad, s->fc[1].Kpad));
-    m->a0_flag_due = false;
-    const unsigned int *fuse_wait = nullptr;
-    unsigned int fuse_wait_val = 0;
     LaunchOpts fwd_lo;
     fwd_lo.stop_event = (train && !m->sh.active && !keys_early && !sort_dev) ? pick_event(m) : nullptr;
     const hipEvent_t fwd_ev = fwd_lo.stop_event;
-    if (fuse) {
-        // the join with the previous step's dense update moves into the GEMM: every workgroup of it waits (normally: looks) for
-        // the update's end flag when it starts -- it reads the dense weights, and the side-chain gather it releases overwrites the
-        // activations the previous step's dW GEMMs read
-        if (s->pending_ev) {
-            // (fwd_gather = 2: a one-wave spinner launch in front of the GEMM instead of a start wait in every workgroup -- when the
-            //  flag is NOT up yet, 512 workgroups that waited each pay an agent-scope acquire)
-            if (s->pending_flag && s->pending_start && g_fwd_gather == 2) PSCHK(launch_spin_until(s->pending_flag, s->pending_val, st, s->werr(), 13));
-            else if (s->pending_flag && s->pending_start) { fuse_wait = s->pending_flag; fuse_wait_val = s->pending_val; }
-            else PSCHK(store_settle(s));
-            s->pending_ev = nullptr; s->pending_flag = nullptr;
-        }
-    } else {
     if (!m->sh.active && s->pending_ev) {
         // the previous fused step's dense update (side chain 1 of the model that ran it) may still be running: this
         // launch's first workgroup ends only once the update's end flag is up -- the gather runs beside the update's
@@ -461,18 +436,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         m->sh.flat_pending = false;
     }
     if (fwd_lo.stop_event && !fwd_lo.launched) HIPCHK(hipEventRecord(fwd_lo.stop_event, st));
-    }
     auto enqueue_sort = [&]() -> int {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
         if (keys_early) {}
         else if (sort_dev) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss, s->werr(), 4));
-        if (fuse) {
-            { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, ss, nullptr, s->werr())); }
-            if (++m->a0_epoch == 0) ++m->a0_epoch;
-            PSCHK(launch_flag_set(m->start_flag + 13, m->a0_epoch, ss));
-            m->a0_flag_due = true;
-        }
         else if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
         static int64_t sort_runs = 0;
@@ -544,11 +512,6 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         LaunchOpts lo;
         if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
         lo.prio = (train && gemm_prio(m)) ? 1 : 0;
-        if (fuse && l == 0) {
-            lo.g_ids = m->cur_ids; lo.g_row_base = s->emb.row_base_dev; lo.g_W = s->emb.W; lo.g_F = c.F;
-            lo.g_X = m->cur_dense; lo.g_nx = c.X;
-            lo.swait[0] = fuse_wait; lo.swait_val[0] = fuse_wait_val;
-        }
         if (pair) {
             FcParams &p2 = s->fc[l + 1];
             float *out2 = l + 2 < nfc ? m->fc[l + 2].A : m->out_last;
@@ -829,9 +792,6 @@ int enqueue_backward(ps_model *m, bool apply) {
                 lo.wait = m->start_flag + (sort_dev_wait ? 1 : 5);          // (multi-hot: the end of the long sort chain)
                 lo.wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
             }
-            // fwd_gather: the activations of the embedding layer (this launch's relu' mask, the dW GEMM it releases) were left by the
-            // gather on side chain 0: it has been done for a while -- every workgroup looks at its flag when it starts
-            if (m->a0_flag_due) { lo.swait[0] = m->start_flag + 13; lo.swait_val[0] = m->a0_epoch; m->a0_flag_due = false; }
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st, &lo, werr));
             s0_joined = lo.wait != nullptr && lo.launched;

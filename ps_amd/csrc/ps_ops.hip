@@ -274,7 +274,6 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "gemm_ks") == 0) { g_gemm_ks = value; return PS_OK; }
     if (strcmp(knob, "tn_prio") == 0) { g_tn_prio = value; return PS_OK; }
     if (strcmp(knob, "dw_late") == 0) { g_dw_late = value; return PS_OK; }
-    if (strcmp(knob, "fwd_gather") == 0) { g_fwd_gather = value; return PS_OK; }
     if (strcmp(knob, "sort_late") == 0) { g_sort_late = value; return PS_OK; }
     if (strcmp(knob, "plan_early") == 0) { g_plan_early = value; return PS_OK; }
     if (strcmp(knob, "shard_overlap") == 0) { g_shard_overlap = value; return PS_OK; }

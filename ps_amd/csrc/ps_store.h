@@ -148,7 +148,6 @@ struct ps_model {
     uint32_t *nseg_cur = nullptr;      // nseg_dev or nseg_dev + 4: the run count of the plan the NEXT backward uses (an early plan of
                                        // step t+1 is written while step t's backward still reads its own)
     bool sort_deferred = false;        // the field sort of this step is enqueued by the backward (late sort)
-    bool a0_flag_due = false; unsigned int a0_epoch = 0;   // fwd_gather: the side-chain gather raises start_flag[13] = a0_epoch behind it (the last delta GEMM waits for it)
     bool fwd_flag_valid = false;       // the running step's first forward GEMM raises start_flag[4] = fwd_epoch when it starts
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
     uint32_t *seg_nseg_scratch = nullptr;                     // run count of a side sort whose nseg the bitmap plan already wrote

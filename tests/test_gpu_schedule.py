@@ -35,7 +35,7 @@ def batches(rng, n, B, F, X, V, WS):
     return out
 
 
-DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "dw_late": 0, "fwd_gather": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
+DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "dw_late": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
 
 
 def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
@@ -80,7 +80,6 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "first dW GEMM on side chain 0": ({"dw_split": 1}, False),
                 "first two forward GEMMs in one launch": ({"fwd_pair": 1}, False),
                 "first dW GEMM held back to the next delta GEMM": ({"dw_late": 1}, False),
-                "embedding gather inside the first FC GEMM": ({"fwd_gather": 1}, False),
                 "round 2's GEMM slab loop": ({"gemm_pipe": 0}, False),
                 "8-wave 128 x 64 tiles": ({"gemm_8w": 1}, False),
                 "the embedding update holds the join with the dense update": ({"tail_defer": 0}, False),
