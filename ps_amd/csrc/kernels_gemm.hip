@@ -97,7 +97,14 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     constexpr int ASZ = WM * TM * 32 * (BKT + 4), BSZ = WN * TN * 32 * (BKT + 4);      // floats per LDS buffer
     constexpr int NTH = WM * WN * 64 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LD = BKT + 4;
+    // SWZ (16-wide slabs, the default loop): rows of 16 floats WITHOUT padding, the 16-byte chunk c of row r at position
+    // c ^ ((r >> 2) & 3).  The padded rows (20 floats) are conflict-free for the fragment reads but not for the staging writes
+    // (4 lanes fill one row: rows r and r + 3 of a 16-lane group overlap in 12 banks -- profiles/r03_gemm_pmc.txt: LDS bank
+    // conflict cycles 0.7 of the busy cycles); with the XOR both are: 16 lanes of a write cover 4 whole rows = 64 banks, 16 lanes
+    // of a read take the same chunk of 16 consecutive rows = 4 (r & 3) x 4 ((r >> 2) & 3) distinct bank groups.
+    constexpr bool SWZ = PIPE == 3 && BKT == 16 && KS == 1;
+    constexpr int LD = SWZ ? 16 : BKT + 4;
+    auto wpos = [](int row, int chunk) -> int { return SWZ ? (chunk ^ ((row >> 2) & 3)) : chunk; };
     constexpr int RF4 = BKT / 4;                               // float4 per tile row
     constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH;
     const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) % (WM * WN), kg = (tid >> 6) / (WM * WN);
@@ -171,13 +178,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * NTH;
             if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + (e % RF4) * 4) = masked(ra[i], k0 + ca[i]);
+                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(ra[i], k0 + ca[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int e = tid + i * NTH;
             if ((BN * RF4) % NTH == 0 || e < BN * RF4)
-                *reinterpret_cast<float4 *>(Bs + buf * BSZ + (e / RF4) * LD + (e % RF4) * 4) = masked(rb[i], k0 + cb[i]);
+                *reinterpret_cast<float4 *>(Bs + buf * BSZ + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(rb[i], k0 + cb[i]);
         }
     };
 
@@ -189,8 +196,9 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
-    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const int arow = (wm * TM * 32 + (lane & 31)) * LD + (SWZ ? 0 : (lane >> 5) * 4);
+    const int brow = (wn * TN * 32 + (lane & 31)) * LD + (SWZ ? 0 : (lane >> 5) * 4);
+    const int fxa = ((wm * TM * 32 + (lane & 31)) >> 2) & 3, fxb = ((wn * TN * 32 + (lane & 31)) >> 2) & 3, fh = lane >> 5;    // (SWZ)
     auto compute = [&](int buf) {
 #pragma unroll
         for (int qq = 0; qq < BKT / 8 / KS; ++qq) {
@@ -272,11 +280,11 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             if (c < A_F4) {
                 const int e = tid + c * NTH;
                 if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + (e % RF4) * 4) = masked(ra[c], k0 + ca[c]);
+                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(ra[c], k0 + ca[c]);
             } else {
                 const int i = c - A_F4, e = tid + i * NTH;
                 if ((BN * RF4) % NTH == 0 || e < BN * RF4)
-                    *reinterpret_cast<float4 *>(Bs + ob + (e / RF4) * LD + (e % RF4) * 4) = masked(rb[i], k0 + cb[i]);
+                    *reinterpret_cast<float4 *>(Bs + ob + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(rb[i], k0 + cb[i]);
             }
         };
         auto fread = [&](float4 (&fa)[TM], float4 (&fb)[TN], int oa, int ob, int g) {
@@ -289,9 +297,10 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
                 return;
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(As + oa + arow + i * 32 * LD + q * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(As + oa + arow + i * 32 * LD + (SWZ ? (((2 * q + fh) ^ fxa) << 2) : q * 8));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = (PS_GEMM_ABLATE & 1) ? fa[0] : *reinterpret_cast<const float4 *>(Bs + ob + brow + j * 32 * LD + q * 8);
+            for (int j = 0; j < TN; ++j)
+                fb[j] = (PS_GEMM_ABLATE & 1) ? fa[0] : *reinterpret_cast<const float4 *>(Bs + ob + brow + j * 32 * LD + (SWZ ? (((2 * q + fh) ^ fxb) << 2) : q * 8));
         };
         // MFMA m of a group: k component m / (TM * TN) of tile m % (TM * TN) -- consecutive MFMAs go to different
         // accumulators where there are several; per accumulator the k order is that of PIPE = 0

@@ -19,6 +19,6 @@ for (name, grid, d), c in agg.items(): per[(name, grid, round(c["dur_us"], -1) >
 for key, v in per.items():
     n=len(v); avg=lambda k: sum(c.get(k, 0) for c in v)/n
     busy=avg("SQ_VALU_MFMA_BUSY_CYCLES"); act=avg("GRBM_GUI_ACTIVE")
-    print("%-44s grid %-8s %s  n=%2d  dur %7.1f us  MFMA busy cycles / (GPU active cycles x 1024 SIMDs... as reported) %.3f  LDS bank conflict cycles / busy %.4f  wait-LDS / wait-any %.3f" % (
+    print("%-44s grid %-8s %s  n=%2d  dur %7.1f us  SQ_VALU_MFMA_BUSY_CYCLES / (4 x GRBM_GUI_ACTIVE) %.3f  LDS bank conflict cycles / busy %.4f  wait-LDS / wait-any %.3f" % (
         key[0], key[1], "long K" if key[2] else "fwd0  ", n, avg("dur_us"), busy / max(act, 1) / 4.0, avg("SQ_LDS_BANK_CONFLICT") / max(avg("SQ_BUSY_CYCLES"), 1), avg("SQ_WAIT_INST_LDS") / max(avg("SQ_WAIT_INST_ANY"), 1)))
 PY
