@@ -94,7 +94,8 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // Same products in the same order per accumulator as PIPE = 0: bit-identical results.
 template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0>
 __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs) {
-    constexpr int ASZ = WM * TM * 32 * (BKT + 4), BSZ = WN * TN * 32 * (BKT + 4);      // floats per LDS buffer
+    constexpr int LDB = (PIPE == 3 && BKT == 16 && KS == 1) ? 16 : BKT + 4;              // (row length: see SWZ below)
+    constexpr int ASZ = WM * TM * 32 * LDB, BSZ = WN * TN * 32 * LDB;                    // floats per LDS buffer
     constexpr int NTH = WM * WN * 64 * KS;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     // SWZ (16-wide slabs, the default loop): rows of 16 floats WITHOUT padding, the 16-byte chunk c of row r at position
@@ -486,7 +487,7 @@ template <int WM, int WN, int TM, int TN, int BKT, int KS = 1, int PIPE = 0>
 __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     static_assert(KS == 1 || (KS == 2 && TM == 1 && TN == 1 && BKT % 16 == 0), "in-workgroup K split: 2 groups, one 32 x 32 tile per wave");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;       // (4 waves -- the default tiles -- or 8)
-    constexpr int LD = BKT + 4;
+    constexpr int LD = (PIPE == 3 && BKT == 16 && KS == 1) ? 16 : BKT + 4;      // (16-wide slabs: swizzled rows without padding, gemm_nt_tile)
     __shared__ __attribute__((aligned(16))) float As[((PIPE && PIPE != 4) ? 3 : 2) * BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[((PIPE && PIPE != 4) ? 3 : 2) * BN * LD];
     // Main-chain kernel: its waves go ahead of the side chains' waves (field sort, dW GEMMs) wherever they share a CU.
