@@ -347,6 +347,23 @@ def test_single_row_updater_keys_are_refused(orc):
     gm.close(); kv.close()
 
 
+def test_more_updater_groups_than_the_kernels_carry_are_refused(orc):
+    """five distinct updaters over the fields of one table group (the kernels carry four): PS_E_UNSUPPORTED, nothing is updated"""
+    import ps_amd
+    F = 6
+    kv = ps_amd.KVStore(0, SEED)
+    kv.create_embedding([6] * F, 4)
+    for f, alfa in enumerate((0.01, 0.02, 0.03, 0.04)):
+        kv.set_updater("emF%d." % f, ps_amd.AdamUpdater(alfa))          # + "default" for fields 4, 5 = the fifth
+    gm = ps_amd.DNN.buildModel(F, 4, 1, [4, 1], store=kv, max_batch=8)
+    before = kv.get_rows(0, np.arange(6)).copy()
+    with pytest.raises(ps_amd.native.PsError) as ei:
+        gm.train({"E": np.zeros((8, F), np.int64), "X": np.zeros((8, 1), f32), "Y": np.ones(8, f32)})
+    assert ei.value.code == ps_amd.native.PS_E_UNSUPPORTED
+    np.testing.assert_array_equal(kv.get_rows(0, np.arange(6)), before)
+    gm.close(); kv.close()
+
+
 def test_loss_slim_stops_backward(orc):
     """model/DNN.java:58-63: loss <= 0.01 (or NaN) returns before backward: nothing is updated."""
     import ps_amd
