@@ -1309,6 +1309,7 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
     return PS_OK;
 }
 
+int g_keys_early = 1;      // ps_tune_set("keys_early", 0): multi-hot: the sort's keys come from the gather again (the sort chain starts behind it)
 int g_dw_late = 0;         // ps_tune_set("dw_late", 1): the first dW GEMM starts with the NEXT delta GEMM (the first delta GEMM runs alone)
 int g_tn_prio = 1;          // ps_tune_set("tn_prio", 0 / 2 / 3): the dW GEMMs' wave priority: none / one / two levels under the main chain's; +8: dW_0 only
 int g_main_prio = 1;        // ps_tune_set("main_prio", 0): no raised wave priority for the fused step's main-chain kernels

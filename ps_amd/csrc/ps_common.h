@@ -141,7 +141,7 @@ struct LaunchOpts {
 };
 extern int g_main_prio;
 extern int g_sort_late;
-extern int g_tn_prio, g_gemm_pipe, g_gemm_ks, g_dw_late;
+extern int g_tn_prio, g_gemm_pipe, g_gemm_ks, g_dw_late, g_keys_early;
 extern int g_tn_start_wait, g_tail_fused, g_shard_overlap, g_dw_split, g_tail_defer;
 extern int g_dev_wait, g_tail_dev, g_gemm_8w, g_radix11, g_end_wait, g_radix_scan_free, g_plan_early;
 // Every device-side wait is BOUNDED: a waiter that has not seen its flag after g_spin_timeout_ticks (10 ns ticks of the

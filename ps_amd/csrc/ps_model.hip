@@ -397,7 +397,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // in front of the gather, 16 us, and releasing the sort by a flag starts the sort chain 40 us earlier and ends the
     // step no sooner: 0.388 vs 0.382 ms -- the later kernels then overlap the dW GEMMs and all of them slow down.  This
     // shape is bound by the sum of its kernels, not by a chain.)
-    const bool keys_early = train && !m->sh.active && m->cur_offsets && side_stream(m, 0) != st;
+    const bool keys_early = g_keys_early && train && !m->sh.active && m->cur_offsets && side_stream(m, 0) != st;
     if (keys_early) {
         PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
         { Prof pf(m, "emb_keys"); PSCHK(launch_emb_keys(e, side_stream(m, 0))); }

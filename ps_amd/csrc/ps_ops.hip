@@ -274,6 +274,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "gemm_ks") == 0) { g_gemm_ks = value; return PS_OK; }
     if (strcmp(knob, "tn_prio") == 0) { g_tn_prio = value; return PS_OK; }
     if (strcmp(knob, "dw_late") == 0) { g_dw_late = value; return PS_OK; }
+    if (strcmp(knob, "keys_early") == 0) { g_keys_early = value; return PS_OK; }
     if (strcmp(knob, "sort_late") == 0) { g_sort_late = value; return PS_OK; }
     if (strcmp(knob, "plan_early") == 0) { g_plan_early = value; return PS_OK; }
     if (strcmp(knob, "shard_overlap") == 0) { g_shard_overlap = value; return PS_OK; }
