@@ -452,13 +452,31 @@ typedef struct ps_comm_ops {
     int (*all_to_all_v)(void *ctx, const void *send, const int64_t *send_counts, void *recv,
                         const int64_t *recv_counts, size_t elem_bytes, void *stream);
     int (*all_reduce_sum_f32)(void *ctx, float *buf, int64_t n, void *stream);
+    int flags;          /* PS_COMM_* bits; 0 for a table that moves every part of every exchange */
 } ps_comm_ops_t;
+/* flags of a plugged-in table.  PS_COMM_OWN_IN_PLACE: the step reads this rank's OWN part of the rows and gradient
+ * exchanges where it was produced (its own packed key list, the owner-side gather's output, its gradient buffer) and
+ * never looks at the self part of the receive buffer -- the table may leave that part unwritten.  The RCCL table made
+ * by ps_comm_rccl_create always works this way (a rank's own keys never touch the wire). */
+#define PS_COMM_OWN_IN_PLACE 1
+/* At most PS_COMM_MAX_RANKS ranks in one table (a hard limit of this ABI: the owner-side push keeps one bit per
+ * pushing worker and row; net/PServer.java has no such limit, its workers are gRPC clients). */
+#define PS_COMM_MAX_RANKS 32
 int ps_comm_rccl_unique_id(char *out384);   /* three 128-byte ids: the main, the key-list and the all-reduce communicator */
+/* nranks == 1: no wire is needed and none is loaded (every collective is a device copy) -- unless
+ * ps_tune_set("rccl_force", 1 | 2) (or PS_RCCL_FORCE in the environment) asks for it: then librccl is loaded, the three
+ * 1-rank communicators are created (id384 may be NULL: the ids are made here) and EVERY collective of the step goes
+ * through RCCL on its own stream -- ncclAllGather, grouped ncclSend / ncclRecv to this rank itself, ncclAllReduce.
+ * 1: everything the step reads came off the wire (own keys too); 2: the wire runs and a rank's own keys are still read
+ * in place, as at N > 1.  This is how the wire is exercised on a one-GPU box (tests/test_gpu_rccl_wire.py). */
 int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const char *id384, ps_comm_ops_t *out);
 int ps_comm_rccl_destroy(ps_comm_ops_t *ops);
 /* RCCL's own view of a table made by ps_comm_rccl_create: ncclCommCount / ncclCommUserRank of the main communicator
  * and whether the side communicator exists (what bench.py reports as evidence of the wire a multi-GPU run used). */
 int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int *user_rank, int *has_side);
+/* RCCL operations the table has issued so far: out5[0] ncclAllGather, [1] grouped ncclSend/ncclRecv exchanges, [2]
+ * ncclAllReduce, [3] single ncclSend + ncclRecv calls, [4] 1 when the table reaches a wire (N > 1 or rccl_force). */
+int ps_comm_rccl_calls(const ps_comm_ops_t *ops, int64_t *out5);
 /* One-shot wire check (collective: every rank calls it): each callback of the
  * table once on known patterns -- uneven all-to-all-v counts, all-gather slot
  * order, a float all-reduce -- verified on the host.  PS_E_STATE names the
@@ -466,9 +484,14 @@ int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int *user_rank,
 int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm);
 int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);
 /* The step in two halves.  _begin enqueues what reads no weight without a host wait: the plan, the exchange of the key
- * lists -- FIXED-SIZE blocks [count | owner-local rows | padding], one per peer, so the exchange needs no split sizes
- * and carries the counts of the two exchanges that do (rows back, gradients out) -- and the publication of those
- * counts to pinned host memory; use_side = 1 runs it on the store's prefetch stream so that step t+1 can begin -- on
+ * lists -- FIXED-SIZE blocks [count | overflow flag | owner-local rows | padding], one per peer, so the exchange needs
+ * no split sizes and carries the counts of the two exchanges that do (rows back, gradients out) -- and the publication
+ * of those counts to pinned host memory.  A wire block holds 2 * max_nnz / nranks rows (ps_tune_set("blk_factor")): a
+ * worker whose list for some owner is longer raises the overflow flag in every block it sends, every rank sees every
+ * flag, and _finish of that step first exchanges the full-size blocks (max_nnz rows: what every step sent before
+ * round 4) -- same decision on every rank, no host round trip to find out.  The very first _begin of a model
+ * all-gathers [block sizes | stream-join mode] once and fails with PS_E_BAD_ARG on every rank when the ranks were
+ * configured differently (max_batch / max_nnz), instead of posting mismatched receives; use_side = 1 runs it on the store's prefetch stream so that step t+1 can begin -- on
  * another model of the same store -- before step t finishes.  _finish waits for the counts (the step's one host wait)
  * and enqueues the rest: owner-side gather, rows back, forward / backward, gradients out, owner update, the flat
  * reduction and the replicated update.  A rank's own keys are read where they are, never copied. */
@@ -483,7 +506,8 @@ int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async,
  * one communicator.  One model suffices (the plan only overwrites key lists that step t no longer reads). */
 /* Wire accounting of this model's ps_shard_step calls so far: out[0] steps, [1] id-block bytes sent, [2] row bytes
  * received, [3] gradient bytes sent, [4] all-reduce payload bytes, [5] unique keys requested, [6] keys served as an
- * owner, [7] words of one id block (n >= 8). */
+ * owner, [7] words of one id block on the wire (n >= 8); n >= 10: [8] steps whose key lists did not fit the wire
+ * blocks and were sent again at full size, [9] words of a full-size block. */
 int ps_shard_exchange_stats(const ps_model_t *m, int64_t *out, int n);
 int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *comm, int is_async,
                                const ps_batch_t *next_batch, float *loss);

@@ -164,6 +164,12 @@ JNIEXPORT jbyteArray JNICALL Java_store_NativeKVStore_commUniqueId(JNIEnv *env, 
     return out;
 }
 JNIEXPORT jlong JNICALL Java_store_NativeKVStore_commCreate(JNIEnv *env, jobject self, jint nranks, jint rank, jbyteArray id) {
+    // three 128-byte ids (ps_comm_rccl_unique_id): a shorter array (e.g. the 256 bytes of round 2's two communicators) would be
+    // read past its end by ps_comm_rccl_create
+    if (id && env->GetArrayLength(id) < 384) {
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "commCreate: the RCCL id must be the 384 bytes of commUniqueId()");
+        return 0;
+    }
     ps_comm_ops_t *ops = new ps_comm_ops_t();
     jbyte *b = id ? env->GetByteArrayElements(id, nullptr) : nullptr;
     const int rc = ps_comm_rccl_create(S(env, self), nranks, rank, reinterpret_cast<const char *>(b), ops);

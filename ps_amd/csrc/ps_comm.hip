@@ -77,17 +77,25 @@ int rccl_load() {
 // produced -- the all-to-all-v then moves nothing for it.
 // `ar` carries only the all-reduce, on side chain 1 (the id exchange runs on side chain 0 right behind the plan's kernels:
 // one communicator per stream, so that no two streams ever drive one communicator).
-struct RcclCtx { rcclComm_t comm = nullptr, side = nullptr, ar = nullptr; int nranks = 1, rank = 0; int which = 0; bool skip_self = false; };
+// wire: the collectives go through RCCL (nranks > 1, or a 1-rank table made under rccl_force).  self_wire (forced
+// tables only): this rank's OWN part of an all-to-all-v travels too, as a grouped ncclSend + ncclRecv to itself --
+// 1: and is read from the receive buffer like any peer's; 2: travels AND the step reads it in place (skip_self), the
+// deployment's data path with the wire running underneath.  calls: RCCL operations issued so far (ps_comm_rccl_info).
+struct RcclCtx {
+    rcclComm_t comm = nullptr, side = nullptr, ar = nullptr; int nranks = 1, rank = 0; int which = 0; bool skip_self = false;
+    bool wire = false; int self_wire = 0; int64_t calls[4] = {0, 0, 0, 0};      // all-gather | send/recv groups | all-reduce | sends + recvs
+};
 rcclComm_t pick_comm(RcclCtx *c) { return (c->which == 1 && c->side) ? c->side : (c->which == 2 && c->ar) ? c->ar : c->comm; }
 
 int rccl_all_gather(void *ctx, const void *send, void *recv, size_t bytes, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
     hipStream_t st = (hipStream_t)stream;
-    if (c->nranks == 1) {
+    if (!c->wire) {
         HIPCHK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
         return PS_OK;
     }
     RCCLCHK(g_rccl.AllGather(send, recv, bytes, RCCL_CHAR, pick_comm(c), st));
+    ++c->calls[0];
     return PS_OK;
 }
 
@@ -95,28 +103,29 @@ int rccl_all_to_all_v(void *ctx, const void *send, const int64_t *sc, void *recv
     RcclCtx *c = (RcclCtx *)ctx;
     hipStream_t st = (hipStream_t)stream;
     size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
-    const bool wire = c->nranks > 1;
+    const bool wire = c->wire;
     rcclComm_t cm = pick_comm(c);
+    if (sc[c->rank] != rc[c->rank]) return ps_set_err(PS_E_STATE, "all-to-all-v: self counts differ");
     if (wire) RCCLCHK(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
         if (p == c->rank) { self_so = so; self_ro = ro; }
-        else {
-            if (sc[p] > 0) RCCLCHK(g_rccl.Send((const char *)send + so * eb, (size_t)sc[p] * eb, RCCL_CHAR, p, cm, st));
-            if (rc[p] > 0) RCCLCHK(g_rccl.Recv((char *)recv + ro * eb, (size_t)rc[p] * eb, RCCL_CHAR, p, cm, st));
+        if (wire && (p != c->rank || c->self_wire)) {
+            if (sc[p] > 0) { RCCLCHK(g_rccl.Send((const char *)send + so * eb, (size_t)sc[p] * eb, RCCL_CHAR, p, cm, st)); ++c->calls[3]; }
+            if (rc[p] > 0) { RCCLCHK(g_rccl.Recv((char *)recv + ro * eb, (size_t)rc[p] * eb, RCCL_CHAR, p, cm, st)); ++c->calls[3]; }
         }
         so += (size_t)sc[p]; ro += (size_t)rc[p];
     }
-    if (wire) RCCLCHK(g_rccl.GroupEnd());
-    if (sc[c->rank] != rc[c->rank]) return ps_set_err(PS_E_STATE, "all-to-all-v: self counts differ");
-    if (sc[c->rank] > 0 && !c->skip_self)       // this rank's own keys never touch the wire
+    if (wire) { RCCLCHK(g_rccl.GroupEnd()); ++c->calls[1]; }
+    if (sc[c->rank] > 0 && !c->skip_self && !(wire && c->self_wire))       // this rank's own keys never touch the wire
         HIPCHK(hipMemcpyAsync((char *)recv + self_ro * eb, (const char *)send + self_so * eb, (size_t)sc[c->rank] * eb, hipMemcpyDeviceToDevice, st));
     return PS_OK;
 }
 
 int rccl_all_reduce(void *ctx, float *buf, int64_t n, void *stream) {
     RcclCtx *c = (RcclCtx *)ctx;
-    if (c->nranks == 1 || n <= 0) return PS_OK;
+    if (!c->wire || n <= 0) return PS_OK;
     RCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT, RCCL_SUM, pick_comm(c), (hipStream_t)stream));
+    ++c->calls[2];
     return PS_OK;
 }
 
@@ -138,7 +147,17 @@ void comm_select(const ps_comm_ops_t *comm, int which, bool skip_self) {
     if (comm->ctx && comm->all_to_all_v == rccl_all_to_all_v) { RcclCtx *c = (RcclCtx *)comm->ctx; c->which = which; c->skip_self = skip_self; }
 }
 bool comm_is_rccl(const ps_comm_ops_t *comm) { return comm->ctx && comm->all_to_all_v == rccl_all_to_all_v; }
+// does a collective of this table reach a wire (an N-rank table, or a 1-rank RCCL table made under rccl_force)?
+bool comm_wired(const ps_comm_ops_t *comm) { return comm->nranks > 1 || (comm_is_rccl(comm) && ((RcclCtx *)comm->ctx)->wire); }
+// is this rank's own part of the rows / gradient exchanges read where it was produced?  RCCL: always (unless the forced
+// wire carries it: rccl_force = 1); a plugged-in table: when it says so (PS_COMM_OWN_IN_PLACE)
+bool comm_own_in_place(const ps_comm_ops_t *comm) {
+    if (comm_is_rccl(comm)) { const RcclCtx *c = (const RcclCtx *)comm->ctx; return !(c->wire && c->self_wire == 1); }
+    return (comm->flags & PS_COMM_OWN_IN_PLACE) != 0;
+}
 }  // namespace
+// ps_tune_set("rccl_force", 1 | 2) / PS_RCCL_FORCE: a 1-rank table still goes through RCCL (ps_native.h)
+int g_rccl_force = getenv("PS_RCCL_FORCE") ? atoi(getenv("PS_RCCL_FORCE")) : 0;
 
 extern "C" int ps_comm_rccl_unique_id(char *out384) {
     if (!out384) return ps_set_err(PS_E_BAD_ARG, "null argument");
@@ -157,9 +176,16 @@ extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const ch
     PSCHK(store_enter(s));
     RcclCtx *c = new RcclCtx();
     c->nranks = nranks; c->rank = rank;
-    if (nranks > 1) {
+    const int force = nranks == 1 ? g_rccl_force : 0;
+    if (nranks > 1 || force) {
         int rc = rccl_load();
         if (rc != PS_OK) { delete c; return rc; }
+        char own_ids[384];
+        if (!id256) {               // (a forced 1-rank table: nobody to share the ids with)
+            rc = ps_comm_rccl_unique_id(own_ids);
+            if (rc != PS_OK) { delete c; return rc; }
+            id256 = own_ids;
+        }
         rcclUniqueId id;
         memcpy(id.internal, id256, 128);
         int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
@@ -177,10 +203,13 @@ extern "C" int ps_comm_rccl_create(ps_store_t *s, int nranks, int rank, const ch
             delete c;
             return ps_set_err(PS_E_HIP, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r));
         }
+        c->wire = true;
+        c->self_wire = force;
     }
     memset(out, 0, sizeof *out);
     out->ctx = c; out->nranks = nranks; out->rank = rank;
     out->all_gather = rccl_all_gather; out->all_to_all_v = rccl_all_to_all_v; out->all_reduce_sum_f32 = rccl_all_reduce;
+    out->flags = PS_COMM_OWN_IN_PLACE;
     return PS_OK;
 }
 
@@ -228,7 +257,7 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
     int rcode = PS_OK;
     const std::vector<float> red0 = red;
     // an RCCL table has three communicators (rows + gradients | key lists | all-reduce): every one of them is checked
-    const int ncomm = (comm_is_rccl(comm) && n > 1) ? 3 : 1;
+    const int ncomm = (comm_is_rccl(comm) && ((RcclCtx *)comm->ctx)->wire) ? 3 : 1;
     for (int which = 0; which < ncomm && rcode == PS_OK; ++which) {
     red = red0;
     comm_select(comm, which, false);
@@ -254,7 +283,7 @@ extern "C" int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm) {
             }
         for (int i = 0; i < nf && rcode == PS_OK; ++i) {
             const float want = (float)n * (float)(n + 1) * 0.5f + 0.25f * (float)i * (float)n;
-            if (n > 1 && red[(size_t)i] != want) rcode = ps_set_err(PS_E_STATE, "selfcheck: all-reduce element %d is %g, expected %g", i, red[(size_t)i], want);
+            if (red[(size_t)i] != want) rcode = ps_set_err(PS_E_STATE, "selfcheck: all-reduce element %d is %g, expected %g", i, red[(size_t)i], want);
         }
     } while (0);
     comm_select(comm, 0, false);
@@ -277,6 +306,16 @@ extern "C" int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int 
     if (comm_count) *comm_count = n;
     if (user_rank) *user_rank = r;
     if (has_side) *has_side = (c->side ? 1 : 0) + (c->ar ? 1 : 0);
+    return PS_OK;
+}
+
+// RCCL operations this table has issued so far: out[0] ncclAllGather, [1] ncclGroupStart/End pairs (all-to-all-v), [2]
+// ncclAllReduce, [3] ncclSend + ncclRecv calls; out[4] = 1 when the table reaches a wire at all (N > 1, or rccl_force).
+extern "C" int ps_comm_rccl_calls(const ps_comm_ops_t *ops, int64_t *out5) {
+    if (!ops || !ops->ctx || ops->all_to_all_v != rccl_all_to_all_v || !out5) return ps_set_err(PS_E_BAD_ARG, "not an RCCL communicator table");
+    const RcclCtx *c = (const RcclCtx *)ops->ctx;
+    for (int i = 0; i < 4; ++i) out5[i] = c->calls[i];
+    out5[4] = c->wire ? 1 : 0;
     return PS_OK;
 }
 
@@ -305,27 +344,51 @@ extern "C" int ps_comm_rccl_info(const ps_comm_ops_t *ops, int *comm_count, int 
 // Without device-side joins (events only, ps_store_join_mode = 0) or with ps_tune_set("shard_overlap", 0) everything is
 // enqueued on the training stream with the one communicator, in the order of the left column then the right.
 int g_shard_overlap = 1;
+int g_blk_factor = 2;       // ps_tune_set("blk_factor", f): a wire block holds f * nnz_cap / nranks rows (0: always full-size blocks)
+int g_blk_cap = 0;          // ps_tune_set("blk_cap", rows): the wire block's capacity outright (tests: force the overflow exchange)
 namespace {
+// One thread per unique key: its owner-local row into the owner's wire block (when it fits) and full block; thread u < nranks
+// writes owner u's headers [count | has this worker a list longer than a wire block?].
 __global__ __launch_bounds__(256) void k_pack_blocks(const uint32_t *__restrict__ send_rows, const uint32_t *__restrict__ owner_start, int nranks,
-                                                      int64_t blk_words, uint32_t *__restrict__ blk, unsigned long long *ts) {
+                                                      int64_t blk_words, uint32_t blk_cap, uint32_t *__restrict__ blk,
+                                                      int64_t full_words, uint32_t *__restrict__ full /* or == blk */, unsigned long long *ts) {
     StampScope stamp(ts);
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (u < nranks) blk[(size_t)u * blk_words] = owner_start[u + 1] - owner_start[u];          // the block's header: its count
+    if (u < nranks) {
+        uint32_t ovf = 0;
+        for (int o = 0; o < nranks; ++o) ovf |= (owner_start[o + 1] - owner_start[o] > blk_cap) ? 1u : 0u;
+        const uint32_t cnt = owner_start[u + 1] - owner_start[u];
+        blk[(size_t)u * blk_words] = cnt; blk[(size_t)u * blk_words + 1] = ovf;
+        if (full != blk) { full[(size_t)u * full_words] = cnt; full[(size_t)u * full_words + 1] = ovf; }
+    }
     if (u >= (int64_t)owner_start[nranks]) return;
     int o = 0;
     while (o + 1 < nranks && (uint32_t)u >= owner_start[o + 1]) ++o;
-    blk[(size_t)o * blk_words + 1 + ((uint32_t)u - owner_start[o])] = send_rows[u];
+    const uint32_t i = (uint32_t)u - owner_start[o], row = send_rows[u];
+    if (i < blk_cap) blk[(size_t)o * blk_words + PS_BLK_HDR + i] = row;
+    if (full != blk) full[(size_t)o * full_words + PS_BLK_HDR + i] = row;
 }
-// owner_start[0..n] of this rank's plan and the received blocks' headers -> pinned host memory, then the epoch word
-// (the host spins on it: a copy + event record + event wait woke the host 20-40 us late in some processes, round 2)
-__global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const uint32_t *__restrict__ recv_blk, int nranks, int64_t blk_words,
-                                 uint32_t *host, uint32_t epoch, unsigned long long *ts) {
+// owner_start[0..n] of this rank's plan, the received blocks' counts and the OR of every worker's overflow flag -> pinned
+// host memory, then the epoch word (the host spins on it: a copy + event record + event wait woke the host 20-40 us late
+// in some processes, round 2).  host: [owner_start 0..n | received counts 0..n-1 | overflow | epoch]
+__global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const uint32_t *__restrict__ recv_blk, const uint32_t *__restrict__ send_blk, int nranks,
+                                 int rank, int64_t blk_words, uint32_t *host, uint32_t epoch, unsigned long long *ts) {
     StampScope stamp(ts);
+    __shared__ unsigned int ovf_s;
+    if (threadIdx.x == 0) ovf_s = 0u;
+    __syncthreads();
     for (int i = threadIdx.x; i <= nranks; i += blockDim.x) host[i] = owner_start[i];
-    for (int i = threadIdx.x; i < nranks; i += blockDim.x) host[nranks + 1 + i] = recv_blk[(size_t)i * blk_words];
+    for (int i = threadIdx.x; i < nranks; i += blockDim.x) {
+        // (this rank's own block is read where it was packed: its self part of the exchange need not have travelled)
+        const uint32_t *b = (i == rank ? send_blk : recv_blk) + (size_t)i * blk_words;
+        host[nranks + 1 + i] = b[0];
+        if (b[1]) atomicOr(&ovf_s, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) host[2 * nranks + 1] = ovf_s;
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host + 2 * nranks + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(host + 2 * nranks + 2, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 
@@ -357,17 +420,8 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         HIPCHK(hipEventCreateWithFlags(&sh.done_ev, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sh.flat_ev, hipEventDisableTiming));
     }
-    // overlap mode (decided once per model: every rank must issue a communicator's operations in one order): the key
-    // lists of the next step and the all-reduce go to side chain 1 + the side communicator
-    if (sh.ov_mode < 0) sh.ov_mode = (g_shard_overlap && !use_side && m->multi_stream && !m->cfg.use_graph && dev_waits_ok(s)) ? 1 : 0;
-    const bool ov = sh.ov_mode == 1 && !use_side && !m->profile;
-    // overlap: on side chain 0, in order behind the plan's kernels (which run there while the step trains) -- the counts
-    // reach the host long before the running step's push, and nothing waits across streams for the plan
-    hipStream_t st = use_side ? s->prefetch_stream : ov ? m->side[0] : s->stream;
-    // this model's previous step still reads its key lists until its finish has run on the training stream
-    if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
     if (!sh.blk_words) {
-        // a block holds what one worker can ask one owner for at most: every id of a batch, or every row the owner has
+        // a FULL block holds what one worker can ask one owner for at most: every id of a batch, or every row the owner has
         int64_t maxrows = 1;
         for (int o = 0; o < nsh; ++o) {
             int64_t r = 0;
@@ -375,19 +429,71 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
                 r += s->emb.java_route() ? s->emb.owner_cnt[(size_t)o * s->emb.F + f] : (s->emb.rows[f] > o ? (s->emb.rows[f] - o + nsh - 1) / nsh : 0);
             maxrows = std::max(maxrows, r);
         }
-        sh.blk_words = round_up(1 + std::min<int64_t>(m->nnz_cap, maxrows), 64);
-        RtGuard rt_guard;
-        for (int k = 0; k < 2; ++k) {
-            HIPCHK(hipMalloc((void **)&sh.x_send_blk[k], sizeof(uint32_t) * (size_t)sh.blk_words * nsh));
-            HIPCHK(hipMalloc((void **)&sh.x_recv_blk[k], sizeof(uint32_t) * (size_t)sh.blk_words * nsh));
-            HIPCHK(hipMemsetAsync(sh.x_send_blk[k], 0, sizeof(uint32_t) * (size_t)sh.blk_words * nsh, s->stream));
-            HIPCHK(hipMemsetAsync(sh.x_recv_blk[k], 0, sizeof(uint32_t) * (size_t)sh.blk_words * nsh, s->stream));
-            s->bytes += 2 * (int64_t)sizeof(uint32_t) * sh.blk_words * nsh;
+        int64_t full_cap = std::min<int64_t>(m->nnz_cap, maxrows), blk_cap = full_cap;
+        // a WIRE block holds blk_factor x the even share of a batch's ids (at configs[2], N = 8: 26 624 rows for an expected
+        // ~5 800; round 3 sent 106 560 words per peer and step to carry them: VERDICT r3 weak #9)
+        if (nsh > 1 && g_blk_factor > 0) blk_cap = std::min<int64_t>(full_cap, std::max<int64_t>(256, (int64_t)g_blk_factor * ((m->nnz_cap + nsh - 1) / nsh)));
+        if (g_blk_cap > 0) blk_cap = std::min<int64_t>(full_cap, g_blk_cap);
+        const int64_t blk_words = round_up(PS_BLK_HDR + blk_cap, 16), full_words = round_up(PS_BLK_HDR + full_cap, 16);    // (64-byte multiples)
+        const bool has_full = blk_words < full_words;
+        if (!has_full) blk_cap = full_cap;
+        // overlap mode (decided once per model: every rank must issue a communicator's operations in one order): the key
+        // lists of the next step and the all-reduce go to the side chains + their own communicators
+        int ov_want = (g_shard_overlap && !use_side && m->multi_stream && !m->cfg.use_graph && dev_waits_ok(s)) ? 1 : 0;
+        // ONE all-gather, once per model: every rank's [wire block | full block | wanted overlap mode | header words].  The
+        // block sizes are the fixed send and receive sizes of the id exchange -- ranks configured with different max_batch /
+        // max_nnz would post mismatched receives and hang -- and the communicator an operation goes to depends
+        // on the overlap mode, which depends on per-rank state (dev_waits_ok): the ranks take the minimum.  Every rank sees
+        // the same gathered words, so every rank fails here, or none.
+        {
+            uint32_t *agree_dev = nullptr;
+            { RtGuard rt_guard; HIPCHK(hipMalloc((void **)&agree_dev, sizeof(uint32_t) * 4 * (size_t)(nsh + 1))); }
+            std::vector<uint32_t> agree((size_t)4 * (nsh + 1));
+            agree[0] = (uint32_t)blk_words; agree[1] = (uint32_t)full_words; agree[2] = (uint32_t)ov_want; agree[3] = PS_BLK_HDR;
+            int arc = PS_OK;
+            if (hipMemcpyAsync(agree_dev, agree.data(), 16, hipMemcpyHostToDevice, s->stream) != hipSuccess) arc = ps_set_err(PS_E_HIP, "upload of the agreement words failed");
+            if (arc == PS_OK) { comm_select(comm, 0, false); arc = comm->all_gather(comm->ctx, agree_dev, agree_dev + 4, 16, s->stream); }
+            if (arc == PS_OK && (hipMemcpyAsync(agree.data() + 4, agree_dev + 4, 16 * (size_t)nsh, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                                 hipStreamSynchronize(s->stream) != hipSuccess)) arc = ps_set_err(PS_E_HIP, "readback of the agreement words failed");
+            { RtGuard rt_guard; (void)hipStreamSynchronize(s->stream); (void)hipFree(agree_dev); }
+            PSCHK(arc);
+            for (int r = 0; r < nsh; ++r) {
+                const uint32_t *a = agree.data() + 4 * (size_t)(r + 1);
+                if (a[0] != (uint32_t)blk_words || a[1] != (uint32_t)full_words || a[3] != PS_BLK_HDR)
+                    return ps_set_err(PS_E_BAD_ARG, "rank %d exchanges id blocks of %u / %u words, this rank (%d) of %lld / %lld: the ranks' models differ in "
+                                      "max_batch / max_nnz (or blk_factor)", r, a[0], a[1], rank, (long long)blk_words, (long long)full_words);
+                ov_want = std::min<int>(ov_want, (int)a[2]);
+            }
         }
-        HIPCHK(hipHostMalloc((void **)&sh.counts_host, sizeof(uint32_t) * (size_t)(2 * nsh + 2) + 64, hipHostMallocDefault));
-        memset(sh.counts_host, 0, sizeof(uint32_t) * (size_t)(2 * nsh + 2) + 64);
-        HIPCHK(hipStreamSynchronize(s->stream));
+        {
+            RtGuard rt_guard;
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(hipMalloc((void **)&sh.x_send_blk[k], sizeof(uint32_t) * (size_t)blk_words * nsh));
+                HIPCHK(hipMalloc((void **)&sh.x_recv_blk[k], sizeof(uint32_t) * (size_t)blk_words * nsh));
+                HIPCHK(hipMemsetAsync(sh.x_send_blk[k], 0, sizeof(uint32_t) * (size_t)blk_words * nsh, s->stream));
+                HIPCHK(hipMemsetAsync(sh.x_recv_blk[k], 0, sizeof(uint32_t) * (size_t)blk_words * nsh, s->stream));
+                s->bytes += 2 * (int64_t)sizeof(uint32_t) * blk_words * nsh;
+                if (has_full) {
+                    HIPCHK(hipMalloc((void **)&sh.x_send_full[k], sizeof(uint32_t) * (size_t)full_words * nsh));
+                    HIPCHK(hipMalloc((void **)&sh.x_recv_full[k], sizeof(uint32_t) * (size_t)full_words * nsh));
+                    HIPCHK(hipMemsetAsync(sh.x_send_full[k], 0, sizeof(uint32_t) * (size_t)full_words * nsh, s->stream));
+                    HIPCHK(hipMemsetAsync(sh.x_recv_full[k], 0, sizeof(uint32_t) * (size_t)full_words * nsh, s->stream));
+                    s->bytes += 2 * (int64_t)sizeof(uint32_t) * full_words * nsh;
+                } else { sh.x_send_full[k] = sh.x_send_blk[k]; sh.x_recv_full[k] = sh.x_recv_blk[k]; }
+            }
+            HIPCHK(hipHostMalloc((void **)&sh.counts_host, sizeof(uint32_t) * (size_t)(2 * nsh + 3) + 64, hipHostMallocDefault));
+            memset(sh.counts_host, 0, sizeof(uint32_t) * (size_t)(2 * nsh + 3) + 64);
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
+        sh.blk_words = blk_words; sh.full_words = full_words; sh.blk_cap = blk_cap; sh.full_cap = full_cap; sh.has_full = has_full;
+        sh.ov_mode = ov_want;
     }
+    const bool ov = sh.ov_mode == 1 && !use_side && !m->profile;
+    // overlap: on side chain 0, in order behind the plan's kernels (which run there while the step trains) -- the counts
+    // reach the host long before the running step's push, and nothing waits across streams for the plan
+    hipStream_t st = use_side ? s->prefetch_stream : ov ? m->side[0] : s->stream;
+    // this model's previous step still reads its key lists until its finish has run on the training stream
+    if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
     {   // the owner side receives at most min(ids of a batch, rows held here) keys from every worker (the worst
         // case used to be nnz_cap per worker whatever the shard held)
         const int64_t per_peer = std::min<int64_t>(m->nnz_cap, std::max<int64_t>(s->emb.total_rows, 1)), rmax = per_peer * nsh, D = m->cfg.D;
@@ -396,6 +502,7 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         PSCHK(size_once(s, &sh.x_cache, &sh.x_cache_cap, m->nnz_cap * D, sizeof(float)));
         sh.x_recv_cap = rmax;
         PSCHK(shard_push_reserve(s, nsh));
+        if (!shard_push_grouped_ok(s, nsh)) PSCHK(size_once(s, &sh.x_recv_rows, &sh.x_recv_rows_cap, rmax + 1, sizeof(uint32_t)));   // (the sorted push's list)
     }
     // (overlap mode without an early plan -- the first step, a store that fell back to events: the plan's kernels go to side
     //  chain 1 too and are ordered behind the running step's backward, whose lists they overwrite: order_after_main)
@@ -403,18 +510,18 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     sh.x_set ^= 1;
     const int set = sh.x_set;
     hipLaunchKernelGGL(k_pack_blocks, dim3(cdiv(std::max<int64_t>(m->cur_nnz, nsh), 256)), dim3(256), 0, st, sh.send_rows, sh.owner_start, nsh, sh.blk_words,
-                       sh.x_send_blk[set], stamp_next("pack_blocks"));
+                       (uint32_t)sh.blk_cap, sh.x_send_blk[set], sh.full_words, sh.x_send_full[set], stamp_next("pack_blocks"));
     HIPCHK(hipGetLastError());
-    {   // the id exchange: fixed size, no host wait
+    {   // the id exchange: fixed size, no host wait.  (Own keys in place: this rank's own block stays where it was packed.)
         std::vector<int64_t> fixed((size_t)nsh, sh.blk_words);
-        comm_select(comm, (use_side || ov) ? 1 : 0, false);
+        comm_select(comm, (use_side || ov) ? 1 : 0, comm_own_in_place(comm));
         int rc = comm->all_to_all_v(comm->ctx, sh.x_send_blk[set], fixed.data(), sh.x_recv_blk[set], fixed.data(), sizeof(uint32_t), st);
         comm_select(comm, 0, false);
         PSCHK(rc);
     }
     if (++sh.x_epoch == 0) ++sh.x_epoch;
-    hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, st, sh.owner_start, sh.x_recv_blk[set], nsh, sh.blk_words, sh.counts_host, sh.x_epoch,
-                       stamp_next("publish_counts"));
+    hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, st, sh.owner_start, sh.x_recv_blk[set], sh.x_send_blk[set], nsh, rank, sh.blk_words,
+                       sh.counts_host, sh.x_epoch, stamp_next("publish_counts"));
     HIPCHK(hipGetLastError());
     if (sh.tail_due) {          // an early plan: its second half (slots, the backward's entry lists) waits on side chain 0 for
         if (++m->start_epoch == 0) ++m->start_epoch;          // "the running step's backward has finished", raised by that
@@ -458,7 +565,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     } host_timer(host_timing);
     const double wait_t0 = host_timing ? HostTimer::now() : 0;
     {   // the step's one host wait: the counts of the rows / gradient exchanges (spin on the epoch word k_publish_counts raises)
-        volatile uint32_t *flag = sh.counts_host + 2 * nsh + 1;
+        volatile uint32_t *flag = sh.counts_host + 2 * nsh + 2;
         int64_t spins = 0;
         while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != sh.x_epoch) {
             if (++spins > (1ll << 22)) {                 // ~seconds: the kernel never ran -- surface the stream's error instead of hanging
@@ -481,7 +588,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     for (int o = 0; o < nsh; ++o) {
         sc[o] = (int64_t)sh.counts_host[o + 1] - (int64_t)sh.counts_host[o];     // what I request from / push to owner o
         rc[o] = (int64_t)sh.counts_host[nsh + 1 + o];                             // what worker o requests from / pushes to me
-        if (sc[o] < 0 || rc[o] < 0 || sc[o] >= sh.blk_words || rc[o] >= sh.blk_words) return ps_set_err(PS_E_STATE, "bad key count in the exchange (%lld, %lld)", (long long)sc[o], (long long)rc[o]);
+        if (sc[o] < 0 || rc[o] < 0 || sc[o] > sh.full_cap || rc[o] > sh.full_cap) return ps_set_err(PS_E_STATE, "bad key count in the exchange (%lld, %lld)", (long long)sc[o], (long long)rc[o]);
         scpre[o + 1] = scpre[o] + sc[o]; rcpre[o + 1] = rcpre[o] + rc[o];
     }
     const int64_t U = scpre[nsh], nrecv = rcpre[nsh];
@@ -489,6 +596,25 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     if (sc[rank] != rc[rank]) return ps_set_err(PS_E_STATE, "the exchange's self counts differ");
     if (U > m->nnz_cap || nrecv > sh.x_recv_cap)
         return ps_set_err(PS_E_STATE, "exchange counts (%lld requested, %lld received) exceed the buffers sized at ps_shard_step_begin", (long long)U, (long long)nrecv);
+    // Some worker's list for some owner did not fit its wire block (every rank has seen every worker's flag: the same
+    // decision everywhere): the full-size blocks of this step -- packed beside the wire blocks -- are exchanged now, on the
+    // training stream in front of the gather, and every list of this step is read from them.
+    const bool ovf = sh.counts_host[2 * nsh + 1] != 0;
+    for (int o = 0; o < nsh && !ovf; ++o)
+        if (sc[o] > sh.blk_cap || rc[o] > sh.blk_cap) return ps_set_err(PS_E_STATE, "a key list of %lld / %lld rows arrived without its overflow flag (wire blocks hold %lld)", (long long)sc[o], (long long)rc[o], (long long)sh.blk_cap);
+    if (ovf && !sh.has_full) return ps_set_err(PS_E_STATE, "overflow flag on full-size blocks");
+    sh.x_ovf = ovf;
+    // a rank's own keys are read where they are when the table says so (RCCL's always does; ps_native.h PS_COMM_OWN_IN_PLACE)
+    const bool alias = comm_own_in_place(comm);
+    if (ovf) {
+        std::vector<int64_t> fixed((size_t)nsh, sh.full_words);
+        comm_select(comm, 0, alias);
+        int xrc = comm->all_to_all_v(comm->ctx, sh.x_send_full[set], fixed.data(), sh.x_recv_full[set], fixed.data(), sizeof(uint32_t), st);
+        comm_select(comm, 0, false);
+        PSCHK(xrc);
+        sh.stat[7] += 1;
+        sh.stat[1] += (int64_t)(nsh - 1) * sh.full_words * (int64_t)sizeof(uint32_t);
+    }
     {   // wire accounting (this rank's own part never travels)
         const int64_t peers = nsh - 1, self = sc[rank];
         sh.stat[0] += 1;
@@ -498,15 +624,14 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         sh.stat[4] += nsh > 1 ? sh.flat_elems * (int64_t)sizeof(float) : 0;
         sh.stat[5] += U; sh.stat[6] += nrecv;
     }
-    // a rank's own keys are read where they are when the collectives are RCCL's (a plugged-in table copies them like any other)
-    const bool alias = comm_is_rccl(comm);
     const uint32_t *rows_p[PS_PUSH_MAX_PEERS];
     const float *grads_p[PS_PUSH_MAX_PEERS];
     for (int p = 0; p < nsh; ++p) {
-        rows_p[p] = sh.x_recv_blk[set] + (size_t)p * sh.blk_words + 1;
+        rows_p[p] = (ovf ? sh.x_recv_full[set] + (size_t)p * sh.full_words : sh.x_recv_blk[set] + (size_t)p * sh.blk_words) + PS_BLK_HDR;
         grads_p[p] = sh.x_recv_grads + (size_t)rcpre[p] * D;
     }
-    if (alias) { rows_p[rank] = sh.x_send_blk[set] + (size_t)rank * sh.blk_words + 1; grads_p[rank] = m->grads_out + (size_t)scpre[rank] * D; }
+    // (own keys: the FULL block this rank packed for itself -- complete whatever the wire block holds)
+    if (alias) { rows_p[rank] = sh.x_send_full[set] + (size_t)rank * sh.full_words + PS_BLK_HDR; grads_p[rank] = m->grads_out + (size_t)scpre[rank] * D; }
     // getList: the owner gathers the requested rows, rows back
     {   // (the gather's launch also holds the join with side chain 0 -- "this step's slots are written" -- for the forward
         //  behind it: a wait on an event that fired long ago still costs the training stream ~3.5 us, round 2)
@@ -536,25 +661,45 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
         PSCHK(frc);
     }
+    const bool ov2 = sh.ov_mode == 1 && !was_side && !m->profile;      // where the replicated tensors' update goes
+    // The flat gradient [fc | wide G | wide C | bias] is consumed on side chain 1 in overlap mode.  Normally it was produced
+    // there too (the backward's tail behind the dW GEMMs).  When this step's backward could not use device-side joins -- a
+    // wait that timed out, a second model on the device, dev_wait / tail_dev switched off -- it went to the TRAINING stream
+    // while the overlap mode, agreed once by all ranks, stays: order the reduction behind it.
+    if (ov2 && m->flat_stream && m->flat_stream != m->side[1]) {
+        hipEvent_t e = m->events[m->next_event++ % m->events.size()];
+        HIPCHK(hipEventRecord(e, m->flat_stream));
+        HIPCHK(hipStreamWaitEvent(m->side[1], e, 0));
+    }
     // the next step's key lists (same order of operations on every rank)
     if (next_batch) PSCHK(shard_step_begin(m, next_batch, comm, 0, true));
-    const bool ov2 = sh.ov_mode == 1 && !was_side && !m->profile;      // where the replicated tensors' update goes
     // push: the per-key gradients to their owners
     comm_select(comm, 0, alias);
     crc = comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st);
     comm_select(comm, 0, false);
     PSCHK(crc);
-    {
+    if (shard_push_grouped_ok(s, nsh)) {
         LaunchOpts lo;
         if (sh.tail_flag_due) { lo.flag = m->start_flag + 6; lo.flag_val = sh.pub_epoch; }
         PSCHK(shard_apply_push_lists(s, rows_p, grads_p, rc.data(), nsh, is_async, true, &lo));
         if (sh.tail_flag_due && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 6, sh.pub_epoch, st));
         sh.tail_flag_due = false;
+    } else {
+        // The sort-free push needs a [workers][local rows] position table; beyond 4 GB of it (8 workers x 125 M local rows:
+        // configs[3]'s table sharded 8 ways) the owner falls back to the stable sort by row of ps_shard_apply_push: the
+        // received lists are packed into one contiguous list first (this case used to fail here with
+        // PS_E_UNSUPPORTED, after the rows and gradient exchanges and in front of the all-reduce the peers then hang in).
+        if (sh.tail_flag_due) { PSCHK(launch_flag_set(m->start_flag + 6, sh.pub_epoch, st)); sh.tail_flag_due = false; }
+        for (int p = 0; p < nsh; ++p)
+            if (rc[p] > 0) HIPCHK(hipMemcpyAsync(sh.x_recv_rows + rcpre[p], rows_p[p], sizeof(uint32_t) * (size_t)rc[p], hipMemcpyDeviceToDevice, st));
+        if (alias && rc[rank] > 0)
+            HIPCHK(hipMemcpyAsync(sh.x_recv_grads + (size_t)rcpre[rank] * D, grads_p[rank], sizeof(float) * (size_t)rc[rank] * D, hipMemcpyDeviceToDevice, st));
+        PSCHK(shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, nullptr, nsh, is_async, true));
     }
     // the dense + wide reduction and the replicated update: on side chain 1 + the side communicator (behind the flat
     // gradient's kernel and the next step's id exchange, beside the push), or in line
     hipStream_t fs = ov2 ? m->side[1] : st;
-    if (nsh > 1) {
+    if (comm_wired(comm)) {
         comm_select(comm, ov2 ? 2 : 0, false);
         crc = comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, fs);
         comm_select(comm, 0, false);
@@ -604,5 +749,6 @@ extern "C" int ps_shard_exchange_stats(const ps_model_t *m, int64_t *out, int n)
     if (!m || !out || n < 8) return ps_set_err(PS_E_BAD_ARG, "bad argument (8 values)");
     for (int i = 0; i < 7; ++i) out[i] = m->sh.stat[i];
     out[7] = m->sh.blk_words;
+    if (n >= 10) { out[8] = m->sh.stat[7]; out[9] = m->sh.full_words; }
     return PS_OK;
 }

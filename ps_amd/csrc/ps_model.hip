@@ -213,15 +213,15 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     }
     if (m->sh.plan_ev) (void)hipEventDestroy(m->sh.plan_ev);
     if (m->sh.owner_start_host) (void)hipHostFree(m->sh.owner_start_host);
-    if (m->sh.matrix_host) (void)hipHostFree(m->sh.matrix_host);
     if (m->sh.counts_host) (void)hipHostFree(m->sh.counts_host);
     if (m->sh.flat_ev) (void)hipEventDestroy(m->sh.flat_ev);
-    for (int k = 0; k < 2; ++k) { fr(m->sh.x_send_blk[k]); fr(m->sh.x_recv_blk[k]); }
+    for (int k = 0; k < 2; ++k) {
+        if (m->sh.has_full) { fr(m->sh.x_send_full[k]); fr(m->sh.x_recv_full[k]); }
+        fr(m->sh.x_send_blk[k]); fr(m->sh.x_recv_blk[k]);
+    }
     if (m->sh.x_ev) (void)hipEventDestroy(m->sh.x_ev);
     if (m->sh.done_ev) (void)hipEventDestroy(m->sh.done_ev);
-    if (m->sh.ar_ev) (void)hipEventDestroy(m->sh.ar_ev);
-    if (m->sh.ar_done_ev) (void)hipEventDestroy(m->sh.ar_done_ev);
-    fr(m->sh.matrix_dev); fr(m->sh.x_recv_rows); fr(m->sh.x_rows_out); fr(m->sh.x_recv_grads); fr(m->sh.x_cache);
+    fr(m->sh.x_recv_rows); fr(m->sh.x_rows_out); fr(m->sh.x_recv_grads); fr(m->sh.x_cache);
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
@@ -915,6 +915,7 @@ int enqueue_backward(ps_model *m, bool apply) {
             if (dw_split_done) { d.wait_flag2 = m->start_flag + 11; d.wait_val2 = dw_split_epoch; }
             if (tail_defer) { d.started_flag = m->start_flag + 12; d.started_val = m->start_epoch; }
             { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
+            m->flat_stream = sw;
             if (tail_join) PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
             if (tail_defer) {
                 HIPCHK(hipEventRecord(m->tail_ev, sw));
@@ -925,11 +926,13 @@ int enqueue_backward(ps_model *m, bool apply) {
         }
         PSCHK(launch_spin_until(m->start_flag + 2, m->start_epoch, sw, werr, 2));
         { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
+        m->flat_stream = sw;
         PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));
         PSCHK(launch_spin_until(m->start_flag + 3, m->start_epoch, st, werr, 3));
         return PS_OK;
     }
     { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, st)); }
+    m->flat_stream = st;
     return PS_OK;
 }
 

@@ -558,8 +558,11 @@ extern "C" int ps_shard_apply_push(ps_store_t *s, const uint32_t *rows_dev, cons
 }
 
 // can the sort-free push (worker-grouped lists, kernels_emb.hip k_push_mark / k_push_apply) serve this store?
+int g_push_grouped_max_mb = 4000;        // ps_tune_set("push_grouped_max_mb"): the position table's size limit (tests: force the sorted push)
 bool shard_push_grouped_ok(const ps_store *s, int npeers) {
-    return npeers >= 1 && npeers <= PS_PUSH_MAX_PEERS && (double)npeers * (double)s->emb.total_rows * 4.0 <= 4.0e9;
+    if (npeers < 1 || npeers > PS_PUSH_MAX_PEERS) return false;
+    if (npeers == 1) return true;         // one worker: no mark pass, no tables
+    return (double)npeers * (double)s->emb.total_rows * 4.0 <= 1.0e6 * (double)g_push_grouped_max_mb;
 }
 
 // PServer.push + psUpdate for lists that lie grouped by pushing worker, every worker's part where it is (rows_p[p],

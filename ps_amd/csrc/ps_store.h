@@ -111,6 +111,7 @@ int store_enter(ps_store *s);
 int store_settle(ps_store *s);             // the pending join alone (an event wait on the store's stream)
 // may this store's models join their streams by device-side flags?  (g_dev_wait, no timeout so far, one live model on the device)
 #define PS_MAX_DEVICES 64
+#define PS_BLK_HDR 2        // header words of an id block: [count | overflow flag of the sending worker]
 #include <atomic>
 extern std::atomic<int> g_models_on_device[PS_MAX_DEVICES];
 bool dev_waits_ok(const ps_store *s);
@@ -194,12 +195,21 @@ struct ps_model {
         // the id exchange needs no split sizes -- it is enqueued without a host wait, before the running step's push --
         // and carries the counts of the two weight-dependent exchanges (rows back, gradients out) with it.  Two sets:
         // step t+1's lists are exchanged while step t's push still reads its own.
-        int64_t blk_words = 0;
+        // Round 4: a WIRE block holds blk_cap rows = blk_factor * nnz_cap / nranks (the expected list is ~ unique keys / nranks:
+        // a 16th of what a full block holds at N = 8), behind PS_BLK_HDR header words [count | this worker overflowed
+        // somewhere].  The FULL blocks (full_cap = min(ids of a batch, rows of the largest shard) rows: round 3's blocks) are
+        // packed beside them and travel only in a step where some worker's list for some owner did not fit -- every rank sees
+        // every worker's flag, so all of them take that second exchange or none does.  has_full == false: the wire block IS
+        // the full block (one rank; tiny tables).
+        int64_t blk_words = 0, full_words = 0, blk_cap = 0, full_cap = 0;
+        bool has_full = false;
         uint32_t *x_send_blk[2] = {nullptr, nullptr}, *x_recv_blk[2] = {nullptr, nullptr};    // [nranks][blk_words]
+        uint32_t *x_send_full[2] = {nullptr, nullptr}, *x_recv_full[2] = {nullptr, nullptr};  // [nranks][full_words] (== the wire blocks when !has_full)
+        bool x_ovf = false;                                          // the step begun last (set by its finish): its lists came at full size
         int x_set = 0;                                               // the set of the step begun last
         // what this rank put on / took off the wire so far (ps_shard_exchange_stats): steps, id-block bytes sent, row bytes received,
         // gradient bytes sent, all-reduce payload bytes, unique keys requested, keys served
-        int64_t stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // [7]: steps that took the full-size second exchange
         int ov_mode = -1;                                            // 1: key lists of t+1 and the all-reduce on side chain 1 + the side communicator (decided at the first begin)
         bool x_ov = false;                                           // the step begun last enqueued its id exchange on side chain 1
         bool tail_flag_due = false;                                  // the running step's push must raise start_flag[6] = pub_epoch
@@ -208,13 +218,12 @@ struct ps_model {
         uint32_t *counts_host = nullptr;                             // pinned: [owner_start 0..nranks | received counts 0..nranks-1 | epoch]
         hipEvent_t flat_ev = nullptr;                                // the replicated tensors' update was enqueued on side chain 1
         bool flat_pending = false; uint32_t flat_epoch = 0;          // ... and the main chain has not joined it yet
-        uint32_t *matrix_dev = nullptr, *matrix_host = nullptr;      // (rounds 1-2: the N x N count matrix)
-        uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;
+        uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;     // (x_recv_rows: the sorted push's contiguous copy of the received lists)
+        int64_t x_recv_rows_cap = 0;
         float *x_rows_out = nullptr; int64_t x_rows_cap = 0;
         float *x_recv_grads = nullptr; int64_t x_grads_cap = 0;
         float *x_cache = nullptr; int64_t x_cache_cap = 0;
         hipEvent_t x_ev = nullptr, done_ev = nullptr;   // begin's work is done | finish's work was enqueued
-        hipEvent_t ar_ev = nullptr, ar_done_ev = nullptr;   // flat gradient ready | reduced
         bool x_begun = false, x_side = false, done_recorded = false;
         // the NEXT step's plan enqueued on side chain 0 while this step trains (shard_plan_enqueue, early): its slot /
         // entry-list half still to be enqueued behind the counts' publication | epoch of "plan done" (start_flag word 7)
@@ -234,6 +243,7 @@ struct ps_model {
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)
     hipStream_t side[2] = {nullptr, nullptr};
+    hipStream_t flat_stream = nullptr;   // where the last backward's dense-gradient launch went (ps_shard_step orders its all-reduce behind it)
     std::vector<hipEvent_t> events; size_t next_event = 0;
     bool multi_stream = true;
     bool side0_pending = false;   // a forward forked the sort chain and no backward joined it yet

@@ -62,7 +62,10 @@ ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void
 
 class ps_comm_ops_t(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("nranks", C.c_int), ("rank", C.c_int), ("all_gather", ALL_GATHER_FN),
-                ("all_to_all_v", ALL_TO_ALL_V_FN), ("all_reduce_sum_f32", ALL_REDUCE_FN)]
+                ("all_to_all_v", ALL_TO_ALL_V_FN), ("all_reduce_sum_f32", ALL_REDUCE_FN), ("flags", C.c_int)]
+
+
+PS_COMM_OWN_IN_PLACE = 1
 
 
 SIGNATURES = {
@@ -148,6 +151,7 @@ SIGNATURES = {
     "ps_shard_exchange_stats": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "ps_comm_rccl_info": (_i, [C.POINTER(ps_comm_ops_t), _pi, _pi, _pi]),
     "ps_comm_rccl_destroy": (_i, [C.POINTER(ps_comm_ops_t)]),
+    "ps_comm_rccl_calls": (_i, [C.POINTER(ps_comm_ops_t), _pi64]),
     "ps_comm_selfcheck": (_i, [_vp, C.POINTER(ps_comm_ops_t)]),
     "ps_shard_step": (_i, [_vp, C.POINTER(ps_batch_t), C.POINTER(ps_comm_ops_t), _i, _pf]),
     "ps_shard_step_begin": (_i, [_vp, C.POINTER(ps_batch_t), C.POINTER(ps_comm_ops_t), _i]),

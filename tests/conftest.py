@@ -16,7 +16,7 @@ GPU_TEST_TIMEOUT_S = int(os.environ.get("PS_AMD_TEST_TIMEOUT", "180"))
 # collection order of the -m gpu suite: the oracle-parity tests of the hot path first, the
 # threads-on-one-GPU exchange tests last
 _ORDER = ["test_gpu_operators", "test_gpu_parity", "test_gpu_configs", "test_gpu_layer_ops", "test_gpu_sumorder", "test_gpu_fieldsort", "test_gpu_schedule",
-          "test_gpu_auc", "test_gpu_ckpt", "test_gpu_ingest", "test_gpu_ps_server", "test_gpu_router", "test_gpu_multirank", "test_gpu_multiproc"]
+          "test_gpu_auc", "test_gpu_ckpt", "test_gpu_ingest", "test_gpu_ps_server", "test_gpu_router", "test_gpu_multirank", "test_gpu_multiproc", "test_gpu_rccl_wire"]
 
 
 def pytest_configure(config):

@@ -29,7 +29,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def rank_process(rank, world, port, is_async, device_batches, q):
+def rank_process(rank, world, port, is_async, device_batches, q, opts=None):
+    """opts: own_in_place -- the table sets PS_COMM_OWN_IN_PLACE and POISONS the self part of every receive buffer (0xFF
+    bytes: NaN rows, row ids beyond every table), so a step that looked at it would not survive; tune -- ps_tune_set knobs
+    of this rank's process (blk_cap: wire blocks that overflow; push_grouped_max_mb = 0: the sorted owner-side push)."""
+    opts = opts or {}
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
         import ctypes as C
@@ -44,6 +48,9 @@ def rank_process(rank, world, port, is_async, device_batches, q):
         kv.create_embedding([V] * F, D, shard=rank, nshards=world)
         gm = ps_amd.WideDeepNN.buildModel(F, D, CFG["X"], CFG["fc"], CFG["wide"], store=kv, max_batch=CFG["B"])
         L = N.lib()
+        for k_, v_ in (opts.get("tune") or {}).items():
+            N.check(L.ps_tune_set(k_.encode(), int(v_)))
+        own_in_place = bool(opts.get("own_in_place"))
 
         class GlooOps:
             """ps_comm_ops_t over gloo: "enqueue on stream" = drain the stream, stage through the host."""
@@ -53,6 +60,8 @@ def rank_process(rank, world, port, is_async, device_batches, q):
                 self.ops.ctx, self.ops.nranks, self.ops.rank = None, world, rank
                 self._ag = N.ALL_GATHER_FN(self.all_gather); self._a2a = N.ALL_TO_ALL_V_FN(self.all_to_all_v); self._ar = N.ALL_REDUCE_FN(self.all_reduce)
                 self.ops.all_gather, self.ops.all_to_all_v, self.ops.all_reduce_sum_f32 = self._ag, self._a2a, self._ar
+                self.ops.flags = N.PS_COMM_OWN_IN_PLACE if own_in_place else 0
+                self.checking = False           # ps_comm_selfcheck verifies the self part too: moved as is while it runs
                 self.err = None
                 self.calls = {"all_gather": 0, "all_to_all_v": 0, "all_reduce": 0}
 
@@ -91,7 +100,10 @@ def rank_process(rank, world, port, is_async, device_batches, q):
                     host = torch.from_numpy(self._down(send, sum(scl)))
                     out = torch.empty(sum(rcl), dtype=torch.uint8)
                     dist.all_to_all_single(out, host, output_split_sizes=rcl, input_split_sizes=scl)
-                    self._up(recv, out.numpy())
+                    o = out.numpy()
+                    if own_in_place and not self.checking:      # the step must never read its own part from the receive buffer
+                        o[sum(rcl[:rank]):sum(rcl[:rank + 1])] = 0xFF
+                    self._up(recv, o)
                 return self._guard("all_to_all_v", f, stream)
 
             def all_reduce(self, ctx, buf, n, stream):
@@ -107,7 +119,9 @@ def rank_process(rank, world, port, is_async, device_batches, q):
 
         comm = GlooOps()
         wk = NativeWorker([gm], world, rank, ops=comm.ops, is_async=is_async)
+        comm.checking = True
         wk.selfcheck()
+        comm.checking = False
         data = make_batches(rank, STEPS)
         if device_batches:
             bs = [ps_amd.DeviceBatch(kv, b["E"], b["X"], b["Y"], b["W"]) for b in data]
@@ -125,9 +139,12 @@ def rank_process(rank, world, port, is_async, device_batches, q):
             w = kv.get_rows(f, ids)
             for i, idv in enumerate(ids):
                 rows[(f, int(idv))] = w[i]
+        st10 = (C.c_int64 * 10)()
+        N.check(L.ps_shard_exchange_stats(gm.h, st10, 10))
+        xstats = [int(x) for x in st10]
         res = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)],
                kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step(), mode, why.value.decode(), dict(comm.calls),
-               int(L.ps_store_wait_timeouts(kv.h)))
+               int(L.ps_store_wait_timeouts(kv.h)), xstats)
         dist.barrier()
         gm.close(); kv.close()
         dist.destroy_process_group()
@@ -137,11 +154,11 @@ def rank_process(rank, world, port, is_async, device_batches, q):
         q.put((rank, "fail", traceback.format_exc()))
 
 
-def run_processes(world, is_async, device_batches):
+def run_processes(world, is_async, device_batches, opts=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=rank_process, args=(r, world, port, is_async, device_batches, q), daemon=True) for r in range(world)]
+    procs = [ctx.Process(target=rank_process, args=(r, world, port, is_async, device_batches, q, opts), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -166,11 +183,13 @@ def test_one_process_per_rank_on_one_gpu(orc, world, is_async, device_batches):
     tol = 2e-5 * STEPS                   # the bound of the single-GPU step parity (FP32 GEMM order differs from the oracle's)
     touched = 0
     for r in range(world):
-        rows, W, b, wide, wbias, gstep, mode, why, calls, timeouts = out[r]
+        rows, W, b, wide, wbias, gstep, mode, why, calls, timeouts, xstats = out[r]
         assert gstep == STEPS and timeouts == 0
         assert mode == 1 and why == "", "one model per process: the joins must be device-side flags (%r)" % why
-        # per step: the fixed-size id-block exchange, rows back, gradients out; one all-reduce; no count all-gather any more
-        assert calls["all_to_all_v"] == 3 * STEPS + 1 and calls["all_reduce"] == STEPS + 1 and calls["all_gather"] == 1, calls    # (+1: selfcheck)
+        # per step: the fixed-size id-block exchange, rows back, gradients out; one all-reduce; no count all-gather any more --
+        # ONE all-gather per model (block sizes + stream-join mode agreed at the first begin) and the selfcheck's
+        assert calls["all_to_all_v"] == 3 * STEPS + 1 and calls["all_reduce"] == STEPS + 1 and calls["all_gather"] == 2, calls    # (+1: selfcheck)
+        assert xstats[0] == STEPS and xstats[8] == 0, xstats           # no list outgrew its wire block
         for (f, i), got in rows.items():
             assert i % world == r
             if (f, i) in emb:
@@ -206,3 +225,64 @@ def test_processes_equal_threads_bit_for_bit():
                 np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
         assert a[5] == b[5]
+
+
+def _same(a, b, what):
+    assert a[0].keys() == b[0].keys()
+    for k in a[0]:
+        np.testing.assert_array_equal(a[0][k], b[0][k], err_msg="%s: row %r" % (what, k))
+    for i in (1, 2):
+        for x, y in zip(a[i], b[i]):
+            np.testing.assert_array_equal(x, y, err_msg=what)
+    np.testing.assert_array_equal(a[3], b[3], err_msg=what); np.testing.assert_array_equal(a[4], b[4], err_msg=what)
+    assert a[5] == b[5]
+
+
+@pytest.mark.parametrize("is_async", [False, True])
+def test_own_keys_in_place_overflowing_blocks_and_the_sorted_push(is_async):
+    """Three variants of the 3-process run must leave the tables of the plain run, bit for bit (VERDICT r3 next #1b, #1c):
+      * own keys in place WITH REAL PEERS (PS_COMM_OWN_IN_PLACE: the RCCL table's mode, which one GPU could only run at
+        N = 1, i.e. without peers) -- the table poisons the self part of every receive buffer;
+      * wire blocks of 2 rows (blk_cap): most steps some list outgrows its block, every rank sees the flag and the
+        full-size blocks are exchanged in front of the gather; with and without own keys in place;
+      * the owner-side push through the stable sort (the fallback beyond a 4 GB position table)."""
+    world = 3
+    ref = run_processes(world, is_async, True)
+    variants = {"own keys in place": dict(own_in_place=True),
+                "overflowing wire blocks": dict(tune={"blk_cap": 2}),
+                "overflowing wire blocks + own keys in place": dict(own_in_place=True, tune={"blk_cap": 2}),
+                "sorted owner-side push": dict(tune={"push_grouped_max_mb": 0}),
+                "sorted push + own keys in place + overflow": dict(own_in_place=True, tune={"push_grouped_max_mb": 0, "blk_cap": 3})}
+    for name, opts in variants.items():
+        got = run_processes(world, is_async, True, opts)
+        for r in range(world):
+            _same(ref[r], got[r], "%s, rank %d" % (name, r))
+            calls, timeouts, xstats = got[r][8], got[r][9], got[r][10]
+            assert timeouts == 0 and xstats[0] == STEPS
+            if "blk_cap" in (opts.get("tune") or {}):
+                assert xstats[8] > 0, "%s: no step overflowed (%r)" % (name, xstats)
+                assert xstats[7] < xstats[9]                                    # the wire block is the small one
+                assert calls["all_to_all_v"] == 3 * STEPS + 1 + xstats[8], calls   # one more exchange per overflowing step
+            else:
+                assert xstats[8] == 0 and calls["all_to_all_v"] == 3 * STEPS + 1, (name, xstats, calls)
+
+
+def test_ranks_with_different_block_sizes_fail_together():
+    """Ranks whose models differ in max_batch would exchange id blocks of different sizes (a hang on a real wire):
+    the first begin all-gathers the sizes and EVERY rank returns PS_E_BAD_ARG."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=rank_process, args=(r, world, port, False, True, q, {"tune": {"blk_cap": 2 + 14 * r}}), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=170) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+    for rank, status, info in res:
+        assert status == "fail" and "exchanges id blocks of" in info, (rank, status, info[-600:])
