@@ -346,6 +346,8 @@ def run_single(args):
             b.close()
         batches = []
         out["multi_hot"] = multi_hot_step(cfg)
+    if args.sharded_leg:
+        out["sharded_n1"] = sharded_n1_leg(args)
     for b in batches:
         b.close()
     gm.close(); kv.close()
@@ -390,6 +392,39 @@ def multi_hot_step(cfg, steps=60):
             "final_loss": loss}
 
 
+def leg_sharded_n1(args):
+    """configs[2]'s step (ps_shard_step: plan, id-block exchange, owner gather, rows, train, gradients, owner push, flat
+    reduction) on ONE GPU with a 1-rank table, timed twice: collectives as device copies, and with every collective through
+    RCCL (three 1-rank communicators on their three streams, self send/recv, all-reduce) -- the wire this box can run."""
+    from ps_amd import sharded
+    cfg = dict(C2)
+    cfg["zipf"] = args.zipf
+    cfg["idgen"] = args.idgen
+    steps = min(args.steps, 1000)
+    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2), with_info=True)
+    return {"workload": "configs[2]'s sharded step on 1 GPU (1-rank table), batch %d; %d steps after 300 priming steps" % (cfg["B"], steps),
+            "ms_per_step": {k: round(v, 5) for k, v in res.items()},
+            "examples_per_s": {k: cfg["B"] / (1e-3 * v) for k, v in res.items()}, "rccl": info}
+
+
+def sharded_n1_leg(args):
+    """leg_sharded_n1 in a child process under a time limit: loading librccl and creating communicators is the one thing in
+    this file that talks to something outside the process (bootstrap sockets on loopback); it must not be able to take the
+    headline line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", "sharded_n1", "--steps", str(min(args.steps, 1000)),
+           "--zipf", str(args.zipf), "--idgen", args.idgen]
+    env = {k: v for k, v in os.environ.items() if k != "PS_BENCH_STDOUT_FD"}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-400:])}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "the sharded_n1 leg did not finish within 180 s"}
+
+
 def gather_roofline(kv, args):
     """BASELINE configs[3] shape: ONE 1e9-row x 64-dim f32 table (256 GB of the 288 GB HBM), uniformly random
     ids: 2^22 single-hot lookups / launch, and 2^17 bags of 32 ids (configs[4]'s multi-hot shape)."""
@@ -429,6 +464,10 @@ def main():
     ap.add_argument("--priming", type=int, default=300, help="sharded path: extra untimed steps before the timed region")
     ap.add_argument("--prefetch-thread", type=int, default=0, help="sharded path: run that prefetch in its own host thread")
     ap.add_argument("--phases", type=int, default=0, help="sharded path: also report a per-phase stopwatch (serialised)")
+    ap.add_argument("--rccl-force", type=int, default=0, help="--sharded on one GPU: 1 | 2 = every collective through RCCL anyway (ps_native.h ps_comm_rccl_create)")
+    ap.add_argument("--wire-cost", type=int, default=1, help="--sharded on one GPU: also time the step with device copies / RCCL / RCCL + own keys in place")
+    ap.add_argument("--sharded-leg", type=int, default=1, help="N = 1: also report configs[2]'s sharded step on this GPU, with device copies and through RCCL (child process)")
+    ap.add_argument("--leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--gather", type=int, default=1)
     ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
@@ -456,6 +495,9 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.leg == "sharded_n1":
+        emit(leg_sharded_n1(args))
+        return
     if args.gpus > 1 or world > 1 or args.sharded:
         from ps_amd import sharded
         out = sharded.run_bench(args, C2, synth_batch)

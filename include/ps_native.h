@@ -511,6 +511,10 @@ int ps_shard_step_finish(ps_model_t *m, const ps_comm_ops_t *comm, int is_async,
 int ps_shard_exchange_stats(const ps_model_t *m, int64_t *out, int n);
 int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *comm, int is_async,
                                const ps_batch_t *next_batch, float *loss);
+/* Measurement: under ps_tune_set("comm_timing", 1) every collective of ps_shard_step is bracketed by HIP events on the
+ * stream it is enqueued on.  out8[2 k] = calls, out8[2 k + 1] = total ms of kind k (0 id blocks, 1 rows back, 2 gradients
+ * out, 3 all-reduce) since the last call; waits for the model's streams and resets the sums. */
+int ps_shard_collective_times(ps_model_t *m, double *out8);
 
 /* Replicated tensors: one flat device buffer
  * [fc weights+biases | wide G | wide C | wide.bias g] to all-reduce(sum);

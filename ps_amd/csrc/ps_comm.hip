@@ -344,6 +344,49 @@ extern "C" int ps_comm_rccl_calls(const ps_comm_ops_t *ops, int64_t *out5) {
 // Without device-side joins (events only, ps_store_join_mode = 0) or with ps_tune_set("shard_overlap", 0) everything is
 // enqueued on the training stream with the one communicator, in the order of the left column then the right.
 int g_shard_overlap = 1;
+int g_comm_timing = 0;      // ps_tune_set("comm_timing", 1): HIP events around every collective of the step (measurement pass)
+namespace {
+int coll_collect(ps_model *m) {
+    ps_model::Shard &sh = m->sh;
+    for (auto &e : sh.coll_ev) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { sh.coll_acc[2 * e.kind] += 1; sh.coll_acc[2 * e.kind + 1] += ms; }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    sh.coll_ev.clear();
+    return PS_OK;
+}
+// one collective of the step, bracketed by events on the stream it is enqueued on when comm_timing is set
+template <class Fn>
+int timed_coll(ps_model *m, int kind, hipStream_t st, Fn &&fn) {
+    if (!g_comm_timing) return fn();
+    ps_model::Shard::CollEv e; e.kind = kind;
+    HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b));
+    HIPCHK(hipEventRecord(e.a, st));
+    const int rc = fn();
+    HIPCHK(hipEventRecord(e.b, st));
+    m->sh.coll_ev.push_back(e);
+    if (m->sh.coll_ev.size() > 2048) {
+        // (events of steps long finished; the newest few may still be in flight: collect all but the last 64)
+        std::vector<ps_model::Shard::CollEv> keep(m->sh.coll_ev.end() - 64, m->sh.coll_ev.end());
+        m->sh.coll_ev.resize(m->sh.coll_ev.size() - 64);
+        coll_collect(m);
+        m->sh.coll_ev = keep;
+    }
+    return rc;
+}
+}  // namespace
+// out[2 k] = calls, out[2 k + 1] = total ms of collective kind k (0 id blocks, 1 rows, 2 gradients, 3 all-reduce) since the
+// last call, measured under ps_tune_set("comm_timing", 1); resets the sums.
+extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
+    if (!m || !out8) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    PSCHK(store_enter(m->s));
+    HIPCHK(hipStreamSynchronize(m->s->stream));
+    for (int i = 0; i < 2; ++i) if (m->side[i]) HIPCHK(hipStreamSynchronize(m->side[i]));
+    coll_collect(m);
+    for (int i = 0; i < 8; ++i) { out8[i] = m->sh.coll_acc[i]; m->sh.coll_acc[i] = 0; }
+    return PS_OK;
+}
 int g_blk_factor = 2;       // ps_tune_set("blk_factor", f): a wire block holds f * nnz_cap / nranks rows (0: always full-size blocks)
 int g_blk_cap = 0;          // ps_tune_set("blk_cap", rows): the wire block's capacity outright (tests: force the overflow exchange)
 namespace {
@@ -515,7 +558,7 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     {   // the id exchange: fixed size, no host wait.  (Own keys in place: this rank's own block stays where it was packed.)
         std::vector<int64_t> fixed((size_t)nsh, sh.blk_words);
         comm_select(comm, (use_side || ov) ? 1 : 0, comm_own_in_place(comm));
-        int rc = comm->all_to_all_v(comm->ctx, sh.x_send_blk[set], fixed.data(), sh.x_recv_blk[set], fixed.data(), sizeof(uint32_t), st);
+        int rc = timed_coll(m, 0, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_send_blk[set], fixed.data(), sh.x_recv_blk[set], fixed.data(), sizeof(uint32_t), st); });
         comm_select(comm, 0, false);
         PSCHK(rc);
     }
@@ -609,7 +652,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     if (ovf) {
         std::vector<int64_t> fixed((size_t)nsh, sh.full_words);
         comm_select(comm, 0, alias);
-        int xrc = comm->all_to_all_v(comm->ctx, sh.x_send_full[set], fixed.data(), sh.x_recv_full[set], fixed.data(), sizeof(uint32_t), st);
+        int xrc = timed_coll(m, 0, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_send_full[set], fixed.data(), sh.x_recv_full[set], fixed.data(), sizeof(uint32_t), st); });
         comm_select(comm, 0, false);
         PSCHK(xrc);
         sh.stat[7] += 1;
@@ -641,7 +684,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         if (lo.wait && lo.launched) sh.slot_ev = nullptr;        // (else ps_shard_forward_backward waits for the event)
     }
     comm_select(comm, 0, alias);
-    int crc = comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st);
+    int crc = timed_coll(m, 1, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st); });
     comm_select(comm, 0, false);
     PSCHK(crc);
     // train on the cache (this rank's own rows straight from the gather's output)
@@ -675,7 +718,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     if (next_batch) PSCHK(shard_step_begin(m, next_batch, comm, 0, true));
     // push: the per-key gradients to their owners
     comm_select(comm, 0, alias);
-    crc = comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st);
+    crc = timed_coll(m, 2, st, [&]() { return comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st); });
     comm_select(comm, 0, false);
     PSCHK(crc);
     if (shard_push_grouped_ok(s, nsh)) {
@@ -701,7 +744,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     hipStream_t fs = ov2 ? m->side[1] : st;
     if (comm_wired(comm)) {
         comm_select(comm, ov2 ? 2 : 0, false);
-        crc = comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, fs);
+        crc = timed_coll(m, 3, fs, [&]() { return comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, fs); });
         comm_select(comm, 0, false);
         PSCHK(crc);
     }

@@ -215,6 +215,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     if (m->sh.owner_start_host) (void)hipHostFree(m->sh.owner_start_host);
     if (m->sh.counts_host) (void)hipHostFree(m->sh.counts_host);
     if (m->sh.flat_ev) (void)hipEventDestroy(m->sh.flat_ev);
+    for (auto &e : m->sh.coll_ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int k = 0; k < 2; ++k) {
         if (m->sh.has_full) { fr(m->sh.x_send_full[k]); fr(m->sh.x_recv_full[k]); }
         fr(m->sh.x_send_blk[k]); fr(m->sh.x_recv_blk[k]);

@@ -210,6 +210,10 @@ struct ps_model {
         // what this rank put on / took off the wire so far (ps_shard_exchange_stats): steps, id-block bytes sent, row bytes received,
         // gradient bytes sent, all-reduce payload bytes, unique keys requested, keys served
         int64_t stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // [7]: steps that took the full-size second exchange
+        // ps_tune_set("comm_timing", 1) (measurement): HIP events around every collective, by kind (0 id blocks, 1 rows, 2 gradients,
+        // 3 all-reduce) -> coll_acc[2 k] calls, [2 k + 1] ms (ps_shard_collective_times)
+        struct CollEv { hipEvent_t a, b; int kind; };
+        std::vector<CollEv> coll_ev; double coll_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int ov_mode = -1;                                            // 1: key lists of t+1 and the all-reduce on side chain 1 + the side communicator (decided at the first begin)
         bool x_ov = false;                                           // the step begun last enqueued its id exchange on side chain 1
         bool tail_flag_due = false;                                  // the running step's push must raise start_flag[6] = pub_epoch

@@ -149,6 +149,7 @@ SIGNATURES = {
     "ps_comm_rccl_unique_id": (_i, [C.c_char_p]),
     "ps_comm_rccl_create": (_i, [_vp, _i, _i, C.c_char_p, C.POINTER(ps_comm_ops_t)]),
     "ps_shard_exchange_stats": (_i, [_vp, C.POINTER(C.c_int64), _i]),
+    "ps_shard_collective_times": (_i, [_vp, _pd]),
     "ps_comm_rccl_info": (_i, [C.POINTER(ps_comm_ops_t), _pi, _pi, _pi]),
     "ps_comm_rccl_destroy": (_i, [C.POINTER(ps_comm_ops_t)]),
     "ps_comm_rccl_calls": (_i, [C.POINTER(ps_comm_ops_t), _pi64]),

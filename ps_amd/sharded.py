@@ -658,10 +658,14 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
         dist.broadcast(idt, 0)
         ok = torch.ones(1, dtype=torch.int32, device=dev)
         wd.kick("ncclCommInitRank x3")
+        force = int(getattr(args, "rccl_force", 0)) if world == 1 else 0
         try:
             if os.environ.get("PS_AMD_FORCE_TORCH_WIRE"):       # exercise the fallback
                 raise RuntimeError("PS_AMD_FORCE_TORCH_WIRE is set")
+            if force:            # one rank, and the wire anyway: every collective of the step through RCCL (ps_native.h)
+                L.ps_tune_set(b"rccl_force", force)
             worker = NativeWorker(gms, world, rank, id256=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
+            L.ps_tune_set(b"rccl_force", 0)
         except Exception as e:      # noqa: BLE001 -- decided collectively below
             worker = None
             ok.zero_()
@@ -693,10 +697,8 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
             if int(jm.item()) == 0:
                 for k in (b"dev_wait", b"end_wait", b"shard_overlap"):
                     L.ps_tune_set(k, 0)
-            cc, ur, hs = C.c_int(), C.c_int(), C.c_int()
-            if world > 1:
-                N.check(L.ps_comm_rccl_info(C.byref(worker.ops), C.byref(cc), C.byref(ur), C.byref(hs)))
-                rccl = {"ncclCommCount": cc.value, "ncclCommUserRank": ur.value, "extra_communicators": hs.value}
+            if world > 1 or force:
+                rccl = rccl_info(worker)
             worker_run = lambda n: worker.run(batches, n)                              # noqa: E731
     if not native:
         overlap = bool(getattr(args, "overlap_torch", 0))     # measured: no gain on this wire (host-bound), keep it simple
@@ -722,9 +724,13 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     # and the host's clocks settle; keep that out of the timed region
     prim = max(args.warmup, 1) + int(getattr(args, "priming", 300))
     wd.kick("priming", 60 + 0.02 * prim)
+    tp = time.perf_counter()
     worker_run(prim)
     kv.sync(); torch.cuda.synchronize()
     dist.barrier()
+    dtp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
+    dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
+    unprimed_ms = 1e3 * float(dtp.item()) / prim       # what a job pays while the communicators' buffers and the host's clocks settle
     wd.kick("timed region", 60 + 0.02 * args.steps)
     t0 = time.perf_counter()
     worker_run(args.steps)
@@ -736,9 +742,11 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     wd.kick("after the timed region", 300)
     loss = worker.step(batches[0], want_loss=True)
     stats = None
+    if native and rccl is not None:
+        rccl = dict(rccl, **rccl_info(worker))          # (with the call counts of the whole run)
     if native:
-        st = (C.c_int64 * 8)()
-        N.check(L.ps_shard_exchange_stats(gms[0].h, st, 8))
+        st = (C.c_int64 * 10)()
+        N.check(L.ps_shard_exchange_stats(gms[0].h, st, 10))
         n_st = max(int(st[0]), 1)
         per = {"id_blocks_sent": st[1] / n_st, "rows_received": st[2] / n_st, "gradients_sent": st[3] / n_st,
                "allreduce_payload": st[4] / n_st}
@@ -747,7 +755,11 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
                  "wire_bytes_per_step_per_rank": int(wire),
                  # the step's average: bytes this rank moves over xGMI per step / the step's duration (the links idle most of a step)
                  "avg_xgmi_GBs_per_rank": wire / (dt / args.steps) / 1e9,
-                 "unique_keys_requested_per_step": st[5] / n_st, "keys_served_per_step": st[6] / n_st, "id_block_words": int(st[7])}
+                 "unique_keys_requested_per_step": st[5] / n_st, "keys_served_per_step": st[6] / n_st, "id_block_words": int(st[7]),
+                 "full_id_block_words": int(st[9]), "steps_with_the_full_size_id_exchange": int(st[8])}
+        ct = collective_times(worker, worker_run, kv, gms[0])
+        if ct:
+            stats["collective_device_us"] = ct
     if os.environ.get("PS_STAMPS") and rank == 0:
         # measurement: the sharded step as the GPU ran it (in-kernel time stamps, tools/gpu_timeline.py's mechanism)
         L.ps_tune_set(b"stamps", 1)
@@ -794,6 +806,11 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     if rank == 0 and world > 1 and int(getattr(args, "n1_reference", 1)):
         wd.kick("1-GPU reference", 300)
         n1 = n1_reference(cfg, synth_batch, local, min(args.steps, 1000))
+    elif world == 1 and native and int(getattr(args, "wire_cost", 1)):
+        # one GPU: what the wire costs -- the same sharded step with device copies, with every collective through RCCL
+        # (a rank's own keys off the wire), and with the wire running under own-keys-in-place (the N > 1 data path)
+        wd.kick("wire cost", 300)
+        n1 = {"wire_cost_ms_per_step": sharded_n1_modes(cfg, synth_batch, local, min(args.steps, 1000))}
     dist.barrier()
     out = None
     if rank == 0:
@@ -813,6 +830,8 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
                        "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
                        "priming_steps_untimed": int(getattr(args, "priming", 300)) + 3},
             "final_loss": loss,
+            # the first steps of a job (untimed above): priming_steps_untimed steps from cold communicators
+            "unprimed_ms_per_step": unprimed_ms,
         }
         if stats:
             out["exchange"] = stats
@@ -824,6 +843,70 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
             out["phase_us_serialised"] = phases
     dist.destroy_process_group()
     return out
+
+
+def rccl_info(worker):
+    """RCCL's own view of the table a NativeWorker made (evidence of the wire a run used) + the operations issued so far."""
+    cc, ur, hs = C.c_int(), C.c_int(), C.c_int()
+    L = N.lib()
+    N.check(L.ps_comm_rccl_info(C.byref(worker.ops), C.byref(cc), C.byref(ur), C.byref(hs)))
+    calls = (C.c_int64 * 5)()
+    N.check(L.ps_comm_rccl_calls(C.byref(worker.ops), calls))
+    return {"ncclCommCount": cc.value, "ncclCommUserRank": ur.value, "extra_communicators": hs.value,
+            "calls": {"ncclAllGather": int(calls[0]), "send_recv_groups": int(calls[1]), "ncclAllReduce": int(calls[2]),
+                      "ncclSend_plus_ncclRecv": int(calls[3])}, "on_the_wire": bool(calls[4])}
+
+
+def collective_times(worker, worker_run, kv, gm, steps=200):
+    """Device time of every collective of the step, by kind (HIP events around each call on the stream it is enqueued on, in a
+    pass of its own after the timed region: the events cost their streams a few microseconds each)."""
+    L = N.lib()
+    if L.ps_tune_set(b"comm_timing", 1) != 0:
+        return None
+    try:
+        worker_run(steps)
+        kv.sync()
+        out = (C.c_double * 8)()
+        N.check(L.ps_shard_collective_times(gm.h, out))
+    finally:
+        L.ps_tune_set(b"comm_timing", 0)
+    names = ["id_blocks", "rows", "gradients", "allreduce"]
+    return {n: {"avg_us": round(1e3 * out[2 * i + 1] / max(out[2 * i], 1), 2), "calls": int(out[2 * i])} for i, n in enumerate(names)}
+
+
+def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info=False):
+    """ps_shard_step on ONE GPU with a 1-rank table: rccl_force 0 (device copies), 1 (everything through RCCL), 2 (RCCL
+    running, own keys in place).  ms per step of `steps` steps after 300 priming steps, each mode on a fresh store."""
+    import ps_amd
+    L = N.lib()
+    res, info = {}, None
+    names = {0: "device_copies", 1: "rccl_everything_off_the_wire", 2: "rccl_with_own_keys_in_place"}
+    for force in modes:
+        rng = np.random.default_rng(cfg["seed"])
+        kv = ps_amd.KVStore(device, cfg["seed"])
+        kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
+        gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+        bs = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(32)]
+        L.ps_tune_set(b"rccl_force", force)
+        try:
+            wk = NativeWorker([gm], 1, 0)
+        finally:
+            L.ps_tune_set(b"rccl_force", 0)
+        if force:
+            wk.selfcheck()
+        wk.run(bs, 300)
+        kv.sync()
+        t0 = time.perf_counter()
+        wk.run(bs, steps)
+        kv.sync()
+        res[names[force]] = 1e3 * (time.perf_counter() - t0) / steps
+        if force and with_info:
+            info = rccl_info(wk)
+        wk.close()
+        for b in bs:
+            b.close()
+        gm.close(); kv.close()
+    return (res, info) if with_info else res
 
 
 def n1_reference(cfg, synth_batch, device, steps):

@@ -16,7 +16,7 @@ GPU_TEST_TIMEOUT_S = int(os.environ.get("PS_AMD_TEST_TIMEOUT", "180"))
 # collection order of the -m gpu suite: the oracle-parity tests of the hot path first, the
 # threads-on-one-GPU exchange tests last
 _ORDER = ["test_gpu_operators", "test_gpu_parity", "test_gpu_configs", "test_gpu_layer_ops", "test_gpu_sumorder", "test_gpu_fieldsort", "test_gpu_schedule",
-          "test_gpu_auc", "test_gpu_ckpt", "test_gpu_ingest", "test_gpu_ps_server", "test_gpu_router", "test_gpu_multirank", "test_gpu_multiproc", "test_gpu_rccl_wire"]
+          "test_gpu_auc", "test_gpu_ckpt", "test_gpu_ingest", "test_gpu_ps_server", "test_gpu_router", "test_gpu_multirank", "test_gpu_multiproc", "test_gpu_rccl_wire", "test_gpu_rehearse_n8"]
 
 
 def pytest_configure(config):
@@ -95,12 +95,14 @@ def _per_test_timeout(request):
         yield
         return
 
+    limit = int(getattr(request.module, "TEST_TIMEOUT_S", GPU_TEST_TIMEOUT_S))     # (a module may ask for more: 8 full-size rank processes)
+
     def on_alarm(signum, frame):
         faulthandler.dump_traceback(all_threads=True)
-        raise TestTimeout("test exceeded %d s" % GPU_TEST_TIMEOUT_S)
+        raise TestTimeout("test exceeded %d s" % limit)
 
     old = signal.signal(signal.SIGALRM, on_alarm)
-    signal.alarm(GPU_TEST_TIMEOUT_S)
+    signal.alarm(limit)
     try:
         yield
     finally:

@@ -290,3 +290,55 @@ def test_a_wait_that_is_never_released_times_out_with_an_error():
     kv2.close()
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, b)
+
+
+def test_overlap_mode_outlives_the_device_side_joins():
+    """The overlap mode of the sharded step (key lists on side chain 0, flat reduction + replicated update on side chain 1)
+    is agreed ONCE, at a model's first begin; whether a step may join its streams by device flags is decided per step, and
+    can go away (a wait that timed out, a second model on the device, ps_tune_set).  The backward then writes the flat
+    gradient [fc | wide G | wide C | bias] on the TRAINING stream while the reduction still runs on side chain 1: the step
+    must order the two (ps_comm.hip).  4 x 30 pipelined sharded steps -- default, dev_wait = 0, tail_dev = 0,
+    both -- equal 120 fused steps bit for bit."""
+    import ps_amd
+    from ps_amd import native as N
+    from ps_amd.sharded import NativeWorker
+    L = N.lib()
+    F, D, X, fc, V, B, WS = 5, 16, 3, [32, 16, 1], 500, 512, 61
+    rng = np.random.default_rng(22)
+    data = batches(rng, 9, B, F, X, V, WS)
+    phases = [{}, {"dev_wait": 0}, {"tail_dev": 0}, {"dev_wait": 0, "tail_dev": 0}]
+    res = []
+    try:
+        for native in (False, True):
+            kv = ps_amd.KVStore(0, SEED)
+            kv.create_embedding([V] * F, D)
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+            bs = [ps_amd.DeviceBatch(kv, E, Xd, Y, W) for E, Xd, Y, W in data]
+            wk = NativeWorker([gm], 1, 0) if native else None
+            for knobs in phases:
+                if native:
+                    for k, v in knobs.items():
+                        L.ps_tune_set(k.encode(), v)
+                    wk.run(bs, 30)
+                    kv.sync()
+                    for k in knobs:
+                        L.ps_tune_set(k.encode(), 1)
+                else:
+                    for i in range(30):
+                        gm.train_async(bs[i % len(bs)])
+            kv.sync()
+            res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)],
+                        kv.get_wide(np.arange(WS)), kv.get("wide.bias"), kv.global_step()))
+            if wk:
+                wk.close()
+            for b in bs:
+                b.close()
+            gm.close(); kv.close()
+    finally:
+        for k in ("dev_wait", "tail_dev"):
+            L.ps_tune_set(k.encode(), 1)
+    a, b = res
+    assert a[4] == b[4] == 120
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
