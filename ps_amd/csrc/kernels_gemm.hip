@@ -1373,6 +1373,17 @@ int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
+__global__ void k_set_then_spin(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, WaitBound b) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(set, set_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        spin_bounded(flag, val, b);
+    }
+}
+int launch_set_then_spin(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code) {
+    hipLaunchKernelGGL(k_set_then_spin, dim3(1), dim3(64), 0, st, set, set_val, flag, val, wait_bound(werr, code));
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
 int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code) {
     hipLaunchKernelGGL(k_spin_until, dim3(1), dim3(64), 0, st, flag, val, wait_bound(werr, code));
     HIPCHK(hipGetLastError());

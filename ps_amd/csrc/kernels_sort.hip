@@ -389,6 +389,7 @@ struct FieldSortArgs {
     unsigned long long *pub;            // [F] look-back words
     uint32_t epoch;
     unsigned long long *ts;
+    unsigned int *start_flag; unsigned int start_val;   // "this launch has started" = everything in front of it on its stream is done (or NULL)
 };
 
 #ifdef PS_FS_TIMING
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(FS_TPB) void k_field_sort_segments(FieldSortArgs a)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int f = blockIdx.x, B = a.B;
     StampScope stamp(a.ts);
+    if (a.start_flag && f == 0 && tid == 0) __hip_atomic_store(a.start_flag, a.start_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 2) base_s[tid] = 0;
     FS_T(0);
     const uint32_t fbase = a.keys_base ? (uint32_t)a.keys_base[f] : 0u;
@@ -666,7 +668,8 @@ bool field_sort_fits(int B, int F) { return B >= 1 && B <= FS_MAX && F >= 1 && F
 
 int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_bits, int B, int F, int long_min,
                         uint32_t *sorted_keys, uint32_t *sorted_ents, uint32_t *seg_start, uint32_t *seg_id,
-                        uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st) {
+                        uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st,
+                        unsigned int *start_flag, unsigned int start_val) {
     if (!field_sort_fits(B, F) || key_bits < 1 || key_bits > 32)
         return ps_set_err(PS_E_BAD_ARG, "field_sort_segments: B = %d, F = %d, key_bits = %d", B, F, key_bits);
     int ept = 1;
@@ -674,7 +677,7 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
     const int NP = FS_TPB * ept;
     const int npass = (key_bits + 7) / 8, digit_bits = (key_bits + npass - 1) / npass;
     FieldSortArgs a{keys, keys_base, B, F, NP, long_min, npass, digit_bits, sorted_keys, sorted_ents, seg_start, seg_id, nseg_dev,
-                    long_list, pub, epoch, stamp_next("field_sort")};
+                    long_list, pub, epoch, stamp_next("field_sort"), start_flag, start_val};
     const size_t lds = (size_t)NP * 16;
     static bool attr_set = false;
     if (!attr_set) {

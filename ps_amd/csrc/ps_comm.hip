@@ -549,9 +549,15 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     }
     // (overlap mode without an early plan -- the first step, a store that fell back to events: the plan's kernels go to side
     //  chain 1 too and are ordered behind the running step's backward, whose lists they overwrite: order_after_main)
-    PSCHK(shard_plan_enqueue(m, batch, nsh, st, false, !use_side, ov));
     sh.x_set ^= 1;
     const int set = sh.x_set;
+    sh.pack_blk = sh.x_send_blk[set]; sh.pack_full = sh.x_send_full[set];      // (the plan's one launch packs them when it can)
+    {
+        const int prc = shard_plan_enqueue(m, batch, nsh, st, false, !use_side, ov);
+        sh.pack_blk = sh.pack_full = nullptr;
+        PSCHK(prc);
+    }
+    if (!sh.packed)
     hipLaunchKernelGGL(k_pack_blocks, dim3(cdiv(std::max<int64_t>(m->cur_nnz, nsh), 256)), dim3(256), 0, st, sh.send_rows, sh.owner_start, nsh, sh.blk_words,
                        (uint32_t)sh.blk_cap, sh.x_send_blk[set], sh.full_words, sh.x_send_full[set], stamp_next("pack_blocks"));
     HIPCHK(hipGetLastError());
@@ -696,13 +702,18 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     // the previous step's replicated update ran on side chain 1: the gather of this step's forward holds the join when the
     // update's end raised a device flag (enqueue_forward: EmbFwdArgs.end_wait), else an event
     if (sh.flat_pending && !(sh.flat_by_flag && m->dev_ok && m->multi_stream && !m->profile)) {
+        // (when the update's end raised a flag its event was not recorded -- a record per step for a wait that normally never
+        //  happens; nothing has been enqueued on side chain 1 since, so an event recorded NOW stands for the same work)
+        if (sh.flat_by_flag) HIPCHK(hipEventRecord(sh.flat_ev, m->side[1]));
         HIPCHK(hipStreamWaitEvent(st, sh.flat_ev, 0));
         sh.flat_pending = false;
     }
     {
+        sh.defer_flag5 = next_batch != nullptr;      // (the next step's plan, enqueued below, opens with a spinner on side chain 0)
         int frc = ps_shard_forward_backward(m, sh.x_cache, nullptr);
+        sh.defer_flag5 = false;
         sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
-        PSCHK(frc);
+        if (frc != PS_OK) { (void)shard_flush_deferred_flag(m); return frc; }
     }
     const bool ov2 = sh.ov_mode == 1 && !was_side && !m->profile;      // where the replicated tensors' update goes
     // The flat gradient [fc | wide G | wide C | bias] is consumed on side chain 1 in overlap mode.  Normally it was produced
@@ -715,7 +726,11 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         HIPCHK(hipStreamWaitEvent(m->side[1], e, 0));
     }
     // the next step's key lists (same order of operations on every rank)
-    if (next_batch) PSCHK(shard_step_begin(m, next_batch, comm, 0, true));
+    if (next_batch) {
+        const int brc = shard_step_begin(m, next_batch, comm, 0, true);
+        (void)shard_flush_deferred_flag(m);          // (a no-op when the plan's spinner took it)
+        PSCHK(brc);
+    }
     // push: the per-key gradients to their owners
     comm_select(comm, 0, alias);
     crc = timed_coll(m, 2, st, [&]() { return comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st); });
@@ -757,7 +772,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             PSCHK(launch_flag_set(m->start_flag + 9, sh.flat_epoch, fs));
             sh.flat_by_flag = true;
         }
-        HIPCHK(hipEventRecord(sh.flat_ev, fs));
+        if (!sh.flat_by_flag) HIPCHK(hipEventRecord(sh.flat_ev, fs));
         sh.flat_pending = true;
         if (!next_batch || loss) {      // nothing follows that would join: close the step on the training stream
             HIPCHK(hipStreamWaitEvent(st, sh.flat_ev, 0));

@@ -120,7 +120,8 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
 bool field_sort_fits(int B, int F);
 int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_bits, int B, int F, int long_min,
                         uint32_t *sorted_keys, uint32_t *sorted_ents, uint32_t *seg_start, uint32_t *seg_id,
-                        uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st);
+                        uint32_t *nseg_dev, uint32_t *long_list, unsigned long long *pub, uint32_t epoch, hipStream_t st,
+                        unsigned int *start_flag = nullptr, unsigned int start_val = 0);     // start_flag: raised by the launch's first workgroup
 
 // What one launch carries beyond its kernel arguments.  Explicit, per launch: the caller fills a LaunchOpts and hands
 // it to the launcher (rounds 1-2 "armed" thread-local globals that the next launcher of the same host thread consumed).
@@ -153,6 +154,8 @@ struct WaitBound { unsigned int *err; unsigned long long ticks; unsigned int cod
 WaitBound wait_bound(unsigned int *werr, unsigned int code);
 int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code = 0);   // a one-wave kernel that ends when *flag reached val
 int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order
+// both in ONE launch: *set = set_val when the kernel starts (what is in front of it on the stream is done), then the wait
+int launch_set_then_spin(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code);
 #define PS_LAUNCH_EV(kernel, grid, block, shmem, st, ev, ...)                                                  \
     do {                                                                                                       \
         hipEvent_t se_ = (ev);                                                                                 \
@@ -251,5 +254,6 @@ extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
+extern int g_plan_fused;
 extern int g_rccl_force, g_blk_factor, g_blk_cap, g_push_grouped_max_mb, g_comm_timing;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

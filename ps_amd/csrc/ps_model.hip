@@ -726,7 +726,9 @@ int enqueue_backward(ps_model *m, bool apply) {
             // side chain 0's end as a flag too: a spinner that finds its flag set costs the main chain a tiny kernel
             // (~1.5 us), a hipStreamWaitEvent on an event that fired long ago ~3.5 (tools/gpu_timeline.py)
             if (++m->start_epoch == 0) ++m->start_epoch;
-            PSCHK(launch_flag_set(m->start_flag + 5, m->start_epoch, s0));
+            if (m->sh.active && m->sh.defer_flag5 && s0 == m->side[0]) {      // (raised by the next plan's spinner on this stream)
+                m->sh.deferred = true; m->sh.def_flag = m->start_flag + 5; m->sh.def_val = m->start_epoch;
+            } else PSCHK(launch_flag_set(m->start_flag + 5, m->start_epoch, s0));
             m->s0_epoch = m->start_epoch;
         } else if (s0 != st) HIPCHK(hipEventRecord(m->s0_ev, s0));
         if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));

@@ -166,6 +166,116 @@ __global__ __launch_bounds__(256) void k_plan_emit(const uint32_t *__restrict__ 
     if (blockIdx.x == gridDim.x - 1 && tid == 0) { owner_start[nshards] = carry_s; *nseg = carry_s; }
 }
 
+// Round 4: count + emit + pack in ONE launch (the sharded step's host enqueues ~29 launches per step).
+// Every workgroup turns its 256 stamp words into bitmap words and popcounts, publishes its total in pub[b] tagged with this
+// plan's sequence number (a 64-bit agent-scope store), and adds up the totals of the workgroups in front of it -- they were
+// dispatched earlier, so spinning on their words cannot deadlock (the field sort's look-back, kernels_sort.hip) -- which
+// gives it the rank of its first set bit and, from the same words, where its owner's run starts (an owner's range of the
+// key space is a whole number of workgroups: sbits - 5 >= 8).  Then every set bit emits its owner-local row three times:
+// send_rows (the plan's list), the owner's wire block when it fits, the owner's full block.  The last workgroup has every
+// total: it writes owner_start, nseg and the blocks' headers [count | overflow].
+constexpr int PLAN_FUSED_MAX_BLOCKS = 2048;
+struct PlanFusedArgs {
+    const uint8_t *stamp; uint8_t epoch;
+    uint32_t *bitmap; int64_t nwords;
+    unsigned long long *pub; uint32_t seq;
+    uint32_t *word_prefix, *send_rows, *owner_start, *nseg;
+    int sbits, nshards;
+    // the id blocks (NULL: plan only)
+    uint32_t *blk; int64_t blk_words; uint32_t blk_cap;
+    uint32_t *full; int64_t full_words;
+    unsigned long long *ts;
+};
+__global__ __launch_bounds__(256) void k_plan_fused(PlanFusedArgs a) {
+    StampScope stamp_scope(a.ts);
+    __shared__ uint32_t red[4], red2[4], wsum[4], carry_s, obase_s;
+    __shared__ uint32_t tot_s[PLAN_FUSED_MAX_BLOCKS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = (int)blockIdx.x, nblk = (int)gridDim.x;
+    const int64_t i = (int64_t)b * PLAN_WPB + tid;
+    uint32_t bits = 0;
+    if (i < a.nwords) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(a.stamp + i * 32), hi = *reinterpret_cast<const uint4 *>(a.stamp + i * 32 + 16);
+        const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) bits |= (((q[k] >> (8 * bb)) & 0xFFu) == (uint32_t)a.epoch ? 1u : 0u) << (4 * k + bb);
+        a.bitmap[i] = bits;
+    }
+    const uint32_t v = (uint32_t)__popc(bits);
+    uint32_t inc = v;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) __hip_atomic_store(&a.pub[b], ((unsigned long long)a.seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // look back: totals of the workgroups in front of this one; those in front of my owner's first workgroup give its run's start
+    const int wpo_blocks = 1 << (a.sbits - 5 - 8);      // workgroups per owner
+    const int owner = b / wpo_blocks, ob = owner * wpo_blocks;
+    const bool last = b == nblk - 1;
+    uint32_t acc_b = 0, acc_o = 0;
+    for (int j = tid; j < b; j += 256) {
+        unsigned long long x;
+        do { x = __hip_atomic_load(&a.pub[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(x >> 32) != a.seq);
+        const uint32_t t = (uint32_t)x;
+        acc_b += t;
+        if (j < ob) acc_o += t;
+        if (last) tot_s[j] = t;
+    }
+    for (int off = 32; off; off >>= 1) { acc_b += __shfl_down(acc_b, off); acc_o += __shfl_down(acc_o, off); }
+    if (lane == 0) { red[w] = acc_b; red2[w] = acc_o; }
+    __syncthreads();
+    if (tid == 0) { carry_s = red[0] + red[1] + red[2] + red[3]; obase_s = red2[0] + red2[1] + red2[2] + red2[3]; if (last) tot_s[b] = total; }
+    __syncthreads();
+    uint32_t wb = carry_s;
+    for (int ww = 0; ww < w; ++ww) wb += wsum[ww];
+    const uint32_t excl = wb + inc - v, obase = obase_s;
+    if (i < a.nwords) {
+        a.word_prefix[i] = excl;
+        uint32_t bb = bits, r = excl;
+        uint32_t *const blk_o = a.blk ? a.blk + (size_t)owner * a.blk_words + PS_BLK_HDR : nullptr;
+        uint32_t *const full_o = (a.full && a.full != a.blk) ? a.full + (size_t)owner * a.full_words + PS_BLK_HDR : nullptr;
+        while (bb) {
+            const int bit = __ffs((int)bb) - 1;
+            bb &= bb - 1;
+            const uint32_t row = (((uint32_t)i << 5) | (uint32_t)bit) & ((1u << a.sbits) - 1u), pos = r - obase;
+            a.send_rows[r] = row;
+            if (blk_o && pos < a.blk_cap) blk_o[pos] = row;
+            if (full_o) full_o[pos] = row;
+            ++r;
+        }
+    }
+    if (!last) return;
+    // the last workgroup: owner_start[0..nshards], nseg, the blocks' headers
+    __shared__ uint32_t os_s[PS_PUSH_MAX_PEERS + 1];
+    __shared__ uint32_t ovf_s;
+    if (tid == 0) ovf_s = 0u;
+    for (int o = w; o <= a.nshards; o += 4) {           // one wave per owner boundary
+        const int end = o * wpo_blocks < nblk ? o * wpo_blocks : nblk;
+        uint32_t s = 0;
+        for (int j = lane; j < end; j += 64) s += tot_s[j];
+        for (int off = 32; off; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) os_s[o] = s;
+    }
+    __syncthreads();
+    if (tid <= a.nshards) a.owner_start[tid] = os_s[tid];
+    if (tid == 0) *a.nseg = os_s[a.nshards];
+    if (a.blk) {
+        if (tid < a.nshards && os_s[tid + 1] - os_s[tid] > a.blk_cap) atomicOr(&ovf_s, 1u);
+        __syncthreads();
+        if (tid < a.nshards) {
+            const uint32_t cnt = os_s[tid + 1] - os_s[tid];
+            a.blk[(size_t)tid * a.blk_words] = cnt; a.blk[(size_t)tid * a.blk_words + 1] = ovf_s;
+            if (a.full != a.blk) { a.full[(size_t)tid * a.full_words] = cnt; a.full[(size_t)tid * a.full_words + 1] = ovf_s; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_plan_slots(const uint32_t *__restrict__ keys, int64_t nnz, const uint32_t *__restrict__ bitmap,
                                                     const uint32_t *__restrict__ word_prefix, uint32_t *__restrict__ slot, unsigned long long *ts) {
     StampScope stamp_scope(ts);
@@ -205,6 +315,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W
 
 }  // namespace
 int g_plan_sort = 0;       // ps_tune_set("plan_sort", 1): the sort-based plan (A/B runs, tests of both paths)
+int g_plan_fused = 1;      // ps_tune_set("plan_fused", 0): count / emit / pack as three launches (round 3)
 namespace {
 
 int ensure_push_ws(ps_store *s, int64_t n) {
@@ -269,6 +380,7 @@ int ensure_shard_state(ps_model *m, int nshards) {
             PSCHK(store_dev_alloc(s, (void **)&sh.stamp, (size_t)kspace + 32, true));
             PSCHK(store_dev_alloc(s, (void **)&sh.word_prefix, sizeof(uint32_t) * (size_t)sh.bm_words, false));
             PSCHK(store_dev_alloc(s, (void **)&sh.blk_sum, sizeof(uint32_t) * (size_t)(cdiv(sh.bm_words, PLAN_WPB) + 1), false));
+            PSCHK(store_dev_alloc(s, (void **)&sh.plan_pub, sizeof(unsigned long long) * (size_t)(cdiv(sh.bm_words, PLAN_WPB) + 1), true));
         }
     }
     PSCHK(store_dev_alloc(s, (void **)&sh.slot, sizeof(uint32_t) * (size_t)(nc + 1), false));
@@ -309,15 +421,20 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
                  sh.word_prefix, sh.slot, stamp_next("plan_slots"));
     if (off_main && !g_ext_events) HIPCHK(hipEventRecord(sh.slot_ev, ss));
     sh.slot_flag = false;
+    const bool fsort = !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
+    unsigned int *fs_flag = nullptr;
     if (off_main && m->dev_ok) {       // ... and a device flag: ps_shard_step hangs this join on its owner-side gather's launch
         if (++m->start_epoch == 0) ++m->start_epoch;
         sh.slot_epoch = m->start_epoch;
-        PSCHK(launch_flag_set(m->start_flag + 10, sh.slot_epoch, ss));
+        // (raised by the START of the field sort behind the slot kernel -- in order, so the slots are written -- rather than
+        //  by a flag-setter launch of its own)
+        if (fsort) fs_flag = m->start_flag + 10;
+        else PSCHK(launch_flag_set(m->start_flag + 10, sh.slot_epoch, ss));
         sh.slot_flag = true;
     }
     HIPCHK(hipGetLastError());
     m->field_sorted = false;
-    if (!m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F)) {
+    if (fsort) {
         // single-hot: one launch sorts the F fields on their own (kernels_sort.hip) instead of the 11-launch radix
         // chain.  A composite key (owner, local row) belongs to one field only, so the runs are the same; they come
         // field by field rather than in send order, and the embedding backward writes each run's gradient at the
@@ -331,7 +448,7 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
             kb = bits_for(span);
         }
         PSCHK(field_sort_segments(m->keys, based ? sh.lrb_dev : nullptr, kb, m->cur_B, F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
-                                  m->seg_start, m->seg_id, m->seg_nseg_scratch, m->long_list, m->fs_pub, m->fs_epoch, ss));
+                                  m->seg_start, m->seg_id, m->seg_nseg_scratch, m->long_list, m->fs_pub, m->fs_epoch, ss, fs_flag, sh.slot_epoch));
         m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
         m->field_sorted = true;
     } else {
@@ -341,6 +458,13 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
     m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
     m->side0_pending = off_main;
     return PS_OK;
+}
+
+int shard_flush_deferred_flag(ps_model *m) {
+    ps_model::Shard &sh = m->sh;
+    if (!sh.deferred) return PS_OK;
+    sh.deferred = false;
+    return launch_flag_set(sh.def_flag, sh.def_val, m->side[0]);
 }
 
 // early plans (see shard_plan_enqueue): the second half, enqueued by the caller once the launch that raises
@@ -367,6 +491,15 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     ps_model::Shard &sh = m->sh;
     const bool fwd_flag = m->fwd_flag_valid;       // (of the step enqueued before this call)
     m->fwd_flag_valid = false;
+    // side chain 0's pending "small kernels done" flag (ps_store.h defer_flag5) rides on an EARLY plan's opening spinner.  Any
+    // other plan raises it first, before anything here can wait for the training stream (a host batch's staging does; the
+    // ordering event of a late plan does) -- the running step's last delta GEMM holds its slot until that flag is up.
+    if (sh.deferred) {
+        const bool will_be_early = early && batch && batch->on_device && !batch->offsets && batch->B > 0 && sh.bitmap && g_plan_sort == 0 && fwd_flag &&
+                                   g_plan_early && dev_waits_ok(s) && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback && g_field_sort &&
+                                   field_sort_fits(batch->B, m->cfg.F);
+        if (!will_be_early) PSCHK(shard_flush_deferred_flag(m));
+    }
     PSCHK(stage_batch(m, batch, true));
     if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
     const int F = m->cfg.F;
@@ -378,6 +511,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     if (plan_debug) fprintf(stderr, "[plan] early=%d (bitmap %d, fwd flag %d, device batch %d, single-hot %d, field sort fits %d)\n", (int)early, (int)bm,
                             (int)fwd_flag, (int)batch->on_device, (int)!m->cur_offsets, (int)field_sort_fits(m->cur_B, F));
     hipStream_t ps = early ? m->side[0] : st;       // where the id-only kernels go
+    if (!early) PSCHK(shard_flush_deferred_flag(m));      // (normally flushed above already)
     if (!early && order_after_main && st != s->stream) {
         // (not early, on another stream than the training stream: the plan overwrites lists the running step's backward
         //  still reads -- behind everything enqueued on the training stream so far)
@@ -385,7 +519,13 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
         HIPCHK(hipEventRecord(e, s->stream));
         HIPCHK(hipStreamWaitEvent(st, e, 0));
     }
-    if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
+    if (early && sh.deferred && ps == m->side[0]) {       // (side chain 0's pending "small kernels done" rides on this spinner's launch)
+        sh.deferred = false;
+        PSCHK(launch_set_then_spin(sh.def_flag, sh.def_val, m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
+    } else {
+        PSCHK(shard_flush_deferred_flag(m));
+        if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
+    }
     m->nseg_cur = early ? (m->nseg_cur == m->nseg_dev ? m->nseg_dev + 4 : m->nseg_dev) : m->nseg_dev;
     if (bm && ++sh.epoch == 0) {          // the byte stamps wrap every 255 plans: start over from a clean map
         HIPCHK(hipMemsetAsync(sh.stamp, 0, (size_t)sh.bm_words * 32, ps));
@@ -395,10 +535,26 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
                        sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), s->emb.owner_dev, s->emb.local_dev, s->emb.grow_base_dev, m->keys,
                        m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev, bm ? sh.stamp : (uint8_t *)nullptr, sh.epoch, stamp_next("shard_keys"));
     HIPCHK(hipGetLastError());
+    sh.packed = false;
     if (bm) {
         const int nblk = cdiv(sh.bm_words, PLAN_WPB);
+        // count + emit (+ the id blocks of ps_shard_step) in one launch when the key space allows the look-back
+        const bool fused = g_plan_fused && nblk <= PLAN_FUSED_MAX_BLOCKS && sh.sbits - 5 >= 8 && sh.plan_pub;
+        PlanFusedArgs fa;
+        memset(&fa, 0, sizeof fa);
+        if (fused) {
+            if (++sh.plan_seq == 0) ++sh.plan_seq;
+            fa.stamp = sh.stamp; fa.epoch = sh.epoch; fa.bitmap = sh.bitmap; fa.nwords = sh.bm_words; fa.pub = sh.plan_pub; fa.seq = sh.plan_seq;
+            fa.word_prefix = sh.word_prefix; fa.send_rows = sh.send_rows; fa.owner_start = sh.owner_start; fa.nseg = m->nseg_cur;
+            fa.sbits = sh.sbits; fa.nshards = nshards;
+            fa.blk = sh.pack_blk; fa.blk_words = sh.blk_words; fa.blk_cap = (uint32_t)sh.blk_cap; fa.full = sh.pack_full; fa.full_words = sh.full_words;
+            fa.ts = stamp_next("plan_fused");
+            sh.packed = sh.pack_blk != nullptr;
+        } else
         hipLaunchKernelGGL(k_plan_count, dim3(nblk), dim3(256), 0, ps, sh.stamp, sh.epoch, sh.bitmap, sh.bm_words, sh.blk_sum, stamp_next("plan_count"));
         if (early) {
+            if (fused) hipLaunchKernelGGL(k_plan_fused, dim3(nblk), dim3(256), 0, ps, fa);
+            else
             hipLaunchKernelGGL(k_plan_emit, dim3(nblk), dim3(256), 0, ps, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix, sh.send_rows,
                                sh.owner_start, m->nseg_cur, sh.sbits, nshards, stamp_next("plan_emit"));
             HIPCHK(hipGetLastError());
@@ -416,6 +572,8 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
         hipStream_t ss = (m->profile || !m->multi_stream) ? st : m->side[0];
         hipEvent_t e1 = nullptr;
         if (ss != st) e1 = m->events[m->next_event++ % m->events.size()];
+        if (fused) PS_LAUNCH_EV(k_plan_fused, dim3(nblk), dim3(256), 0, st, g_ext_events ? e1 : nullptr, fa);
+        else
         PS_LAUNCH_EV(k_plan_emit, dim3(nblk), dim3(256), 0, st, g_ext_events ? e1 : nullptr, sh.bitmap, sh.bm_words, sh.blk_sum, sh.word_prefix,
                      sh.send_rows, sh.owner_start, m->nseg_cur, sh.sbits, nshards, stamp_next("plan_emit"));
         if (ss != st) {

@@ -187,6 +187,13 @@ struct ps_model {
         int64_t U = 0;
         uint32_t *bitmap = nullptr, *word_prefix = nullptr, *blk_sum = nullptr; int64_t bm_words = 0;   // sort-free plan
         uint8_t *stamp = nullptr, epoch = 0;    // presence bytes of the composite key space, stamped with the plan's epoch
+        unsigned long long *plan_pub = nullptr; uint32_t plan_seq = 0;   // k_plan_fused: per-workgroup totals tagged with the plan's number
+        // where the NEXT plan packs its unique keys (set by ps_shard_step_begin; NULL: plan only) | it did (one launch with the plan)
+        // ps_shard_step's pipeline: "side chain 0's small kernels are done" (start_flag[5]) is not raised by a launch of its own
+        // but by the spinner that opens the NEXT step's plan on the same stream (launch_set_then_spin) -- requested by
+        // ps_shard_step_finish_begin around the backward, consumed by shard_plan_enqueue, flushed as a plain launch otherwise
+        bool defer_flag5 = false, deferred = false; unsigned int *def_flag = nullptr; unsigned int def_val = 0;
+        uint32_t *pack_blk = nullptr, *pack_full = nullptr; bool packed = false;
         uint32_t *owner_start_host = nullptr;   // pinned readback of owner_start
         hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
         bool plan_pending = false;
@@ -268,6 +275,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
 int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early = false,
                        bool order_after_main = false);   // ps_shard.hip
 int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st);
+int shard_flush_deferred_flag(ps_model *m);       // ps_shard.hip
 int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st);      // early plans: the slots + the backward's entry lists
 int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
 int enqueue_backward(ps_model *m, bool apply);
