@@ -69,12 +69,22 @@ int head_last_bwd_fusable(int rows_per_wg);
 // resolves one updater per FIELD (store_fill_field_upd); when they are all the same -- the common case -- ngroups is 1 and
 // a kernel uses its `upd` argument with no lookup at all.  Otherwise a row's field (from row_base) picks `upd` (group 0)
 // or alt[group - 1].
-#define PS_EMB_UPD_GROUPS 4
+// An updater key that IS a row's key ("emF3.17.0": Float.toString of the id, layer/EmbeddingField.java:71) is the exact match
+// KVStore.update(Map) tries first (store/KVStore.java:242): up to PS_EMB_ROW_OVERRIDES such rows ride along as (local row,
+// group) pairs and win over their field's group.  Hard limits of this ABI (refused with PS_E_UNSUPPORTED beyond them, the
+// reference's HashMap has none): PS_EMB_UPD_GROUPS distinct embedding updaters, PS_EMB_ROW_OVERRIDES exact-key rows, 64
+// fields with per-field updaters; an updater key that ends inside a row's id ("emF3.1": a prefix of emF3.1.0, emF3.10.0,
+// emF3.17.0, ...) is refused too.
+#define PS_EMB_UPD_GROUPS 8
+#define PS_EMB_ROW_OVERRIDES 16
 struct FieldUpd {
     const int64_t *row_base;           // [F + 1] first local row of every field (device)
     int F, ngroups;
     unsigned char grp[64];             // field -> group
     UpdParams alt[PS_EMB_UPD_GROUPS - 1];
+    int nover;                         // exact-key rows
+    uint32_t over_row[PS_EMB_ROW_OVERRIDES];        // local row
+    unsigned char over_grp[PS_EMB_ROW_OVERRIDES];   // its group
 };
 #define PS_EMB_SEQ_TILE 16             // sequential order: runs above this many entries are "long" (own workgroup)
 struct EmbBwdArgs {

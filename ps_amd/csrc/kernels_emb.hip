@@ -542,7 +542,9 @@ template <class ARGS>
 __device__ __forceinline__ UpdParams row_upd(const ARGS &a, uint32_t row) {
     int f = 0;
     while (f + 1 < a.fu.F && (int64_t)row >= a.fu.row_base[f + 1]) ++f;
-    const int g = a.fu.grp[f];
+    int g = a.fu.grp[f];
+    for (int i = 0; i < a.fu.nover; ++i)          // exact-key rows win over their field (store/KVStore.java:242)
+        if (a.fu.over_row[i] == row) g = a.fu.over_grp[i];
     return g ? a.fu.alt[g - 1] : a.upd;
 }
 template <int VEC, bool BAG>

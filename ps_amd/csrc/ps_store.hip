@@ -293,7 +293,15 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
 // device every join takes its event form.
 std::atomic<int> g_models_on_device[PS_MAX_DEVICES];
 bool dev_waits_ok(const ps_store *s) {
-    return g_dev_wait && !s->dev_wait_off && s->device >= 0 && s->device < PS_MAX_DEVICES && g_models_on_device[s->device].load() <= 1;
+    const bool one_model = s->device >= 0 && s->device < PS_MAX_DEVICES && g_models_on_device[s->device].load() <= 1;
+    if (g_dev_wait && !s->dev_wait_off && !one_model) {
+        // a second live model (a train + an eval model, the two-model prefetch) silently costs every join ~3-10 us: say so once
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true) && getenv("PS_AMD_QUIET") == nullptr)
+            fprintf(stderr, "[ps_amd] more than one model drives device %d from this process: stream joins take their event form (slower steps); "
+                            "ps_store_join_mode() reports the mode\n", s->device);
+    }
+    return g_dev_wait && !s->dev_wait_off && one_model;
 }
 
 int store_settle(ps_store *s) {
@@ -317,11 +325,15 @@ int store_check_bad_ids(ps_store *s) {
         // a bounded device-side wait gave up: whatever ran behind it ran without one of its dependencies.  From here
         // on this store's models use the event form of every join (the caller decides what to do with the tables:
         // the steps since the last successful check are suspect).
-        HIPCHK(hipMemsetAsync(s->err_dev, 0, sizeof err, s->stream));
+        // (words 1..3 only: the bad-id count and the XCD-mismatch count stay for the next check -- ADVICE r3 -- but are named here too)
+        HIPCHK(hipMemsetAsync(s->err_dev + 1, 0, 3 * sizeof(int), s->stream));
         s->dev_wait_off = true;
         s->wait_timeouts += err[1];
+        if (err[4]) { HIPCHK(hipMemsetAsync(s->err_dev + 4, 0, sizeof(int), s->stream)); s->fwd_pair_off = true; }
         return ps_set_err(PS_E_STATE, "%d device-side wait(s) timed out after %.0f ms (first: wait %d, last: wait %d); the steps since the last check ran "
-                          "without a dependency -- this store now joins its streams by events", err[1], (double)g_spin_timeout_ticks * 1e-5, err[3] - 1000, err[2]);
+                          "without a dependency -- this store now joins its streams by events%s%s", err[1], (double)g_spin_timeout_ticks * 1e-5, err[3] - 1000, err[2],
+                          err[0] ? " [ids outside their table were seen too: reported by the next check]" : "",
+                          err[4] ? " [workgroups of the paired forward GEMM off their XCD too: the forward GEMMs are launched one by one from now on]" : "");
     }
     if (err[4]) {
         // k_fc_fwd_pair hands a row panel from one workgroup to another through the L2 of "their" XCD, which it takes to be
@@ -370,38 +382,69 @@ int store_fill_field_upd(const ps_store *s, UpdParams *upd, FieldUpd *fu, bool *
     fu->row_base = s->emb.row_base_dev; fu->F = s->emb.F; fu->ngroups = 1;
     const int F = s->emb.F;
     bool field_level = false;
+    struct RowKey { int field; int64_t id; ps_updater_t u; };
+    std::vector<RowKey> row_keys;
     for (auto &kv : s->updaters) {
         const std::string &k = kv.first;
         if (k.compare(0, 3, "emF") != 0 || k.size() == 3) continue;
         const size_t dot = k.find('.');
-        if (dot != std::string::npos && dot + 1 < k.size())
-            return ps_set_err(PS_E_UNSUPPORTED, "updater key %s names single embedding rows: updaters are resolved per field (\"emF<f>.\")", k.c_str());
+        if (dot != std::string::npos && dot + 1 < k.size()) {
+            // "emF<f>.<id>.0": a row's own key, KVStore.update(Map)'s exact match (store/KVStore.java:242); anything that ends
+            // inside the id is a prefix of a family of rows (emF3.1 -> 1, 10 .. 19, 100 ..): refused, not guessed at
+            ParsedKey pk;
+            if (!store_parse_key(k.c_str(), &pk) || pk.kind != 0 || k.compare(k.size() - 2, 2, ".0") != 0)
+                return ps_set_err(PS_E_UNSUPPORTED, "updater key %s is neither a field prefix (\"emF<f>.\") nor a row's key (\"emF<f>.<id>.0\")", k.c_str());
+            row_keys.push_back({pk.idx, pk.id, kv.second});
+            continue;
+        }
         field_level = true;
     }
-    ps_updater_t u0;
-    if (!field_level || F <= 0) {          // one updater for every row: the "emF" prefix (or "default")
-        PSCHK(store_resolve_updater(s, "emF", &u0));
-        *upd = make_upd_params(u0);
-        if (stateful) *stateful = u0.kind != PS_UPD_SIMPLE;
-        return PS_OK;
-    }
-    if (F > 64) return ps_set_err(PS_E_UNSUPPORTED, "per-field updaters need F <= 64 (F = %d)", F);
     ps_updater_t groups[PS_EMB_UPD_GROUPS];
     int ng = 0;
     bool st = false;
-    for (int f = 0; f < F; ++f) {
-        char probe[32];
-        snprintf(probe, sizeof probe, "emF%d.", f);
-        ps_updater_t u;
-        PSCHK(store_resolve_updater(s, probe, &u));
-        st = st || u.kind != PS_UPD_SIMPLE;
+    auto group_of = [&](const ps_updater_t &u) -> int {
         int g = 0;
         while (g < ng && memcmp(&groups[g], &u, sizeof u) != 0) ++g;
         if (g == ng) {
-            if (ng == PS_EMB_UPD_GROUPS) return ps_set_err(PS_E_UNSUPPORTED, "more than %d distinct embedding updaters", PS_EMB_UPD_GROUPS);
+            if (ng == PS_EMB_UPD_GROUPS) return -1;
             groups[ng++] = u;
         }
-        fu->grp[f] = (unsigned char)g;
+        st = st || u.kind != PS_UPD_SIMPLE;
+        return g;
+    };
+    if (!field_level || F <= 0) {          // one updater for every field: the "emF" prefix (or "default")
+        ps_updater_t u0;
+        PSCHK(store_resolve_updater(s, "emF", &u0));
+        (void)group_of(u0);
+        if (row_keys.empty()) {
+            *upd = make_upd_params(u0);
+            if (stateful) *stateful = st;
+            return PS_OK;
+        }
+        if (F > 64) return ps_set_err(PS_E_UNSUPPORTED, "row-level updaters need F <= 64 (F = %d)", F);
+    } else {
+        if (F > 64) return ps_set_err(PS_E_UNSUPPORTED, "per-field updaters need F <= 64 (F = %d)", F);
+        for (int f = 0; f < F; ++f) {
+            char probe[32];
+            snprintf(probe, sizeof probe, "emF%d.", f);
+            ps_updater_t u;
+            PSCHK(store_resolve_updater(s, probe, &u));
+            const int g = group_of(u);
+            if (g < 0) return ps_set_err(PS_E_UNSUPPORTED, "more than %d distinct embedding updaters", PS_EMB_UPD_GROUPS);
+            fu->grp[f] = (unsigned char)g;
+        }
+    }
+    for (const RowKey &rk : row_keys) {
+        if (rk.field < 0 || rk.field >= F) continue;                    // (names no row of this store)
+        const int64_t row = store_local_row(s, rk.field, rk.id);
+        if (row < 0) continue;                                          // another shard's row (or beyond the vocabulary)
+        const int g = group_of(rk.u);
+        if (g < 0) return ps_set_err(PS_E_UNSUPPORTED, "more than %d distinct embedding updaters", PS_EMB_UPD_GROUPS);
+        if (g == fu->grp[rk.field]) continue;                           // the row's field already resolves to this updater
+        if (fu->nover == PS_EMB_ROW_OVERRIDES)
+            return ps_set_err(PS_E_UNSUPPORTED, "more than %d embedding rows with an updater of their own (exact updater keys \"emF<f>.<id>.0\")", PS_EMB_ROW_OVERRIDES);
+        fu->over_row[fu->nover] = (uint32_t)row; fu->over_grp[fu->nover] = (unsigned char)g;
+        ++fu->nover;
     }
     *upd = make_upd_params(groups[0]);
     for (int g = 1; g < ng; ++g) fu->alt[g - 1] = make_upd_params(groups[g]);

