@@ -74,6 +74,14 @@ __device__ __forceinline__ float sigmoid_clip_dev(float x) {
 #ifndef PS_GEMM_ABLATE
 #define PS_GEMM_ABLATE 0
 #endif
+// PS_GEMM_LAB (a MEASUREMENT build: tools/gemm_lab_build.sh -> ps_amd/lib/libps_amd_lab.so): every tile shape, slab loop and
+// kernel that rounds 2-3 built, measured and did NOT make the default -- k_gemm_nt16 (16x16x4 MFMAs), k_fc_fwd_pair (two
+// forward GEMMs in one launch), k_gemm_nt_lds (operands DMA'd to LDS), PIPE = 0 / 1 / 2 / 4, the in-workgroup K split of the
+// NT kernel, 8-wave and 128-wide tiles, the pipelined dW GEMM.  The product library compiles only what gemm_nt_cfg = 0 /
+// gemm_tn_cfg = 0 can reach; asking it for anything else is PS_E_UNSUPPORTED.  DESIGN.md 4.2 has the numbers.
+#ifndef PS_GEMM_LAB
+#define PS_GEMM_LAB 0
+#endif
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -506,6 +514,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     gemm_nt_tile<WM, WN, TM, TN, BKT, KS, PIPE>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
 }
 
+#if PS_GEMM_LAB
 // ---------------------------------------------------------------------------------------------------------------
 // The same contraction on v_mfma_f32_16x16x4_f32 (round 3).  What the ablation builds showed about the 32x32x2 loop above:
 // MFMAs alone run at 96 % of the f32 MFMA rate; the fragment reads from LDS cost 23 % of it EVEN WHEN NO MFMA DEPENDS ON
@@ -875,6 +884,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(NtArgs a) {
     }
 }
 
+#endif      // PS_GEMM_LAB
+
 struct TnArgs {
     const float *A; int lda; int a_cols;
     const float *D; int ldd; int d_cols;
@@ -1196,25 +1207,34 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models
         // (measured best on MI355X for M=4096, N in 256..512, K in 256..528); narrow N: 128x32.
         auto tiles = [&](int bm, int bn) { return (long long)cdiv(M, bm) * cdiv(N, bn); };
+        if (N <= 32) cfg = 8;
+        else if (tiles(64, 128) >= 2048) cfg = 6;
+#if PS_GEMM_LAB
         // 8-wave workgroups on 128 x 64 tiles where that still gives ~one workgroup per CU: the A panel is shared by
         // twice the waves (global traffic per flop -25%); measured alone (tools/gemm_sweep2.py, M = 4096):
         // fwd0 22.7 -> 21.1 us, delta1 14.8 -> 14.0, delta0 (224 workgroups) 23.9 -> 23.1; N = 256 (128 workgroups) 15.4 -> 23.3.
         // In the step the difference disappears (0.1613 vs 0.1614 ms, six runs each): off by default.
-        // gemm_pipe: the software-pipelined slab loop (3: three register sets, the default; 0: round 2's loop);
+        // gemm_pipe: the software-pipelined slab loop (5: 16-wide slabs, three register sets, the default; 0: round 2's loop);
         // gemm_ks: the in-workgroup K split where 64 x 64 tiles give at most ~one workgroup per CU
-        if (N <= 32) cfg = 8;
-        else if (tiles(64, 128) >= 2048) cfg = 6;
         else if (g_gemm_8w && tiles(128, 64) >= 200 && tiles(128, 64) <= 1024) cfg = g_gemm_pipe == 5 ? 143 : g_gemm_pipe == 4 ? 133 : g_gemm_pipe == 3 ? 113 : g_gemm_pipe ? 53 : 13;
         else if (g_gemm_ks && tiles(64, 64) <= 320 && K % 16 == 0) cfg = g_gemm_pipe == 3 ? 120 : g_gemm_pipe ? 60 : 20;
         else cfg = g_gemm_pipe == 5 ? 140 : g_gemm_pipe == 4 ? 125 : g_gemm_pipe == 3 ? 105 : g_gemm_pipe ? 45 : 5;
+#else
+        else cfg = 140;
+#endif
     }
     switch (cfg) {
+    // ---- the product's three shapes: 64 x 64 tiles on 16-wide slabs with the software-pipelined loop (PIPE = 3); 64 x 128 for
+    //      very large problems; 128 x 32 for narrow N
+    case 140: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 16-wide slabs: 24 KB of LDS
+    case 6: NT_LAUNCH(2, 2, 1, 2, 32); break;
+    case 8: NT_LAUNCH(4, 1, 1, 1, 32); break;
+#if PS_GEMM_LAB
     case 1: NT_LAUNCH(2, 2, 2, 2, 16); break;
     case 2: NT_LAUNCH(2, 2, 1, 2, 16); break;
     case 3: NT_LAUNCH(2, 2, 1, 1, 16); break;
     case 4: NT_LAUNCH(4, 1, 1, 1, 16); break;
     case 5: NT_LAUNCH(2, 2, 1, 1, 32); break;
-    case 6: NT_LAUNCH(2, 2, 1, 2, 32); break;
     case 7: NT_LAUNCH(2, 2, 2, 2, 32); break;
     case 9: NT_LAUNCH(2, 2, 2, 1, 32); break;
     case 10: NT_LAUNCH(2, 2, 1, 1, 64); break;
@@ -1235,19 +1255,18 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 48: NT_LAUNCH_P(4, 1, 1, 1, 32, 1); break;
     case 53: NT_LAUNCH_P(4, 2, 1, 1, 32, 1); break;
     case 60: NT_LAUNCH_P(2, 2, 1, 1, 32, 2); break;
-    // ... fragments read two groups ahead (PIPE = 2)
     case 105: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;      // PIPE = 3
     case 113: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 32, 1, 3>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 120: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 2, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 125: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 32, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;      // PIPE = 4
     case 133: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 32, 1, 4>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
-    case 140: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 16-wide slabs: 30 KB / 20 KB of LDS
     case 141: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 16, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;
     case 143: PS_LAUNCH_EV((k_gemm_nt<4, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;    // 8 waves, 128 x 64: 46 KB
     case 144: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;    // 64 x 128
     case 145: PS_LAUNCH_EV((k_gemm_nt<2, 1, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 32)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 64 x 32
     case 146: PS_LAUNCH_EV((k_gemm_nt<1, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 32) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 32 x 64
     case 142: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 64, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 64-wide slabs: 70 KB
+    // ... fragments read two groups ahead (PIPE = 2)
     case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
     case 86: NT_LAUNCH_P2(2, 2, 1, 2, 32, 1); break;
     case 93: NT_LAUNCH_P2(4, 2, 1, 1, 32, 1); break;
@@ -1258,7 +1277,9 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 67: PS_LAUNCH_EV((k_gemm_nt16<2, 2, 2, 2, 32>), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;
     case 73: PS_LAUNCH_EV((k_gemm_nt16<4, 2, 1, 1, 32>), dim3(cdiv(M, 128) * cdiv(N, 64)), dim3(512), 0, st, stop_ev, a); break;
     case 30: PS_LAUNCH_EV((k_gemm_nt_lds<3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;   // operands DMA'd global -> LDS, 3 stages
-    default: NT_LAUNCH(4, 1, 1, 1, 32); break;
+#endif
+    default:
+        return ps_set_err(PS_E_UNSUPPORTED, "gemm_nt_cfg %d is not in this build%s", cfg, PS_GEMM_LAB ? "" : " (the rejected variants live in the lab build: tools/gemm_lab_build.sh)");
     }
     HIPCHK(hipGetLastError());
     if (lo) lo->launched = true;
@@ -1278,6 +1299,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
 // them buys nothing, and the resident waiting workgroups cost the side chains their CU slots (the field sort started 50 us late).
 int g_fwd_pair = 0;         // ps_tune_set("fwd_pair", 1): the first two forward GEMMs in one launch (k_fc_fwd_pair)
 int gemm_nt_fwd_pair_ok(int M, int N1, int N2, int K1, int K2) {
+    if (!PS_GEMM_LAB) return 0;
     if (!g_fwd_pair || g_gemm_nt_cfg != 0) return 0;
     if (M <= 0 || N1 <= 32 || N2 <= 32 || (K1 & 3) || (K2 & 3)) return 0;
     auto tiles = [&](int n) { return (long long)cdiv(M, 64) * cdiv(n, 64); };
@@ -1288,7 +1310,8 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
                      const float *W2t, int ldb2, int N2, float *Y2, int ldy2, int K2, int M, unsigned int *ctr, unsigned int *epoch,
                      unsigned int *xcc_err, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
     if (lo) lo->launched = false;
-    if (!gemm_nt_fwd_pair_ok(M, N1, N2, K1, K2)) return ps_set_err(PS_E_UNSUPPORTED, "gemm_nt_fwd_pair: shapes");
+    if (!gemm_nt_fwd_pair_ok(M, N1, N2, K1, K2)) return ps_set_err(PS_E_UNSUPPORTED, "gemm_nt_fwd_pair: shapes (or not a lab build)");
+#if PS_GEMM_LAB
     const LaunchOpts none;
     const LaunchOpts &o = lo ? *lo : none;
     PairArgs q;
@@ -1306,6 +1329,7 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
     PS_LAUNCH_EV((k_fc_fwd_pair<2, 2, 1, 1, 32>), dim3(grid), dim3(256), 0, st, o.stop_event, q);
     HIPCHK(hipGetLastError());
     if (lo) lo->launched = true;
+#endif
     return PS_OK;
 }
 
@@ -1437,11 +1461,14 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     // 0.1437 -> 0.1413 ms (A/B x2, round 3)
     if (cfg == 0) cfg = N <= 32 ? 5 : 6;
     switch (cfg) {
+    // ---- the product's two shapes
+    case 6: TN_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;    // 8 waves on 64 x 64: two wave groups split every slab's batch rows
+    case 5: TN_LAUNCH(4, 1, 1, 1, 32); break;          // narrow N: 128 x 32
+#if PS_GEMM_LAB
     case 1: TN_LAUNCH(2, 2, 1, 1, 16); break;
     case 2: TN_LAUNCH(2, 2, 1, 1, 32); break;
     case 3: TN_LAUNCH(2, 2, 2, 2, 16); break;
     case 4: TN_LAUNCH(4, 1, 1, 1, 16); break;
-    case 6: TN_LAUNCH_KS(2, 2, 1, 1, 32, 2); break;    // 8 waves on 64 x 64: two wave groups split every slab's batch rows
     case 7: TN_LAUNCH_KS(2, 2, 1, 1, 64, 2); break;    // ... with 64-row slabs
     case 12: TN_LAUNCH_P(2, 2, 1, 1, 32, 1); break;    // software-pipelined slab loop (PIPE = 3), 4 waves
     case 16: TN_LAUNCH_P(2, 2, 1, 1, 32, 2); break;    // ... 8 waves (K split)
@@ -1450,7 +1477,9 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     case 26: TN_LAUNCH_P4(2, 2, 1, 1, 32, 2); break;   // ... 8 waves (K split)
     case 27: TN_LAUNCH_P4(2, 2, 1, 1, 64, 2); break;   // ... 64-row slabs
     case 32: TN_LAUNCH_P(2, 2, 1, 1, 16, 1); break;    // PIPE = 3 on 16-row slabs (24 KB of LDS), 4 waves
-    default: TN_LAUNCH(4, 1, 1, 1, 32); break;
+#endif
+    default:
+        return ps_set_err(PS_E_UNSUPPORTED, "gemm_tn_cfg %d is not in this build%s", cfg, PS_GEMM_LAB ? "" : " (the rejected variants live in the lab build: tools/gemm_lab_build.sh)");
     }
     HIPCHK(hipGetLastError());
     return PS_OK;

@@ -58,7 +58,10 @@ int ps_set_err(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *ps_last_error(void) { return g_err; }
-extern "C" const char *ps_version(void) { return "ps_amd 0.1 gfx950 hip"; }
+#ifndef PS_GEMM_LAB
+#define PS_GEMM_LAB 0
+#endif
+extern "C" const char *ps_version(void) { return PS_GEMM_LAB ? "ps_amd 0.1 gfx950 hip +gemm_lab" : "ps_amd 0.1 gfx950 hip"; }
 extern "C" int ps_device_count(int *count) {
     if (!count) return ps_set_err(PS_E_BAD_ARG, "count is NULL");
     int n = 0;

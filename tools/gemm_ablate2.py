@@ -1,5 +1,5 @@
 """The FC shapes through k_gemm_nt, 200 back-to-back launches each, for one build of the library (PS_AMD_LIB): used with
-tools/gemm_ablate_build.sh to price the parts of a slab (LDS reads, MFMAs, barriers, global loads, LDS writes)."""
+tools/gemm_lab_build.sh <bits> to price the parts of a slab (LDS reads, MFMAs, barriers, global loads, LDS writes)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ps_amd
