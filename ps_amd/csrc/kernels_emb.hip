@@ -370,9 +370,17 @@ __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
     float *__restrict__ dp = a.dprev;
     // (requesting the first LAST_ROWS x column before the head, to overlap the two round trips, measured slower:
     // kernel span 12.9 -> 15.5 us)
-    for (int k = tid; k < a.Kp; k += 256) {
-        const bool in = k <= a.K;                               // k == K is the ones column (bias)
-        const float w = (k < a.K) ? a.W[(size_t)k * a.ldw] : 0.f;
+    // The ones column (k == K: db = the rows' delta summed in order, x = 1 exactly) needs no load of A at all: one thread adds
+    // it up from the deltas.  As one more trip of the loop below -- k = K .. Kp - 1 for 16 threads at K = 256 -- it was a
+    // second full memory round trip of the whole workgroup for one useful column (round 4).
+    if (tid == 255) {
+        float accb = 0.f;
+        for (int b = r0; b < r1; ++b) accb += 1.0f * (HEAD ? dsh[b - r0] : dl[(size_t)b * a.ldd]);
+        a.part[(size_t)blockIdx.x * a.part_stride + (size_t)a.K * a.ldpart] = accb;
+    }
+    for (int k = tid; k < a.K; k += 256) {
+        const bool in = true;
+        const float w = a.W[(size_t)k * a.ldw];
         float acc = 0.f;
         for (int b0 = r0; b0 < r1; b0 += LAST_ROWS) {
             float x[LAST_ROWS], d[LAST_ROWS];
@@ -1135,6 +1143,30 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = n0 + tx;
     const int row_lo = L.row_cnt > 0 ? L.row_lo : 0, row_hi = L.row_cnt > 0 ? L.row_lo + L.row_cnt - 1 : L.K;
+    // The element's W, S1, S2 (and, on the multi-worker path, its flat gradient) are requested FIRST, unconditionally and from
+    // clamped addresses, so that they travel with the slab loads below: as loads inside the per-element loop -- behind its
+    // `continue`s and between four Adam evaluations -- each element paid its own memory round trip, and this kernel closes the
+    // step (round 4: the dense update's tail is what the next step's first GEMM waits for).
+    size_t wi4[4];
+    int64_t t4[4];
+    float w4[4] = {0.f, 0.f, 0.f, 0.f}, s14[4] = {0.f, 0.f, 0.f, 0.f}, s24[4] = {0.f, 0.f, 0.f, 0.f}, fg4[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int nc = n < L.N ? n : L.N - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + ty + 8 * j, kc = k < row_lo ? row_lo : k > row_hi ? row_hi : k;
+            wi4[j] = (size_t)kc * L.ldw + nc;
+            t4[j] = L.elem_begin + (int64_t)kc * L.N + nc;
+        }
+        if (a.apply) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w4[j] = L.W[wi4[j]]; s14[j] = L.S1[wi4[j]]; s24[j] = L.S2[wi4[j]]; }
+        }
+        if (a.flat_grad) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fg4[j] = a.flat_grad[t4[j]];
+        }
+    }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (!a.flat_grad && n < L.N) {
         const float *__restrict__ pn = L.part + n;
@@ -1161,19 +1193,19 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
     for (int j = 0; j < 4; ++j) {
         const int k = k0 + ty + 8 * j;                    // k in [0, K] (K = bias row), n in [0, N)
         if (k < row_lo || k > row_hi || n >= L.N) continue;
-        const int64_t t = L.elem_begin + (int64_t)k * L.N + n;
+        const int64_t t = t4[j];
         float g;
         if (a.flat_grad) {
             // multi-worker path: the (all-reduced) mean gradient was materialised flat
-            g = a.flat_grad[t];
+            g = fg4[j];
             if (a.flat_div > 0.f) g = div_rn(g, a.flat_div);
         } else {
             g = div_rn(s[j], (float)a.B);                 // divi(delta.columns) FcLayer.java:105 / rowMeans :103
         }
         if (a.grad_out) a.grad_out[t] = g;
         if (!a.apply) continue;
-        const size_t wi = (size_t)k * L.ldw + n;
-        float w = L.W[wi], s1 = L.S1[wi], s2 = L.S2[wi];
+        const size_t wi = wi4[j];
+        float w = w4[j], s1 = s14[j], s2 = s24[j];
         if (a.upd.kind == PS_UPD_ADAM) adam_elem(a.upd, g, w, s1, s2);
         else if (a.upd.kind == PS_UPD_SIMPLE) w = (g * -a.upd.eta) + w;
         else ftrl_elem(a.upd, g, w, s1, s2);   // per-tensor "dw[0]==0" skip is not meaningful for dense tensors
@@ -1389,7 +1421,7 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     const int grid = a.gather_blocks + dense_blocks;
     if (grid == 0) return PS_OK;
     // multi-hot: ids handed round a lane group by shuffle when the group sits inside one wave
-    const int mhi = (multi && 64 % a.LPR == 0) ? (a.LPR <= 4 ? a.LPR : a.LPR == 8 ? 2 : (g_mh_ilp16 > 0 ? g_mh_ilp16 : 1)) : 0;
+    const int mhi = (multi && 64 % a.LPR == 0) ? (a.LPR <= 4 ? a.LPR : a.LPR == 8 ? 2 : (g_mh_ilp16 > 0 ? g_mh_ilp16 : 4)) : 0;      // (D = 64: four row loads in flight per 16-lane group -- 192.8 us against 195.8 with one on the 256 GB table, bags of 32, tools/gather_sweep.py)
 #define EMB_FWD_MH(V, S)                                                                                           \
     do {                                                                                                           \
         if (mhi == 4) PS_LAUNCH_EV((k_emb_fwd<V, true, S, 4>), dim3(grid), dim3(256), 0, st, stop_ev, a);          \
