@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0   # MI355X_MICROARCH.md: measured device-to-device copy ceiling (read + write)
 F32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA peak (exact f32; no TF32 on gfx950)
 
 C2 = dict(F=26, V=100000, D=16, X=13, fc=[512, 256, 1], B=4096, wide=100000, zipf=1.05, seed=0x5EED, idgen="zipf_truncated")
@@ -364,12 +365,15 @@ def multi_hot_step(cfg, steps=60):
     kv = ps_amd.KVStore(0, cfg["seed"])
     kv.create_embedding([V] * F, cfg["D"])
     kv.set_updater("emF", ps_amd.FtrlUpdater())
-    bs, nnz_max, nnz_sum = [], 0, 0
+    bs, nnz_max, nnz_sum, uniq = [], 0, 0, []
     for _ in range(16):
         lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         nnz = int(offsets[-1]); nnz_max = max(nnz_max, nnz); nnz_sum += nnz
         ids = synth.draw_ids(rng, 1.05, V, nnz, cfg.get("idgen", "zipf_truncated"))
+        if len(uniq) < 3:       # unique (field, id) rows of a batch: what the fused backward + Ftrl reads and writes once each
+            field = np.repeat(np.tile(np.arange(F, dtype=np.int64), B), lens)
+            uniq.append(int(np.unique(field * V + ids).size))
         W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)
         bs.append(ps_amd.DeviceBatch(kv, ids, rng.standard_normal((B, cfg["X"])).astype(np.float32),
                                      (rng.random(B) < 0.25).astype(np.float32), W, offsets))
@@ -386,9 +390,17 @@ def multi_hot_step(cfg, steps=60):
     for b in bs:
         b.close()
     gm.close(); kv.close()
+    # its own roofline: the step's algorithmic HBM bytes -- gather nnz (4 D + 8) + 8 (B F + 1), fused backward + Ftrl
+    # nnz 4 D + U 6 * 4 D + nnz 8 -- over the WHOLE step's time against 8 TB/s (the FC chain and the sort run inside that time too)
+    D, nnz_avg, U = cfg["D"], nnz_sum / 16, float(np.mean(uniq))
+    gather_b = nnz_avg * (4 * D + 8) + 8 * (B * F + 1)
+    bwd_b = nnz_avg * 4 * D + U * 6 * 4 * D + nnz_avg * 8
     return {"workload": "configs[4] shape on 1 GPU: bags of Poisson(30) ids per (sample, field), Zipf(1.05), FTRL rows, batch 4096",
             "id_generator": cfg.get("idgen", "zipf_truncated"),
-            "ids_per_step": nnz_sum // 16, "ms_per_step": 1e3 * dt, "examples_per_s": B / dt, "ids_per_s": nnz_sum / 16 / dt,
+            "ids_per_step": nnz_sum // 16, "unique_rows_per_step": int(U), "ms_per_step": 1e3 * dt, "examples_per_s": B / dt, "ids_per_s": nnz_sum / 16 / dt,
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": {"gather": gather_b, "backward_plus_ftrl": bwd_b},
+                         "achieved": (gather_b + bwd_b) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gather_b + bwd_b) / dt / 1e9 / HBM_PEAK_GBS,
+                         "note": "whole step (gather, sort, FC chain, per-key reduce + Ftrl) over the algorithmic bytes of its two HBM-bound kernels"},
             "final_loss": loss}
 
 
@@ -442,7 +454,10 @@ def gather_roofline(kv, args):
                     "avg_launch_us": ms.value * 1e3, "read_GBs": br.value / ms.value / 1e6,
                     "read_plus_write_GBs": (br.value + bw.value) / ms.value / 1e6,
                     "frac_of_8TBs_read": br.value / ms.value / 1e6 / HBM_PEAK_GBS,
-                    "frac_of_8TBs_read_plus_write": (br.value + bw.value) / ms.value / 1e6 / HBM_PEAK_GBS})
+                    "frac_of_8TBs_read_plus_write": (br.value + bw.value) / ms.value / 1e6 / HBM_PEAK_GBS,
+                    # what is physically left: against the guide's MEASURED copy ceiling (MI355X_MICROARCH.md: 6.29 TB/s read + write) --
+                    # the single-hot gather writes as many bytes as it reads, so its read-only fraction cannot pass one half of that
+                    "frac_of_6.29TBs_read_plus_write": (br.value + bw.value) / ms.value / 1e6 / HBM_COPY_CEILING_GBS})
     return res
 
 

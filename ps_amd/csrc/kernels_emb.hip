@@ -687,6 +687,10 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
     if (a.fu.ngroups > 1) update_key<VEC>(a, row_upd(a, row), row, S, part);      // (a lane group's lanes share the row)
     else update_key<VEC>(a, a.upd, row, S, part);
 }
+// (Round 4, measured and taken out again: requesting the row's W / state as soon as the row is known -- together with the key's
+// delta rows instead of behind the store of its gradient -- changes nothing for single-hot batches (0.1329 against 0.1331 ms / step,
+// A/B on one box: the long-key role decides that kernel) and costs the multi-hot step 35 us (0.390 -> 0.425 ms: twelve more
+// live VGPRs in a role that already holds 32 rows in flight).)
 
 // The REFERENCE order for a key seen n > PS_EMB_CHUNK times (layer/EmbeddingField.java:86-104: one addi per sample,
 // strictly in batch order; then the second pass of App. A.6).  A strict f32 chain of n (compat: 2n) dependent adds
@@ -706,7 +710,8 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
 #define SEQ_ILP 4
 #define SEQ_TILE PS_EMB_SEQ_TILE  // SEQ mode: keys above this many entries go to a long-key workgroup (at most one such run
                                   // can start in a SEQ_TILE-entry tile); 16 keeps the short role at 64 row registers
-#define SEQ_LONG_GRID 512         // long-key workgroups when the sort handed over a list of the long runs
+#define SEQ_LONG_GRID 2048        // long-key workgroups when the sort handed over a list of the long runs (round 4: 512 -> 2048, ~1500 runs above 16 entries
+                                  // in a configs[1] batch: one run per workgroup instead of three in a row; 0.1333 -> 0.1325 ms / step)
 #define SEQ_LDS_FLOATS 4096       // per buffer: D * (3 * (64 / LPR) * SEQ_ILP + 4) <= 768 * VEC + 4 * D
 __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magic, uint32_t &rem) {
     uint32_t q = __umulhi(x, magic);            // magic = floor(2^32 / d): q is the quotient or one less

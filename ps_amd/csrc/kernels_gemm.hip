@@ -1265,6 +1265,11 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     case 144: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;    // 64 x 128
     case 145: PS_LAUNCH_EV((k_gemm_nt<2, 1, 1, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 32)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 64 x 32
     case 146: PS_LAUNCH_EV((k_gemm_nt<1, 2, 1, 1, 16, 1, 3>), dim3(cdiv(M, 32) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // 2 waves: 32 x 64
+    // round 4: fewer LDS fragment reads per MFMA at the SAME 64 x 64 output tile -- two waves, two accumulators each
+    case 147: PS_LAUNCH_EV((k_gemm_nt<2, 1, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // waves 32 x 64
+    case 148: PS_LAUNCH_EV((k_gemm_nt<1, 2, 2, 1, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // waves 64 x 32
+    case 149: PS_LAUNCH_EV((k_gemm_nt<2, 1, 1, 2, 32, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(128), 0, st, stop_ev, a); break;     // ... 32-wide slabs
+    case 151: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 2, 16, 1, 3>), dim3(cdiv(M, 64) * cdiv(N, 128)), dim3(256), 0, st, stop_ev, a); break;    // (= 144) 64 x 128, 4 waves
     case 142: PS_LAUNCH_EV((k_gemm_nt<2, 2, 1, 1, 64, 1, 4>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a); break;     // 64-wide slabs: 70 KB
     // ... fragments read two groups ahead (PIPE = 2)
     case 85: NT_LAUNCH_P2(2, 2, 1, 1, 32, 1); break;
