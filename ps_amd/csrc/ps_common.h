@@ -223,7 +223,9 @@ struct StampScope {
         if (p && threadIdx.x == 0 && blockIdx.x == 0) p[0] = (unsigned long long)wall_clock64();
     }
     __device__ __forceinline__ ~StampScope() {
-        if (p && threadIdx.x == 0 && ((blockIdx.x & 31u) == 31u || blockIdx.x == gridDim.x - 1 || blockIdx.x < always))
+        // (a large `always` range is sampled too, every 8th: 2048 long-key workgroups with an atomic each on this one word made the
+        //  stamped embedding update 31 us instead of 18 -- the measurement, not the kernel)
+        if (p && threadIdx.x == 0 && ((blockIdx.x & 31u) == 31u || blockIdx.x == gridDim.x - 1 || (blockIdx.x < always && (always <= 256u || (blockIdx.x & 7u) == 7u))))
             atomicMax(p + 1, (unsigned long long)wall_clock64());
     }
 };
@@ -254,6 +256,6 @@ extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
-extern int g_plan_fused;
+extern int g_plan_fused, g_shard_sort_defer;
 extern int g_rccl_force, g_blk_factor, g_blk_cap, g_push_grouped_max_mb, g_comm_timing;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

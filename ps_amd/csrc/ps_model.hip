@@ -523,13 +523,17 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
                       nullptr, 0, 0, nullptr, st, &lo, s->werr()));
         if (lo.flag && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st));      // (an empty GEMM)
-        if (fwd_flag_due) { fwd_flag_due = false; m->fwd_flag_valid = true; }
+        if (fwd_flag_due) {
+            fwd_flag_due = false; m->fwd_flag_valid = true;
+            if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, true));      // (the waiter after the launch that releases it)
+        }
         if (sort_due) {         // the waiter is enqueued after the launch that releases it
             PSCHK(enqueue_sort());
             sort_due = false;
         }
         if (pair) ++l;          // (layer l + 1 went with this launch)
     }
+    if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, false));      // (no GEMM carried the start flag: the sort at once)
     // LRLayer.forward + AddLayer.forward + loss
     HeadArgs h;
     memset(&h, 0, sizeof h);

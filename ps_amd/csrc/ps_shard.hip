@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W
 
 }  // namespace
 int g_plan_sort = 0;       // ps_tune_set("plan_sort", 1): the sort-based plan (A/B runs, tests of both paths)
+int g_shard_sort_defer = 1;      // ps_tune_set("shard_sort_defer", 0): the plan's field sort right behind its slots again (round 3)
 int g_plan_fused = 1;      // ps_tune_set("plan_fused", 0): count / emit / pack as three launches (round 3)
 namespace {
 
@@ -422,19 +423,33 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
     if (off_main && !g_ext_events) HIPCHK(hipEventRecord(sh.slot_ev, ss));
     sh.slot_flag = false;
     const bool fsort = !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
+    // the sort leaves this call when the step's forward can launch it behind its first GEMM's start (Shard::sort_due)
+    const bool defer_sort = fsort && off_main && m->dev_ok && g_shard_sort_defer && ss == m->side[0] && !m->cfg.use_graph && !m->profile && m->multi_stream;
     unsigned int *fs_flag = nullptr;
     if (off_main && m->dev_ok) {       // ... and a device flag: ps_shard_step hangs this join on its owner-side gather's launch
         if (++m->start_epoch == 0) ++m->start_epoch;
         sh.slot_epoch = m->start_epoch;
         // (raised by the START of the field sort behind the slot kernel -- in order, so the slots are written -- rather than
-        //  by a flag-setter launch of its own)
-        if (fsort) fs_flag = m->start_flag + 10;
+        //  by a flag-setter launch of its own; a deferred sort comes too late for that)
+        if (fsort && !defer_sort) fs_flag = m->start_flag + 10;
         else PSCHK(launch_flag_set(m->start_flag + 10, sh.slot_epoch, ss));
         sh.slot_flag = true;
     }
     HIPCHK(hipGetLastError());
     m->field_sorted = false;
-    if (fsort) {
+    sh.sort_due = false;
+    if (defer_sort) {
+        int kb = sh.sbits + bits_for(nshards);
+        const bool based = nshards == 1 && !s->emb.java_route();
+        if (based) {
+            int64_t span = 1;
+            for (int f = 0; f < F; ++f) span = std::max(span, s->emb.rows[f]);
+            kb = bits_for(span);
+        }
+        sh.sort_due = true; sh.sort_kb = kb; sh.sort_based = based;
+        m->sorted_keys = m->fs_keys; m->sorted_ents = m->fs_ents;
+        m->field_sorted = true;
+    } else if (fsort) {
         // single-hot: one launch sorts the F fields on their own (kernels_sort.hip) instead of the 11-launch radix
         // chain.  A composite key (owner, local row) belongs to one field only, so the runs are the same; they come
         // field by field rather than in send order, and the embedding backward writes each run's gradient at the
@@ -457,6 +472,21 @@ static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream
     }
     m->long_list_valid = true; m->nlong_ptr = m->seg_nseg_scratch + 1;
     m->side0_pending = off_main;
+    return PS_OK;
+}
+
+// the plan's field sort, enqueued by the step's forward on side chain 0: behind a spinner on its first GEMM's start
+// (behind_fwd_flag; the launch that raises start_flag[4] = fwd_epoch is already on the training stream), or at once
+int shard_launch_deferred_sort(ps_model *m, bool behind_fwd_flag) {
+    ps_model::Shard &sh = m->sh;
+    if (!sh.sort_due) return PS_OK;
+    sh.sort_due = false;
+    hipStream_t ss = m->side[0];
+    if (behind_fwd_flag) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss, m->s->werr(), 15));
+    if (++m->fs_epoch == 0) ++m->fs_epoch;
+    PSCHK(field_sort_segments(m->keys, sh.sort_based ? sh.lrb_dev : nullptr, sh.sort_kb, m->cur_B, m->cfg.F, PS_EMB_SEQ_TILE, m->fs_keys, m->fs_ents,
+                              m->seg_start, m->seg_id, m->seg_nseg_scratch, m->long_list, m->fs_pub, m->fs_epoch, ss));
+    m->side0_pending = true;
     return PS_OK;
 }
 

@@ -193,6 +193,11 @@ struct ps_model {
         // but by the spinner that opens the NEXT step's plan on the same stream (launch_set_then_spin) -- requested by
         // ps_shard_step_finish_begin around the backward, consumed by shard_plan_enqueue, flushed as a plain launch otherwise
         bool defer_flag5 = false, deferred = false; unsigned int *def_flag = nullptr; unsigned int def_val = 0;
+        // The field sort of a step's plan (the backward's entry lists) is needed ~100 us after the slots: it is not launched with
+        // them but by the step's FORWARD, behind a spinner on its first GEMM's start -- like the fused step's sort.  Launched
+        // with the slots it ran beside the gather and the first forward GEMM, whose 512 workgroups then found 26 CUs taken:
+        // that GEMM took 24.1 us in the sharded step against 18.7 in the fused one (profiles/r04_shard_gpu_timeline.txt).
+        bool sort_due = false; int sort_kb = 0; bool sort_based = false;
         uint32_t *pack_blk = nullptr, *pack_full = nullptr; bool packed = false;
         uint32_t *owner_start_host = nullptr;   // pinned readback of owner_start
         hipEvent_t plan_ev = nullptr;           // the plan's kernels + readback are done
@@ -276,6 +281,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
                        bool order_after_main = false);   // ps_shard.hip
 int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st);
 int shard_flush_deferred_flag(ps_model *m);       // ps_shard.hip
+int shard_launch_deferred_sort(ps_model *m, bool behind_fwd_flag);   // ps_shard.hip: the plan's field sort, enqueued by the forward
 int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st);      // early plans: the slots + the backward's entry lists
 int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
 int enqueue_backward(ps_model *m, bool apply);
