@@ -511,7 +511,9 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
                           gemm_nt_fwd_pair_ok(B, p.N, s->fc[l + 1].N, p.Kpad, s->fc[l + 1].Kpad);
         Prof pf(m, pair ? (l == 0 ? "fc_fwd01" : "fc_fwd_pair") : names[l]);
         LaunchOpts lo;
-        if (sort_due || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
+        // (sort_layer: which forward GEMM's start releases the field sort -- 0, the first; measurement knob)
+        const bool sort_here = sort_due && (l >= g_sort_layer || l + 1 >= nfc - 1);
+        if (sort_here || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
         lo.prio = (train && gemm_prio(m)) ? 1 : 0;
         if (pair) {
             FcParams &p2 = s->fc[l + 1];
@@ -527,7 +529,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
             fwd_flag_due = false; m->fwd_flag_valid = true;
             if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, true));      // (the waiter after the launch that releases it)
         }
-        if (sort_due) {         // the waiter is enqueued after the launch that releases it
+        if (sort_here) {        // the waiter is enqueued after the launch that releases it
             PSCHK(enqueue_sort());
             sort_due = false;
         }

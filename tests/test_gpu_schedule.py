@@ -133,10 +133,11 @@ def test_plan_epoch_wraps():
     np.testing.assert_array_equal(a[2], b[2])
 
 
-@pytest.mark.parametrize("early", [1, 0])
-def test_pipelined_sharded_steps_on_device_batches(early):
+@pytest.mark.parametrize("early,extra", [(1, {}), (0, {}), (1, {"shard_sort_defer": 0}), (1, {"plan_fused": 0}), (1, {"shard_sort_defer": 0, "plan_fused": 0})])
+def test_pipelined_sharded_steps_on_device_batches(early, extra):
     """ps_shard_step's one-model pipeline on device-resident batches (what bench.py --sharded / --gpus N runs): with the next
-    step's plan on side chain 0 while the step trains (early = 1, the default) and with the plan in the step's tail (0) --
+    step's plan on side chain 0 while the step trains (early = 1, the default) and with the plan in the step's tail (0); with the
+    plan's field sort launched by the forward (default) or right behind the slots; count / emit / pack in one launch or three --
     120 steps each, equal to 120 fused steps bit for bit (the 8-bit plan epoch does not wrap here; the run count's two
     buffers alternate 120 times)."""
     import ps_amd
@@ -147,6 +148,8 @@ def test_pipelined_sharded_steps_on_device_batches(early):
     data = batches(rng, 9, B, F, X, V, WS)
     res = []
     N.lib().ps_tune_set(b"plan_early", early)
+    for k, v in extra.items():          # round 3's forms of round 4's changes: the sort right behind the slots; count / emit / pack as three launches
+        N.lib().ps_tune_set(k.encode(), v)
     try:
         for native in (False, True):
             kv = ps_amd.KVStore(0, SEED)
@@ -168,6 +171,8 @@ def test_pipelined_sharded_steps_on_device_batches(early):
             gm.close(); kv.close()
     finally:
         N.lib().ps_tune_set(b"plan_early", 1)
+        for k in extra:
+            N.lib().ps_tune_set(k.encode(), 1)
     a, b = res
     assert a[3] == b[3] == 120
     for x, y in zip(a[0] + a[1], b[0] + b[1]):
