@@ -327,3 +327,61 @@ def test_overlap_mode_outlives_the_device_side_joins():
     for x, y in zip(a[0] + a[1], b[0] + b[1]):
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("knobs", [{}, {"blk_cap": 64}, {"plan_fused": 0, "blk_cap": 64}, {"rccl_force": 2, "blk_cap": 64}])
+def test_sharded_steps_with_the_one_launch_plan(knobs):
+    """A key space large enough for the one-launch plan (k_plan_fused: 20 000 rows -> 4 look-back workgroups; the toy shapes
+    above take the three-launch form), 60 pipelined sharded steps == 60 fused steps bit for bit -- also with wire blocks of 64
+    rows, so that EVERY step's lists overflow and travel again at full size (packed by the plan's launch, or by
+    k_pack_blocks), and with that second exchange going through RCCL (1-rank communicators, self send/recv)."""
+    import ps_amd
+    from ps_amd import native as N
+    from ps_amd.sharded import NativeWorker
+    import ctypes as C
+    L = N.lib()
+    F, D, X, fc, V, B, WS = 4, 16, 3, [32, 16, 1], 5000, 512, 61
+    rng = np.random.default_rng(23)
+    data = []
+    for _ in range(7):
+        E = rng.integers(0, V, size=(B, F)).astype(np.int64)
+        E[: B // 4] = np.minimum(rng.zipf(1.3, (B // 4, F)) - 1, V - 1)        # some hot keys, many distinct ones
+        data.append((E, rng.standard_normal((B, X)).astype(f32), (rng.random(B) < 0.3).astype(f32), E % WS))
+    res, st10 = [], None
+    try:
+        for native in (False, True):
+            kv = ps_amd.KVStore(0, SEED)
+            kv.create_embedding([V] * F, D)
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+            bs = [ps_amd.DeviceBatch(kv, E, Xd, Y, W) for E, Xd, Y, W in data]
+            if native:
+                for k, v in knobs.items():
+                    L.ps_tune_set(k.encode(), v)
+                wk = NativeWorker([gm], 1, 0)
+                wk.run(bs, 60)
+                kv.sync()
+                st = (C.c_int64 * 10)()
+                N.check(L.ps_shard_exchange_stats(gm.h, st, 10))
+                st10 = [int(x) for x in st]
+                wk.close()
+            else:
+                for i in range(60):
+                    gm.train_async(bs[i % len(bs)])
+            kv.sync()
+            res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)],
+                        kv.get_wide(np.arange(WS)), kv.global_step()))
+            for b in bs:
+                b.close()
+            gm.close(); kv.close()
+    finally:
+        for k in knobs:
+            L.ps_tune_set(k.encode(), {"plan_fused": 1}.get(k, 0))
+    a, b = res
+    assert a[3] == b[3] == 60
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2])
+    if "blk_cap" in knobs:
+        assert st10[8] == 60 and st10[7] < st10[9], st10        # every step took the full-size exchange
+    else:
+        assert st10[8] == 0, st10
