@@ -12,7 +12,10 @@
 namespace {
 
 constexpr int RS_TPB = 256;
-constexpr int RS_IPT = 16;
+#ifndef PS_RS_IPT
+#define PS_RS_IPT 16
+#endif
+constexpr int RS_IPT = PS_RS_IPT;       // keys per thread (tile = 256 x RS_IPT pairs); -DPS_RS_IPT=8 for A/B builds
 constexpr int RS_TILE = RS_TPB * RS_IPT;  // 4096 keys per workgroup
 constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 1024 consecutive keys per wave
 constexpr int RS_SB_LOG = 5, RS_SB = 1 << RS_SB_LOG;   // tiles per superblock (second level of the digit counts)
