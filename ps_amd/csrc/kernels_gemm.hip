@@ -17,7 +17,6 @@
 // the fragment reads stay simple: ds_read_b128 along k with a k-permutation
 // (per 8 k's: lanes 0-31 take k 0-3, lanes 32-63 take k 4-7).
 #include "ps_common.h"
-#include "kernels_head.h"
 #include <string.h>
 #include <strings.h>
 #include <stdlib.h>
@@ -43,13 +42,7 @@ struct NtArgs {
     const unsigned int *wait_flag; unsigned int wait_val;   // workgroup 0 ends only once *wait_flag has reached wait_val
     int prio;                                               // raise the waves' priority (a main-chain launch of the fused step)
     WaitBound bound;                                        // ... or gives up after bound.ticks and reports it in *bound.err
-    // k_gemm_nt_head only (the first delta GEMM of a training step): A holds the out = 1 layer's INPUT x; the operand is formed
-    // while it is staged, A'[r][c] = (w[c] * delta_L[r]) * (x[r][c] > 0) -- FcLayer.backward of that layer as k_last_bwd writes it
-    const float *pro_w; int pro_ldw, pro_cols;              // w[c] = pro_w[c * pro_ldw] for c < pro_cols, 0 beyond (padding columns of the operand)
-    unsigned int *pro_done;                                 // += 1 per workgroup once its head is computed: what the head READS (the wide weights)
-                                                            // may be written again when the count has grown by the grid size
 };
-#define PS_PRO_KMAX 1024                                    // columns of x (floats of LDS for w)
 
 // XCD-aware work-group order.  MI355X dispatches block b to XCD b % 8 (observed, used for speed
 // only), each XCD with its own 4 MiB L2.  The remap gives every XCD a CONTIGUOUS chunk of logical
@@ -107,13 +100,8 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 //   * the masks / LDS writes / next global loads are dealt out one chunk per MFMA of the first group, so the VALU work sits
 //     in the shadow of a running MFMA instead of between two groups.
 // Same products in the same order per accumulator as PIPE = 0: bit-identical results.
-// PRO (k_gemm_nt_head): the workgroup first computes delta_L of its BM rows with the head's own device function (the same
-// lanes, loads and summation order as the head's launch: the same bits), then forms the A operand from the out = 1 layer's
-// input on the way to LDS.  hp / dsh [BM] / wsh [K]: the head's arguments and two small LDS arrays.
-template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0, bool PRO = false>
-__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs,
-                                             const HeadArgs *hp = nullptr, float *dsh = nullptr, float *wsh = nullptr) {
-    static_assert(!PRO || (PIPE == 3 && KS == 1 && WM * WN == 4), "the head prologue: 256 threads, the default loop");
+template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0>
+__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs) {
     constexpr int LDB = (PIPE == 3 && BKT == 16 && KS == 1) ? 16 : BKT + 4;              // (row length: see SWZ below)
     constexpr int ASZ = WM * TM * 32 * LDB, BSZ = WN * TN * 32 * LDB;                    // floats per LDS buffer
     constexpr int NTH = WM * WN * 64 * KS;
@@ -193,26 +181,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
         return v;
     };
-    float drow[A_F4];                                       // (PRO) delta_L of the row this thread stages
-    auto xform = [&](float4 v, int i, int c) -> float4 {
-        if constexpr (PRO) {
-            const float d = drow[i];
-            const float4 w = *reinterpret_cast<const float4 *>(wsh + (c < a.K ? c : 0));
-            float t;
-            t = w.x * d; t *= v.x > 0.f ? 1.f : 0.f; v.x = t;      // (k_last_bwd: v = w * d; v *= relu'(x))
-            t = w.y * d; t *= v.y > 0.f ? 1.f : 0.f; v.y = t;
-            t = w.z * d; t *= v.z > 0.f ? 1.f : 0.f; v.z = t;
-            t = w.w * d; t *= v.w > 0.f ? 1.f : 0.f; v.w = t;
-        }
-        return v;
-    };
     auto swrite = [&](int buf, int kt, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * NTH;
             if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(xform(ra[i], i, k0 + ca[i]), k0 + ca[i]);
+                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(ra[i], k0 + ca[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
@@ -314,7 +289,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             if (c < A_F4) {
                 const int e = tid + c * NTH;
                 if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(xform(ra[c], c, k0 + ca[c]), k0 + ca[c]);
+                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(ra[c], k0 + ca[c]);
             } else {
                 const int i = c - A_F4, e = tid + i * NTH;
                 if ((BN * RF4) % NTH == 0 || e < BN * RF4)
@@ -423,20 +398,6 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             gload(0, ra0, rb0);
             gload(1, ra1, rb1);
             gload(2, ra2, rb2);
-            if constexpr (PRO) {
-                // the head of this tile's rows, behind the first three slabs' requests (its own round trips -- the row of x and the
-                // wide ids, then the wide weights -- overlap theirs): 8 lanes per row, 32 rows per sweep
-                for (int base = 0; base < BM; base += NTH / 8) {
-                    const int rl = base + (tid >> 3), b = m0 + rl;
-                    const float d = head_one(*hp, b < a.M ? b : a.M - 1, tid & 63, false);
-                    if ((tid & 7) == 0) dsh[rl] = d;
-                }
-                for (int k = tid; k < a.K; k += NTH) wsh[k] = k < a.pro_cols ? a.pro_w[(size_t)k * a.pro_ldw] : 0.f;
-                __syncthreads();
-                if (tid == 0 && a.pro_done) __hip_atomic_fetch_add(a.pro_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int i = 0; i < A_F4; ++i) { const int e = tid + i * NTH; drow[i] = dsh[e / RF4 < BM ? e / RF4 : BM - 1]; }
-            }
             swrite(0, 0, ra0, rb0);
             gload(3, ra0, rb0);
             swrite(1, 1, ra1, rb1);
@@ -551,27 +512,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     const int tn = (a.N + BN - 1) / BN;
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     gemm_nt_tile<WM, WN, TM, TN, BKT, KS, PIPE>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
-}
-
-// The FIRST delta GEMM of a training step with the head of its rows as a prologue (round 4): the head's launch -- 9 us and two
-// kernel boundaries for 1 MFLOP -- leaves the main chain (it still runs, on side chain 1, for everything else it produces:
-// P, the loss terms, delta_L for the wide update, the out = 1 layer's dW slabs and the delta the first dW GEMM reads).
-template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt_head(NtArgs a, HeadArgs h) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LD = BKT == 16 ? 16 : BKT + 4;
-    __shared__ __attribute__((aligned(16))) float As[3 * BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[3 * BN * LD];
-    __shared__ float dsh[BM];
-    __shared__ __attribute__((aligned(16))) float wsh[PS_PRO_KMAX];
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);
-    StampScope stamp(a.ts);
-    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.skip && *a.skip) return;
-    const int tn = (a.N + BN - 1) / BN;
-    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    gemm_nt_tile<WM, WN, TM, TN, BKT, 1, 3, true>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs, &h, dsh, wsh);
 }
 
 #if PS_GEMM_LAB
@@ -956,7 +896,6 @@ struct TnArgs {
     unsigned long long *ts;
     int prio;        // raise the waves' priority (per launch like NtArgs.prio)
     const unsigned int *wait_flag; unsigned int wait_val; WaitBound bound;    // start wait (ps_common.h start_wait)
-    unsigned int *flag; unsigned int flag_val;       // "this launch has started" (everything in front of it on its stream is done)
 };
 
 // Cpart[z][kout][n] = sum_{m in split z} A[m][kout] * D[m][n]
@@ -979,7 +918,6 @@ __global__ __launch_bounds__(256 * KS) void k_gemm_tn(TnArgs a) {
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(1);
     StampScope stamp(a.ts);
-    if (a.flag && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     start_wait(a.wait_flag, a.wait_val, a.bound);
     if (a.skip && *a.skip) return;
     const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, kg = tid >> 8;
@@ -1261,7 +1199,7 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     const LaunchOpts none;
     const LaunchOpts &o = lo ? *lo : none;
     NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"),
-             o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100), nullptr, 0, 0, nullptr};
+             o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100)};
     const hipEvent_t stop_ev = o.stop_event;
     int cfg = g_gemm_nt_cfg;
     if (cfg == 30 && (K & 15)) cfg = 0;       // the LDS-DMA kernel multiplies whole or half slabs
@@ -1349,31 +1287,6 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
         return ps_set_err(PS_E_UNSUPPORTED, "gemm_nt_cfg %d is not in this build%s", cfg, PS_GEMM_LAB ? "" : " (the rejected variants live in the lab build: tools/gemm_lab_build.sh)");
     }
     HIPCHK(hipGetLastError());
-    if (lo) lo->launched = true;
-    return PS_OK;
-}
-
-// C = epi(A' Bt^T) with A'[r][c] = (w[c] * delta_L[r]) * (x[r][c] > 0), delta_L from the head of row r (k_gemm_nt_head).  x = the
-// out = 1 layer's input [M][ldx] (K <= ldx columns read), w[c] = w_last[c * ldw] for c < w_cols and 0 beyond.  The product's 64 x 64 tiles only.
-// heads_done: a device counter every workgroup adds 1 to once it has computed its rows' heads (*nwg_out workgroups): whoever
-// writes what the head reads -- the wide update of the same step -- waits until the count has grown by that much.
-int gemm_nt_head_ok(int M, int N, int K) {
-    return g_gemm_nt_cfg == 0 && N > 32 && (long long)cdiv(M, 64) * cdiv(N, 128) < 2048 && K <= PS_PRO_KMAX && (K & 3) == 0;      // (where gemm_nt picks cfg 140)
-}
-int gemm_nt_head(const HeadArgs &h, const float *x, int ldx, int x_rows, const float *w_last, int ldw, int w_cols, const float *Bt, int ldb, int b_rows, float *C,
-                 int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
-                 const int *skip_flag, hipStream_t st, LaunchOpts *lo, unsigned int *werr, unsigned int *heads_done, unsigned int *nwg_out) {
-    if (lo) lo->launched = false;
-    if (nwg_out) *nwg_out = 0;
-    if (!gemm_nt_head_ok(M, N, K) || (ldx & 3) || (ldb & 3)) return ps_set_err(PS_E_UNSUPPORTED, "gemm_nt_head: shape %d x %d x %d", M, N, K);
-    if (M <= 0 || N <= 0) return PS_OK;
-    const LaunchOpts none;
-    const LaunchOpts &o = lo ? *lo : none;
-    NtArgs a{x, ldx, x_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, 0, stamp_next("gemm_nt"),
-             o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100), w_last, ldw, w_cols, heads_done};
-    PS_LAUNCH_EV((k_gemm_nt_head<2, 2, 1, 1, 16>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, o.stop_event, a, h);
-    HIPCHK(hipGetLastError());
-    if (nwg_out) *nwg_out = (unsigned int)(cdiv(M, 64) * cdiv(N, 64));
     if (lo) lo->launched = true;
     return PS_OK;
 }
@@ -1547,7 +1460,7 @@ int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd,
     if (Kout <= 0 || N <= 0 || nsplit <= 0) return PS_OK;
     const int mchunk = (int)round_up(cdiv(M > 0 ? M : 1, nsplit), 32);
     TnArgs a{A, lda, a_cols, D, ldd, d_cols, Cpart, ldc, (long long)part_stride, Kout, N, M, mchunk, skip_flag, g_gemm_xcd, stamp_next("gemm_tn"), lo ? lo->prio : 0,
-             lo ? lo->wait : nullptr, lo ? lo->wait_val : 0u, wait_bound(werr, 101), lo ? lo->flag : nullptr, lo ? lo->flag_val : 0u};
+             lo ? lo->wait : nullptr, lo ? lo->wait_val : 0u, wait_bound(werr, 101)};
     int cfg = g_gemm_tn_cfg;
     // 8 waves per 64 x 64 tile, the slab's batch rows split over two wave groups: ~224 workgroups of 4 waves are ONE wave
     // per SIMD -- nothing hides a barrier or an LDS round trip; alone dW0 27.3 -> 25.3 us, dW1 17.5 -> 16.5, in the step

@@ -240,18 +240,11 @@ enum { EPI_NONE = 0, EPI_RELU = 1, EPI_SIGMOID = 2, EPI_MASK_POS = 3 };
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
             const int *skip_flag, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);
-// the first delta GEMM of a training step with the head of its rows as a prologue (kernels_gemm.hip k_gemm_nt_head)
-struct HeadArgs;
-int gemm_nt_head_ok(int M, int N, int K);
-int gemm_nt_head(const HeadArgs &h, const float *x, int ldx, int x_rows, const float *w_last, int ldw, int w_cols, const float *Bt, int ldb, int b_rows, float *C,
-                 int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
-                 const int *skip_flag, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr, unsigned int *heads_done = nullptr,
-                 unsigned int *nwg_out = nullptr);
 // Cpart[z][Kout][ldc] = sum over m in split z of A[m][kout] * D[m][n]  (split-K over M)
 int gemm_tn_splitk(const float *A, int lda, int a_cols, const float *D, int ldd, int d_cols,
                    float *Cpart, int ldc, int64_t part_stride, int Kout, int N, int M, int nsplit,
                    const int *skip_flag, hipStream_t st, const LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: prio, and
-                   // wait = a START wait: no workgroup reads its operands before *wait reached wait_val; flag: raised when the launch starts
+                   // wait = a START wait: no workgroup reads its operands before *wait reached wait_val
 int gemm_tn_choose_split(int Kout, int N, int M);
 // two consecutive relu FcLayer.forward GEMMs in one launch (kernels_gemm.hip k_fc_fwd_pair); _ok: do the shapes fit
 int gemm_nt_fwd_pair_ok(int M, int N1, int N2, int K1, int K2);
@@ -263,6 +256,6 @@ extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
-extern int g_plan_fused, g_shard_sort_defer, g_sort_layer, g_head_fold;
+extern int g_plan_fused, g_shard_sort_defer, g_sort_layer;
 extern int g_rccl_force, g_blk_factor, g_blk_cap, g_push_grouped_max_mb, g_comm_timing;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

@@ -356,23 +356,6 @@ static bool dev_release(const ps_model *m) {
     return m->dev_ok && !c.use_graph && !m->profile && m->multi_stream && c.nfc >= 2 && m->s->fc[c.nfc - 1].N == 1;
 }
 
-// Can the head's launch leave the main chain (kernels_gemm.hip k_gemm_nt_head)?  The backward must follow at once (the fused
-// step, ps_shard_forward_backward), its side chains be released from the device -- or everything run on one stream -- and the
-// first delta GEMM be one of the product's 64 x 64-tile launches whose operand rows the out = 1 layer's input covers.
-int g_head_fold = 1;        // ps_tune_set("head_fold", 0): the head's launch on the main chain between the forward and the first delta GEMM again (round 3)
-static bool head_fold_ok(ps_model *m, bool backward_follows) {
-    const ps_model_config_t &c = m->cfg;
-    ps_store *s = m->s;
-    if (!g_head_fold || !backward_follows || c.nfc < 2 || s->fc[c.nfc - 1].N != 1 || c.use_graph) return false;
-    if (g_dw_late || g_dw_split || g_sort_late) return false;          // (measurement arrangements of the old chain)
-    hipStream_t st = s->stream;
-    const bool one_stream = side_stream(m, 0) == st && side_stream(m, 1) == st;
-    if (!one_stream && !(dev_release(m) && side_stream(m, 1) != st)) return false;
-    const int l = c.nfc - 2;
-    const int N = l > 0 ? s->fc[l].K : c.F * c.D;
-    return gemm_nt_head_ok(m->cur_B, N, m->fc[l].ldD) && m->fc[c.nfc - 1].ldA >= m->fc[l].ldD && s->fc[c.nfc - 1].K <= m->fc[l].ldD;
-}
-
 // the one-launch field sort of a single-hot batch (keys left in m->keys by the gather) on stream ss
 static int enqueue_field_sort(ps_model *m, hipStream_t ss) {
     ps_store *s = m->s;
@@ -574,14 +557,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     m->head_bwd_done = false;
     const FcParams &pl = s->fc[nfc - 1];
     FcBuf &bl = m->fc[nfc - 1];
-    m->head_folded = false;
-    if (train && pl.N == 1 && h.labels && head_last_bwd_fusable(cdiv(B, bl.nsplit)) && head_fold_ok(m, defer_loss)) {
-        // ... and that launch off the main chain altogether (round 4): the first delta GEMM computes the head of its own rows as
-        // a prologue (k_gemm_nt_head) and forms its operand -- the out = 1 layer's backward -- while staging it; the head's
-        // launch goes to side chain 1 in front of the first dW GEMM (enqueue_backward, which follows at once: defer_loss)
-        m->head_folded = true;
-        m->head_bwd_done = true;
-    } else if (train && pl.N == 1 && h.labels && head_last_bwd_fusable(cdiv(B, bl.nsplit))) {
+    if (train && pl.N == 1 && h.labels && head_last_bwd_fusable(cdiv(B, bl.nsplit))) {
         // training: the head and the out = 1 layer's backward of the same rows in ONE launch (three tiny kernels
         // of the critical chain become one; the loss reduction leaves the chain altogether, see enqueue_backward)
         LastBwdArgs q;
@@ -764,16 +740,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         if (sl != s0) HIPCHK(hipEventRecord(m->loss_ev, sl));
         return PS_OK;
     };
-    // (the head's launch left the main chain: enqueued below, behind the first delta GEMM -- which does the head of its own rows)
-    const bool folded = m->head_folded;
-    m->head_folded = false;
-    auto launch_folded_head = [&](hipStream_t hs) -> int {
-        LastBwdArgs q;
-        fill_last_bwd(m, q);
-        Prof pf(m, "head_last_bwd");
-        return launch_head_last_bwd(m->head_args, q, m->fc[nfc - 1].nsplit, hs, nullptr);
-    };
-    if (!dev_wait && !folded) PSCHK(small_kernels());
+    if (!dev_wait) PSCHK(small_kernels());
     // FcLayer.backward, last to first (layer/FcLayer.java:93-110)
     for (int l = nfc - 1; l >= 0; --l) {
         FcParams &p = s->fc[l];
@@ -821,16 +788,8 @@ int enqueue_backward(ps_model *m, bool apply) {
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
-        const bool fold_here = folded && l == nfc - 2;
-        unsigned int fold_nwg = 0;
-        const FcParams &plast = s->fc[nfc - 1];
-        const FcBuf &blast = m->fc[nfc - 1];
         if (l > 0) {
             Prof pf(m, nd[l]);
-            if (fold_here)
-                PSCHK(gemm_nt_head(m->head_args, blast.A, blast.ldA, B, plast.W, plast.ldw, plast.K, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
-                                   EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st, &lo, werr, m->start_flag + 13, &fold_nwg));
-            else
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st, &lo, werr));
         } else {
@@ -842,22 +801,12 @@ int enqueue_backward(ps_model *m, bool apply) {
                 lo.wait = m->start_flag + (sort_dev_wait ? 1 : 5);          // (multi-hot: the end of the long sort chain)
                 lo.wait_val = sort_dev_wait ? m->sort_epoch : m->s0_epoch;
             }
-            if (fold_here)
-                PSCHK(gemm_nt_head(m->head_args, blast.A, blast.ldA, B, plast.W, plast.ldw, plast.K, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
-                                   EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st, &lo, werr, m->start_flag + 13, &fold_nwg));
-            else
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, c.F * c.D, m->dx, m->ldx, B, c.F * c.D, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, c.F * c.D, nullptr, st, &lo, werr));
             s0_joined = lo.wait != nullptr && lo.launched;
         }
         PSCHK(settle_event(m, lo));
         main_dirty = true;
-        m->heads_done += fold_nwg;      // (host mirror of start_flag[13]: what that launch will have added when all its heads are done)
-        bool small_after = false;       // (folded head) side chain 0's small kernels wait for "the first dW GEMM has started"
-        if (fold_here && !dev_wait) {   // one stream: the head's launch and what hangs off it right behind this GEMM
-            PSCHK(launch_folded_head(st));
-            PSCHK(small_kernels());
-        }
         if (dev_wait) {             // every waiter is enqueued AFTER the launch that releases it: none can be left spinning
             if (!lo.launched) PSCHK(launch_flag_set(m->start_flag, m->start_epoch, st));   // (an empty GEMM)
             // The FIRST dW GEMM of the chain sits behind a one-wave spinner launch (its stream is idle: without it the
@@ -869,21 +818,8 @@ int enqueue_backward(ps_model *m, bool apply) {
             else if (defer_this) {}  // (released together with the next one)
             else if (!sw_gated || !g_tn_start_wait) { PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sw, werr, 0)); sw_gated = true; }
             else { tn_lo.wait = m->start_flag; tn_lo.wait_val = m->start_epoch; }
-            if (fold_here) {
-                // the head's launch: at the front of side chain 1, released with it by this GEMM's start (the forward is done then).
-                // The first dW GEMM is in order behind it; side chain 0's small kernels wait for that GEMM's START
-                PSCHK(launch_folded_head(sw));
-                if (sl != sw) {
-                    if (++m->start_epoch == 0) ++m->start_epoch;
-                    tn_lo.flag = m->start_flag + 8; tn_lo.flag_val = m->start_epoch;
-                    small_after = true;
-                }
-            }
-            if (first_release && !small_after) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
+            if (first_release) {     // the head's small kernels: on their own chain behind a spinner, or in front of dW_l
                 if (sl != sw) PSCHK(launch_spin_until(m->start_flag, m->start_epoch, sl, werr, 10));
-                // (folded head, small kernels on side chain 1 behind the head's launch: the wide update among them writes what the
-                //  folded GEMM's heads read -- see below)
-                else if (fold_here) PSCHK(launch_spin_until(m->start_flag + 13, m->heads_done, sl, werr, 13));
                 if (m->sort_deferred) { PSCHK(enqueue_field_sort(m, sl)); m->sort_deferred = false; }
                 PSCHK(small_kernels());
                 first_release = false;
@@ -906,14 +842,6 @@ int enqueue_backward(ps_model *m, bool apply) {
         tn_lo.prio = gemm_prio(m) ? (((g_tn_prio & 8) && l > 0) ? 1 : (g_tn_prio & 7)) : 0;
         PSCHK(gemm_tn_splitk(b.A, b.ldA, b.ldA, b.dOut, b.ldD, b.ldD, b.part, b.ldp, b.part_stride, p.K + 1, p.N, B,
                              b.nsplit, nullptr, dws, &tn_lo, werr));
-        if (small_after) {          // (enqueued after the launch that releases them)
-            PSCHK(launch_spin_until(m->start_flag + 8, tn_lo.flag_val, sl, werr, 8));
-            // ... and the wide update among them writes what the folded GEMM's heads read: not before every workgroup of that GEMM
-            // has computed its heads (start_flag[13] counts them; the GEMM has been running for a head's launch and more by now)
-            PSCHK(launch_spin_until(m->start_flag + 13, m->heads_done, sl, werr, 13));
-            PSCHK(small_kernels());
-            first_release = false;
-        }
         if (split_here) {
             if (++m->start_epoch == 0) ++m->start_epoch;
             dw_split_epoch = m->start_epoch;

@@ -149,8 +149,6 @@ struct ps_model {
     uint32_t *nseg_cur = nullptr;      // nseg_dev or nseg_dev + 4: the run count of the plan the NEXT backward uses (an early plan of
                                        // step t+1 is written while step t's backward still reads its own)
     bool sort_deferred = false;        // the field sort of this step is enqueued by the backward (late sort)
-    unsigned int heads_done = 0;       // host mirror of start_flag[13]: workgroups of the folded delta GEMMs that have computed their heads
-    bool head_folded = false;          // this step's head launch was left to enqueue_backward (ps_model.hip head_fold_ok)
     bool fwd_flag_valid = false;       // the running step's first forward GEMM raises start_flag[4] = fwd_epoch when it starts
     uint32_t *sorted_keys = nullptr, *sorted_ents = nullptr;   // where the last sort left its result
     uint32_t *seg_nseg_scratch = nullptr;                     // run count of a side sort whose nseg the bitmap plan already wrote

@@ -16,8 +16,6 @@ leave identical tables:
   * ps_tune_set("dw_split", 1)                (the first dW GEMM on side chain 0 -- measured slower, off)
   * ps_tune_set("dw_late", 1)                 (the first dW GEMM released with the next delta GEMM)
   * ps_tune_set("gemm_pipe", 0) / gemm_8w   (other slab loops / tiles of the SAME contraction order: k_gemm_nt / k_gemm_tn)
-  * ps_tune_set("head_fold", 0)               (the head's launch between the forward and the first delta GEMM; default (round 4): that GEMM
-                                                does the head of its own rows as a prologue and the head's launch runs on side chain 1)
   * profile mode                              (everything on ONE stream: the serial order is the definition)
 Also: the sharded plan's presence map is stamped with an 8-bit epoch (no clearing between steps): more than 256
 consecutive plans must still equal the fused step (the map is re-zeroed when the epoch wraps)."""
@@ -87,8 +85,6 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "8-wave 128 x 64 tiles": ({"gemm_8w": 1}, False),
                 "the embedding update holds the join with the dense update": ({"tail_defer": 0}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
-                "the head's launch on the main chain": ({"head_fold": 0}, False),
-                "the head's launch on the main chain, one stream": ({"head_fold": 0}, True),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
     from ps_amd import native as N
