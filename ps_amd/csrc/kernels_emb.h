@@ -30,6 +30,7 @@ struct EmbFwdArgs {
 };
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: stop_event, wait (an END wait)
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st);      // multi-hot: key_out / ent_bag from the ids alone
+int launch_emb_keys_seg(const EmbFwdArgs &a, const uint32_t *pre, const uint32_t *ftotal, int tile, uint32_t *kp, uint32_t *vp, hipStream_t st);   // (segmented sort)
 
 struct HeadArgs {
     int B, F, wide, train;

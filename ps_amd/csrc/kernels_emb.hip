@@ -1396,6 +1396,51 @@ __global__ __launch_bounds__(256) void k_emb_keys(EmbFwdArgs a) {
     }
 }
 
+// ... for the segmented sort (kernels_sort.hip k_bag_scan): the pair (id inside the field, bag) of every entry at its place among
+// its FIELD's entries -- pb[f] (the field's first slot, a multiple of tile) + pre[bag] (entries of the field in earlier samples)
+// + position in the bag -- so that the sort needs no pass over the field bits
+template <int LANES>
+__global__ __launch_bounds__(256) void k_emb_keys_seg(EmbFwdArgs a, const uint32_t *__restrict__ pre, const uint32_t *__restrict__ ftotal, int tile,
+                                                      uint32_t *__restrict__ kp, uint32_t *__restrict__ vp) {
+    StampScope stamp(a.ts);
+    __shared__ uint32_t pb[64];
+    if (threadIdx.x == 0) {
+        uint32_t p = 0;
+        for (int f = 0; f < a.F; ++f) { pb[f] = p; p += (ftotal[f] + (uint32_t)tile - 1) / (uint32_t)tile * (uint32_t)tile; }
+    }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nb = (int64_t)a.B * a.F;
+    int64_t bag = t / LANES;
+    const int l = (int)(t % LANES);
+    const bool live = bag < nb;
+    if (!live) bag = nb - 1;
+    const int f = (int)(bag % a.F);
+    const int64_t rn = a.row_base[f + 1] - a.row_base[f];
+    const int64_t p0 = a.offsets[bag], p1 = live ? a.offsets[bag + 1] : p0;
+    const int64_t dst = (int64_t)pb[f] + pre[bag] - p0;         // entry p of the bag goes to dst + p
+    for (int64_t p = p0 + l; p < p1; p += 2 * LANES) {
+        const int64_t q = p + LANES;
+        int64_t id0 = a.ids[p], id1 = a.ids[q < p1 ? q : p];
+        if (id0 < 0 || id0 >= rn) id0 = 0;
+        if (id1 < 0 || id1 >= rn) id1 = 0;
+        kp[dst + p] = (uint32_t)id0;
+        vp[dst + p] = (uint32_t)bag;
+        if (q < p1) { kp[dst + q] = (uint32_t)id1; vp[dst + q] = (uint32_t)bag; }
+    }
+}
+
+int launch_emb_keys_seg(const EmbFwdArgs &a, const uint32_t *pre, const uint32_t *ftotal, int tile, uint32_t *kp, uint32_t *vp, hipStream_t st) {
+    if (!a.offsets || !pre || !ftotal || !kp || !vp || a.F > 64) return ps_set_err(PS_E_BAD_ARG, "launch_emb_keys_seg: multi-hot batches of <= 64 fields only");
+    const int64_t nb = (int64_t)a.B * a.F;
+    if (nb <= 0) return PS_OK;
+    EmbFwdArgs b = a;
+    b.ts = stamp_next("emb_keys");
+    hipLaunchKernelGGL(k_emb_keys_seg<8>, dim3(cdiv(nb * 8, 256)), dim3(256), 0, st, b, pre, ftotal, tile, kp, vp);
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st) {
     if (!a.offsets || !a.key_out || !a.ent_bag) return ps_set_err(PS_E_BAD_ARG, "launch_emb_keys: multi-hot batches only");
     const int64_t nb = (int64_t)a.B * a.F;

@@ -267,6 +267,245 @@ __global__ __launch_bounds__(RS_TPB) void k_radix_scatter(const uint32_t *__rest
     }
 }
 
+// ---- the segmented sort of a multi-hot batch (round 4) ---------------------------------------------------------------
+// A multi-hot batch's keys are (field, id).  An entry's FIELD follows from its bag, so the partition by field costs no
+// radix pass: a column scan of the bag lengths (k_bag_scan) gives every bag its place among its field's entries, the key
+// kernel (kernels_emb.hip k_emb_keys_seg) writes (id, bag) there, and two 9-bit passes over the ids, each field sorted on
+// its own, finish the job -- two passes over 3.2 M pairs instead of three (configs[4]'s shape: 22-bit keys).
+// Layout between the launches: field f's entries start at a multiple of the tile, pb[f] = sum over f' < f of
+// round_up(ftotal[f'], RS_TILE), so that no tile holds two fields; the slots behind a field's last entry are never read
+// (every kernel knows the field's count).  The last pass writes the compact array the backward expects: all entries in
+// (field, id, batch order), keys = rows of the concatenated table again.
+// Same result as radix_sort_pairs on the 22-bit keys, entry for entry (stable: equal keys keep their batch order).
+constexpr int SG_DB = 9, SG_ND = 1 << SG_DB, SG_DPT = SG_ND / RS_TPB;
+struct SegSortArgs {
+    int F;
+    const uint32_t *ftotal;         // [F] entries of every field (k_bag_scan)
+    const int64_t *row_base;        // [F + 1] first row of every field in the concatenated table
+    uint32_t *ftot;                 // [F][SG_ND] this pass's digit totals per field (zero at the start of the pass)
+    uint32_t *tcounts;              // [tiles][SG_ND] this pass's digit counts per tile
+};
+// padded bases of all fields into LDS (pb[F] = end); returns nothing: call from every thread, ends with a barrier
+__device__ __forceinline__ void seg_bases(const SegSortArgs &s, uint32_t *pb, uint32_t *cb) {
+    if (threadIdx.x == 0) {
+        uint32_t p = 0, c = 0;
+        for (int f = 0; f < s.F; ++f) {
+            pb[f] = p; cb[f] = c;
+            const uint32_t n = s.ftotal[f];
+            p += (n + RS_TILE - 1) / RS_TILE * RS_TILE; c += n;
+        }
+        pb[s.F] = p; cb[s.F] = c;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ int seg_field_of(const uint32_t *pb, int F, uint32_t pos) {
+    int f = 0;
+    while (f + 1 < F && pos >= pb[f + 1]) ++f;
+    return f;
+}
+
+// pre[b * F + f] = entries of field f in samples < b; ftotal[f]; also zeroes zero_words words at zero (the sort's per-field totals).
+// One workgroup per field; a thread takes BS_SPT consecutive samples per sweep, all of its loads issued up front
+// (the first version -- 256 threads, 16 samples each behind a runtime trip count -- took 47 us beside the gather: a chain of
+// strided loads).
+constexpr int BS_TPB = 256, BS_SPT = 16;     // (1024-thread workgroups waited ~30 us for a CU with 16 free wave slots beside the gather)
+__global__ __launch_bounds__(BS_TPB) void k_bag_scan(const int64_t *__restrict__ offsets, int B, int F, uint32_t *__restrict__ pre,
+                                                     uint32_t *__restrict__ ftotal, uint32_t *__restrict__ zero, int zero_words, unsigned long long *ts) {
+    StampScope stamp(ts);
+    __shared__ uint32_t wsum[BS_TPB / 64];
+    __shared__ uint32_t carry_s;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid + f * BS_TPB; i < zero_words; i += BS_TPB * gridDim.x) zero[i] = 0u;
+    if (tid == 0) carry_s = 0u;
+    __syncthreads();
+    for (int base = 0; base < B; base += BS_TPB * BS_SPT) {
+        const int b0 = base + tid * BS_SPT;
+        int64_t o[BS_SPT + 1];
+        // bag (b, f) and the bag behind it: offsets[b F + f], offsets[b F + f + 1] -- both loaded (the next sample's bag of this field
+        // is F bags further on)
+        uint32_t len[BS_SPT];
+#pragma unroll
+        for (int j = 0; j < BS_SPT; ++j) {
+            const int b = b0 + j < B ? b0 + j : B - 1;
+            const int64_t bag = (int64_t)b * F + f;
+            o[j] = offsets[bag + 1] - offsets[bag];
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < BS_SPT; ++j) { len[j] = b0 + j < B ? (uint32_t)o[j] : 0u; sum += len[j]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t run = carry_s + inc - sum;
+        for (int ww = 0; ww < w; ++ww) run += wsum[ww];
+#pragma unroll
+        for (int j = 0; j < BS_SPT; ++j) {
+            if (b0 + j < B) pre[(int64_t)(b0 + j) * F + f] = run;
+            run += len[j];
+        }
+        __syncthreads();
+        if (tid == BS_TPB - 1) carry_s = run;
+        __syncthreads();
+    }
+    if (tid == 0) ftotal[f] = carry_s;
+}
+
+__global__ __launch_bounds__(RS_TPB) void k_seg_hist(const uint32_t *__restrict__ keys, int shift, SegSortArgs s, unsigned long long *ts) {
+    __shared__ uint32_t h[SG_ND];
+    __shared__ uint32_t pb[65], cb[65];
+    StampScope stamp(ts);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < SG_DPT; ++q) h[tid + q * RS_TPB] = 0;
+    seg_bases(s, pb, cb);
+    const uint32_t bbase = blockIdx.x * (uint32_t)RS_TILE;
+    if (bbase >= pb[s.F]) return;                          // (the grid is an upper bound)
+    const int f = seg_field_of(pb, s.F, bbase);
+    const uint32_t in_f = bbase - pb[f], nf = s.ftotal[f];
+    const uint32_t nvalid = nf > in_f ? (nf - in_f < (uint32_t)RS_TILE ? nf - in_f : (uint32_t)RS_TILE) : 0u;
+    uint32_t k[RS_IPT];
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const uint32_t i = j * RS_TPB + tid;
+        k[j] = keys[bbase + (i < nvalid ? i : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j)
+        if ((uint32_t)(j * RS_TPB + tid) < nvalid) atomicAdd(&h[(k[j] >> shift) & (uint32_t)(SG_ND - 1)], 1u);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SG_DPT; ++q) {
+        const int d = tid + q * RS_TPB;
+        const uint32_t c = h[d];
+        s.tcounts[(size_t)blockIdx.x * SG_ND + d] = c;
+        if (c) atomicAdd(&s.ftot[(size_t)f * SG_ND + d], c);
+    }
+}
+
+// (ranking and staging as k_radix_scatter<false, true, .>; LAST: compact output, keys = rows of the concatenated table)
+template <bool LAST>
+__global__ __launch_bounds__(RS_TPB) void k_seg_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                        uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int shift,
+                                                        SegSortArgs s, unsigned long long *ts) {
+    StampScope stamp(ts);
+    constexpr uint32_t DMASK = SG_ND - 1;
+    __shared__ uint32_t cur[4][SG_ND];
+    __shared__ uint32_t gdelta[SG_ND];
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t sk[RS_TILE], sv[RS_TILE];
+    __shared__ uint32_t pb[65], cb[65];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 4 * SG_ND; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
+    seg_bases(s, pb, cb);
+    const uint32_t bbase = blockIdx.x * (uint32_t)RS_TILE;
+    if (bbase >= pb[s.F]) return;
+    const int f = seg_field_of(pb, s.F, bbase);
+    const uint32_t in_f = bbase - pb[f], nf = s.ftotal[f];
+    const uint32_t nvalid = nf > in_f ? (nf - in_f < (uint32_t)RS_TILE ? nf - in_f : (uint32_t)RS_TILE) : 0u;
+    const int t0 = (int)(pb[f] / RS_TILE), ti = (int)blockIdx.x - t0;       // this field's first tile, my index among its tiles
+    const uint32_t wbase = (uint32_t)w * RS_WAVE_SPAN;                       // (inside the tile)
+    uint32_t k[RS_IPT], v[RS_IPT];
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const uint32_t i = wbase + j * 64 + lane;
+        const uint32_t ci = bbase + (i < nvalid ? i : 0);
+        k[j] = kin[ci];
+        v[j] = vin[ci];
+    }
+    // keys of my digits in the field's earlier tiles (all loads independent, clamped), and the field's digit totals
+    uint32_t in_digit[SG_DPT], dtot[SG_DPT];
+#pragma unroll
+    for (int q = 0; q < SG_DPT; ++q) {
+        const int d = tid * SG_DPT + q;
+        const uint32_t *lo = s.tcounts + (size_t)t0 * SG_ND + d;
+        uint32_t pre = 0;
+        for (int i0 = 0; i0 < ti; i0 += 16) {
+            uint32_t lv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lv[i] = lo[(size_t)(i0 + i < ti ? i0 + i : 0) * SG_ND];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (i0 + i < ti) pre += lv[i];
+        }
+        in_digit[q] = pre;
+        dtot[q] = s.ftot[(size_t)f * SG_ND + d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j)
+        if (wbase + j * 64 + lane < nvalid) atomicAdd(&cur[w][(k[j] >> shift) & DMASK], 1u);
+    // exclusive scan of the field's digit totals (digit bases inside the field) and of this tile's digit counts (local bases)
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int q = 0; q < SG_DPT; ++q) tsum += dtot[q];
+    uint32_t ginc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(ginc, off); if (lane >= off) ginc += t; }
+    if (lane == 63) wtot[w] = ginc;
+    __syncthreads();
+    uint32_t gbase = ginc - tsum + (LAST ? cb[f] : pb[f]);
+    for (int ww = 0; ww < w; ++ww) gbase += wtot[ww];
+    uint32_t c0[SG_DPT], c1[SG_DPT], c2[SG_DPT], c3[SG_DPT];
+    uint32_t bsum = 0;
+#pragma unroll
+    for (int q = 0; q < SG_DPT; ++q) {
+        const int d = tid * SG_DPT + q;
+        c0[q] = cur[0][d]; c1[q] = cur[1][d]; c2[q] = cur[2][d]; c3[q] = cur[3][d];
+        bsum += c0[q] + c1[q] + c2[q] + c3[q];
+    }
+    uint32_t linc = bsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(linc, off); if (lane >= off) linc += t; }
+    __syncthreads();                       // wtot is re-used
+    if (lane == 63) wtot[w] = linc;
+    __syncthreads();
+    uint32_t lbase = linc - bsum;
+    for (int ww = 0; ww < w; ++ww) lbase += wtot[ww];
+#pragma unroll
+    for (int q = 0; q < SG_DPT; ++q) {
+        const int d = tid * SG_DPT + q;
+        cur[0][d] = lbase; cur[1][d] = lbase + c0[q]; cur[2][d] = lbase + c0[q] + c1[q]; cur[3][d] = lbase + c0[q] + c1[q] + c2[q];
+        gdelta[d] = gbase + in_digit[q] - lbase;
+        lbase += c0[q] + c1[q] + c2[q] + c3[q];
+        gbase += dtot[q];
+    }
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const bool valid = wbase + j * 64 + lane < nvalid;
+        const uint32_t d = (k[j] >> shift) & DMASK;
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < SG_DB; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            same &= bit ? m : ~m;
+        }
+        uint32_t rank = 0, cnt = 0;
+        if (valid) {
+            rank = (uint32_t)__popcll(same & below);
+            cnt = (uint32_t)__popcll(same);
+            const uint32_t pos = cur[w][d] + rank;
+            sk[pos] = k[j]; sv[pos] = v[j];
+        }
+        if (valid && rank + 1 == cnt) cur[w][d] += cnt;  // last lane of the group advances the cursor
+    }
+    __syncthreads();
+    const uint32_t rb = LAST ? (uint32_t)s.row_base[f] : 0u;
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const uint32_t lp = j * RS_TPB + tid;
+        if (lp < nvalid) {
+            const uint32_t key = sk[lp];
+            const uint32_t gp = lp + gdelta[(key >> shift) & DMASK];
+            kout[gp] = key + rb;
+            vout[gp] = sv[lp];
+        }
+    }
+}
+
 // ---- segments -------------------------------------------------------------
 // head(idx) = idx == 0 || keys[idx] != keys[idx-1], from two unconditional loads
 __device__ __forceinline__ bool head_of(uint32_t cur, uint32_t prev, int64_t idx, int64_t n) {
@@ -642,6 +881,59 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
         t = vin; vin = vout; vout = t;
     }
     *keys_res = kin; *vals_res = vin;  // where the sorted pairs ended up (keys/vals or the alt buffers)
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+
+// The segmented sort's launches (see k_bag_scan): offsets -> pre / ftotal (and the sort's totals zeroed) is enqueued by
+// seg_sort_scan; the key kernel then fills (kp, vp); seg_sort_pairs sorts them into (keys_out, vals_out) [n], compact.
+int g_mh_seg_sort = 1;      // ps_tune_set("mh_seg_sort", 0): multi-hot batches through the three-pass radix sort on 22-bit keys again (round 3)
+int seg_sort_alloc(SegSortWs &ws, int64_t nnz_cap, int64_t nbags_cap, int F) {
+    seg_sort_free(ws);
+    ws.cap = nnz_cap + (int64_t)F * RS_TILE;               // every field padded to whole tiles
+    ws.ntile = (int)(ws.cap / RS_TILE) + 1;
+    ws.F = F;
+    HIPCHK(hipMalloc(&ws.pre, sizeof(uint32_t) * (size_t)(nbags_cap + 1)));
+    HIPCHK(hipMalloc(&ws.ftotal, sizeof(uint32_t) * 64));
+    HIPCHK(hipMalloc(&ws.ftot, sizeof(uint32_t) * 2 * (size_t)F * SG_ND));
+    HIPCHK(hipMalloc(&ws.tcounts, sizeof(uint32_t) * (size_t)ws.ntile * SG_ND));
+    HIPCHK(hipMalloc(&ws.kp, sizeof(uint32_t) * (size_t)ws.cap));
+    HIPCHK(hipMalloc(&ws.vp, sizeof(uint32_t) * (size_t)ws.cap));
+    HIPCHK(hipMalloc(&ws.kq, sizeof(uint32_t) * (size_t)ws.cap));
+    HIPCHK(hipMalloc(&ws.vq, sizeof(uint32_t) * (size_t)ws.cap));
+    // (nothing to initialise: k_bag_scan writes ftotal[0 .. F) and zeroes ftot in front of every sort.  A hipMemset here is
+    //  NOT ordered with the store's non-blocking stream: it zeroed ftotal after the first step's scan had filled it -- one
+    //  run in ten of a test whose model trains once)
+    return PS_OK;
+}
+void seg_sort_free(SegSortWs &ws) {
+    uint32_t *ps[] = {ws.pre, ws.ftotal, ws.ftot, ws.tcounts, ws.kp, ws.vp, ws.kq, ws.vq};
+    for (uint32_t *p : ps) if (p) (void)hipFree(p);
+    ws = SegSortWs();
+}
+int seg_sort_tile() { return RS_TILE; }
+int64_t seg_sort_bytes(const SegSortWs &ws) { return (int64_t)sizeof(uint32_t) * (4 * ws.cap + (int64_t)ws.ntile * SG_ND + 2 * (int64_t)ws.F * SG_ND); }
+bool seg_sort_fits(const int64_t *rows_per_field, int F) {
+    if (!g_mh_seg_sort || F > 64) return false;
+    for (int f = 0; f < F; ++f) if (rows_per_field[f] > (1 << (2 * SG_DB))) return false;      // two 9-bit passes cover the field's ids
+    return true;
+}
+int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipStream_t st) {
+    if (F != ws.F) return ps_set_err(PS_E_BAD_ARG, "seg_sort_scan: %d fields, workspace made for %d", F, ws.F);
+    hipLaunchKernelGGL(k_bag_scan, dim3(F), dim3(BS_TPB), 0, st, offsets_dev, B, F, ws.pre, ws.ftotal, ws.ftot, 2 * F * SG_ND, stamp_next("bag_scan"));
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st) {
+    if (n + (int64_t)ws.F * RS_TILE > ws.cap) return ps_set_err(PS_E_BAD_ARG, "seg_sort_pairs: n=%lld > cap", (long long)n);
+    if (n <= 0) return PS_OK;
+    const int grid = (int)cdiv(n, RS_TILE) + ws.F;         // upper bound on the tiles of the padded layout
+    SegSortArgs a{ws.F, ws.ftotal, row_base_dev, ws.ftot, ws.tcounts};
+    hipLaunchKernelGGL(k_seg_hist, dim3(grid), dim3(RS_TPB), 0, st, ws.kp, 0, a, stamp_next("radix_hist"));
+    hipLaunchKernelGGL(k_seg_scatter<false>, dim3(grid), dim3(RS_TPB), 0, st, ws.kp, ws.vp, ws.kq, ws.vq, 0, a, stamp_next("radix_scatter"));
+    a.ftot = ws.ftot + (size_t)ws.F * SG_ND;
+    hipLaunchKernelGGL(k_seg_hist, dim3(grid), dim3(RS_TPB), 0, st, ws.kq, SG_DB, a, stamp_next("radix_hist"));
+    hipLaunchKernelGGL(k_seg_scatter<true>, dim3(grid), dim3(RS_TPB), 0, st, ws.kq, ws.vq, keys_out, vals_out, SG_DB, a, stamp_next("radix_scatter"));
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

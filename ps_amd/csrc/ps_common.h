@@ -99,6 +99,23 @@ struct SortWorkspace {
     int64_t cap = 0;
     int nblk = 0;
 };
+// the segmented (per-field) two-pass sort of a multi-hot batch (kernels_sort.hip k_bag_scan / k_seg_hist / k_seg_scatter)
+struct SegSortWs {
+    uint32_t *pre = nullptr;        // [bags] entries of the bag's field in earlier samples
+    uint32_t *ftotal = nullptr;     // [64] entries per field
+    uint32_t *ftot = nullptr;       // [2 passes][F][512] digit totals per field
+    uint32_t *tcounts = nullptr;    // [tiles][512] digit counts per tile
+    uint32_t *kp = nullptr, *vp = nullptr, *kq = nullptr, *vq = nullptr;      // (id, bag) pairs, every field padded to whole tiles
+    int64_t cap = 0; int ntile = 0, F = 0;
+};
+int seg_sort_alloc(SegSortWs &ws, int64_t nnz_cap, int64_t nbags_cap, int F);
+void seg_sort_free(SegSortWs &ws);
+int64_t seg_sort_bytes(const SegSortWs &ws);
+int seg_sort_tile();
+bool seg_sort_fits(const int64_t *rows_per_field, int F);
+int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipStream_t st);
+int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st);
+extern int g_mh_seg_sort;
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap);
 void sort_ws_free(SortWorkspace &ws);
 // Stable LSD radix sort of (key, val) pairs on `key_bits` low bits.

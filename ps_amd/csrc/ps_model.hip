@@ -226,7 +226,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);
     fr(m->ids_dev); fr(m->offsets_dev); fr(m->wide_ids_dev); fr(m->dense_dev); fr(m->labels_dev);
-    sort_ws_free(m->ws); sort_ws_free(m->wws);
+    sort_ws_free(m->ws); sort_ws_free(m->wws); seg_sort_free(m->seg);
     fr(m->wkeys); fr(m->wents); fr(m->wseg_start); fr(m->wseg_id); fr(m->wnseg);
     fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub); fr(m->start_flag); fr(m->pair_ctr);
     fr(m->seg_nseg_scratch); fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
@@ -399,11 +399,31 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // step no sooner: 0.388 vs 0.382 ms -- the later kernels then overlap the dW GEMMs and all of them slow down.  This
     // shape is bound by the sum of its kernels, not by a chain.)
     const bool keys_early = g_keys_early && train && !m->sh.active && m->cur_offsets && side_stream(m, 0) != st;
+    // ... and the partition by FIELD costs no radix pass (round 4, kernels_sort.hip k_bag_scan): a column scan of the bag lengths, the
+    // key kernel writes (id, bag) at the entry's place among its field's entries, two 9-bit passes sort every field on its own
+    bool seg_sort = false;
     if (keys_early) {
+        std::vector<int64_t> rows_f((size_t)c.F);
+        for (int f = 0; f < c.F; ++f) rows_f[f] = s->emb.row_base[f + 1] - s->emb.row_base[f];
+        seg_sort = seg_sort_fits(rows_f.data(), c.F);
+        if (seg_sort && !m->seg.pre) {
+            RtGuard rt_guard;
+            PSCHK(seg_sort_alloc(m->seg, m->nnz_cap, (int64_t)m->Bcap * c.F, c.F));
+            s->bytes += seg_sort_bytes(m->seg);
+        }
+        // The column scan on the MAIN chain in front of the gather, 7 us.  (Beside the gather it takes the gather's 45-57 us like
+        // everything else that shares the memory system with it, and the key kernel -- with it the whole sort chain -- starts
+        // behind it: 0.400 against 0.391 ms.  It reads the batch's offsets only and could run beside the PREVIOUS step's
+        // embedding update -- but a device batch is valid in the order of the store's stream, which side chain 0 joins only here.)
+        if (seg_sort) { Prof pf(m, "emb_bag_scan"); PSCHK(seg_sort_scan(m->seg, m->cur_offsets, B, c.F, st)); }
         PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
-        { Prof pf(m, "emb_keys"); PSCHK(launch_emb_keys(e, side_stream(m, 0))); }
+        if (seg_sort) {
+            Prof pf(m, "emb_keys");
+            PSCHK(launch_emb_keys_seg(e, m->seg.pre, m->seg.ftotal, seg_sort_tile(), m->seg.kp, m->seg.vp, side_stream(m, 0)));
+        } else { Prof pf(m, "emb_keys"); PSCHK(launch_emb_keys(e, side_stream(m, 0))); }
         e.key_out = nullptr; e.ent_bag = nullptr;
     }
+    m->seg_sorted = seg_sort;
     // single-hot field sort released from the device: the FIRST forward GEMM's start (it starts only after the gather
     // has finished) flips a flag, the sort sits behind a spinner on side chain 0 -- the gather's launch carries no
     // event (a launch with a stop event starts ~2 us later than a plain one)
@@ -466,7 +486,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
                 // needs each entry's delta row (its bag's) in entry order, which the stable sort keeps: carrying the bag
                 // through the sort saves the entry -> bag indirection (a random 4-byte load per entry) in both backward
                 // kernels.  ent_bag is consumed as ping-pong storage here.
-                if (m->cur_offsets)
+                if (m->cur_offsets && m->seg_sorted) {
+                    PSCHK(seg_sort_pairs(m->seg, nnz, s->emb.row_base_dev, m->ws.keys_alt, m->ws.vals_alt, ss));
+                    m->sorted_keys = m->ws.keys_alt; m->sorted_ents = m->ws.vals_alt;
+                } else if (m->cur_offsets)
                     PSCHK(radix_sort_pairs(m->ws, m->keys, m->ent_bag, nnz, bits_for(s->emb.total_rows), false, &m->sorted_keys,
                                            &m->sorted_ents, ss));
                 else

@@ -95,3 +95,71 @@ def test_long_run_list_many_runs(orc):
     for f in range(2):
         np.testing.assert_array_equal(rows_f[f], rows_g[f])
         np.testing.assert_array_equal(grads_f[f][1], grads_g[f][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# multi-hot batches: the segmented two-pass sort (k_bag_scan + k_emb_keys_seg + 2 x (k_seg_hist, k_seg_scatter): the partition by
+# field costs no radix pass) against the three-pass radix sort on (field, id) keys it replaces -- ps_tune_set("mh_seg_sort", 0)
+# selects the latter.  The two must produce the same sorted pairs, so the same tables bit for bit after training.
+MH_CASES = [
+    # B, vocab per field, mean bag length, id pattern
+    (7, [5, 7], 3, "rand"),                       # a handful of entries: one tile per field, most of it padding
+    (300, [50, 1, 2000], 4, "rand"),              # a field of one row (one run of all its entries), empty bags
+    (512, [262144, 9], 6, "rand"),                # 18-bit ids: both passes' digits fully used
+    (700, [100000, 100000, 33], 30, "zipf"),      # hot keys, fields of ~21 000 entries (6 tiles each)
+    (1024, [3000], 160, "zipf"),                  # ONE field of ~164 000 entries: 41 tiles (the scatter's look-back beyond 32 tiles)
+    (2048, [100000] * 6, 12, "zipf"),
+    (256, [40, 40, 40, 40], 0, "rand"),           # mean 0: most bags empty, some fields with no entry at all
+]
+
+
+def mh_batch(rng, B, vocab, mean_len, pattern):
+    F = len(vocab)
+    lens = rng.poisson(mean_len, size=B * F) if mean_len > 0 else (rng.random(B * F) < 0.02).astype(np.int64)
+    if mean_len == 0:
+        lens.reshape(B, F)[:, 1] = 0              # field 1: nothing
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    field = np.repeat(np.tile(np.arange(F), B), lens)
+    V = np.asarray(vocab)[field]
+    if pattern == "zipf":
+        ids = np.minimum(rng.zipf(1.1, field.size) - 1, V - 1).astype(np.int64)
+    else:
+        ids = (rng.random(field.size) * V).astype(np.int64)
+    return ids, offsets
+
+
+def mh_run(seg, B, vocab, batches, Xd, Y, nnz_max):
+    import ps_amd
+    from ps_amd import native as N
+    N.lib().ps_tune_set(b"mh_seg_sort", seg)
+    try:
+        F, D = len(vocab), 8
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding(vocab, D)
+        kv.set_updater("emF", ps_amd.FtrlUpdater())
+        gm = ps_amd.DNN.buildModel(F, D, Xd.shape[1], [16, 1], store=kv, max_batch=B, max_nnz=nnz_max)
+        losses = [gm.train(ps_amd.Batch(ids, Xd, Y, None, offsets)) for ids, offsets in batches]
+        rows = [kv.get_rows(f, np.arange(vocab[f])) for f in range(F)]
+        w = [kv.get("fc%d.weights" % i) for i in range(2)]
+        gm.close(); kv.close()
+        return losses, rows, w
+    finally:
+        N.lib().ps_tune_set(b"mh_seg_sort", 1)
+
+
+@pytest.mark.parametrize("B,vocab,mean_len,pattern", MH_CASES)
+def test_segmented_sort_equals_three_pass_sort(B, vocab, mean_len, pattern):
+    rng = np.random.default_rng(B * 7 + len(vocab) + mean_len)
+    batches = [mh_batch(rng, B, vocab, mean_len, pattern) for _ in range(3)]
+    nnz_max = max(max(b[0].size for b in batches), 1)
+    Xd = rng.standard_normal((B, 2)).astype(f32)
+    Y = (rng.random(B) < 0.3).astype(f32)
+    a = mh_run(1, B, vocab, batches, Xd, Y, nnz_max)
+    b = mh_run(0, B, vocab, batches, Xd, Y, nnz_max)
+    assert a[0] == b[0], (a[0], b[0])
+    for f in range(len(vocab)):
+        np.testing.assert_array_equal(a[1][f], b[1][f], err_msg="field %d rows" % f)
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    if sum(bt[0].size for bt in batches) > 0:
+        assert any(np.abs(r).max() > 0 for r in a[1])
