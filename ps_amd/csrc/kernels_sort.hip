@@ -914,7 +914,7 @@ void seg_sort_free(SegSortWs &ws) {
 int seg_sort_tile() { return RS_TILE; }
 int64_t seg_sort_bytes(const SegSortWs &ws) { return (int64_t)sizeof(uint32_t) * (4 * ws.cap + (int64_t)ws.ntile * SG_ND + 2 * (int64_t)ws.F * SG_ND); }
 bool seg_sort_fits(const int64_t *rows_per_field, int F) {
-    if (!g_mh_seg_sort || F > 64) return false;
+    if (F > 64) return false;
     for (int f = 0; f < F; ++f) if (rows_per_field[f] > (1 << (2 * SG_DB))) return false;      // two 9-bit passes cover the field's ids
     return true;
 }

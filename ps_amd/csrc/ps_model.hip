@@ -403,9 +403,12 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // key kernel writes (id, bag) at the entry's place among its field's entries, two 9-bit passes sort every field on its own
     bool seg_sort = false;
     if (keys_early) {
-        std::vector<int64_t> rows_f((size_t)c.F);
-        for (int f = 0; f < c.F; ++f) rows_f[f] = s->emb.row_base[f + 1] - s->emb.row_base[f];
-        seg_sort = seg_sort_fits(rows_f.data(), c.F);
+        if (m->seg_fits < 0) {          // (the tables' shapes do not change: decided once)
+            std::vector<int64_t> rows_f((size_t)c.F);
+            for (int f = 0; f < c.F; ++f) rows_f[f] = s->emb.row_base[f + 1] - s->emb.row_base[f];
+            m->seg_fits = seg_sort_fits(rows_f.data(), c.F) ? 1 : 0;
+        }
+        seg_sort = m->seg_fits == 1 && g_mh_seg_sort;
         if (seg_sort && !m->seg.pre) {
             RtGuard rt_guard;
             PSCHK(seg_sort_alloc(m->seg, m->nnz_cap, (int64_t)m->Bcap * c.F, c.F));

@@ -144,6 +144,7 @@ struct ps_model {
     int cur_B = 0; int64_t cur_nnz = 0; bool fwd_done = false, bwd_done = false;
     // embedding backward workspaces
     SortWorkspace ws;
+    int seg_fits = -1;                 // do the tables' shapes allow the segmented sort (kernels_sort.hip seg_sort_fits); -1: not asked yet
     SegSortWs seg; bool seg_sorted = false;      // multi-hot: the segmented two-pass sort's buffers (allocated at the first such batch) | used by this step
     uint32_t *keys = nullptr, *ents = nullptr, *ent_bag = nullptr, *seg_start = nullptr, *seg_id = nullptr,
              *nseg_dev = nullptr, *uniq_row = nullptr, *uniq_cnt = nullptr;
