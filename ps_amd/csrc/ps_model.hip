@@ -451,6 +451,17 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // the gather's first workgroup ends only once the update's end flag is up (normally it has been for a while)
         fwd_lo.wait = m->start_flag + 9; fwd_lo.wait_val = m->sh.flat_epoch;
     }
+    if (m->sh.active && m->sh.flat_start_valid) {
+        // ... and no workgroup of the gather STARTS before that step's flat-gradient launch has started: the dW GEMMs in front of it
+        // read the activations this launch overwrites (see enqueue_backward)
+        if (m->dev_ok && !m->profile) { e.start_wait = m->start_flag + 12; e.start_val = m->sh.flat_start_epoch; }
+        else if (m->flat_stream && m->flat_stream != st) {        // (no device-side joins any more: an event behind that launch)
+            hipEvent_t ev = m->events[m->next_event++ % m->events.size()];
+            HIPCHK(hipEventRecord(ev, m->flat_stream));
+            HIPCHK(hipStreamWaitEvent(st, ev, 0));
+        }
+        m->sh.flat_start_valid = false;
+    }
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st, &fwd_lo, s->werr())); }
     if (fwd_lo.wait && !m->sh.active) {          // (the fused step's deferred join)
         if (!fwd_lo.launched) PSCHK(store_settle(s));
@@ -949,6 +960,12 @@ int enqueue_backward(ps_model *m, bool apply) {
             d.wait_flag = m->start_flag + 2; d.wait_val = m->start_epoch; d.bound = wait_bound(werr, 2);
             if (dw_split_done) { d.wait_flag2 = m->start_flag + 11; d.wait_val2 = dw_split_epoch; }
             if (tail_defer) { d.started_flag = m->start_flag + 12; d.started_val = m->start_epoch; }
+            // sharded step in overlap mode: nothing on the training stream waits for this launch, and the NEXT step's gather
+            // overwrites the first layer's input while the last dW GEMM, in front of this launch on side chain 1, may still
+            // read it (at configs[2]'s size 25 us lie between the two; at toy sizes they met: one run in ten of the pipelined
+            // schedule tests, round 4).  This launch's START -- that GEMM is done then -- is what the next gather's workgroups
+            // wait for at theirs (enqueue_forward)
+            if (!tail_join) { d.started_flag = m->start_flag + 12; d.started_val = m->start_epoch; m->sh.flat_start_epoch = m->start_epoch; m->sh.flat_start_valid = true; }
             { Prof pf(m, "dense_update"); PSCHK(launch_dense_update(d, sw)); }
             m->flat_stream = sw;
             if (tail_join) PSCHK(launch_flag_set(m->start_flag + 3, m->start_epoch, sw));

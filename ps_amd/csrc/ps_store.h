@@ -235,6 +235,7 @@ struct ps_model {
         const float *alt_W = nullptr; uint32_t alt_lo = 0, alt_hi = 0;   // this rank's own rows of the running step (EmbFwdArgs.W_alt)
         uint32_t *counts_host = nullptr;                             // pinned: [owner_start 0..nranks | received counts 0..nranks-1 | epoch]
         hipEvent_t flat_ev = nullptr;                                // the replicated tensors' update was enqueued on side chain 1
+        bool flat_start_valid = false; uint32_t flat_start_epoch = 0;   // the last backward's flat-gradient launch raises start_flag[12] when it starts
         bool flat_pending = false; uint32_t flat_epoch = 0;          // ... and the main chain has not joined it yet
         uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;     // (x_recv_rows: the sorted push's contiguous copy of the received lists)
         int64_t x_recv_rows_cap = 0;

@@ -134,13 +134,17 @@ def test_plan_epoch_wraps():
     np.testing.assert_array_equal(a[2], b[2])
 
 
-@pytest.mark.parametrize("early,extra", [(1, {}), (0, {}), (1, {"shard_sort_defer": 0}), (1, {"plan_fused": 0}), (1, {"shard_sort_defer": 0, "plan_fused": 0})])
+@pytest.mark.parametrize("early,extra", [(1, {}), (0, {}), (1, {"shard_sort_defer": 0}), (1, {"plan_fused": 0}), (1, {"shard_sort_defer": 0, "plan_fused": 0}),
+                                         (1, {"tn_start_wait": 0}), (1, {"tn_start_wait": 0, "main_prio": 0})])
 def test_pipelined_sharded_steps_on_device_batches(early, extra):
     """ps_shard_step's one-model pipeline on device-resident batches (what bench.py --sharded / --gpus N runs): with the next
     step's plan on side chain 0 while the step trains (early = 1, the default) and with the plan in the step's tail (0); with the
     plan's field sort launched by the forward (default) or right behind the slots; count / emit / pack in one launch or three --
     120 steps each, equal to 120 fused steps bit for bit (the 8-bit plan epoch does not wrap here; the run count's two
-    buffers alternate 120 times)."""
+    buffers alternate 120 times).  tn_start_wait = 0 (a spinner launch in front of every dW GEMM) is here for what it does to the
+    timing: it delays side chain 1, and at these toy sizes the NEXT step's gather then overwrote the first layer's input while the
+    last dW GEMM still read it -- in overlap mode nothing on the training stream waits for that chain (6 of 10 runs on some boxes,
+    1 of 100 with the default knobs; round 4: the gather's workgroups now wait for the flat-gradient launch's start)."""
     import ps_amd
     from ps_amd import native as N
     from ps_amd.sharded import NativeWorker
