@@ -22,6 +22,7 @@ oracle (tests/ only).
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -520,8 +521,14 @@ class NativeWorker:
             # step i's backward and its push, so the host's wait for the counts overlaps GPU work
             if steps > 0:
                 self.begin(0, batches[0], side=False)
+            trace = [] if (os.environ.get("PS_BENCH_DEBUG") and steps <= 64) else None
             for i in range(steps):
+                if trace is not None:
+                    trace.append(time.perf_counter())
                 loss = self.finish_begin(0, batches[(i + 1) % nb] if i + 1 < steps else None, want_loss and i + 1 == steps)
+            if trace:
+                trace.append(time.perf_counter())
+                print("[ps_shard_step calls, us] " + " ".join("%.0f" % (1e6 * (b - a)) for a, b in zip(trace, trace[1:])), file=sys.stderr, flush=True)
             return loss
         if steps > 0:
             self.begin(0, batches[0])
@@ -725,20 +732,31 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     prim = max(args.warmup, 1) + int(getattr(args, "priming", 300))
     wd.kick("priming", 60 + 0.02 * prim)
     tp = time.perf_counter()
-    worker_run(prim)
+    # (in two pieces with a wait in between: the first ~18 calls behind a wait that follows a LONG asynchronous run take the host
+    #  180 us instead of 142 -- the HIP runtime recycling what 300 steps of launches left behind; behind a short run they do not.
+    #  tools/shard_short_run.py, PS_BENCH_DEBUG=1: 64-step regions behind 305 and behind 5 steps)
+    tail = min(32, prim // 2)
+    worker_run(prim - tail)
+    kv.sync(); torch.cuda.synchronize()
+    worker_run(tail)
     kv.sync(); torch.cuda.synchronize()
     dist.barrier()
-    dtp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
-    dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
-    unprimed_ms = 1e3 * float(dtp.item()) / prim       # what a job pays while the communicators' buffers and the host's clocks settle
+    dtp_local = time.perf_counter() - tp               # (reduced over the ranks AFTER the timed region: nothing but the barrier in front of it)
     wd.kick("timed region", 60 + 0.02 * args.steps)
     t0 = time.perf_counter()
     worker_run(args.steps)
+    t_enq = time.perf_counter()
     kv.sync(); torch.cuda.synchronize()
+    t_sync = time.perf_counter()
     dist.barrier()
+    if os.environ.get("PS_BENCH_DEBUG") and rank == 0:
+        print("[timed region] enqueue %.0f us, sync %.0f us, barrier %.0f us" % (1e6 * (t_enq - t0), 1e6 * (t_sync - t_enq), 1e6 * (time.perf_counter() - t_sync)), file=sys.stderr, flush=True)
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    dtp = torch.tensor([dtp_local], dtype=torch.float64, device=dev)
+    dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
+    unprimed_ms = 1e3 * float(dtp.item()) / prim       # what a job pays while the communicators' buffers and the host's clocks settle
     wd.kick("after the timed region", 300)
     loss = worker.step(batches[0], want_loss=True)
     stats = None
