@@ -247,7 +247,7 @@ def run_single(args):
     gm.sync()
     rep = gm.profile_report()
     gm.set_profile(False)
-    # ---- the same step once the GPU has reached its sustained clocks (reported BESIDE the headline, never as `value`): a short
+    # ---- the same step once the GPU's clocks have ramped up (reported BESIDE the headline, never as `value`): a short
     # region runs on a ramping clock -- tools/ramp_probe.py: 143 us per step in steps 0-19 after an idle queue, 139 in 40-59, 133
     # from step ~120 on, the first forward GEMM 20.4 -> 18.5 us -- so K = 20 prices the ramp, K >= 1000 the step
     steady = None
@@ -273,7 +273,7 @@ def run_single(args):
         steady = {"after_untimed_steps": 300 + 2 * args.steps + args.warmup + 20, "steps": 300, "ms_per_step": 1e3 * dts,
                   "roofline_avg_launch_us": avg_s_s * 1e6, "roofline_frac": work_s / avg_s_s / peak_s,
                   "note": "the headline's %d steps run while the GPU's clocks still ramp (tools/ramp_probe.py: ~120 steps from an idle queue); "
-                          "this is the same step at sustained clocks, not part of `value`" % args.steps}
+                          "this is the same step behind the ramp (still inside the boost window: the first 0.6 s of load), not part of `value`" % args.steps}
     loss = gm.train(batches[0])
     if not loss > 0.01:
         raise RuntimeError("loss %.4g is under the reference's stop threshold (no backward below 0.01): the timed steps are not "
@@ -337,7 +337,7 @@ def run_single(args):
         "host": host_info(),
     }
     if steady:
-        out["sustained_clocks"] = steady
+        out["after_clock_ramp"] = steady
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg)
         nthr = min(os.cpu_count() or 1, 64)
