@@ -390,3 +390,40 @@ def test_sharded_steps_with_the_one_launch_plan(knobs):
         assert st10[8] == 60 and st10[7] < st10[9], st10        # every step took the full-size exchange
     else:
         assert st10[8] == 0, st10
+
+
+@pytest.mark.parametrize("kind,F,D,X,fc,V,B", [("widedeep", 5, 16, 3, [32, 16, 1], 500, 512), ("widedeep", 8, 16, 4, [128, 64, 1], 20000, 4096),
+                                               ("dnn", 4, 8, 2, [48, 1], 300, 256)])
+def test_steps_enqueued_back_to_back_equal_steps_with_a_wait_in_between(kind, F, D, X, fc, V, B):
+    """Consecutive fused steps overlap at their edges (the next gather beside the dense update's tail, the side chains of one step
+    beside the main chain of the next): 80 steps enqueued without a wait (train_async on device-resident batches) must leave
+    the tables of 80 steps with a wait behind each -- at toy sizes, where a step is a few kernels of a few microseconds and
+    whatever is not ordered explicitly does meet."""
+    import ps_amd
+    rng = np.random.default_rng(B + F)
+    WS = 61
+    data = batches(rng, 7, B, F, X, V, WS)
+    res = []
+    for waits in (True, False, False):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        if kind == "widedeep":
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+        else:
+            gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+        bs = [ps_amd.DeviceBatch(kv, E, Xd, Y, W if kind == "widedeep" else None) for E, Xd, Y, W in data]
+        for i in range(80):
+            gm.train_async(bs[i % len(bs)])
+            if waits:
+                gm.sync()
+        kv.sync()
+        out = [kv.get_rows(f, np.arange(V)) for f in range(F)] + [kv.get("fc%d.weights" % i) for i in range(len(fc))] + [kv.get("fc%d.bias" % i) for i in range(len(fc))]
+        if kind == "widedeep":
+            out += [kv.get_wide(np.arange(WS)), kv.get("wide.bias")]
+        res.append(out)
+        for b in bs:
+            b.close()
+        gm.close(); kv.close()
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            np.testing.assert_array_equal(x, y)
