@@ -427,3 +427,43 @@ def test_steps_enqueued_back_to_back_equal_steps_with_a_wait_in_between(kind, F,
     for other in res[1:]:
         for x, y in zip(res[0], other):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("seg", [1, 0])
+def test_multi_hot_steps_enqueued_back_to_back(seg):
+    """The same for multi-hot batches (key kernel and sort chain beside the gather, the segmented sort's scan in front of it;
+    FTRL rows): 40 steps without a wait == 40 steps with a wait behind each."""
+    import ps_amd
+    from ps_amd import native as N
+    F, D, X, fc, V, B = 4, 16, 2, [32, 1], 3000, 600
+    rng = np.random.default_rng(77)
+    data = []
+    for _ in range(5):
+        lens = rng.poisson(9, size=B * F)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = np.minimum(rng.zipf(1.2, int(offsets[-1])) - 1, V - 1).astype(np.int64)
+        data.append((ids, offsets, rng.standard_normal((B, X)).astype(f32), (rng.random(B) < 0.3).astype(f32)))
+    nnz_max = max(int(d[1][-1]) for d in data)
+    N.lib().ps_tune_set(b"mh_seg_sort", seg)
+    res = []
+    try:
+        for waits in (True, False, False):
+            kv = ps_amd.KVStore(0, SEED)
+            kv.create_embedding([V] * F, D)
+            kv.set_updater("emF", ps_amd.FtrlUpdater())
+            gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, max_nnz=nnz_max)
+            bs = [ps_amd.DeviceBatch(kv, ids, Xd, Y, None, offsets) for ids, offsets, Xd, Y in data]
+            for i in range(40):
+                gm.train_async(bs[i % len(bs)])
+                if waits:
+                    gm.sync()
+            kv.sync()
+            res.append([kv.get_rows(f, np.arange(V)) for f in range(F)] + [kv.get("fc%d.weights" % i) for i in range(2)])
+            for b in bs:
+                b.close()
+            gm.close(); kv.close()
+    finally:
+        N.lib().ps_tune_set(b"mh_seg_sort", 1)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            np.testing.assert_array_equal(x, y)
