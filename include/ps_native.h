@@ -114,9 +114,16 @@ int ps_store_create_fc(ps_store_t *s, int layer, int in_dims, int out_dims);
 /* "default" / "wide.weights" / "wide.bias" / "emF" / "emF3." ... -> updater
  * (the Map<String,Updater> of model/DNN.java:33, looked up exact-key, then
  * prefix, then "default": store/KVStore.java:242-252).  Embedding rows
- * resolve per FIELD (the lookup of "emF<f>."): up to 4 distinct updaters
- * over the fields of a table group; a key that names one row ("emF1.3")
- * makes every update of embedding rows fail with PS_E_UNSUPPORTED. */
+ * resolve per FIELD (the lookup of "emF<f>.") and, in front of that, per ROW:
+ * a key that IS one row's key ("emF3.17.0", Float.toString of the id -- the
+ * exact match KVStore.update(Map) tries first, store/KVStore.java:242) wins
+ * over its field's updater.  Hard limits of this ABI (the reference's
+ * HashMap has none; kernels_emb.h PS_EMB_UPD_GROUPS / PS_EMB_ROW_OVERRIDES):
+ * 8 distinct updaters over the fields of a table group, 16 exact-key rows,
+ * per-field resolution for at most 64 fields.  Beyond them, or for a key
+ * that ends INSIDE an id ("emF1.3": by String.startsWith a prefix of
+ * emF1.3.0, emF1.30.0, emF1.31.0 ...), every update of embedding rows
+ * fails with PS_E_UNSUPPORTED. */
 int ps_store_set_updater(ps_store_t *s, const char *key_or_prefix, const ps_updater_t *u);
 
 /* KVStore.get(key) / put(key,val) by reference-style string key:

@@ -1326,6 +1326,12 @@ int g_seq_ablate = 0;    // measurement only (results wrong): 1 = the fold wave 
 // flight per wave), then reads them back, applies relu and stores.  Kept as a measured alternative (ps_tune_set
 // "gather_lds"): on the 256 GB table it is NOT faster than plain 16-byte vector loads -- the gather is bound by the
 // DRAM/TLB behaviour of random 256-byte reads, not by registers or issue slots (numbers in DESIGN.md).
+// A rejected measurement variant: compiled into the LAB build only (tools/gemm_lab_build.sh, -DPS_GEMM_LAB=1), like the
+// rejected GEMM variants; the product library has no such kernel and ps_tune_set("gather_lds", 1) is refused there.
+#ifndef PS_GEMM_LAB
+#define PS_GEMM_LAB 0
+#endif
+#if PS_GEMM_LAB
 namespace {
 __global__ __launch_bounds__(256) void k_emb_fwd_lds(EmbFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float stage[4][GATHER_ILP][64 * 4];      // [wave][slot][lane * 4 floats]
@@ -1364,7 +1370,8 @@ __global__ __launch_bounds__(256) void k_emb_fwd_lds(EmbFwdArgs a) {
     }
 }
 }  // namespace
-int g_gather_lds = 0;      // measurement: 1 = the LDS-staged single-hot gather above
+#endif      // PS_GEMM_LAB
+int g_gather_lds = 0;      // measurement (lab build): 1 = the LDS-staged single-hot gather above
 
 int g_gather_nt = -1;      // -1: automatic (streaming hints when the tables exceed the caches); 0..3: forced (bit 0 loads, bit 1 stores)
 
@@ -1485,9 +1492,12 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
         else { if (slot) PS_LAUNCH_EV((k_emb_fwd<V, false, true, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a);   \
                else PS_LAUNCH_EV((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a); }      \
     } while (0)
+#if PS_GEMM_LAB
     if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0 && !stop_ev && !a.end_wait)
         hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);       // (measurement variant: carries no event / end wait)
-    else if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
+    else
+#endif
+    if (vec == 4) EMB_FWD_LAUNCH(4); else EMB_FWD_LAUNCH(1);
 #undef EMB_FWD_LAUNCH
 #undef EMB_FWD_MH
     HIPCHK(hipGetLastError());

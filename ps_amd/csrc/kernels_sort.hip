@@ -893,14 +893,16 @@ int seg_sort_alloc(SegSortWs &ws, int64_t nnz_cap, int64_t nbags_cap, int F) {
     ws.cap = nnz_cap + (int64_t)F * RS_TILE;               // every field padded to whole tiles
     ws.ntile = (int)(ws.cap / RS_TILE) + 1;
     ws.F = F;
-    HIPCHK(hipMalloc(&ws.pre, sizeof(uint32_t) * (size_t)(nbags_cap + 1)));
-    HIPCHK(hipMalloc(&ws.ftotal, sizeof(uint32_t) * 64));
-    HIPCHK(hipMalloc(&ws.ftot, sizeof(uint32_t) * 2 * (size_t)F * SG_ND));
-    HIPCHK(hipMalloc(&ws.tcounts, sizeof(uint32_t) * (size_t)ws.ntile * SG_ND));
-    HIPCHK(hipMalloc(&ws.kp, sizeof(uint32_t) * (size_t)ws.cap));
-    HIPCHK(hipMalloc(&ws.vp, sizeof(uint32_t) * (size_t)ws.cap));
-    HIPCHK(hipMalloc(&ws.kq, sizeof(uint32_t) * (size_t)ws.cap));
-    HIPCHK(hipMalloc(&ws.vq, sizeof(uint32_t) * (size_t)ws.cap));
+    // (all or nothing: a partial workspace would make the caller skip the allocation next time and sort through null buffers)
+    struct { uint32_t **p; size_t n; } want[] = {
+        {&ws.pre, (size_t)(nbags_cap + 1)}, {&ws.ftotal, 64}, {&ws.ftot, 2 * (size_t)F * SG_ND}, {&ws.tcounts, (size_t)ws.ntile * SG_ND},
+        {&ws.kp, (size_t)ws.cap}, {&ws.vp, (size_t)ws.cap}, {&ws.kq, (size_t)ws.cap}, {&ws.vq, (size_t)ws.cap}};
+    for (auto &w : want)
+        if (hipMalloc((void **)w.p, sizeof(uint32_t) * w.n) != hipSuccess) {
+            (void)hipGetLastError();
+            seg_sort_free(ws);
+            return ps_set_err(PS_E_HIP, "segmented sort workspace: hipMalloc of %zu bytes failed", sizeof(uint32_t) * w.n);
+        }
     // (nothing to initialise: k_bag_scan writes ftotal[0 .. F) and zeroes ftot in front of every sort.  A hipMemset here is
     //  NOT ordered with the store's non-blocking stream: it zeroed ftotal after the first step's scan had filled it -- one
     //  run in ten of a test whose model trains once)

@@ -545,7 +545,10 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         PSCHK(size_once(s, &sh.x_cache, &sh.x_cache_cap, m->nnz_cap * D, sizeof(float)));
         sh.x_recv_cap = rmax;
         PSCHK(shard_push_reserve(s, nsh));
-        if (!shard_push_grouped_ok(s, nsh)) PSCHK(size_once(s, &sh.x_recv_rows, &sh.x_recv_rows_cap, rmax + 1, sizeof(uint32_t)));   // (the sorted push's list)
+        // grouped or sorted owner-side push: decided once per model (push_grouped_max_mb is a mutable knob; a finish that
+        // re-evaluated it could find the sorted push's list unallocated -- ADVICE r4)
+        if (sh.push_grouped < 0) sh.push_grouped = shard_push_grouped_ok(s, nsh) ? 1 : 0;
+        if (!sh.push_grouped) PSCHK(size_once(s, &sh.x_recv_rows, &sh.x_recv_rows_cap, rmax + 1, sizeof(uint32_t)));   // (the sorted push's list)
     }
     // (overlap mode without an early plan -- the first step, a store that fell back to events: the plan's kernels go to side
     //  chain 1 too and are ordered behind the running step's backward, whose lists they overwrite: order_after_main)
@@ -715,6 +718,10 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
         if (frc != PS_OK) { (void)shard_flush_deferred_flag(m); return frc; }
     }
+    // (start_flag[5], "side chain 0's small kernels are done", may be deferred to the next plan's opening spinner: every
+    //  return between here and that plan's enqueue raises it first -- the running step's last delta GEMM holds its slot
+    //  until the flag is up)
+    struct DeferredFlagGuard { ps_model *m; ~DeferredFlagGuard() { (void)shard_flush_deferred_flag(m); } } deferred_flag_guard{m};
     const bool ov2 = sh.ov_mode == 1 && !was_side && !m->profile;      // where the replicated tensors' update goes
     // The flat gradient [fc | wide G | wide C | bias] is consumed on side chain 1 in overlap mode.  Normally it was produced
     // there too (the backward's tail behind the dW GEMMs).  When this step's backward could not use device-side joins -- a
@@ -736,7 +743,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     crc = timed_coll(m, 2, st, [&]() { return comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st); });
     comm_select(comm, 0, false);
     PSCHK(crc);
-    if (shard_push_grouped_ok(s, nsh)) {
+    if (sh.push_grouped == 1) {
         LaunchOpts lo;
         if (sh.tail_flag_due) { lo.flag = m->start_flag + 6; lo.flag_val = sh.pub_epoch; }
         PSCHK(shard_apply_push_lists(s, rows_p, grads_p, rc.data(), nsh, is_async, true, &lo));

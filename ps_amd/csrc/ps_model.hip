@@ -411,8 +411,9 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         seg_sort = m->seg_fits == 1 && g_mh_seg_sort;
         if (seg_sort && !m->seg.pre) {
             RtGuard rt_guard;
-            PSCHK(seg_sort_alloc(m->seg, m->nnz_cap, (int64_t)m->Bcap * c.F, c.F));
-            s->bytes += seg_sort_bytes(m->seg);
+            // (no memory for the workspace: this model sorts its multi-hot batches with the three-pass radix sort from now on)
+            if (seg_sort_alloc(m->seg, m->nnz_cap, (int64_t)m->Bcap * c.F, c.F) != PS_OK) { m->seg_fits = 0; seg_sort = false; }
+            else s->bytes += seg_sort_bytes(m->seg);
         }
         // The column scan on the MAIN chain in front of the gather, 7 us.  (Beside the gather it takes the gather's 45-57 us like
         // everything else that shares the memory system with it, and the key kernel -- with it the whole sort chain -- starts

@@ -288,7 +288,14 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "seq_long_grid") == 0) { g_seq_long_grid = value; return PS_OK; }
     if (strcmp(knob, "emb_short_grid") == 0) { g_emb_short_grid = value > 0 ? value : 4096; return PS_OK; }
     if (strcmp(knob, "gather_nt") == 0) { g_gather_nt = value; return PS_OK; }
-    if (strcmp(knob, "gather_lds") == 0) { g_gather_lds = value; return PS_OK; }
+    if (strcmp(knob, "gather_lds") == 0) {
+#if defined(PS_GEMM_LAB) && PS_GEMM_LAB
+        g_gather_lds = value; return PS_OK;
+#else
+        if (value) return ps_set_err(PS_E_UNSUPPORTED, "the LDS-staged gather is a rejected variant: it lives in the lab build (tools/gemm_lab_build.sh)");
+        return PS_OK;
+#endif
+    }
     if (strcmp(knob, "plan_sort") == 0) { g_plan_sort = value; return PS_OK; }
     if (strcmp(knob, "plan_fused") == 0) { g_plan_fused = value; return PS_OK; }
     if (strcmp(knob, "mh_seg_sort") == 0) { g_mh_seg_sort = value; return PS_OK; }

@@ -569,7 +569,10 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
     if (bm) {
         const int nblk = cdiv(sh.bm_words, PLAN_WPB);
         // count + emit (+ the id blocks of ps_shard_step) in one launch when the key space allows the look-back
-        const bool fused = g_plan_fused && nblk <= PLAN_FUSED_MAX_BLOCKS && sh.sbits - 5 >= 8 && sh.plan_pub;
+        // (its last workgroup keeps the owner boundaries in os_s[PS_PUSH_MAX_PEERS + 1] and writes them with tid <= nshards:
+        //  more owners than that -- ps_shard_plan_launch takes any shard count, stores shard up to 255 ways -- go through
+        //  k_plan_count + k_plan_emit, which handle any count)
+        const bool fused = g_plan_fused && nblk <= PLAN_FUSED_MAX_BLOCKS && sh.sbits - 5 >= 8 && sh.plan_pub && nshards <= PS_PUSH_MAX_PEERS;
         PlanFusedArgs fa;
         memset(&fa, 0, sizeof fa);
         if (fused) {
@@ -759,7 +762,9 @@ int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const flo
                            int is_async, bool bump_step, LaunchOpts *lo) {
     if (lo) lo->launched = false;
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
-    if (!shard_push_grouped_ok(s, npeers)) return ps_set_err(PS_E_UNSUPPORTED, "the sort-free push needs 1..%d workers and a position table under 4 GB", PS_PUSH_MAX_PEERS);
+    // (tables reserved earlier -- a model that decided for this push at its first begin -- stay good whatever the knob says now)
+    const bool reserved = npeers >= 1 && npeers <= PS_PUSH_MAX_PEERS && (npeers == 1 || (s->push_mask && s->push_pos_peers >= npeers));
+    if (!reserved && !shard_push_grouped_ok(s, npeers)) return ps_set_err(PS_E_UNSUPPORTED, "the sort-free push needs 1..%d workers and a position table under 4 GB", PS_PUSH_MAX_PEERS);
     PushApplyArgs a;
     memset(&a, 0, sizeof a);
     PSCHK(store_fill_field_upd(s, &a.upd, &a.fu));
@@ -771,7 +776,7 @@ int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const flo
     }
     a.peer_start[npeers] = (uint32_t)n;
     if (n > 0) {
-        if (npeers > 1) PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
+        if (npeers > 1 && !reserved) PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
         a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = s->emb.total_rows;
         a.mask = s->push_mask; a.pos = s->push_pos;
         a.W = s->emb.W; a.state = s->emb.state; a.err = s->err_dev;

@@ -239,6 +239,7 @@ struct ps_model {
         bool flat_pending = false; uint32_t flat_epoch = 0;          // ... and the main chain has not joined it yet
         uint32_t *x_recv_rows = nullptr; int64_t x_recv_cap = 0;     // (x_recv_rows: the sorted push's contiguous copy of the received lists)
         int64_t x_recv_rows_cap = 0;
+        int push_grouped = -1;        // the sort-free owner-side push serves this model (decided ONCE, at its first begin: the knob behind it may move later)
         float *x_rows_out = nullptr; int64_t x_rows_cap = 0;
         float *x_recv_grads = nullptr; int64_t x_grads_cap = 0;
         float *x_cache = nullptr; int64_t x_cache_cap = 0;

@@ -671,8 +671,10 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
                 raise RuntimeError("PS_AMD_FORCE_TORCH_WIRE is set")
             if force:            # one rank, and the wire anyway: every collective of the step through RCCL (ps_native.h)
                 L.ps_tune_set(b"rccl_force", force)
-            worker = NativeWorker(gms, world, rank, id256=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
-            L.ps_tune_set(b"rccl_force", 0)
+            try:
+                worker = NativeWorker(gms, world, rank, id256=bytes(idt.cpu().numpy().tobytes()), is_async=bool(getattr(args, "is_async", 0)))
+            finally:             # (a process-global knob: a constructor that raised must not leave later 1-rank tables on the wire)
+                L.ps_tune_set(b"rccl_force", 0)
         except Exception as e:      # noqa: BLE001 -- decided collectively below
             worker = None
             ok.zero_()

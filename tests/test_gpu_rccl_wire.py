@@ -12,7 +12,10 @@ the 128-byte ids, three communicators driven from three streams -- and it had ne
   force = 2  the wire runs and a rank's own keys are read in place, as at N > 1 (PS_COMM_OWN_IN_PLACE)
 
 Both must leave the tables of the fused single-GPU step, bit for bit, after 200 pipelined steps; ps_comm_selfcheck runs
-its patterns through all three communicators first.  Each case runs in a child process (its own HIP + RCCL runtime)."""
+its patterns through all three communicators first.  Each case runs in a child process (its own HIP + RCCL runtime).
+
+Round 5: one force = 2 case on MULTI-HOT batches (bags of 0..5 ids, Ftrl on the embedding rows, async push: configs[4]'s
+shape of step -- the plan takes the radix sort, the backward the chunked per-key sums, the push one Ftrl step per push)."""
 import multiprocessing as mp
 import os
 import sys
@@ -28,7 +31,7 @@ SEED = 0x5EED
 STEPS = 200
 
 
-def child(force, is_async, q):
+def child(force, is_async, q, bags=False):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
         import ctypes as C
@@ -40,12 +43,21 @@ def child(force, is_async, q):
         F, D, X, fc, V, B, WS = 5, 16, 3, [32, 16, 1], 500, 512, 61
         rng = np.random.default_rng(21)
         data = batches(rng, 9, B, F, X, V, WS)
+        if bags:            # (ids, offsets) in place of one id per (sample, field); empty bags included
+            bagged = []
+            for E, Xd, Y, W in data:
+                lens = rng.integers(0, 6, size=B * F)
+                offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                bagged.append((rng.integers(0, V, size=int(offsets[-1])).astype(np.int64), Xd, Y, W, offsets))
+            data = bagged
         res, info = [], {}
         for native in (False, True):
             kv = ps_amd.KVStore(0, SEED)
             kv.create_embedding([V] * F, D)
-            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
-            bs = [ps_amd.DeviceBatch(kv, E, Xd, Y, W) for E, Xd, Y, W in data]
+            if bags:
+                kv.set_updater("emF", ps_amd.FtrlUpdater())
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B, max_nnz=B * F * 5 if bags else 0)
+            bs = [ps_amd.DeviceBatch(kv, *d) for d in data]
             if native:
                 assert "librccl" not in open("/proc/self/maps").read(), "RCCL was mapped before anybody asked for a wire"
                 N.check(L.ps_tune_set(b"rccl_force", force))
@@ -81,11 +93,11 @@ def child(force, is_async, q):
         q.put(("fail", traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("force,is_async", [(1, False), (2, False), (2, True)])
-def test_the_rccl_wire_runs_on_one_gpu(force, is_async):
+@pytest.mark.parametrize("force,is_async,bags", [(1, False, False), (2, False, False), (2, True, False), (2, True, True)])
+def test_the_rccl_wire_runs_on_one_gpu(force, is_async, bags):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=child, args=(force, is_async, q), daemon=True)
+    p = ctx.Process(target=child, args=(force, is_async, q, bags), daemon=True)
     p.start()
     try:
         status, res, info = q.get(timeout=170)       # (the first load of librccl's 570 MB on a cold box takes a while)

@@ -15,7 +15,13 @@ Checked:
   * after step 1, every FC tensor of rank 0 against Adam on the rank-order sum of the eight workers' dense gradients / 8;
   * after 4 pipelined steps: no error, no device-side wait timed out, joins by device flags on every rank, no list
     outgrew its wire block, the replicated tensors (FC, wide) bit-identical on the 8 ranks;
-  * the exchange's sizes: id blocks <= 0.8 MB per rank and step (round 3: 2.98 MB)."""
+  * the exchange's sizes: id blocks <= 0.8 MB per rank and step (round 3: 2.98 MB).
+
+Round 5: configs[4] the same way -- "multi-hot variable-length bags (avg 30 ids/field), fused FTRL
+sparse update, 8 GPUs async push (-DisAsync)": 8 rank processes, Poisson(30) bags (~3.2 M ids per rank and step), FTRL on
+the embedding rows, is_async = 1 (net/PServer.java:176-184: kvStore.sum + update(updater, key) PER PUSH, no averaging,
+arrival = rank order), own keys in place + poisoned self blocks.  After step 1 every row (w, z, n) of ranks 0 and 5 in
+three fields is bit-equal to the oracle's ftrl_update applied per push in rank order to the workers' per-key gradients."""
 import multiprocessing as mp
 import os
 import socket
@@ -33,7 +39,22 @@ CHECK_FIELDS = (0, 7, 25)
 CHECK_RANKS = (0, 5)
 
 
-def rank_process(rank, world, port, steps, q, snapshot=True):
+C4_MAX_NNZ = 4096 * 26 * 31          # Poisson(30) bags: 3.195 M ids expected per batch, sd ~1 800 (every rank sizes its blocks from this)
+
+
+def c4_batch(cfg, rng):
+    """bench.py multi_hot_step's batch: bag lengths Poisson(30) clipped to [1, 100] per (sample, field), ids
+    Zipf(1.05) over V, wide ids uniform"""
+    from ps_amd import synth
+    B, F, V = cfg["B"], cfg["F"], cfg["V"]
+    lens = np.clip(rng.poisson(30, size=B * F), 1, 100)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ids = synth.draw_ids(rng, 1.05, V, int(offsets[-1]), "zipf_truncated")
+    W = rng.integers(0, cfg["wide"], size=(B, F)).astype(np.int64)
+    return ids, rng.standard_normal((B, cfg["X"])).astype(f32), (rng.random(B) < 0.25).astype(f32), W, offsets
+
+
+def rank_process(rank, world, port, steps, q, snapshot=True, case="c2"):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
         import ctypes as C, hashlib, time
@@ -45,9 +66,14 @@ def rank_process(rank, world, port, steps, q, snapshot=True):
         t0 = time.time()
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
         cfg = dict(C2)
+        c4 = case == "c4"
         kv = ps_amd.KVStore(0, cfg["seed"])
         kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"], shard=rank, nshards=world)
-        gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
+        if c4:
+            kv.set_updater("emF", ps_amd.FtrlUpdater())
+            gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"], max_nnz=C4_MAX_NNZ)
+        else:
+            gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
         L = N.lib()
 
         class GlooOps:
@@ -93,10 +119,10 @@ def rank_process(rank, world, port, steps, q, snapshot=True):
                 return self._g(f, stream)
 
         comm = GlooOps()
-        wk = NativeWorker([gm], world, rank, ops=comm.ops)
+        wk = NativeWorker([gm], world, rank, ops=comm.ops, is_async=c4)
         comm.checking = True; wk.selfcheck(); comm.checking = False
         rng = np.random.default_rng(cfg["seed"] + 1000 * rank)
-        bs = [ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)) for _ in range(4)]
+        bs = [ps_amd.DeviceBatch(kv, *(c4_batch(cfg, rng) if c4 else synth_batch(cfg, rng))) for _ in range(3 if c4 else 4)]
         snap = None
         wk.run(bs, 1)                       # step 1 on its own: its result is checked key by key
         kv.sync()
@@ -104,6 +130,8 @@ def rank_process(rank, world, port, steps, q, snapshot=True):
         if snapshot and rank in CHECK_RANKS:
             ids = np.arange(rank, cfg["V"], world)
             snap = {"rows": {f: kv.get_rows(f, ids) for f in CHECK_FIELDS}}
+            if c4:
+                snap["z"] = {f: kv.get_rows(f, ids, 1) for f in CHECK_FIELDS}; snap["n"] = {f: kv.get_rows(f, ids, 2) for f in CHECK_FIELDS}
             if rank == 0:
                 snap["fcW"] = [kv.get("fc%d.weights" % l) for l in range(3)]; snap["fcb"] = [kv.get("fc%d.bias" % l) for l in range(3)]
         wk.run(bs[1:] + bs[:1], steps - 1)  # ... and the pipeline: begin of step t + 1 inside finish of step t
@@ -125,11 +153,11 @@ def rank_process(rank, world, port, steps, q, snapshot=True):
         q.put((rank, "fail", traceback.format_exc()))
 
 
-def run_ranks(world, steps, snapshot=True, timeout=600):
+def run_ranks(world, steps, snapshot=True, timeout=600, case="c2"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=rank_process, args=(r, world, port, steps, q, snapshot), daemon=True) for r in range(world)]
+    ps = [ctx.Process(target=rank_process, args=(r, world, port, steps, q, snapshot, case), daemon=True) for r in range(world)]
     for p in ps: p.start()
     try:
         res = [q.get(timeout=timeout) for _ in ps]
@@ -233,5 +261,111 @@ def test_config2_full_size_eight_ranks_on_one_gpu(orc):
                              st[2] // n, st[3] // n, st[4] // n, st[8], i["seconds"]))
             fo.write("8 ranks x %d steps at configs[2] size: replicated tensors bit-identical; %d pushed rows of ranks %s and rank 0's FC tensors equal the "
                      "PS semantics after step 1 bit for bit\n" % (steps + 1, pushed, list(CHECK_RANKS)))
+    except OSError:
+        pass
+
+
+def ps_async_semantics_after_one_step(orc, world):
+    """net/PServer.java:176-184 (-DisPsAsync=1) on the eight workers' first configs[4] batches, from the initial parameters:
+    every push is kvStore.sum + update(updater, key) on arrival -- no averaging -- and arrival order is rank order; the
+    updater of the embedding rows is Ftrl (update/FtrlUpdater.java:51-76, w lags z and n by one update, a gradient whose
+    first component is 0 is skipped).  The workers' per-key gradients come from the single-GPU split step on an unsharded
+    store (verified against the oracle in test_gpu_configs.py::test_config4_*).  Returns per checked field the pushed ids
+    with their expected (w, z, n), the initial rows, and the expected FC tensors (dense: rank-order sum / workers, Adam)."""
+    import ps_amd
+    from bench import C2
+    cfg = dict(C2)
+    F, D, V = cfg["F"], cfg["D"], cfg["V"]
+    kv = ps_amd.KVStore(0, cfg["seed"])
+    kv.create_embedding([V] * F, D)
+    kv.set_updater("emF", ps_amd.FtrlUpdater())
+    gm = ps_amd.WideDeepNN.buildModel(F, D, cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"], max_nnz=C4_MAX_NNZ)
+    W0 = {f: kv.get_rows(f, np.arange(V)) for f in CHECK_FIELDS}
+    fc0 = [(kv.get("fc%d.weights" % l), kv.get("fc%d.bias" % l)) for l in range(3)]
+    pushes = {f: [] for f in CHECK_FIELDS}
+    dW = [None] * 3; db = [None] * 3
+    nnz = []
+    for w in range(world):
+        rng = np.random.default_rng(cfg["seed"] + 1000 * w)
+        ids, X, Y, Wd, offsets = c4_batch(cfg, rng)
+        nnz.append(ids.size)
+        gm.forward({"E": ids, "X": X, "Y": Y, "W": Wd, "offsets": offsets})
+        gm.backward()
+        for f in CHECK_FIELDS:
+            pushes[f].append(gm.emb_grads(f))
+        for l in range(3):
+            gw, gb = gm.fc_grad(l), gm.fc_grad(l, bias=True)
+            dW[l] = gw if dW[l] is None else (dW[l] + gw).astype(f32)
+            db[l] = gb if db[l] is None else (db[l] + gb).astype(f32)
+    rows = {}
+    for f in CHECK_FIELDS:
+        ids = np.unique(np.concatenate([p[0] for p in pushes[f]]))
+        w = W0[f][ids].copy(); z = np.zeros_like(w); n = np.zeros_like(w)
+        npush = np.zeros(len(ids), np.int64)
+        for pid, g in pushes[f]:                                   # arrival = worker order; one Ftrl step per push
+            ix = np.searchsorted(ids, pid)
+            # the oracle's ftrl_update takes ONE key's vectors (its "dw[0] == 0 -> skip" is per key): all keys of this push
+            # in one call as one long vector, then the skipped keys put back
+            w1, z1, n1, _ = orc.ftrl_update(w[ix].reshape(-1), g.reshape(-1), z[ix].reshape(-1), n[ix].reshape(-1))
+            w1 = w1.reshape(-1, D); z1 = z1.reshape(-1, D); n1 = n1.reshape(-1, D)
+            skip = g[:, 0] == 0
+            w1[skip] = w[ix][skip]; z1[skip] = z[ix][skip]; n1[skip] = n[ix][skip]
+            w[ix] = w1; z[ix] = z1; n[ix] = n1
+            npush[ix] += 1
+        rows[f] = (ids, w, z, n, npush)
+    fc1 = []
+    for l in range(3):
+        gw = (dW[l] / f32(world)).astype(f32); gb = (db[l] / f32(world)).astype(f32)
+        fc1.append((orc.adam_update(fc0[l][0], gw, np.zeros_like(gw), np.zeros_like(gw))[0],
+                    orc.adam_update(fc0[l][1], gb, np.zeros_like(gb), np.zeros_like(gb))[0]))
+    gm.close(); kv.close()
+    return rows, W0, fc1, nnz
+
+
+def test_config4_full_size_eight_ranks_async_ftrl_on_one_gpu(orc):
+    world, steps = 8, 3
+    res = run_ranks(world, steps, timeout=380, case="c4")
+    bad = [r for r in res if r[1] != "ok"]
+    assert not bad, "\n".join("rank %d:\n%s" % (r[0], r[2]) for r in bad)
+    info = [r[2] for r in res]
+    for r, i in enumerate(info):
+        assert i["timeouts"] == 0 and i["join_mode"] == 1 and i["why"] == "", (r, i["why"], i["timeouts"])
+        st = i["stats"]
+        assert st[0] == steps + 1 and st[8] == 0, st                       # steps counted; no list outgrew its wire block
+        assert 500000 < st[5] / st[0] < 720000 and 500000 < st[6] / st[0] < 720000, st      # ~617 k unique rows requested / served
+        assert np.isfinite(i["loss"]) and 0.2 < i["loss"] < 20, i["loss"]
+    assert all(i["digest"] == info[0]["digest"] for i in info), "replicated tensors differ across ranks"
+    rows, W0, fc1, nnz = ps_async_semantics_after_one_step(orc, world)
+    assert all(3.0e6 < x <= C4_MAX_NNZ for x in nnz), nnz
+    pushed = many = 0
+    for r in CHECK_RANKS:
+        snap = info[r]["snap"]
+        own = np.arange(r, 100000, world)
+        for f in CHECK_FIELDS:
+            ids, w1, z1, n1, npush = rows[f]
+            mine = ids % world == r
+            at = (ids[mine] - r) // world
+            want_w = W0[f][own].copy(); want_z = np.zeros_like(want_w); want_n = np.zeros_like(want_w)     # rows nobody pushed: untouched
+            want_w[at] = w1[mine]; want_z[at] = z1[mine]; want_n[at] = n1[mine]
+            np.testing.assert_array_equal(snap["rows"][f], want_w, err_msg="rank %d, field %d: w" % (r, f))
+            np.testing.assert_array_equal(snap["z"][f], want_z, err_msg="rank %d, field %d: z" % (r, f))
+            np.testing.assert_array_equal(snap["n"][f], want_n, err_msg="rank %d, field %d: n" % (r, f))
+            pushed += int(mine.sum()); many += int((npush[mine] == world).sum())
+    assert pushed > 20000 and many > 1000, (pushed, many)      # rows pushed by all eight workers exist: the per-push order matters
+    for l in range(3):
+        np.testing.assert_array_equal(info[0]["snap"]["fcW"][l], fc1[l][0], err_msg="fc%d.weights after step 1" % l)
+        np.testing.assert_array_equal(info[0]["snap"]["fcb"][l], fc1[l][1], err_msg="fc%d.bias after step 1" % l)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "rehearse_c4_n8.log"), "w") as fo:
+            for r, i in enumerate(info):
+                st = i["stats"]; n = st[0]
+                fo.write("rank %d: loss %.5f  joins %s  timeouts %d  per step: %d keys requested, %d served, id blocks %d B (wire block %d words, full %d), rows %d B, "
+                         "gradients %d B, all-reduce %d B, steps with the full-size id exchange (a list overflowed its wire block) %d  (%.1f s)\n" % (
+                             r, i["loss"], "flags" if i["join_mode"] == 1 else "events", i["timeouts"], st[5] // n, st[6] // n, st[1] // n, st[7], st[9],
+                             st[2] // n, st[3] // n, st[4] // n, st[8], i["seconds"]))
+            fo.write("8 ranks x %d steps at configs[4] size (%d..%d ids per rank and step, Ftrl rows, async push): replicated tensors bit-identical; %d pushed rows "
+                     "(w, z, n) of ranks %s in fields %s -- %d of them pushed by all 8 workers -- and rank 0's FC tensors equal net/PServer.java:176-184's "
+                     "per-push semantics after step 1 bit for bit\n" % (steps + 1, min(nnz), max(nnz), pushed, list(CHECK_RANKS), list(CHECK_FIELDS), many))
     except OSError:
         pass

@@ -102,6 +102,43 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 np.testing.assert_array_equal(a, b, err_msg=name)
 
 
+@pytest.mark.parametrize("kind,F,D,X,fc,V,B", [("widedeep", 6, 16, 5, [64, 32, 1], 3000, 2048), ("dnn", 3, 8, 2, [24, 12, 6, 1], 40, 130)])
+def test_graph_replay_is_bit_identical(kind, F, D, X, fc, V, B):
+    """ps_model_config_t.use_graph (ps_model.hip train_graph: the step captured once per (batch pointers, B, nnz) and replayed as
+    a hipGraph -- streams joined by events, no device-side flags) leaves the eager three-stream step's tables, bit for bit:
+    host batches (staged into the model's fixed buffers: ONE graph) and device-resident batches (one graph per batch, replayed
+    on the second round)."""
+    import ps_amd
+    rng = np.random.default_rng(F * 10 + B)
+    WS = 97
+    data = batches(rng, 4, B, F, X, V, WS)
+    res = []
+    for graph, resident in ((0, False), (1, False), (1, True)):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        if kind == "widedeep":
+            gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B, use_graph=graph)
+        else:
+            gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, use_graph=graph)
+        mk = (lambda *a: ps_amd.DeviceBatch(kv, *a)) if resident else ps_amd.Batch
+        bs = [mk(E, Xd, Y, W if kind == "widedeep" else None) for E, Xd, Y, W in data]
+        losses = [gm.train(bs[i % len(bs)]) for i in range(3 * len(bs))]
+        out = (losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get_rows(f, np.arange(V), 1) for f in range(F)],
+               [kv.get("fc%d.weights" % i) for i in range(len(fc))], [kv.get("fc%d.bias" % i) for i in range(len(fc))])
+        if kind == "widedeep":
+            out += ([kv.get_wide(np.arange(WS))], [kv.get("wide.bias")])
+        if resident:
+            for b in bs:
+                b.close()
+        gm.close(); kv.close()
+        res.append(out)
+    for name, got in (("graph replay, host batches", res[1]), ("graph replay, resident batches", res[2])):
+        assert got[0] == res[0][0], "%s: losses %s vs %s" % (name, got[0], res[0][0])
+        for a, b in zip(res[0][1:], got[1:]):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y, err_msg=name)
+
+
 def test_plan_epoch_wraps():
     """300 consecutive sharded steps (the plan's 8-bit epoch wraps after 255) == 300 fused steps, bit for bit."""
     import ps_amd
