@@ -1346,6 +1346,7 @@ int g_gemm_pipe = 5;        // ps_tune_set("gemm_pipe", ...): 0 round 2's slab l
 int g_gemm_ks = 0;          // ps_tune_set("gemm_ks", 1): 8 waves (K split inside the workgroup) on shapes with <= ~one 64 x 64 tile per CU
 int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles where they fit (faster alone, no gain in the step)
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
+int g_plan_mid = 1;         // ps_tune_set("plan_mid", 0): ps_shard_step's next plan head behind the running step's backward enqueue again (side chain 0; round 4)
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
 int g_sort_layer = 0;       // ps_tune_set("sort_layer", l): the single-hot field sort is released by forward GEMM l's start (0: the first)
 int g_sort_late = 0;        // ps_tune_set("sort_late", 1): the single-hot field sort behind the first delta GEMM's release instead of the first forward GEMM's
@@ -1411,6 +1412,19 @@ __global__ void k_set_then_spin(unsigned int *set, unsigned int set_val, const u
 }
 int launch_set_then_spin(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code) {
     hipLaunchKernelGGL(k_set_then_spin, dim3(1), dim3(64), 0, st, set, set_val, flag, val, wait_bound(werr, code));
+    HIPCHK(hipGetLastError());
+    return PS_OK;
+}
+__global__ void k_set_then_spin2(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, const unsigned int *flag2, unsigned int val2, WaitBound b) {
+    if (threadIdx.x == 0) {
+        if (set) __hip_atomic_store(set, set_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        spin_bounded(flag, val, b);
+        if (flag2) spin_bounded(flag2, val2, b);
+    }
+}
+int launch_set_then_spin2(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, const unsigned int *flag2, unsigned int val2,
+                          hipStream_t st, unsigned int *werr, unsigned int code) {
+    hipLaunchKernelGGL(k_set_then_spin2, dim3(1), dim3(64), 0, st, set, set_val, flag, val, flag2, val2, wait_bound(werr, code));
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -382,7 +382,7 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
     if (!m || !out8) return ps_set_err(PS_E_BAD_ARG, "null argument");
     PSCHK(store_enter(m->s));
     HIPCHK(hipStreamSynchronize(m->s->stream));
-    for (int i = 0; i < 2; ++i) if (m->side[i]) HIPCHK(hipStreamSynchronize(m->side[i]));
+    for (int i = 0; i < 3; ++i) if (m->side[i]) HIPCHK(hipStreamSynchronize(m->side[i]));
     coll_collect(m);
     for (int i = 0; i < 8; ++i) { out8[i] = m->sh.coll_acc[i]; m->sh.coll_acc[i] = 0; }
     return PS_OK;
@@ -414,8 +414,11 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const uint32_t *__restrict_
 // owner_start[0..n] of this rank's plan, the received blocks' counts and the OR of every worker's overflow flag -> pinned
 // host memory, then the epoch word (the host spins on it: a copy + event record + event wait woke the host 20-40 us late
 // in some processes, round 2).  host: [owner_start 0..n | received counts 0..n-1 | overflow | epoch]
+// done_flag (round 5, or NULL): "the plan head in front of this launch on the list chain is done" for the device -- the plan's
+// tail on side chain 0 (slots, entry lists) waits for it (start_flag[7]); like k_flag_set it stands for the launches in front
+// of it on its stream, which have finished and released their writes.
 __global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const uint32_t *__restrict__ recv_blk, const uint32_t *__restrict__ send_blk, int nranks,
-                                 int rank, int64_t blk_words, uint32_t *host, uint32_t epoch, unsigned long long *ts) {
+                                 int rank, int64_t blk_words, uint32_t *host, uint32_t epoch, unsigned long long *ts, unsigned int *done_flag, unsigned int done_val) {
     StampScope stamp(ts);
     __shared__ unsigned int ovf_s;
     if (threadIdx.x == 0) ovf_s = 0u;
@@ -431,7 +434,10 @@ __global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const
     if (threadIdx.x == 0) host[2 * nranks + 1] = ovf_s;
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host + 2 * nranks + 2, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(host + 2 * nranks + 2, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (done_flag) __hip_atomic_store(done_flag, done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 }  // namespace
 
@@ -439,12 +445,25 @@ __global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const
 // exchange's counts -- enqueued without a host wait.  use_side != 0 runs it on the store's prefetch stream (and the
 // side communicator) so it can run beside the previous step's training: call begin for step t+1 (on ANOTHER model of
 // the same store: its own key lists and activations) before finish of step t.
-static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side, bool inside_finish);
+// Round 5: a begin has two halves.  HEAD: keys, presence map, unique lists, the id blocks, their exchange and the counts'
+// publication -- everything that reads the ids only.  TAIL: what overwrites lists the running step's backward still reads
+// (slots, entry lists), parked on side chain 0 behind that step's push.  ps_shard_step_finish_begin hands the head of step
+// t+1 to step t's forward (BEGIN_HEAD_HOOK: enqueued between the forward's and the backward's launches, on the list chain
+// side[2], released by the first forward GEMM's start) and calls BEGIN_TAIL behind the backward; any other begin is BEGIN_ALL.
+enum { BEGIN_ALL = 0, BEGIN_HEAD_HOOK = 1, BEGIN_TAIL = 2 };
+static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side, bool inside_finish, int mode = BEGIN_ALL);
 extern "C" int ps_shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side) {
     return shard_step_begin(m, batch, comm, use_side, false);
 }
+int shard_step_begin_hook(ps_model *m) {
+    ps_model::Shard &sh = m->sh;
+    if (!m->fwd_flag_valid || !sh.hook_batch || !sh.hook_comm) return PS_OK;       // (no forward GEMM announces its start: the begin behind the backward)
+    PSCHK(shard_step_begin(m, sh.hook_batch, sh.hook_comm, 0, true, BEGIN_HEAD_HOOK));
+    sh.head_done = true;
+    return PS_OK;
+}
 // inside_finish: called by ps_shard_step_finish_begin between a running step's backward and its push
-static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side, bool inside_finish) {
+static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int use_side, bool inside_finish, int mode) {
     RoctxRange roctx_range("ps_shard_step_begin");
     if (!m || !batch || !comm || !comm->all_gather || !comm->all_to_all_v || !comm->all_reduce_sum_f32)
         return ps_set_err(PS_E_BAD_ARG, "bad argument");
@@ -532,9 +551,11 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         sh.ov_mode = ov_want;
     }
     const bool ov = sh.ov_mode == 1 && !use_side && !m->profile;
-    // overlap: on side chain 0, in order behind the plan's kernels (which run there while the step trains) -- the counts
-    // reach the host long before the running step's push, and nothing waits across streams for the plan
-    hipStream_t st = use_side ? s->prefetch_stream : ov ? m->side[0] : s->stream;
+    // overlap: on the list chain (round 5; side chain 0 in rounds 3-4: ps_tune_set("plan_mid", 0)), in order behind the plan
+    // head's kernels (which run there while the step trains) -- the counts reach the host long before the running step's
+    // push, and nothing waits across streams for the plan head
+    hipStream_t st = use_side ? s->prefetch_stream : ov ? (g_plan_mid ? m->side[2] : m->side[0]) : s->stream;
+    if (mode == BEGIN_HEAD_HOOK && (!ov || st != m->side[2] || !sh.blk_words)) return ps_set_err(PS_E_STATE, "the plan head's hook needs the overlap mode");
     // this model's previous step still reads its key lists until its finish has run on the training stream
     if (use_side && sh.done_recorded) HIPCHK(hipStreamWaitEvent(st, sh.done_ev, 0));
     {   // the owner side receives at most min(ids of a batch, rows held here) keys from every worker (the worst
@@ -552,16 +573,23 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     }
     // (overlap mode without an early plan -- the first step, a store that fell back to events: the plan's kernels go to side
     //  chain 1 too and are ordered behind the running step's backward, whose lists they overwrite: order_after_main)
+    if (mode == BEGIN_TAIL) {
+        // the head of this batch's plan went with the running step's forward: stage the batch (the running step's backward is
+        // enqueued by now) and go on with the tail
+        if (!sh.tail_due) return ps_set_err(PS_E_STATE, "no plan head in front of this tail");
+        PSCHK(stage_batch(m, batch, true));
+        if (m->cur_nnz != sh.plan_nnz) return ps_set_err(PS_E_STATE, "the plan head was made for another batch");
+    } else {
     sh.x_set ^= 1;
     const int set = sh.x_set;
     sh.pack_blk = sh.x_send_blk[set]; sh.pack_full = sh.x_send_full[set];      // (the plan's one launch packs them when it can)
     {
-        const int prc = shard_plan_enqueue(m, batch, nsh, st, false, !use_side, ov);
+        const int prc = shard_plan_enqueue(m, batch, nsh, st, false, !use_side, ov, mode == BEGIN_HEAD_HOOK);
         sh.pack_blk = sh.pack_full = nullptr;
         PSCHK(prc);
     }
     if (!sh.packed)
-    hipLaunchKernelGGL(k_pack_blocks, dim3(cdiv(std::max<int64_t>(m->cur_nnz, nsh), 256)), dim3(256), 0, st, sh.send_rows, sh.owner_start, nsh, sh.blk_words,
+    hipLaunchKernelGGL(k_pack_blocks, dim3(cdiv(std::max<int64_t>(sh.plan_nnz, nsh), 256)), dim3(256), 0, st, sh.send_rows, sh.owner_start, nsh, sh.blk_words,
                        (uint32_t)sh.blk_cap, sh.x_send_blk[set], sh.full_words, sh.x_send_full[set], stamp_next("pack_blocks"));
     HIPCHK(hipGetLastError());
     {   // the id exchange: fixed size, no host wait.  (Own keys in place: this rank's own block stays where it was packed.)
@@ -572,9 +600,15 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         PSCHK(rc);
     }
     if (++sh.x_epoch == 0) ++sh.x_epoch;
+    // (a plan head on the list chain: this launch also tells the DEVICE that the head is done -- the tail, on side chain 0, waits for it)
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, st, sh.owner_start, sh.x_recv_blk[set], sh.x_send_blk[set], nsh, rank, sh.blk_words,
-                       sh.counts_host, sh.x_epoch, stamp_next("publish_counts"));
+                       sh.counts_host, sh.x_epoch, stamp_next("publish_counts"), (sh.tail_due && sh.head_on_list) ? m->start_flag + 7 : (unsigned int *)nullptr, sh.plan_epoch);
     HIPCHK(hipGetLastError());
+    if (mode == BEGIN_HEAD_HOOK) {
+        if (!sh.tail_due) return ps_set_err(PS_E_STATE, "the hooked plan head left no tail");
+        return PS_OK;       // (the tail: BEGIN_TAIL, behind the running step's backward)
+    }
+    }
     if (sh.tail_due) {          // an early plan: its second half (slots, the backward's entry lists) waits on side chain 0 for
         if (++m->start_epoch == 0) ++m->start_epoch;          // "the running step's backward has finished", raised by that
         sh.pub_epoch = m->start_epoch;                        // step's push (ps_shard_step_finish_begin)
@@ -713,7 +747,13 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     }
     {
         sh.defer_flag5 = next_batch != nullptr;      // (the next step's plan, enqueued below, opens with a spinner on side chain 0)
+        // the next step's plan head goes with this step's forward (round 5: BEGIN_HEAD_HOOK) when it can run on the list chain
+        sh.head_done = false;
+        if (next_batch && sh.ov_mode == 1 && !was_side && !m->profile && sh.blk_words && g_plan_mid && shard_plan_hook_ok(m, next_batch)) {
+            sh.hook_batch = next_batch; sh.hook_comm = comm;
+        }
         int frc = ps_shard_forward_backward(m, sh.x_cache, nullptr);
+        sh.hook_batch = nullptr; sh.hook_comm = nullptr;
         sh.defer_flag5 = false;
         sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
         if (frc != PS_OK) { (void)shard_flush_deferred_flag(m); return frc; }
@@ -734,7 +774,8 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     }
     // the next step's key lists (same order of operations on every rank)
     if (next_batch) {
-        const int brc = shard_step_begin(m, next_batch, comm, 0, true);
+        const int brc = shard_step_begin(m, next_batch, comm, 0, true, sh.head_done ? BEGIN_TAIL : BEGIN_ALL);
+        sh.head_done = false;
         (void)shard_flush_deferred_flag(m);          // (a no-op when the plan's spinner took it)
         PSCHK(brc);
     }

@@ -173,6 +173,9 @@ int launch_spin_until(const unsigned int *flag, unsigned int val, hipStream_t st
 int launch_flag_set(unsigned int *flag, unsigned int val, hipStream_t st);             // *flag = val, in stream order
 // both in ONE launch: *set = set_val when the kernel starts (what is in front of it on the stream is done), then the wait
 int launch_set_then_spin(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, hipStream_t st, unsigned int *werr, unsigned int code);
+// ... with an optional set (NULL: none) and TWO waits (flag2 NULL: one)
+int launch_set_then_spin2(unsigned int *set, unsigned int set_val, const unsigned int *flag, unsigned int val, const unsigned int *flag2, unsigned int val2,
+                          hipStream_t st, unsigned int *werr, unsigned int code);
 #define PS_LAUNCH_EV(kernel, grid, block, shmem, st, ev, ...)                                                  \
     do {                                                                                                       \
         hipEvent_t se_ = (ev);                                                                                 \
@@ -273,6 +276,6 @@ extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
-extern int g_plan_fused, g_shard_sort_defer, g_sort_layer;
+extern int g_plan_fused, g_shard_sort_defer, g_sort_layer, g_plan_mid;
 extern int g_rccl_force, g_blk_factor, g_blk_cap, g_push_grouped_max_mb, g_comm_timing;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

@@ -172,7 +172,7 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     {   // the side chains (sort, dW + dense update) yield to the main FC chain, which is the critical path
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent (numerically largest)
-        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&m->side[i], hipStreamNonBlocking, lo));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&m->side[i], hipStreamNonBlocking, lo));
     }
     m->events.resize(64);
     for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -195,7 +195,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     (void)hipStreamSynchronize(m->s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (int i = 0; i < 2; ++i) if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
+    for (int i = 0; i < 3; ++i) if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
     for (auto &e : m->events) (void)hipEventDestroy(e);
     if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
     if (m->s0_ev) (void)hipEventDestroy(m->s0_ev);
@@ -229,7 +229,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     sort_ws_free(m->ws); sort_ws_free(m->wws); seg_sort_free(m->seg);
     fr(m->wkeys); fr(m->wents); fr(m->wseg_start); fr(m->wseg_id); fr(m->wnseg);
     fr(m->fs_keys); fr(m->fs_ents); fr(m->long_list); fr(m->fs_pub); fr(m->start_flag); fr(m->pair_ctr);
-    fr(m->seg_nseg_scratch); fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
+    fr(m->sh.keys2); fr(m->seg_nseg_scratch); fr(m->keys); fr(m->ents); fr(m->ent_bag); fr(m->seg_start); fr(m->seg_id); fr(m->nseg_dev); fr(m->uniq_row); fr(m->uniq_cnt);
     fr(m->partials); fr(m->partials2); fr(m->grads_out); fr(m->dense_grad_flat);
     delete m;
     return PS_OK;

@@ -385,6 +385,7 @@ int ensure_shard_state(ps_model *m, int nshards) {
         }
     }
     PSCHK(store_dev_alloc(s, (void **)&sh.slot, sizeof(uint32_t) * (size_t)(nc + 1), false));
+    PSCHK(store_dev_alloc(s, (void **)&sh.keys2, sizeof(uint32_t) * (size_t)(nc + 1), false));      // (m->keys' twin: ps_store.h)
     PSCHK(store_dev_alloc(s, (void **)&sh.send_rows, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(store_dev_alloc(s, (void **)&sh.owner_start, sizeof(uint32_t) * (size_t)(nshards + 2), true));
     sh.flat_elems = m->dense_elems + (m->cfg.kind == PS_MODEL_WIDEDEEP ? 2 * s->wide.rows + 1 : 0);
@@ -504,7 +505,11 @@ int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st) {
     if (!sh.tail_due) return PS_OK;
     sh.tail_due = false;
     hipStream_t ss = m->side[0];
-    PSCHK(launch_spin_until(m->start_flag + 6, sh.pub_epoch, ss, m->s->werr(), 6));
+    // (one launch: raises side chain 0's pending "small kernels done" -- it is in order behind them -- then waits for the running
+    //  step's push and, when the plan head ran on the list chain, for that chain's "plan head done")
+    unsigned int *set = nullptr; unsigned int set_val = 0;
+    if (sh.deferred) { set = sh.def_flag; set_val = sh.def_val; sh.deferred = false; }
+    PSCHK(launch_set_then_spin2(set, set_val, m->start_flag + 6, sh.pub_epoch, sh.head_on_list ? m->start_flag + 7 : nullptr, sh.plan_epoch, ss, m->s->werr(), 6));
     return plan_slots_and_lists(m, nshards, sh.tail_nnz, st, ss);
 }
 
@@ -515,32 +520,54 @@ int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st) {
 // trains instead of in its tail; the main stream only parks a spinner on "plan done".  What overwrites lists the
 // running backward still reads (slots, entry lists) is enqueued later by shard_plan_enqueue_tail; the run count is
 // double-buffered (nseg_cur).
-int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early, bool order_after_main) {
+// hook (round 5, ps_comm.hip shard_step_begin_hook): called BETWEEN the forward and the backward of the running step, for a
+// device-resident single-hot batch that shard_plan_hook_ok accepted -- the running step's batch stays staged (m->cur_*: its
+// backward is not enqueued yet), the plan takes its inputs from `batch` itself, and its kernels go to the list chain side[2].
+bool shard_plan_hook_ok(const ps_model *m, const ps_batch_t *batch) {
+    const ps_model::Shard &sh = m->sh;
+    return g_plan_mid && g_plan_early && batch && batch->on_device && !batch->offsets && batch->B > 0 && batch->B <= m->Bcap && batch->ids &&
+           (int64_t)batch->B * m->cfg.F <= m->nnz_cap && sh.bitmap && sh.keys2 && g_plan_sort == 0 && m->dev_ok && dev_waits_ok(m->s) &&
+           !m->cfg.use_graph && !m->profile && m->multi_stream && g_field_sort && field_sort_fits(batch->B, m->cfg.F) && g_plan_fused && sh.plan_pub &&
+           cdiv(sh.bm_words, PLAN_WPB) <= PLAN_FUSED_MAX_BLOCKS && sh.sbits - 5 >= 8 && sh.nshards <= PS_PUSH_MAX_PEERS && m->side[2];
+}
+int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early, bool order_after_main, bool hook) {
     ps_store *s = m->s;
     PSCHK(ensure_shard_state(m, nshards));
     ps_model::Shard &sh = m->sh;
     const bool fwd_flag = m->fwd_flag_valid;       // (of the step enqueued before this call)
     m->fwd_flag_valid = false;
-    // side chain 0's pending "small kernels done" flag (ps_store.h defer_flag5) rides on an EARLY plan's opening spinner.  Any
-    // other plan raises it first, before anything here can wait for the training stream (a host batch's staging does; the
-    // ordering event of a late plan does) -- the running step's last delta GEMM holds its slot until that flag is up.
-    if (sh.deferred) {
+    // side chain 0's pending "small kernels done" flag (ps_store.h defer_flag5) rides on the opening spinner of an EARLY plan that
+    // goes to side chain 0, or on its tail's spinner there when the head goes to the list chain.  Any other plan raises it first,
+    // before anything here can wait for the training stream (a host batch's staging does; the ordering event of a late plan does)
+    // -- the running step's last delta GEMM holds its slot until that flag is up.
+    if (sh.deferred && !hook) {
         const bool will_be_early = early && batch && batch->on_device && !batch->offsets && batch->B > 0 && sh.bitmap && g_plan_sort == 0 && fwd_flag &&
                                    g_plan_early && dev_waits_ok(s) && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback && g_field_sort &&
                                    field_sort_fits(batch->B, m->cfg.F);
         if (!will_be_early) PSCHK(shard_flush_deferred_flag(m));
     }
-    PSCHK(stage_batch(m, batch, true));
-    if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
+    if (!hook) {
+        PSCHK(stage_batch(m, batch, true));
+        if (st != s->stream && !batch->on_device) HIPCHK(hipStreamSynchronize(s->stream));   // host batch: uploads ran on the store's stream
+    }
     const int F = m->cfg.F;
-    const int64_t nbags = (int64_t)m->cur_B * F, nnz = m->cur_nnz;
+    // (hook: a device-resident single-hot batch, checked by shard_plan_hook_ok -- what stage_batch would have made of it)
+    const int plan_B = hook ? batch->B : m->cur_B;
+    const int64_t *const plan_ids = hook ? batch->ids : m->cur_ids, *const plan_offsets = hook ? nullptr : m->cur_offsets;
+    const int64_t nbags = (int64_t)plan_B * F, nnz = hook ? nbags : m->cur_nnz;
+    sh.plan_nnz = nnz;
     const bool bm = sh.bitmap != nullptr && nnz > 0 && g_plan_sort == 0;
     early = early && bm && fwd_flag && g_plan_early && m->dev_ok && !m->cfg.use_graph && !m->profile && m->multi_stream && !readback &&
-            batch->on_device && !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
+            batch->on_device && !plan_offsets && g_field_sort && field_sort_fits(plan_B, F);
     static const bool plan_debug = getenv("PS_PLAN_DEBUG") != nullptr;      // measurement: which way did the plan go
-    if (plan_debug) fprintf(stderr, "[plan] early=%d (bitmap %d, fwd flag %d, device batch %d, single-hot %d, field sort fits %d)\n", (int)early, (int)bm,
-                            (int)fwd_flag, (int)batch->on_device, (int)!m->cur_offsets, (int)field_sort_fits(m->cur_B, F));
-    hipStream_t ps = early ? m->side[0] : st;       // where the id-only kernels go
+    if (plan_debug) fprintf(stderr, "[plan] early=%d hook=%d (bitmap %d, fwd flag %d, device batch %d, single-hot %d, field sort fits %d)\n", (int)early, (int)hook, (int)bm,
+                            (int)fwd_flag, (int)batch->on_device, (int)!plan_offsets, (int)field_sort_fits(plan_B, F));
+    if (hook && !early) return ps_set_err(PS_E_STATE, "the plan head was handed to the forward's hook but cannot run early");
+    // where the id-only kernels go: an early plan runs beside the step that trains -- on the list chain (the caller's stream in
+    // overlap mode: the id exchange follows in order, nothing waits across streams), else on side chain 0
+    const bool on_list = early && st == m->side[2] && m->side[2] != nullptr;
+    hipStream_t ps = early ? (on_list ? st : m->side[0]) : st;
+    sh.head_on_list = on_list;
     if (!early) PSCHK(shard_flush_deferred_flag(m));      // (normally flushed above already)
     if (!early && order_after_main && st != s->stream) {
         // (not early, on another stream than the training stream: the plan overwrites lists the running step's backward
@@ -553,7 +580,7 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
         sh.deferred = false;
         PSCHK(launch_set_then_spin(sh.def_flag, sh.def_val, m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
     } else {
-        PSCHK(shard_flush_deferred_flag(m));
+        if (!on_list) PSCHK(shard_flush_deferred_flag(m));      // (on the list chain: the tail's spinner on side chain 0 takes it)
         if (early) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ps, s->werr(), 14));
     }
     m->nseg_cur = early ? (m->nseg_cur == m->nseg_dev ? m->nseg_dev + 4 : m->nseg_dev) : m->nseg_dev;
@@ -561,9 +588,13 @@ int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStr
         HIPCHK(hipMemsetAsync(sh.stamp, 0, (size_t)sh.bm_words * 32, ps));
         sh.epoch = 1;
     }
-    hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, ps, m->cur_ids, m->cur_offsets, nbags, F, nshards,
+    // On the list chain the keys are written while the running step's field sort (side chain 0, beside its forward) may still read
+    // its own: the other buffer.  (Every reader takes the pointer when it is enqueued: the sort of the step this plan is for, its
+    // slot kernel -- both enqueued after this swap.)
+    if (on_list) std::swap(m->keys, sh.keys2);
+    hipLaunchKernelGGL(k_shard_keys, dim3(cdiv(nbags, 256)), dim3(256), 0, ps, plan_ids, plan_offsets, nbags, F, nshards,
                        sh.sbits, sh.lrb_dev, sh.lrb_dev + (size_t)nshards * (F + 1), s->emb.owner_dev, s->emb.local_dev, s->emb.grow_base_dev, m->keys,
-                       m->cur_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev, bm ? sh.stamp : (uint8_t *)nullptr, sh.epoch, stamp_next("shard_keys"));
+                       plan_offsets ? m->ent_bag : (uint32_t *)nullptr, s->err_dev, bm ? sh.stamp : (uint8_t *)nullptr, sh.epoch, stamp_next("shard_keys"));
     HIPCHK(hipGetLastError());
     sh.packed = false;
     if (bm) {
@@ -708,6 +739,10 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     m->sh.cache = cache_dev;
     if (m->sh.slot_ev) { HIPCHK(hipStreamWaitEvent(s->stream, m->sh.slot_ev, 0)); m->sh.slot_ev = nullptr; }   // the plan's slots (side stream)
     int rc = enqueue_forward(m, true, true);
+    // (ps_shard_step's pipeline: the NEXT step's plan head goes to the list chain here -- behind this forward's launches, whose
+    //  first GEMM releases it, and in front of the backward's, so that the host enqueues it ~60 us earlier than behind them)
+    if (rc == PS_OK && m->sh.hook_batch) rc = shard_step_begin_hook(m);
+    m->sh.hook_batch = nullptr; m->sh.hook_comm = nullptr;
     if (rc == PS_OK) rc = enqueue_backward(m, false);     // gradients only: the owners apply them (the flat buffer's wide part
                                                           // [G | C | bias] is filled by the dense gradient's launch)
     m->sh.active = false;

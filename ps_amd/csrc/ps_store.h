@@ -250,6 +250,17 @@ struct ps_model {
         bool tail_due = false;
         uint32_t plan_epoch = 0, pub_epoch = 0;
         int64_t tail_nnz = 0;
+        // Round 5: the plan head of step t+1 is enqueued BETWEEN the forward and the backward of step t (ps_shard_forward_backward
+        // calls back into ps_comm.hip: hook_*), on the list chain side[2], released by step t's first forward GEMM: the counts of
+        // step t+1 reach the host ~50 us into step t instead of ~116 (they were behind side chain 0's small kernels), so the
+        // host -- which needs them to size the rows / gradient exchanges of step t+1 -- is no longer 20 us from starving the GPU.
+        // keys2: the plan head writes step t+1's sort keys while step t's field sort still reads its own (m->keys and keys2 swap).
+        // head_on_list: the tail (slots, entry lists; side chain 0) also waits for "plan head done" (start_flag[7] = plan_epoch,
+        // raised by the counts' publication on side[2]).
+        uint32_t *keys2 = nullptr;
+        const ps_batch_t *hook_batch = nullptr; const ps_comm_ops_t *hook_comm = nullptr;
+        bool head_done = false, head_on_list = false;
+        int64_t plan_nnz = 0;                                        // ids of the batch the last plan head was made for
     } sh;
     // host batches: pinned staging + two device slots on a copy stream (stage_batch)
     struct HostStage {
@@ -262,7 +273,8 @@ struct ps_model {
     } hstage;
     // side streams: independent chains of the step (sort | dW + dense update | wide update) run
     // beside the main FC chain; fork/join through events (also what the captured graph records)
-    hipStream_t side[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};     // [2]: the sharded step's LIST chain (the next step's plan head, the id exchange, the
+                                                           // counts' publication: ps_comm.hip), beside the running step's forward
     hipStream_t flat_stream = nullptr;   // where the last backward's dense-gradient launch went (ps_shard_step orders its all-reduce behind it)
     std::vector<hipEvent_t> events; size_t next_event = 0;
     bool multi_stream = true;
@@ -282,9 +294,11 @@ struct ps_model {
 // shared between ps_model.hip and ps_shard.hip
 int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
 int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early = false,
-                       bool order_after_main = false);   // ps_shard.hip
+                       bool order_after_main = false, bool hook = false);   // ps_shard.hip
 int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st);
 int shard_flush_deferred_flag(ps_model *m);       // ps_shard.hip
+bool shard_plan_hook_ok(const ps_model *m, const ps_batch_t *batch);     // ps_shard.hip: may this batch's plan head go through the hook
+int shard_step_begin_hook(ps_model *m);           // ps_comm.hip: the next step's plan head, called by ps_shard_forward_backward between forward and backward
 int shard_launch_deferred_sort(ps_model *m, bool behind_fwd_flag);   // ps_shard.hip: the plan's field sort, enqueued by the forward
 int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st);      // early plans: the slots + the backward's entry lists
 int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: enqueue_backward launches the loss reduction
