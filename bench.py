@@ -213,16 +213,22 @@ def run_single(args):
     uniq = int(round(np.mean([s_["unique_keys"] for s_ in stats])))      # unique (field, id) keys of a batch, mean of 16
     hottest = int(max(s_["hottest_run"] for s_ in stats))               # longest run of one key in one field
     nnz = cfg["B"] * cfg["F"]
-    for i in range(max(args.warmup, 1)):          # untimed warm-up (module load, caches, clocks)
+    for i in range(3):                            # (module load, first launches)
         gm.train_async(batches[i % nb])
     gm.sync()
-    # short pass with every kernel group bracketed by HIP events: finds the dominant kernel
+    # a pass with every kernel group bracketed by HIP events (one stream, every one of the resident batches once): finds the
+    # dominant kernel.  It runs IN FRONT of the warm-up and the timed region, so both start on a GPU that has been under load
+    # for ~15 ms (tools/ramp_probe.py: a region right behind an idle queue runs on ramping clocks, 143 -> 133 us per step over
+    # the first ~120 steps; round 4's 20-step pass left the driver's 20-step region on that ramp)
+    PROFILE_STEPS = 64
     gm.set_profile(True)
-    for i in range(20):
+    for i in range(PROFILE_STEPS):
         gm.train_async(batches[i % nb])
     gm.sync()
     prof = gm.profile_report()
     gm.set_profile(False)
+    for i in range(max(args.warmup, 1)):          # the W untimed warm-up steps, the step as it is timed
+        gm.train_async(batches[i % nb])
     gm.sync()
     # ---- the timed region: K steps, nothing else on the stream ----
     t0 = time.perf_counter()
@@ -270,7 +276,7 @@ def run_single(args):
         avg_s_s = sum(rs[g][1] for g in dom_groups) / cnt_s / 1e3
         work_s = sum(group_algorithmic(cfg, g, nnz, uniq)[1] * rs[g][0] for g in dom_groups) / cnt_s
         peak_s = F32_MFMA_PEAK_TFS * 1e12 if group_algorithmic(cfg, dom_groups[0], nnz, uniq)[0] == "mfma" else HBM_PEAK_GBS * 1e9
-        steady = {"after_untimed_steps": 300 + 2 * args.steps + args.warmup + 20, "steps": 300, "ms_per_step": 1e3 * dts,
+        steady = {"after_untimed_steps": 300 + 2 * args.steps + args.warmup + 3 + PROFILE_STEPS, "steps": 300, "ms_per_step": 1e3 * dts,
                   "roofline_avg_launch_us": avg_s_s * 1e6, "roofline_frac": work_s / avg_s_s / peak_s,
                   "note": "the headline's %d steps run while the GPU's clocks still ramp (tools/ramp_probe.py: ~120 steps from an idle queue); "
                           "this is the same step behind the ramp (still inside the boost window: the first 0.6 s of load), not part of `value`" % args.steps}
@@ -324,7 +330,8 @@ def run_single(args):
                    "global_batch": cfg["B"], "parallelism": "single", "resident_inputs": True, "hip_graph": bool(args.graph),
                    # "ids ~ Zipf(1.05) over V": the truncated law by inverse CDF (ps_amd/synth.py)
                    "id_generator": ("uniform" if cfg["zipf"] <= 1.0 else cfg["idgen"]) + ("(alpha=%g, V=%d)" % (cfg["zipf"], cfg["V"])),
-                   "lookups_per_batch": nnz, "unique_keys_per_batch": uniq, "hottest_run": hottest},
+                   "lookups_per_batch": nnz, "unique_keys_per_batch": uniq, "hottest_run": hottest,
+                   "untimed_steps_before_the_timed_region": {"first_launches": 3, "kernel_group_profile_pass": PROFILE_STEPS, "warmup": max(args.warmup, 1)}},
         "roofline": roof,
         "roofline_groups": roof_groups,
         # all FC flops of the step / step time / f32 MFMA peak: the matrix cores' utilisation over the WHOLE step
@@ -371,16 +378,17 @@ def run_single(args):
                                "hottest_run": int(max(s_["hottest_run"] for s_ in st_c))}
     if args.gather:
         out["gather_hbm"] = gather_roofline(kv, args)
+    # the headline model and its store are CLOSED before the other legs: with two live models on the device every stream join of
+    # the multi-hot leg would take its event form (ps_store.hip dev_waits_ok) and the leg would under-measure its own step
+    # (0.411 ms in the driver's line against 0.390-0.395 stand-alone)
+    for b in batches:
+        b.close()
+    batches = []
+    gm.close(); kv.close()
     if args.multi_hot:
-        for b in batches:
-            b.close()
-        batches = []
         out["multi_hot"] = multi_hot_step(cfg)
     if args.sharded_leg:
         out["sharded_n1"] = sharded_n1_leg(args)
-    for b in batches:
-        b.close()
-    gm.close(); kv.close()
     return out
 
 
@@ -416,6 +424,10 @@ def multi_hot_step(cfg, steps=60):
     gm.sync()
     dt = (time.perf_counter() - t0) / steps
     loss = gm.train(bs[0])
+    import ctypes as C_
+    from ps_amd import native as N_
+    why = C_.create_string_buffer(256)
+    joins = "device flags" if N_.lib().ps_store_join_mode(kv.h, why, 256) == 1 else "events (%s)" % why.value.decode()
     for b in bs:
         b.close()
     gm.close(); kv.close()
@@ -430,7 +442,7 @@ def multi_hot_step(cfg, steps=60):
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_step": {"gather": gather_b, "backward_plus_ftrl": bwd_b},
                          "achieved": (gather_b + bwd_b) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (gather_b + bwd_b) / dt / 1e9 / HBM_PEAK_GBS,
                          "note": "whole step (gather, sort, FC chain, per-key reduce + Ftrl) over the algorithmic bytes of its two HBM-bound kernels"},
-            "final_loss": loss}
+            "stream_joins": joins, "final_loss": loss}
 
 
 def leg_sharded_n1(args):
@@ -442,10 +454,14 @@ def leg_sharded_n1(args):
     cfg["zipf"] = args.zipf
     cfg["idgen"] = args.idgen
     steps = min(args.steps, 1000)
-    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2), with_info=True)
-    return {"workload": "configs[2]'s sharded step on 1 GPU (1-rank table), batch %d; %d steps after 300 priming steps" % (cfg["B"], steps),
+    ct = {}
+    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2), with_info=True, coll_times=ct)
+    return {"workload": "configs[2]'s sharded step on 1 GPU (1-rank table), batch %d; %d steps after 300 priming steps (268 + a wait + 32)" % (cfg["B"], steps),
             "ms_per_step": {k: round(v, 5) for k, v in res.items()},
-            "examples_per_s": {k: cfg["B"] / (1e-3 * v) for k, v in res.items()}, "rccl": info}
+            "wire_cost_ms_per_step": round(res["rccl_with_own_keys_in_place"] - res["device_copies"], 5),
+            "examples_per_s": {k: cfg["B"] / (1e-3 * v) for k, v in res.items()},
+            # device time of every collective of the step by kind (HIP events around each call, a pass of its own)
+            "collective_device_us": ct, "rccl": info}
 
 
 def sharded_n1_leg(args):

@@ -592,6 +592,10 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     hipLaunchKernelGGL(k_pack_blocks, dim3(cdiv(std::max<int64_t>(sh.plan_nnz, nsh), 256)), dim3(256), 0, st, sh.send_rows, sh.owner_start, nsh, sh.blk_words,
                        (uint32_t)sh.blk_cap, sh.x_send_blk[set], sh.full_words, sh.x_send_full[set], stamp_next("pack_blocks"));
     HIPCHK(hipGetLastError());
+    // (a plugged-in table's collective may BLOCK THE HOST -- the tests' gloo tables drain the stream and stage through the host --
+    //  while the running step's last delta GEMM holds its slot for side chain 0's "small kernels done": raised now, not by the
+    //  tail's spinner behind the exchange.  With rank processes time-slicing one GPU that wait ran into its 2 s bound.)
+    if (!comm_is_rccl(comm)) PSCHK(shard_flush_deferred_flag(m));
     {   // the id exchange: fixed size, no host wait.  (Own keys in place: this rank's own block stays where it was packed.)
         std::vector<int64_t> fixed((size_t)nsh, sh.blk_words);
         comm_select(comm, (use_side || ov) ? 1 : 0, comm_own_in_place(comm));

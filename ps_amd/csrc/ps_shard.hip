@@ -741,10 +741,15 @@ extern "C" int ps_shard_forward_backward(ps_model_t *m, const float *cache_dev, 
     int rc = enqueue_forward(m, true, true);
     // (ps_shard_step's pipeline: the NEXT step's plan head goes to the list chain here -- behind this forward's launches, whose
     //  first GEMM releases it, and in front of the backward's, so that the host enqueues it ~60 us earlier than behind them)
+    // (the plan head flips the run-count buffer, nseg_cur, to the NEXT plan's: this step's backward, enqueued below, still reads its own)
+    uint32_t *const nseg_this = m->nseg_cur;
     if (rc == PS_OK && m->sh.hook_batch) rc = shard_step_begin_hook(m);
     m->sh.hook_batch = nullptr; m->sh.hook_comm = nullptr;
+    uint32_t *const nseg_next = m->nseg_cur;
+    m->nseg_cur = nseg_this;
     if (rc == PS_OK) rc = enqueue_backward(m, false);     // gradients only: the owners apply them (the flat buffer's wide part
                                                           // [G | C | bias] is filled by the dense gradient's launch)
+    m->nseg_cur = nseg_next;
     m->sh.active = false;
     PSCHK(rc);
     m->fwd_done = true; m->bwd_done = true;

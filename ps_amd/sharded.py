@@ -894,11 +894,17 @@ def collective_times(worker, worker_run, kv, gm, steps=200):
     return {n: {"avg_us": round(1e3 * out[2 * i + 1] / max(out[2 * i], 1), 2), "calls": int(out[2 * i])} for i, n in enumerate(names)}
 
 
-def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info=False):
+def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info=False, coll_times=None):
     """ps_shard_step on ONE GPU with a 1-rank table: rccl_force 0 (device copies), 1 (everything through RCCL), 2 (RCCL
-    running, own keys in place).  ms per step of `steps` steps after 300 priming steps, each mode on a fresh store."""
+    running, own keys in place).  ms per step of `steps` steps after 300 priming steps, each mode on a fresh store.
+    The priming runs in two pieces with a wait in between, like run_bench's (a short region right behind a LONG asynchronous
+    run pays the HIP runtime's housekeeping: tools/shard_short_run.py).  coll_times (a dict): filled with the device time of
+    every collective by kind and mode (a pass of its own after the timed region)."""
     import ps_amd
     L = N.lib()
+    for kv_ in os.environ.get("PS_TUNE", "").split(","):      # measurement knobs for A/B runs of this leg
+        if "=" in kv_:
+            L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
     res, info = {}, None
     names = {0: "device_copies", 1: "rccl_everything_off_the_wire", 2: "rccl_with_own_keys_in_place"}
     for force in modes:
@@ -914,7 +920,9 @@ def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info
             L.ps_tune_set(b"rccl_force", 0)
         if force:
             wk.selfcheck()
-        wk.run(bs, 300)
+        wk.run(bs, 268)
+        kv.sync()
+        wk.run(bs, 32)
         kv.sync()
         t0 = time.perf_counter()
         wk.run(bs, steps)
@@ -922,6 +930,10 @@ def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info
         res[names[force]] = 1e3 * (time.perf_counter() - t0) / steps
         if force and with_info:
             info = rccl_info(wk)
+        if coll_times is not None:
+            ct = collective_times(wk, lambda n: wk.run(bs, n), kv, gm, steps=100)
+            if ct:
+                coll_times[names[force]] = {k: v["avg_us"] for k, v in ct.items()}
         wk.close()
         for b in bs:
             b.close()
