@@ -173,6 +173,19 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent (numerically largest)
         for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&m->side[i], hipStreamNonBlocking, lo));
+        // Measurement (VERDICT r4 next #4b; PS_CU_MASK_DW=<n>): side chain 1 -- the dW GEMMs and the dense update -- confined to the
+        // first n CUs of the mask's order by hipExtStreamCreateWithCUMask.  (The training stream keeps every CU unless
+        // PS_CU_MASK_MAIN=1 takes those n away from it: ps_store.hip.)  DESIGN.md 4.1.3 has the numbers.
+        if (const char *e = getenv("PS_CU_MASK_DW")) {
+            const int n = atoi(e);
+            if (n > 0 && n < 256) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < n; ++b) mask[b >> 5] |= 1u << (b & 31);
+                hipStream_t cs = nullptr;
+                if (hipExtStreamCreateWithCUMask(&cs, 8, mask) == hipSuccess) { (void)hipStreamDestroy(m->side[1]); m->side[1] = cs; }
+                else (void)hipGetLastError();
+            }
+        }
     }
     m->events.resize(64);
     for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

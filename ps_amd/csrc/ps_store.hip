@@ -251,6 +251,17 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&s->own_stream, hipStreamNonBlocking, hi));   // main chain: most urgent
+        // Measurement (PS_CU_MASK_DW=<n> with PS_CU_MASK_MAIN=1): the training stream on the CUs side chain 1 does NOT get (ps_model.hip)
+        if (getenv("PS_CU_MASK_MAIN") && getenv("PS_CU_MASK_DW")) {
+            const int n = atoi(getenv("PS_CU_MASK_DW"));
+            if (n > 0 && n < 256) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int b = n; b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+                hipStream_t cs = nullptr;
+                if (hipExtStreamCreateWithCUMask(&cs, 8, mask) == hipSuccess) { (void)hipStreamDestroy(s->own_stream); s->own_stream = cs; }
+                else (void)hipGetLastError();
+            }
+        }
     }
     s->stream = s->own_stream;
     PSCHK(store_dev_alloc(s, (void **)&s->err_dev, 8 * sizeof(int), true));      // [0] bad ids | [1] timed-out device waits, [2] last, [3] first | [4] XCD mismatches
