@@ -201,7 +201,13 @@ enum { PS_SUM_AUTO = 0, PS_SUM_SEQUENTIAL = 1, PS_SUM_CHUNKED = 2 };
 /* One minibatch.  Single-hot (the reference): offsets == NULL and ids is
  * [B][F] (the bytes of the F x B matrix "E", CTR.java:47-68).  Multi-hot:
  * offsets[B*F+1] is a CSR over bags in (sample, field) order, sum pooling.
- * on_device != 0: every pointer is a device pointer (inputs resident in HBM). */
+ * on_device != 0: every pointer is a device pointer (inputs resident in HBM).
+ * A device batch must be COMPLETE when it is handed over (written by a
+ * host-synchronous copy such as ps_dev_upload, or by ps_ingest_next, which
+ * synchronises its own copies) and stay unchanged until the step that uses
+ * it has run: the step reads its ids on side streams that are not ordered
+ * behind earlier work of the store's stream (the sharded step's next plan
+ * since round 3; the multi-hot step's key/sort kernels since round 5). */
 typedef struct ps_batch {
     int B;
     const int64_t *ids;       /* nnz ids, bag-major                          */

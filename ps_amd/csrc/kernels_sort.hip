@@ -603,6 +603,73 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_emit(const uint32_t *__restrict_
 }
 
 
+// Round 5: count + emit in ONE launch (the two segment launches and their boundaries were a 35 us hole
+// behind the multi-hot step's sort).  Every workgroup counts the run heads of its tile, publishes the count tagged with the
+// launch's sequence number and adds up the counts of the workgroups in front of it -- they were dispatched earlier, so
+// spinning on their words cannot deadlock (the look-back of k_field_sort_segments and the sharded plan) -- then writes
+// seg_id / seg_start exactly as k_seg_emit does.  One pass over the sorted keys instead of two.
+__global__ __launch_bounds__(RS_TPB) void k_seg_fused(const uint32_t *__restrict__ keys, int64_t n, unsigned long long *__restrict__ pub, uint32_t seq,
+                                                      uint32_t *__restrict__ seg_start, uint32_t *__restrict__ seg_id,
+                                                      uint32_t *__restrict__ nseg_dev, unsigned long long *ts) {
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t wave_heads[4];
+    StampScope stamp(ts);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = (int)blockIdx.x;
+    const int64_t wbase = (int64_t)b * RS_TILE + (int64_t)w * RS_WAVE_SPAN;
+    uint32_t kc[RS_IPT], kp[RS_IPT];
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const int64_t idx = wbase + j * 64 + lane;
+        const int64_t ci = idx < n ? idx : n - 1;
+        kc[j] = keys[ci];
+        kp[j] = keys[ci > 0 ? ci - 1 : 0];
+    }
+    uint32_t hbits = 0, wcount = 0;
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const bool h = head_of(kc[j], kp[j], wbase + j * 64 + lane, n);
+        hbits |= (h ? 1u : 0u) << j;
+        wcount += (uint32_t)__popcll(__ballot(h));
+    }
+    if (lane == 0) wave_heads[w] = wcount;
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(&pub[b], ((unsigned long long)seq << 32) | (unsigned long long)(wave_heads[0] + wave_heads[1] + wave_heads[2] + wave_heads[3]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // heads in all earlier workgroups
+    uint32_t acc = 0;
+    for (int i = tid; i < b; i += RS_TPB) {
+        unsigned long long x;
+        do { x = __hip_atomic_load(&pub[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(x >> 32) != seq);
+        acc += (uint32_t)x;
+    }
+    for (int off = 32; off; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    uint32_t run = red[0] + red[1] + red[2] + red[3];
+    for (int ww = 0; ww < w; ++ww) run += wave_heads[ww];
+    const uint64_t le = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+#pragma unroll
+    for (int j = 0; j < RS_IPT; ++j) {
+        const int64_t idx = wbase + j * 64 + lane;
+        const bool h = (hbits >> j) & 1u;
+        const uint64_t hm = __ballot(h);
+        if (idx < n) {
+            const uint32_t incl = run + (uint32_t)__popcll(hm & le);  // heads up to and incl. idx
+            const uint32_t sid = incl - 1;
+            seg_id[idx] = sid;
+            if (h) seg_start[sid] = (uint32_t)idx;
+            if (idx == n - 1) {
+                seg_start[sid + 1] = (uint32_t)n;
+                nseg_dev[0] = sid + 1;
+                nseg_dev[1] = 0;                        // long-run counter (k_long_runs, when asked for)
+            }
+        }
+        run += (uint32_t)__popcll(hm);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Single-hot batches: the whole "sort the (row key, entry) pairs, cut them into per-key runs" chain in ONE launch.
 // Field f's B keys occupy their own interval of the key space (row = row_base[f] + id, kernels_emb.hip), so the
@@ -824,6 +891,9 @@ int sort_ws_alloc(SortWorkspace &ws, int64_t cap) {
     HIPCHK(hipMalloc(&ws.counts, sizeof(uint32_t) * 2048 * (size_t)ws.nblk));       // up to 11-bit digits
     HIPCHK(hipMalloc(&ws.blk_heads, sizeof(uint32_t) * (size_t)ws.nblk));
     HIPCHK(hipMalloc(&ws.totals, sizeof(uint32_t) * 2048));
+    HIPCHK(hipMalloc(&ws.seg_pub, sizeof(unsigned long long) * (size_t)(ws.nblk + 1)));
+    HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), 0));       // (tag 0 = no launch yet)
+    HIPCHK(hipStreamSynchronize(0));                    // (done before any stream of the store can launch on it)
     HIPCHK(hipMalloc(&ws.hi, sizeof(uint32_t) * 4 * 2048 * (size_t)cdiv(ws.nblk, RS_SB)));     // <= 4 passes x 2048 digits x superblocks
     return PS_OK;
 }
@@ -834,6 +904,7 @@ void sort_ws_free(SortWorkspace &ws) {
     if (ws.counts) (void)hipFree(ws.counts);
     if (ws.blk_heads) (void)hipFree(ws.blk_heads);
     if (ws.totals) (void)hipFree(ws.totals);
+    if (ws.seg_pub) (void)hipFree(ws.seg_pub);
     if (ws.hi) (void)hipFree(ws.hi);
     ws = SortWorkspace();
 }
@@ -887,6 +958,14 @@ int radix_sort_pairs(SortWorkspace &ws, uint32_t *keys, uint32_t *vals, int64_t 
 
 // The segmented sort's launches (see k_bag_scan): offsets -> pre / ftotal (and the sort's totals zeroed) is enqueued by
 // seg_sort_scan; the key kernel then fills (kp, vp); seg_sort_pairs sorts them into (keys_out, vals_out) [n], compact.
+// ps_tune_set("mh_presort", v): where the multi-hot step's scan / key kernel / first sort pass run (ps_model.hip enqueue_forward).
+//   0  behind the join with the training stream, beside the gather (round 4)                                   0.387-0.389 ms / step
+//   1  on side chain 0 at once, no join: they land beside the PREVIOUS step's FC chain and slow its GEMMs       0.394-0.402
+//   2  ... held until the previous step's embedding backward has started                                        0.380-0.384
+//   3  ... and the sort's second half released by the first forward GEMM's start (default)                      0.376-0.378
+// (tools/r05_mh_check.sh, interleaved on one box: profiles/r05_mh_presort_ab.txt)
+int g_mh_presort = 3;
+int g_seg_fused = 1;        // ps_tune_set("seg_fused", 0): build_segments as two launches (count, emit) again
 int g_mh_seg_sort = 1;      // ps_tune_set("mh_seg_sort", 0): multi-hot batches through the three-pass radix sort on 22-bit keys again (round 3)
 int seg_sort_alloc(SegSortWs &ws, int64_t nnz_cap, int64_t nbags_cap, int F) {
     seg_sort_free(ws);
@@ -926,16 +1005,22 @@ int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipSt
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
-int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st) {
+// which: 1 = the first pass only ((kp, vp) -> (kq, vq): touches the workspace alone), 2 = the second pass only ((kq, vq) ->
+// (keys_out, vals_out)), 3 = both
+int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st, int which) {
     if (n + (int64_t)ws.F * RS_TILE > ws.cap) return ps_set_err(PS_E_BAD_ARG, "seg_sort_pairs: n=%lld > cap", (long long)n);
     if (n <= 0) return PS_OK;
     const int grid = (int)cdiv(n, RS_TILE) + ws.F;         // upper bound on the tiles of the padded layout
     SegSortArgs a{ws.F, ws.ftotal, row_base_dev, ws.ftot, ws.tcounts};
+    if (which & 1) {
     hipLaunchKernelGGL(k_seg_hist, dim3(grid), dim3(RS_TPB), 0, st, ws.kp, 0, a, stamp_next("radix_hist"));
     hipLaunchKernelGGL(k_seg_scatter<false>, dim3(grid), dim3(RS_TPB), 0, st, ws.kp, ws.vp, ws.kq, ws.vq, 0, a, stamp_next("radix_scatter"));
+    }
     a.ftot = ws.ftot + (size_t)ws.F * SG_ND;
+    if (which & 2) {
     hipLaunchKernelGGL(k_seg_hist, dim3(grid), dim3(RS_TPB), 0, st, ws.kq, SG_DB, a, stamp_next("radix_hist"));
     hipLaunchKernelGGL(k_seg_scatter<true>, dim3(grid), dim3(RS_TPB), 0, st, ws.kq, ws.vq, keys_out, vals_out, SG_DB, a, stamp_next("radix_scatter"));
+    }
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
@@ -948,9 +1033,14 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
         return PS_OK;
     }
     const int nblk = cdiv(n, RS_TILE);
+    if (g_seg_fused && ws.seg_pub) {
+        if (++ws.seg_seq == 0) ++ws.seg_seq;
+        hipLaunchKernelGGL(k_seg_fused, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.seg_pub, ws.seg_seq, seg_start, seg_id, nseg_dev, stamp_next("seg_emit"));
+    } else {
     hipLaunchKernelGGL(k_seg_count, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads);
     hipLaunchKernelGGL(k_seg_emit, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads,
                        seg_start, seg_id, nseg_dev, stamp_next("seg_emit"));
+    }
     if (long_list)      // at most n / (long_min + 1) runs can be that long; one thread per run, any order
         hipLaunchKernelGGL(k_long_runs, dim3(cdiv(n, 256)), dim3(256), 0, st, seg_start, nseg_dev, long_list, (uint32_t)long_min);
     HIPCHK(hipGetLastError());

@@ -96,6 +96,7 @@ struct SortWorkspace {
     uint32_t *blk_heads = nullptr;                      // [nblk]
     uint32_t *totals = nullptr;                         // [2048] keys per digit of the current pass
     uint32_t *hi = nullptr;                             // [passes][digits][superblocks] second level of counts (scan-free passes)
+    unsigned long long *seg_pub = nullptr; uint32_t seg_seq = 0;     // build_segments in one launch: per-workgroup head counts tagged with the launch's number (look-back)
     int64_t cap = 0;
     int nblk = 0;
 };
@@ -114,8 +115,8 @@ int64_t seg_sort_bytes(const SegSortWs &ws);
 int seg_sort_tile();
 bool seg_sort_fits(const int64_t *rows_per_field, int F);
 int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipStream_t st);
-int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st);
-extern int g_mh_seg_sort;
+int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st, int which = 3);
+extern int g_mh_seg_sort, g_mh_presort, g_mh_prio;
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap);
 void sort_ws_free(SortWorkspace &ws);
 // Stable LSD radix sort of (key, val) pairs on `key_bits` low bits.
@@ -276,6 +277,6 @@ extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
-extern int g_plan_fused, g_shard_sort_defer, g_sort_layer, g_plan_mid;
+extern int g_plan_fused, g_shard_sort_defer, g_sort_layer, g_plan_mid, g_seg_fused;
 extern int g_rccl_force, g_blk_factor, g_blk_cap, g_push_grouped_max_mb, g_comm_timing;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

@@ -280,6 +280,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
     }
     if (nnz < 0 || nnz > m->nnz_cap) return ps_set_err(PS_E_BAD_ARG, "nnz %lld exceeds max_nnz %lld", (long long)nnz, (long long)m->nnz_cap);
     m->cur_B = b->B; m->cur_nnz = nnz;
+    m->cur_on_device = b->on_device != 0;
     if (b->on_device) {
         m->cur_ids = b->ids; m->cur_offsets = b->offsets; m->cur_dense = b->dense;
         m->cur_labels = b->labels; m->cur_wide = b->wide_ids;
@@ -342,7 +343,8 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // Raised wave priority for the step's GEMMs and head (s_setprio, kernels_gemm.hip): where the critical path is the FC chain
 // (single-hot: fused and sharded step).  A multi-hot step is bound by its sort chain and the sum of its kernels, and the
 // priority takes from exactly those: 0.387 against 0.382 ms.
-static bool gemm_prio(const ps_model *m) { return g_main_prio && m->cur_offsets == nullptr; }
+int g_mh_prio = 0;      // ps_tune_set("mh_prio", 1): raised wave priority for the GEMMs and the head of a MULTI-HOT step too (its sort chain left the critical path with mh_presort)
+static bool gemm_prio(const ps_model *m) { return g_main_prio && (m->cur_offsets == nullptr || g_mh_prio); }
 
 // FcLayer.backward arguments of the out = 1 layer (layer/FcLayer.java:93-110): delta_prev = W^T delta (outer
 // product) and dW/db (column sums over the batch) in one pass over the layer's input instead of two sliver GEMMs
@@ -414,7 +416,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     const bool keys_early = g_keys_early && train && !m->sh.active && m->cur_offsets && side_stream(m, 0) != st;
     // ... and the partition by FIELD costs no radix pass (round 4, kernels_sort.hip k_bag_scan): a column scan of the bag lengths, the
     // key kernel writes (id, bag) at the entry's place among its field's entries, two 9-bit passes sort every field on its own
-    bool seg_sort = false;
+    bool seg_sort = false, presort = false;
     if (keys_early) {
         if (m->seg_fits < 0) {          // (the tables' shapes do not change: decided once)
             std::vector<int64_t> rows_f((size_t)c.F);
@@ -432,12 +434,28 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // everything else that shares the memory system with it, and the key kernel -- with it the whole sort chain -- starts
         // behind it: 0.400 against 0.391 ms.  It reads the batch's offsets only and could run beside the PREVIOUS step's
         // embedding update -- but a device batch is valid in the order of the store's stream, which side chain 0 joins only here.)
-        if (seg_sort) { Prof pf(m, "emb_bag_scan"); PSCHK(seg_sort_scan(m->seg, m->cur_offsets, B, c.F, st)); }
-        PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
+        // Round 5 (mh_presort): for a device-resident batch the scan, the key kernel and the sort's FIRST pass touch nothing but the
+        // batch and the sort's own workspace -- they go to side chain 0 WITHOUT a join with the training stream, i.e. they run while
+        // the PREVIOUS step's backward (chunk partials, per-key reduce + Ftrl: latency-bound, a quarter of the HBM rate) still runs,
+        // as far ahead as the host is.  The second pass writes the arrays that backward reads (sorted pairs, segments): the join with
+        // the training stream sits in front of it.  (A device batch is complete when it is handed over: ps_native.h ps_batch_t.)
+        presort = seg_sort && g_mh_presort && m->cur_on_device && !m->profile && m->multi_stream && !c.use_graph && side_stream(m, 0) != st;
+        // (host batches are staged in the training stream's order: they keep the join in front of the key kernel)
+        // (mh_presort = 2: held back until the previous step's embedding backward has STARTED -- beside the FC chain of that step,
+        //  where an idle side chain 0 would otherwise start them at once, they slow its GEMMs: 0.402 against 0.388 ms)
+        if (presort && g_mh_presort >= 2 && m->emb_started_valid && m->dev_ok)
+            PSCHK(launch_spin_until(m->start_flag + 2, m->emb_started_epoch, side_stream(m, 0), s->werr(), 16));
+        if (seg_sort) { Prof pf(m, "emb_bag_scan"); PSCHK(seg_sort_scan(m->seg, m->cur_offsets, B, c.F, presort ? side_stream(m, 0) : st)); }
+        if (!presort) PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
         if (seg_sort) {
             Prof pf(m, "emb_keys");
             PSCHK(launch_emb_keys_seg(e, m->seg.pre, m->seg.ftotal, seg_sort_tile(), m->seg.kp, m->seg.vp, side_stream(m, 0)));
         } else { Prof pf(m, "emb_keys"); PSCHK(launch_emb_keys(e, side_stream(m, 0))); }
+        if (presort) {
+            Prof pf(m, "emb_sort");
+            PSCHK(seg_sort_pairs(m->seg, m->cur_nnz, s->emb.row_base_dev, m->ws.keys_alt, m->ws.vals_alt, side_stream(m, 0), 1));
+            PSCHK(fork(m, st, side_stream(m, 0)));      // the previous step's backward reads what the second pass overwrites
+        }
         e.key_out = nullptr; e.ent_bag = nullptr;
     }
     m->seg_sorted = seg_sort;
@@ -485,10 +503,15 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         m->sh.flat_pending = false;
     }
     if (fwd_lo.stop_event && !fwd_lo.launched) HIPCHK(hipEventRecord(fwd_lo.stop_event, st));
+    // mh_presort = 3: the sort's second half (second pass, run boundaries) is released by the first forward GEMM's START, like the
+    // single-hot field sort: launched right behind the join it ran beside the gather (its histogram pass 37 us instead of 10) and
+    // its 806-workgroup scatter was being placed when the first GEMM arrived -- that GEMM started 20 us after the gather's end
+    const bool mh_late = presort && g_mh_presort == 3 && m->dev_ok && !c.use_graph && !(nfc == 1 && s->fc[0].N == 1);
     auto enqueue_sort = [&]() -> int {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);
-        if (keys_early) {}
+        if (mh_late) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss, s->werr(), 17));
+        else if (keys_early) {}
         else if (sort_dev) PSCHK(launch_spin_until(m->start_flag + 4, m->fwd_epoch, ss, s->werr(), 4));
         else if (fwd_ev) PSCHK(wait_event(m, ss, fwd_ev)); else PSCHK(fork(m, st, ss));
         const int64_t nnz = m->cur_nnz;
@@ -515,7 +538,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
                 // through the sort saves the entry -> bag indirection (a random 4-byte load per entry) in both backward
                 // kernels.  ent_bag is consumed as ping-pong storage here.
                 if (m->cur_offsets && m->seg_sorted) {
-                    PSCHK(seg_sort_pairs(m->seg, nnz, s->emb.row_base_dev, m->ws.keys_alt, m->ws.vals_alt, ss));
+                    PSCHK(seg_sort_pairs(m->seg, nnz, s->emb.row_base_dev, m->ws.keys_alt, m->ws.vals_alt, ss, presort ? 2 : 3));
                     m->sorted_keys = m->ws.keys_alt; m->sorted_ents = m->ws.vals_alt;
                 } else if (m->cur_offsets)
                     PSCHK(radix_sort_pairs(m->ws, m->keys, m->ent_bag, nnz, bits_for(s->emb.total_rows), false, &m->sorted_keys,
@@ -537,12 +560,12 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         return PS_OK;
     };
     if (sort_dev) m->field_sorted = true;            // (dev_release() below looks at it before the sort is enqueued)
-    else if (train && !m->sh.active) PSCHK(enqueue_sort());
+    else if (train && !m->sh.active && !mh_late) PSCHK(enqueue_sort());
     // late: the sort is not released by the first forward GEMM but enqueued by the backward behind the first delta GEMM's
     // release -- beside the forward GEMMs its 26 workgroups share CUs with fc_fwd1's one-workgroup-per-CU grid
     const bool sort_late = sort_dev && g_sort_late;
     m->sort_deferred = false;
-    bool sort_due = sort_dev && !sort_late;
+    bool sort_due = (sort_dev && !sort_late) || mh_late;
     // sharded worker: the first forward GEMM announces its start too -- everything of this step in front of it (the id and
     // row exchanges, the gather) is then done, which is what the NEXT step's plan waits for on side chain 0
     bool fwd_flag_due = train && m->sh.active && m->dev_ok && !c.use_graph && !m->profile && m->multi_stream;
@@ -951,6 +974,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     const bool tail_defer = tail_fused && tail_join && g_tail_defer && !m->sh.active && apply;
     if (tail_fused && tail_join && !tail_defer) { emb_lo.wait = m->start_flag + 3; emb_lo.wait_val = m->start_epoch; }
     { Prof pf(m, "emb_bwd_update"); PSCHK(launch_emb_bwd(g, st, &emb_lo, werr)); }
+    m->emb_started_valid = tail_dev && emb_lo.launched; m->emb_started_epoch = m->start_epoch;
     if (tail_dev && !emb_lo.launched)       // nothing was launched (an empty batch): announce the start ourselves
         PSCHK(launch_flag_set(m->start_flag + 2, m->start_epoch, st));
     // The dense update runs LAST ON THE MAIN CHAIN.  A stream that reaches a wait before its event has fired resumes

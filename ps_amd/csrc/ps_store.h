@@ -142,6 +142,8 @@ struct ps_model {
     const int64_t *cur_ids = nullptr, *cur_offsets = nullptr, *cur_wide = nullptr;
     const float *cur_dense = nullptr, *cur_labels = nullptr;
     int cur_B = 0; int64_t cur_nnz = 0; bool fwd_done = false, bwd_done = false;
+    bool emb_started_valid = false; unsigned int emb_started_epoch = 0;    // the last backward's embedding launch raises start_flag[2] to this when it starts
+    bool cur_on_device = false;        // the staged batch is the caller's device-resident batch (complete when handed over: ps_native.h)
     // embedding backward workspaces
     SortWorkspace ws;
     int seg_fits = -1;                 // do the tables' shapes allow the segmented sort (kernels_sort.hip seg_sort_fits); -1: not asked yet

@@ -504,3 +504,46 @@ def test_multi_hot_steps_enqueued_back_to_back(seg):
     for other in res[1:]:
         for x, y in zip(res[0], other):
             np.testing.assert_array_equal(x, y)
+
+
+def test_multi_hot_presort_and_one_launch_segments_change_no_bit():
+    """Round 5: the multi-hot step's scan / key kernel / first sort pass run on side chain 0 WITHOUT a join with the training
+    stream (beside the previous step's backward: ps_tune_set("mh_presort"), modes 0..3 of kernels_sort.hip), and the run boundaries
+    come from ONE look-back launch (k_seg_fused: "seg_fused").  60 steps enqueued back to back under every combination leave the same tables, bit for bit --
+    batches of very different sizes in a row, so that a sort that started early on the wrong buffers would show."""
+    import ps_amd
+    from ps_amd import native as N
+    F, D, X, fc, V, B = 5, 16, 2, [32, 1], 4000, 700
+    rng = np.random.default_rng(78)
+    data = []
+    for k in range(6):
+        lens = rng.poisson(3 + 5 * (k % 3), size=B * F)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = np.minimum(rng.zipf(1.2, int(offsets[-1])) - 1, V - 1).astype(np.int64)
+        data.append((ids, offsets, rng.standard_normal((B, X)).astype(f32), (rng.random(B) < 0.3).astype(f32)))
+    nnz_max = max(int(d[1][-1]) for d in data)
+    res = []
+    L = N.lib()
+    try:
+        for knobs in ({}, {"mh_presort": 0}, {"mh_presort": 1}, {"mh_presort": 2}, {"seg_fused": 0}, {"mh_presort": 0, "seg_fused": 0}, {"mh_presort": 3, "mh_prio": 1}):
+            for k, v in knobs.items():
+                N.check(L.ps_tune_set(k.encode(), v))
+            kv = ps_amd.KVStore(0, SEED)
+            kv.create_embedding([V] * F, D)
+            kv.set_updater("emF", ps_amd.FtrlUpdater())
+            gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, max_nnz=nnz_max)
+            bs = [ps_amd.DeviceBatch(kv, ids, Xd, Y, None, offsets) for ids, offsets, Xd, Y in data]
+            for i in range(60):
+                gm.train_async(bs[i % len(bs)])
+            kv.sync()
+            res.append([kv.get_rows(f, np.arange(V)) for f in range(F)] + [kv.get_rows(f, np.arange(V), 1) for f in range(F)] + [kv.get("fc%d.weights" % i) for i in range(2)])
+            for b in bs:
+                b.close()
+            gm.close(); kv.close()
+            for k in knobs:
+                L.ps_tune_set(k.encode(), {"mh_presort": 3, "mh_prio": 0}.get(k, 1))
+    finally:
+        L.ps_tune_set(b"mh_presort", 3); L.ps_tune_set(b"seg_fused", 1); L.ps_tune_set(b"mh_prio", 0)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            np.testing.assert_array_equal(x, y)
