@@ -82,14 +82,14 @@ def test_config1_full_size_step_vs_oracle(orc, idgen):
     ch = Chain(True, F, D, X, fc, WS)
     ch.load_fc([kv_before["fc%d.weights" % i] for i in range(3)], [kv_before["fc%d.bias" % i] for i in range(3)])
     c64 = ch.step(E, Xd, Y, Wd, lambda f, ids: w0[f][np.searchsorted(uniq[f], ids)], update=False)
-    e_loss = bound(loss_g, loss_o, c64["loss"], "loss vs the float64 chain")
-    e_p = bound(gm.p(B), om.p(), c64["P"], "P vs the float64 chain")
+    e_loss = bound(loss_g, loss_o, c64["loss"], "loss vs the float64 chain", floor=c64["e_loss"])
+    e_p = bound(gm.p(B), om.p(), c64["P"], "P vs the float64 chain", floor=c64["e_P"])
     gm.backward()
     layerwise_f64(gm, kv_before, E, Y, F, D, X, fc, True)
     e_d = [bound(gm.delta(2 + li), om.delta(2 + li)[:, :F * D] * (om.act(0) > 0) if li == 0 else om.delta(2 + li), c64["delta"][li],
-                 "delta into fc%d vs the float64 chain" % li, floor=8 * EPS * c64["mag_delta"][li]) for li in range(3)]
+                 "delta into fc%d vs the float64 chain" % li, floor=c64["e_delta"][li]) for li in range(3)]
     e_w = [bound(gm.fc_grad(li), om.grad("fc%d.weights" % li), c64["dW"][li].reshape(-1), "dW%d vs the float64 chain" % li,
-                 floor=8 * EPS * c64["mag_dW"][li].reshape(-1)) for li in range(3)]
+                 floor=c64["e_dW"][li].reshape(-1)) for li in range(3)]
     import json, os
     try:        # (max |gpu - f64|, max |oracle - f64|) on the record
         os.makedirs("gpurun_out", exist_ok=True)
@@ -130,9 +130,9 @@ def test_config1_full_size_step_vs_oracle(orc, idgen):
     for f in range(0, F, 5):
         wo = np.stack([st.get(orc.emb_key(f, float(i))) for i in uniq[f][:400]])
         w64 = np.stack([ch.rows[f][int(i)][0] for i in uniq[f][:400]])
-        bound(kv.get_rows(f, uniq[f][:400]), wo, w64, "rows of field %d after the step" % f)
+        bound(kv.get_rows(f, uniq[f][:400]), wo, w64, "rows of field %d after the step" % f, floor=ch.floor_rows(f, uniq[f][:400]))
     for li in range(3):
-        bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after the step" % li)
+        bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after the step" % li, floor=ch.floor_W(li).reshape(-1))
     gm.close(); kv.close()
 
 
@@ -171,12 +171,14 @@ def test_config0_ctr_shape_b1000_from_libsvm_text(orc, tmp_path):
         sl = slice(step * B, (step + 1) * B)
         lo = om.train(Eo[sl].astype(f32), Xo[sl], Yo[sl], None, do_update=False)
         lg = gm.forward(b)
+        if step:        # (the floors' input: how far the GPU's parameters are from the chain's at the start of this step)
+            ch.anchor([kv.get("fc%d.weights" % i) for i in range(3)], [kv.get("fc%d.bias" % i) for i in range(3)], lambda f, ids: kv.get_rows(f, ids))
         c64 = ch.step(Eo[sl].astype(np.int64), Xo[sl], Yo[sl], None, lambda f, ids: kv.get_rows(f, ids))
         if step == 0:
             np.testing.assert_array_equal(gm.act(1), om.act(1))            # parser + gather + concat: bit-exact
         # end to end: |gpu - f64| <= 1e-5 |f64| + 4 |oracle - f64| (the oracle's own f32 chain as the yardstick)
-        bound(lg, lo, c64["loss"], "loss step %d" % step)
-        bound(gm.p(B), om.p(), c64["P"], "P step %d" % step)
+        bound(lg, lo, c64["loss"], "loss step %d" % step, floor=c64["e_loss"])
+        bound(gm.p(B), om.p(), c64["P"], "P step %d" % step, floor=c64["e_P"])
         kvb = {"fc%d.%s" % (i, k): kv.get("fc%d.%s" % (i, k)) for i in range(3) for k in ("weights", "bias")}
         gm.backward()
         layerwise_f64(gm, kvb, Eo[sl].astype(np.int64), Yo[sl], F, D, X, fc, False)   # every contraction: 1e-5 + f32 floor
@@ -189,7 +191,7 @@ def test_config0_ctr_shape_b1000_from_libsvm_text(orc, tmp_path):
                 np.testing.assert_array_equal(g[i], orc.emb_geff(dx[ks, f * D:(f + 1) * D], orc.GRAD_COMPAT, 0))
         gm.update(); om.apply_update()
         for li in range(3):
-            bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after step %d" % (li, step))
+            bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after step %d" % (li, step), floor=ch.floor_W(li).reshape(-1))
     ds.close(); gm.close(); kv.close()
 
 

@@ -210,6 +210,9 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
         loss_o = om.train(E.astype(f32), Xd, Y, None if Wd is None else Wd.astype(f32), do_update=False)
         loss_g = gm.forward({"E": E, "X": Xd, "Y": Y, "W": Wd})
         # (ids the chain has not seen were never trained on the GPU either: their rows are still the initial ones)
+        if step:        # the parameters the GPU holds at the start of this step: their distance to the chain's is the floors' input (f64_chain.Chain)
+            ch.anchor([kv_before["fc%d.weights" % i] for i in range(nfc)], [kv_before["fc%d.bias" % i] for i in range(nfc)],
+                      lambda f, ids: kv.get_rows(f, ids), kv.get_wide(np.arange(97)) if wide else None, kv.get("wide.bias") if wide else None)
         c64 = ch.step(E, Xd, Y, Wd, lambda f, ids: kv.get_rows(f, ids))
         # ---- forward: gather + relu + concat are copies -> bit-exact (when weights are)
         if step == 0:
@@ -222,8 +225,8 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
                       [kv_before["fc%d.weights" % i] for i in range(nfc)], [kv_before["fc%d.bias" % i] for i in range(nfc)],
                       [st_before["fc%d.weights" % i] for i in range(nfc)] if step else None, [st_before["fc%d.bias" % i] for i in range(nfc)] if step else None,
                       e_wide=e_wide, tag="step %d: " % step)
-        worst["P"] = bound(gm.p(B), om.p(), c64["P"], "P (step %d)" % step)
-        worst["loss"] = bound(loss_g, loss_o, c64["loss"], "loss (step %d)" % step)
+        worst["P"] = bound(gm.p(B), om.p(), c64["P"], "P (step %d)" % step, floor=c64["e_P"])
+        worst["loss"] = bound(loss_g, loss_o, c64["loss"], "loss (step %d)" % step, floor=c64["e_loss"])
         gm.backward()
         # ---- every FC contraction against float64 on ITS OWN inputs: 1e-5 relative + f32 roundoff floor
         layerwise_f64(gm, kv_before, E, Y, F, D, X, fc, wide)
@@ -233,11 +236,11 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
             d_o = om.delta(2 + li)
             if li == 0:
                 d_o = d_o[:, :F * D] * (om.act(0) > 0)       # our dx is already relu'-masked, embedding columns only
-            worst["delta"] = bound(gm.delta(2 + li), d_o, c64["delta"][li], "delta into fc%d (step %d)" % (li, step), floor=8 * EPS * c64["mag_delta"][li])
+            worst["delta"] = bound(gm.delta(2 + li), d_o, c64["delta"][li], "delta into fc%d (step %d)" % (li, step), floor=c64["e_delta"][li])
         for li in range(nfc):
             worst["dW"] = bound(gm.fc_grad(li), om.grad("fc%d.weights" % li), c64["dW"][li].reshape(-1), "dW%d (step %d)" % (li, step),
-                                floor=8 * EPS * c64["mag_dW"][li].reshape(-1))
-            worst["db"] = bound(gm.fc_grad(li, True), om.grad("fc%d.bias" % li), c64["db"][li], "db%d (step %d)" % (li, step), floor=8 * EPS * c64["mag_db"][li])
+                                floor=c64["e_dW"][li].reshape(-1))
+            worst["db"] = bound(gm.fc_grad(li, True), om.grad("fc%d.bias" % li), c64["db"][li], "db%d (step %d)" % (li, step), floor=c64["e_db"][li])
         # ---- per-key embedding gradient: BIT-EXACT against the oracle's reduction of OUR delta
         dx = gm.delta(2)
         g_gpu = []
@@ -250,7 +253,7 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
                 np.testing.assert_array_equal(g[i], orc.emb_geff(gk, orc.GRAD_COMPAT, 0), err_msg="emF%d.%d" % (f, idv))
             ids64, g64 = c64["geff"][f]
             np.testing.assert_array_equal(ids, ids64)
-            worst["g_eff"] = bound(g, np.stack([om.grad(orc.emb_key(f, float(idv))) for idv in ids]), g64, "per-key gradients of field %d (step %d)" % (f, step))
+            worst["g_eff"] = bound(g, np.stack([om.grad(orc.emb_key(f, float(idv))) for idv in ids]), g64, "per-key gradients of field %d (step %d)" % (f, step), floor=c64["e_geff"][f])
             g_gpu.append(g)
         gm.update()
         om.apply_update()
@@ -267,15 +270,16 @@ def test_step_parity(orc, wide, F, D, X, fc, V, B, zipf):
             w1 = kv.get_rows(f, uniq[f])
             wo = np.stack([st.get(orc.emb_key(f, float(i))) for i in uniq[f]])
             w64 = np.stack([ch.rows[f][int(i)][0] for i in uniq[f]])
-            worst["rows"] = bound(w1, wo, w64, "embedding rows of field %d after step %d" % (f, step))
+            worst["rows"] = bound(w1, wo, w64, "embedding rows of field %d after step %d" % (f, step), floor=ch.floor_rows(f, uniq[f]))
         for li in range(nfc):
-            worst["W"] = bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after step %d" % (li, step))
-            worst["b"] = bound(kv.get("fc%d.bias" % li), st.get("fc%d.bias" % li), ch.b[li], "fc%d.bias after step %d" % (li, step))
+            worst["W"] = bound(kv.get("fc%d.weights" % li), st.get("fc%d.weights" % li), ch.W[li].reshape(-1), "fc%d.weights after step %d" % (li, step),
+                               floor=ch.floor_W(li).reshape(-1))
+            worst["b"] = bound(kv.get("fc%d.bias" % li), st.get("fc%d.bias" % li), ch.b[li], "fc%d.bias after step %d" % (li, step), floor=ch.floor_b(li))
         if wide:
             touched = np.unique(E % 97)
             wo = np.array([st.get(orc.wide_key(float(i)))[0] for i in touched], f32)
-            worst["wide"] = bound(kv.get_wide(touched), wo, ch.ww[touched], "wide weights after step %d" % step)
-            worst["wide.bias"] = bound(kv.get("wide.bias"), st.get("wide.bias"), ch.wb, "wide.bias after step %d" % step)
+            worst["wide"] = bound(kv.get_wide(touched), wo, ch.ww[touched], "wide weights after step %d" % step, floor=ch.floor_wide(touched))
+            worst["wide.bias"] = bound(kv.get("wide.bias"), st.get("wide.bias"), ch.wb, "wide.bias after step %d" % step, floor=ch.floor_wide_bias())
     # (max |gpu - f64|, max |oracle - f64|) of the last step, per kind of quantity: on the record
     import json, os
     try:
@@ -618,6 +622,9 @@ def test_against_committed_golden(name):
         p = "s%d_" % s
         E = z[p + "E"]
         loss = gm.forward({"E": E, "X": z[p + "X"], "Y": z[p + "Y"], "W": (E % WS) if wide else None})
+        if s:
+            ch.anchor([kv.get("fc%d.weights" % l) for l in range(len(fc))], [kv.get("fc%d.bias" % l) for l in range(len(fc))],
+                      lambda f, ids: kv.get_rows(f, ids), kv.get_wide(np.arange(WS)) if wide else None, kv.get("wide.bias") if wide else None)
         c64 = ch.step(E, z[p + "X"], z[p + "Y"], (E % WS) if wide else None, lambda f, ids: z["init_emb"][f][ids])
         if s == 0:
             np.testing.assert_array_equal(gm.act(0), z[p + "embA"])
@@ -636,24 +643,25 @@ def test_against_committed_golden(name):
         gm.backward()
         # end to end: against the float64 chain, the stored (restatement) values' own distance to it as the yardstick
         for l in range(len(fc)):
-            bound(gm.fc_grad(l), z[p + "fc%d_dW" % l], c64["dW"][l].reshape(-1), "dW%d" % l, floor=8 * EPS * c64["mag_dW"][l].reshape(-1))
-            bound(gm.fc_grad(l, True), z[p + "fc%d_db" % l], c64["db"][l], "db%d" % l, floor=8 * EPS * c64["mag_db"][l])
+            bound(gm.fc_grad(l), z[p + "fc%d_dW" % l], c64["dW"][l].reshape(-1), "dW%d" % l, floor=c64["e_dW"][l].reshape(-1))
+            bound(gm.fc_grad(l, True), z[p + "fc%d_db" % l], c64["db"][l], "db%d" % l, floor=c64["e_db"][l])
         for f in range(F):
             ids, g = gm.emb_grads(f)
             np.testing.assert_array_equal(ids, np.nonzero(z[p + "emb_touched"][f])[0])
             np.testing.assert_array_equal(ids, c64["geff"][f][0])
-            bound(g, z[p + "emb_grad"][f][ids], c64["geff"][f][1], "emb grad f%d" % f)
+            bound(g, z[p + "emb_grad"][f][ids], c64["geff"][f][1], "emb grad f%d" % f, floor=c64["e_geff"][f])
         gm.update()
         for f in range(F):
             have = np.nonzero(z[p + "emb_have"][f])[0]
             w64 = np.stack([ch.rows[f][int(i)][0] if int(i) in ch.rows[f] else z["init_emb"][f][i].astype(np.float64) for i in have])
-            bound(kv.get_rows(f, have), z[p + "emb_W"][f][have], w64, "rows of field %d after step %d" % (f, s))
+            fl = np.stack([ch.floor_rows(f, [i])[0] if int(i) in ch.rows[f] else np.zeros(D) for i in have])      # (rows never trained: initial values, no floor)
+            bound(kv.get_rows(f, have), z[p + "emb_W"][f][have], w64, "rows of field %d after step %d" % (f, s), floor=fl)
         for l in range(len(fc)):
-            bound(kv.get("fc%d.weights" % l), z[p + "fc%d_w" % l], ch.W[l].reshape(-1), "fc%d.weights after step %d" % (l, s))
-            bound(kv.get("fc%d.bias" % l), z[p + "fc%d_b" % l], ch.b[l], "fc%d.bias after step %d" % (l, s))
+            bound(kv.get("fc%d.weights" % l), z[p + "fc%d_w" % l], ch.W[l].reshape(-1), "fc%d.weights after step %d" % (l, s), floor=ch.floor_W(l).reshape(-1))
+            bound(kv.get("fc%d.bias" % l), z[p + "fc%d_b" % l], ch.b[l], "fc%d.bias after step %d" % (l, s), floor=ch.floor_b(l))
         if wide:
-            bound(kv.get_wide(np.arange(WS)), z[p + "wide_w"], ch.ww, "wide weights after step %d" % s)
-            bound(kv.get("wide.bias"), z[p + "wide_bias"], ch.wb, "wide.bias after step %d" % s)
+            bound(kv.get_wide(np.arange(WS)), z[p + "wide_w"], ch.ww, "wide weights after step %d" % s, floor=ch.floor_wide())
+            bound(kv.get("wide.bias"), z[p + "wide_bias"], ch.wb, "wide.bias after step %d" % s, floor=ch.floor_wide_bias())
     gm.close(); kv.close()
 
 
