@@ -727,7 +727,14 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         //  behind it: a wait on an event that fired long ago still costs the training stream ~3.5 us, round 2)
         LaunchOpts lo;
         if (sh.slot_ev && sh.slot_flag && m->dev_ok) { lo.wait = m->start_flag + 10; lo.wait_val = sh.slot_epoch; }
-        PSCHK(shard_serve_pull_lists(s, rows_p, rc.data(), nsh, sh.x_rows_out, &lo));
+        GatherSlots gsl;
+        memset(&gsl, 0, sizeof gsl);
+        if (sh.slots_due) {        // (the plan's slot kernel rides on this launch: shard_plan_enqueue_tail)
+            gsl.keys = sh.slots_keys; gsl.nnz = sh.slots_nnz; gsl.bitmap = sh.bitmap; gsl.word_prefix = sh.word_prefix; gsl.slot = sh.slot;
+            gsl.wait = m->start_flag + 7; gsl.wait_val = sh.plan_epoch;
+            sh.slots_due = false;
+        }
+        PSCHK(shard_serve_pull_lists(s, rows_p, rc.data(), nsh, sh.x_rows_out, &lo, &gsl));
         if (lo.wait && lo.launched) sh.slot_ev = nullptr;        // (else ps_shard_forward_backward waits for the event)
     }
     comm_select(comm, 0, alias);

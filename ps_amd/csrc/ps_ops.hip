@@ -281,6 +281,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "seg_fused") == 0) { g_seg_fused = value; return PS_OK; }
     if (strcmp(knob, "mh_presort") == 0) { g_mh_presort = value; return PS_OK; }
     if (strcmp(knob, "mh_prio") == 0) { g_mh_prio = value; return PS_OK; }
+    if (strcmp(knob, "slots_in_gather") == 0) { g_slots_in_gather = value; return PS_OK; }
     if (strcmp(knob, "shard_overlap") == 0) { g_shard_overlap = value; return PS_OK; }
     if (strcmp(knob, "radix_scan_free") == 0) { g_radix_scan_free = value; return PS_OK; }
     if (strcmp(knob, "gemm_8w") == 0) { g_gemm_8w = value; return PS_OK; }

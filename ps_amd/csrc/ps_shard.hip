@@ -295,12 +295,23 @@ struct PeerLists {
 };
 // end_wait: the first workgroup ends only once *end_wait reached end_val (the sharded step: "the slots of this step's
 // plan are written" -- the gather is the launch in front of the forward, and holds the join with side chain 0 for it)
+// gs.keys != NULL (round 5): workgroups [gather_blocks, gridDim.x) compute the slots of the step this gather serves (k_plan_slots'
+// arithmetic) -- they wait at their start for "the plan head is done" (long since: it ran beside the previous step's forward)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, PeerLists pl, int64_t n,
                                                      int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err, unsigned long long *ts,
-                                                     const unsigned int *end_wait, unsigned int end_val, WaitBound bound) {
+                                                     const unsigned int *end_wait, unsigned int end_val, WaitBound bound, GatherSlots gs, int gather_blocks) {
     EndWait end_wait_scope(end_wait, end_val, bound);
     StampScope stamp_scope(ts);
+    if ((int)blockIdx.x >= gather_blocks) {
+        start_wait(gs.wait, gs.wait_val, bound);
+        const int64_t p = (int64_t)((int)blockIdx.x - gather_blocks) * 256 + threadIdx.x;
+        if (p < gs.nnz) {
+            const uint32_t key = gs.keys[p], wd = key >> 5;
+            gs.slot[p] = gs.word_prefix[wd] + (uint32_t)__popc(gs.bitmap[wd] & ((1u << (key & 31u)) - 1u));
+        }
+        return;
+    }
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int part = (int)(t % LPR);
@@ -314,6 +325,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W
 }
 
 }  // namespace
+int g_slots_in_gather = 1;      // ps_tune_set("slots_in_gather", 0): the plan's slot kernel behind a spinner on side chain 0 + a flag setter again (round 4)
 int g_plan_sort = 0;       // ps_tune_set("plan_sort", 1): the sort-based plan (A/B runs, tests of both paths)
 int g_shard_sort_defer = 1;      // ps_tune_set("shard_sort_defer", 0): the plan's field sort right behind its slots again (round 3)
 int g_plan_fused = 1;      // ps_tune_set("plan_fused", 0): count / emit / pack as three launches (round 3)
@@ -412,22 +424,36 @@ extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
 // The slot of every entry (the forward reads it ~50 us later) and the entry lists of the backward (stable sort + runs),
 // on side stream 0 beside the exchange and the forward.  k_plan_slots before the sort in stream order: the general
 // sort ping-pongs through m->keys.
-static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream_t st, hipStream_t ss) {
+// can the plan's field sort leave plan_slots_and_lists for the step's forward (Shard::sort_due)?
+static bool plan_sort_deferrable(const ps_model *m, hipStream_t ss) {
+    const bool fsort = !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, m->cfg.F);
+    return fsort && ss != m->s->stream && m->dev_ok && g_shard_sort_defer && ss == m->side[0] && !m->cfg.use_graph && !m->profile && m->multi_stream;
+}
+// by_gather: no launch at all here -- the slots are computed by the next owner-side gather's launch (Shard::slots_due), the sort by
+// the step's forward (the caller has checked plan_sort_deferrable)
+static int plan_slots_and_lists(ps_model *m, int nshards, int64_t nnz, hipStream_t st, hipStream_t ss, bool by_gather = false) {
     ps_store *s = m->s;
     ps_model::Shard &sh = m->sh;
     const int F = m->cfg.F;
     const bool off_main = ss != s->stream;        // (the forward, on the training stream, waits for the slots)
+    sh.slots_due = false;
+    if (by_gather) {
+        sh.slots_due = true; sh.slots_keys = m->keys; sh.slots_nnz = nnz;
+        sh.slot_ev = nullptr;
+    } else {
     if (off_main) sh.slot_ev = m->events[m->next_event++ % m->events.size()];
     // (the event the forward waits for rides on the slot kernel's launch: no record packet on the side chain)
     PS_LAUNCH_EV(k_plan_slots, dim3(cdiv(nnz, 256)), dim3(256), 0, ss, (off_main && g_ext_events) ? sh.slot_ev : nullptr, m->keys, nnz, sh.bitmap,
                  sh.word_prefix, sh.slot, stamp_next("plan_slots"));
     if (off_main && !g_ext_events) HIPCHK(hipEventRecord(sh.slot_ev, ss));
+    }
     sh.slot_flag = false;
     const bool fsort = !m->cur_offsets && g_field_sort && field_sort_fits(m->cur_B, F);
     // the sort leaves this call when the step's forward can launch it behind its first GEMM's start (Shard::sort_due)
     const bool defer_sort = fsort && off_main && m->dev_ok && g_shard_sort_defer && ss == m->side[0] && !m->cfg.use_graph && !m->profile && m->multi_stream;
+    if (by_gather && !defer_sort) return ps_set_err(PS_E_STATE, "the slots were left to the gather but the sort cannot be deferred");
     unsigned int *fs_flag = nullptr;
-    if (off_main && m->dev_ok) {       // ... and a device flag: ps_shard_step hangs this join on its owner-side gather's launch
+    if (off_main && m->dev_ok && !by_gather) {       // ... and a device flag: ps_shard_step hangs this join on its owner-side gather's launch
         if (++m->start_epoch == 0) ++m->start_epoch;
         sh.slot_epoch = m->start_epoch;
         // (raised by the START of the field sort behind the slot kernel -- in order, so the slots are written -- rather than
@@ -505,6 +531,14 @@ int shard_plan_enqueue_tail(ps_model *m, int nshards, hipStream_t st) {
     if (!sh.tail_due) return PS_OK;
     sh.tail_due = false;
     hipStream_t ss = m->side[0];
+    // Round 5 (slots_in_gather): behind a plan head on the list chain nothing is launched here at all -- the slots are computed by
+    // the next step's owner-side gather (in order behind the running step's backward and push on the training stream; its slot
+    // workgroups wait for "plan head done" themselves), the field sort by that step's forward.  Three launches less per step.
+    if (g_slots_in_gather && sh.head_on_list && sh.tail_flag_due && plan_sort_deferrable(m, ss)) {
+        PSCHK(shard_flush_deferred_flag(m));          // (side chain 0's "small kernels done": a flag-setter launch of its own now)
+        sh.tail_flag_due = false;                     // (nobody waits for the push's start any more)
+        return plan_slots_and_lists(m, nshards, sh.tail_nnz, st, ss, true);
+    }
     // (one launch: raises side chain 0's pending "small kernels done" -- it is in order behind them -- then waits for the running
     //  step's push and, when the plan head ran on the list chain, for that chain's "plan head done")
     unsigned int *set = nullptr; unsigned int set_val = 0;
@@ -696,7 +730,7 @@ extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards
 }
 
 // PServer.getList for key lists that lie grouped by requesting worker (rows_p[p]: counts[p] owner-local rows)
-int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev, LaunchOpts *lo) {
+int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev, LaunchOpts *lo, const GatherSlots *gs) {
     if (lo) lo->launched = false;
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (npeers < 1 || npeers > PS_PUSH_MAX_PEERS) return ps_set_err(PS_E_BAD_ARG, "1..%d workers", PS_PUSH_MAX_PEERS);
@@ -706,15 +740,26 @@ int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int
     int64_t n = 0;
     for (int p = 0; p < npeers; ++p) { pl.start[p] = (uint32_t)n; pl.rows_p[p] = rows_p[p]; n += counts[p]; }
     pl.start[npeers] = (uint32_t)n;
-    if (n == 0) return PS_OK;
+    GatherSlots g0;
+    memset(&g0, 0, sizeof g0);
+    if (gs && gs->keys && gs->nnz > 0) g0 = *gs;
+    const bool slots = g0.keys != nullptr;
+    if (n == 0 && !slots) return PS_OK;
+    if (n == 0) {       // (nothing to gather: the slot kernel on its own, behind the wait its workgroups would have held)
+        if (g0.wait) PSCHK(launch_spin_until(g0.wait, g0.wait_val, s->stream, s->werr(), 19));
+        hipLaunchKernelGGL(k_plan_slots, dim3(cdiv(g0.nnz, 256)), dim3(256), 0, s->stream, g0.keys, g0.nnz, g0.bitmap, g0.word_prefix, g0.slot, stamp_next("plan_slots"));
+        HIPCHK(hipGetLastError());
+        return PS_OK;
+    }
     const int D = s->emb.D, vec = D % 4 == 0 ? 4 : 1, LPR = D / vec;
     const unsigned int *ew = lo ? lo->wait : nullptr;
     const unsigned int ev = lo ? lo->wait_val : 0u;
     const WaitBound wb = wait_bound(s->werr(), 104);
+    const int gb = (int)cdiv(n * LPR, 256), sb = slots ? (int)cdiv(g0.nnz, 256) : 0;
     if (vec == 4)
-        hipLaunchKernelGGL(k_gather_rows<4>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb);
+        hipLaunchKernelGGL(k_gather_rows<4>, dim3(gb + sb), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb, g0, gb);
     else
-        hipLaunchKernelGGL(k_gather_rows<1>, dim3(cdiv(n * LPR, 256)), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb);
+        hipLaunchKernelGGL(k_gather_rows<1>, dim3(gb + sb), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb, g0, gb);
     HIPCHK(hipGetLastError());
     if (lo) lo->launched = true;
     return PS_OK;

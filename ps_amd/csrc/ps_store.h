@@ -263,6 +263,9 @@ struct ps_model {
         const ps_batch_t *hook_batch = nullptr; const ps_comm_ops_t *hook_comm = nullptr;
         bool head_done = false, head_on_list = false;
         int64_t plan_nnz = 0;                                        // ids of the batch the last plan head was made for
+        // slots_due (round 5, ps_tune_set("slots_in_gather")): the plan's slot kernel did not get a launch of its own (behind a spinner on side
+        // chain 0, a flag setter behind it): the NEXT owner-side gather's launch computes the slots in extra workgroups (ps_shard.hip)
+        bool slots_due = false; const uint32_t *slots_keys = nullptr; int64_t slots_nnz = 0;
     } sh;
     // host batches: pinned staging + two device slots on a copy stream (stage_batch)
     struct HostStage {
@@ -307,8 +310,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss);   // defer_loss: 
 int enqueue_backward(ps_model *m, bool apply);
 int shard_push_reserve(ps_store *s, int npeers);   // ps_shard.hip
 bool shard_push_grouped_ok(const ps_store *s, int npeers);
+// the slot kernel's arguments when it rides on the gather's launch (Shard::slots_due); keys == NULL: none
+struct GatherSlots { const uint32_t *keys; int64_t nnz; const uint32_t *bitmap, *word_prefix; uint32_t *slot; const unsigned int *wait; unsigned int wait_val; };
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
-                           LaunchOpts *lo);       // lo: wait (an END wait of the gather's launch)
+                           LaunchOpts *lo, const GatherSlots *gs = nullptr);       // lo: wait (an END wait of the gather's launch)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
                            int is_async, bool bump_step, LaunchOpts *lo);
 int finish_step(ps_model *m, float *loss);

@@ -371,7 +371,11 @@ def test_overlap_mode_outlives_the_device_side_joins():
     np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
 
 
-@pytest.mark.parametrize("knobs", [{}, {"blk_cap": 64}, {"plan_fused": 0, "blk_cap": 64}, {"rccl_force": 2, "blk_cap": 64}])
+@pytest.mark.parametrize("knobs", [{}, {"blk_cap": 64}, {"plan_fused": 0, "blk_cap": 64}, {"rccl_force": 2, "blk_cap": 64},
+                                   # round 5: the plan head with the forward / behind the backward, the slot kernel inside the gather's launch
+                                   # or behind its own spinner -- every combination
+                                   {"plan_mid": 0}, {"slots_in_gather": 0}, {"plan_mid": 0, "slots_in_gather": 0},
+                                   {"slots_in_gather": 0, "blk_cap": 64}, {"rccl_force": 2, "slots_in_gather": 0}])
 def test_sharded_steps_with_the_one_launch_plan(knobs):
     """A key space large enough for the one-launch plan (k_plan_fused: 20 000 rows -> 4 look-back workgroups; the toy shapes
     above take the three-launch form), 60 pipelined sharded steps == 60 fused steps bit for bit -- also with wire blocks of 64
@@ -417,7 +421,7 @@ def test_sharded_steps_with_the_one_launch_plan(knobs):
             gm.close(); kv.close()
     finally:
         for k in knobs:
-            L.ps_tune_set(k.encode(), {"plan_fused": 1}.get(k, 0))
+            L.ps_tune_set(k.encode(), {"plan_fused": 1, "plan_mid": 1, "slots_in_gather": 1}.get(k, 0))
     a, b = res
     assert a[3] == b[3] == 60
     for x, y in zip(a[0] + a[1], b[0] + b[1]):

@@ -13,6 +13,6 @@ PS_STAMPS=$O/shard_stamps.json timeout 200 python bench.py --sharded --wire-cost
 python tools/shard_timeline.py $O/shard_stamps.json > $O/shard_gpu_timeline.txt 2>&1; rm -f $O/shard_stamps.json; cat $O/shard_gpu_timeline.txt
 if [ $# -gt 0 ]; then STEPS=1500 timeout 500 bash tools/shard_ab.sh 2 "" "$@" 2>&1 | tee $O/ab.txt; fi
 # the driver's view: the 20-step sharded_n1 leg of the default bench line (child process), under the same knob sets
-for r in 1 2 3; do for k in "" "$@"; do printf '%-24s ' "[leg20 $k]"; PS_TUNE="$k" timeout 200 python bench.py --leg sharded_n1 --steps 20 2>/dev/null | python -c "
+for r in 1 2; do for k in "" "$@"; do printf '%-24s ' "[leg20 $k]"; PS_TUNE="$k" timeout 200 python bench.py --leg sharded_n1 --steps 20 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('collective_device_us'))"; done; done 2>&1 | tee $O/leg20.txt
