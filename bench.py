@@ -244,6 +244,9 @@ def run_single(args):
     # stands for runs for millions of steps -- the timed region starts on the clocks it would run on
     for i in range(args.priming):
         gm.train_async(batches[i % nb])
+    if args.priming:
+        gm.sync()       # (a wait between the priming and the warm-up: a short region right behind a LONG asynchronous run pays the HIP
+                        #  runtime's housekeeping on the host -- 0.18 ms per step for 20 steps behind 305; tools/shard_short_run.py, round 4)
     for i in range(max(args.warmup, 1)):          # the W untimed warm-up steps
         gm.train_async(batches[i % nb])
     gm.sync()

@@ -892,8 +892,10 @@ int sort_ws_alloc(SortWorkspace &ws, int64_t cap) {
     HIPCHK(hipMalloc(&ws.blk_heads, sizeof(uint32_t) * (size_t)ws.nblk));
     HIPCHK(hipMalloc(&ws.totals, sizeof(uint32_t) * 2048));
     HIPCHK(hipMalloc(&ws.seg_pub, sizeof(unsigned long long) * (size_t)(ws.nblk + 1)));
-    HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), 0));       // (tag 0 = no launch yet)
-    HIPCHK(hipStreamSynchronize(0));                    // (done before any stream of the store can launch on it)
+    ws.seg_seq = 0;         // (the words are zeroed by the first build_segments, on ITS stream: nothing here may touch the null stream --
+                            //  a hipMemsetAsync / hipStreamSynchronize on stream 0 brought the default stream's hardware queue into play,
+                            //  and every store + model created after that ran its multi-stream steps 1.6-2.2x slower: 0.60 ms for the
+                            //  multi-hot step, 0.33 for the sharded one, bench.py's legs of round 5's first evidence run)
     HIPCHK(hipMalloc(&ws.hi, sizeof(uint32_t) * 4 * 2048 * (size_t)cdiv(ws.nblk, RS_SB)));     // <= 4 passes x 2048 digits x superblocks
     return PS_OK;
 }
@@ -1034,7 +1036,8 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
     }
     const int nblk = cdiv(n, RS_TILE);
     if (g_seg_fused && ws.seg_pub) {
-        if (++ws.seg_seq == 0) ++ws.seg_seq;
+        if (ws.seg_seq == 0) HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), st));     // (tag 0 = no launch yet)
+        if (++ws.seg_seq == 0) { HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), st)); ++ws.seg_seq; }
         hipLaunchKernelGGL(k_seg_fused, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.seg_pub, ws.seg_seq, seg_start, seg_id, nseg_dev, stamp_next("seg_emit"));
     } else {
     hipLaunchKernelGGL(k_seg_count, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.blk_heads);

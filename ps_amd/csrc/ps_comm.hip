@@ -472,9 +472,7 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     if (nsh < 1 || nsh > PS_PUSH_MAX_PEERS || rank < 0 || rank >= nsh) return ps_set_err(PS_E_BAD_ARG, "bad communicator (1..%d ranks)", PS_PUSH_MAX_PEERS);
     PSCHK(store_enter(s));
     if (use_side && !s->prefetch_stream) {
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&s->prefetch_stream, hipStreamNonBlocking, hi));
+        PSCHK(pool_stream_acquire(s->device, 1, &s->prefetch_stream));
     }
     ps_model::Shard &sh = m->sh;
     if (!sh.x_ev) {

@@ -169,24 +169,9 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->partials2, sizeof(float) * 2 * (size_t)((nc + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->grads_out, sizeof(float) * (size_t)(nc + 1) * D, false));
     PSCHK(model_alloc(m, (void **)&m->dense_grad_flat, sizeof(float) * (size_t)m->dense_elems, true));
-    {   // the side chains (sort, dW + dense update) yield to the main FC chain, which is the critical path
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent (numerically largest)
-        for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&m->side[i], hipStreamNonBlocking, lo));
-        // Measurement (VERDICT r4 next #4b; PS_CU_MASK_DW=<n>): side chain 1 -- the dW GEMMs and the dense update -- confined to the
-        // first n CUs of the mask's order by hipExtStreamCreateWithCUMask.  (The training stream keeps every CU unless
-        // PS_CU_MASK_MAIN=1 takes those n away from it: ps_store.hip.)  DESIGN.md 4.1.3 has the numbers.
-        if (const char *e = getenv("PS_CU_MASK_DW")) {
-            const int n = atoi(e);
-            if (n > 0 && n < 256) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int b = 0; b < n; ++b) mask[b >> 5] |= 1u << (b & 31);
-                hipStream_t cs = nullptr;
-                if (hipExtStreamCreateWithCUMask(&cs, 8, mask) == hipSuccess) { (void)hipStreamDestroy(m->side[1]); m->side[1] = cs; }
-                else (void)hipGetLastError();
-            }
-        }
-    }
+    // the side chains (sort, dW + dense update, the sharded step's list chain) yield to the main FC chain, which is the critical
+    // path: least urgent streams, from the process-wide pool (ps_store.h pool_stream_acquire)
+    for (int i = 0; i < 3; ++i) PSCHK(pool_stream_acquire(s->device, 0, &m->side[i]));
     m->events.resize(64);
     for (auto &e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
@@ -208,7 +193,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     (void)hipStreamSynchronize(m->s->stream);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (int i = 0; i < 3; ++i) if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
+    for (int i = 0; i < 3; ++i) pool_stream_release(m->s->device, 0, m->side[i]);
     for (auto &e : m->events) (void)hipEventDestroy(e);
     if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
     if (m->s0_ev) (void)hipEventDestroy(m->s0_ev);
@@ -222,7 +207,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
             if (m->hstage.copied[k]) (void)hipEventDestroy(m->hstage.copied[k]);
             if (m->hstage.done[k]) (void)hipEventDestroy(m->hstage.done[k]);
         }
-        (void)hipStreamDestroy(m->hstage.copy_stream);
+        pool_stream_release(m->s->device, 2, m->hstage.copy_stream);
     }
     if (m->sh.plan_ev) (void)hipEventDestroy(m->sh.plan_ev);
     if (m->sh.owner_start_host) (void)hipHostFree(m->sh.owner_start_host);
@@ -295,7 +280,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
     const size_t nb_dense = c.X > 0 ? sizeof(float) * (size_t)b->B * c.X : 0, nb_lab = b->labels ? sizeof(float) * (size_t)b->B : 0;
     const size_t nb_wide = c.kind == PS_MODEL_WIDEDEEP ? sizeof(int64_t) * (size_t)nbags : 0;
     if (!hs.copy_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&hs.copy_stream, hipStreamNonBlocking));
+        PSCHK(pool_stream_acquire(m->s->device, 2, &hs.copy_stream));
         const size_t cap_ids = sizeof(int64_t) * (size_t)m->nnz_cap, cap_off = sizeof(int64_t) * ((size_t)m->Bcap * c.F + 1);
         const size_t cap_wide = sizeof(int64_t) * (size_t)m->Bcap * c.F, cap_dense = sizeof(float) * (size_t)m->Bcap * (c.X > 0 ? c.X : 1);
         const size_t cap_lab = sizeof(float) * (size_t)m->Bcap;

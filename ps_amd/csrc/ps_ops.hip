@@ -370,8 +370,12 @@ int stamps_enable(int on) {
     if (!g_stamp_buf) HIPCHK(hipMalloc((void **)&g_stamp_buf, sizeof(unsigned long long) * 2 * STAMP_SLOTS));
     std::vector<unsigned long long> init(2 * STAMP_SLOTS);
     for (int i = 0; i < STAMP_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(g_stamp_buf, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
+    // (on a stream of its own, never the null stream -- ps_store.h: the default stream's hardware queue slows every multi-stream step
+    //  enqueued after it, i.e. exactly the steps about to be stamped.  The caller has waited for its stores' streams.)
+    static hipStream_t stamp_stream = nullptr;
+    if (!stamp_stream) HIPCHK(hipStreamCreateWithFlags(&stamp_stream, hipStreamNonBlocking));
+    HIPCHK(hipMemcpyAsync(g_stamp_buf, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice, stamp_stream));
+    HIPCHK(hipStreamSynchronize(stamp_stream));
     g_stamps_on = true;
     return PS_OK;
 }
@@ -383,9 +387,10 @@ unsigned long long *stamp_next(const char *name) {
 // names: '\n'-separated, vals: [n][2]; returns the number of stamped launches (after a device synchronize)
 extern "C" int ps_dbg_stamps(char *names, int names_cap, unsigned long long *vals, int vals_cap) {
     if (!g_stamp_buf) return 0;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    // (the measurement is over when this is called: a device-wide wait and a synchronous copy may touch the null stream here)
+    if (hipDeviceSynchronize() != hipSuccess) return -1;                                                                              // null-stream-ok
     const int n = (int)std::min<size_t>(g_stamp_names.size(), (size_t)vals_cap);
-    if (hipMemcpy(vals, g_stamp_buf, sizeof(unsigned long long) * 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(vals, g_stamp_buf, sizeof(unsigned long long) * 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;     // null-stream-ok
     std::string s;
     for (int i = 0; i < n; ++i) { s += g_stamp_names[i]; s += '\n'; }
     snprintf(names, (size_t)names_cap, "%s", s.c_str());

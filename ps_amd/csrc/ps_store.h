@@ -108,6 +108,15 @@ int store_ensure_scratch(ps_store *s, int64_t rows, int D);
 int store_check_bad_ids(ps_store *s);      // (... and of bounded device-side waits that timed out: PS_E_STATE)
 // every entry point that enqueues on (or waits for) the store's stream: hipSetDevice + the pending join of the last fused step
 int store_enter(ps_store *s);
+// Streams come from a process-wide pool per device and priority class and go back to it (idle) when their store / model is
+// destroyed: 0 = least urgent (a model's side chains), 1 = most urgent (a store's training stream, the prefetch stream), 2 = default
+// (copy streams).  A process that builds store after store (tests, bench.py's legs) keeps driving the SAME few streams -- and
+// nothing in this library ever touches the NULL stream: one hipMemsetAsync(.., 0) + hipStreamSynchronize(0) in a workspace
+// allocator (round 5) brought the default stream's hardware queue into play, and every store + model created after it ran its
+// multi-stream steps 1.6-2.2x slower (multi-hot 0.60 ms instead of 0.378, sharded 0.33 instead of 0.15: tools/r05_mh_inproc.py,
+// profiles/r05_null_stream.txt; tests/test_abi.py greps the sources for it).
+int pool_stream_acquire(int device, int cls, hipStream_t *out);
+void pool_stream_release(int device, int cls, hipStream_t st);
 int store_settle(ps_store *s);             // the pending join alone (an event wait on the store's stream)
 // may this store's models join their streams by device-side flags?  (g_dev_wait, no timeout so far, one live model on the device)
 #define PS_MAX_DEVICES 64

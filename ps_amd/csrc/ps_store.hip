@@ -8,6 +8,8 @@
 
 #include <atomic>
 
+#include <mutex>
+
 #include "ps_store.h"
 
 // ---------------------------------------------------------------------------
@@ -224,6 +226,30 @@ extern "C" int ps_router_shard_id(int route_mode, int field, int64_t id, int nsh
 // ---------------------------------------------------------------------------
 // store
 // ---------------------------------------------------------------------------
+namespace {
+struct StreamPool { std::mutex mu; std::vector<hipStream_t> free_[PS_MAX_DEVICES][3]; } g_stream_pool;
+}
+int pool_stream_acquire(int device, int cls, hipStream_t *out) {
+    if (device < 0 || device >= PS_MAX_DEVICES || cls < 0 || cls > 2) return ps_set_err(PS_E_BAD_ARG, "stream pool: bad device / class");
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool.mu);
+        auto &v = g_stream_pool.free_[device][cls];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return PS_OK; }
+    }
+    if (cls == 2) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return PS_OK; }
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent (numerically largest)
+    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls == 1 ? hi : lo));
+    return PS_OK;
+}
+void pool_stream_release(int device, int cls, hipStream_t st) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    if (device < 0 || device >= PS_MAX_DEVICES || cls < 0 || cls > 2) { (void)hipStreamDestroy(st); return; }
+    std::lock_guard<std::mutex> lk(g_stream_pool.mu);
+    g_stream_pool.free_[device][cls].push_back(st);
+}
+
 int store_dev_alloc(ps_store *s, void **p, size_t bytes, bool zero) {
     RtGuard rt_guard;
     if (bytes == 0) bytes = 16;
@@ -247,22 +273,7 @@ extern "C" int ps_store_create(int device, uint64_t seed, ps_store_t **out) {
     ps_store *s = new ps_store();
     s->device = device;
     s->seed = seed;
-    {
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&s->own_stream, hipStreamNonBlocking, hi));   // main chain: most urgent
-        // Measurement (PS_CU_MASK_DW=<n> with PS_CU_MASK_MAIN=1): the training stream on the CUs side chain 1 does NOT get (ps_model.hip)
-        if (getenv("PS_CU_MASK_MAIN") && getenv("PS_CU_MASK_DW")) {
-            const int n = atoi(getenv("PS_CU_MASK_DW"));
-            if (n > 0 && n < 256) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int b = n; b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
-                hipStream_t cs = nullptr;
-                if (hipExtStreamCreateWithCUMask(&cs, 8, mask) == hipSuccess) { (void)hipStreamDestroy(s->own_stream); s->own_stream = cs; }
-                else (void)hipGetLastError();
-            }
-        }
-    }
+    PSCHK(pool_stream_acquire(device, 1, &s->own_stream));      // main chain: most urgent (from the process-wide pool: ps_store.h)
     s->stream = s->own_stream;
     PSCHK(store_dev_alloc(s, (void **)&s->err_dev, 8 * sizeof(int), true));      // [0] bad ids | [1] timed-out device waits, [2] last, [3] first | [4] XCD mismatches
     ps_updater_t a;
@@ -293,8 +304,8 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     sort_ws_free(s->push_ws);
     fr(s->push_keys); fr(s->push_ents); fr(s->push_seg_start); fr(s->push_seg_id); fr(s->push_nseg);
     fr(s->push_mask); fr(s->push_pos);
-    (void)hipStreamDestroy(s->own_stream);    // an adopted stream belongs to the host
-    if (s->prefetch_stream) (void)hipStreamDestroy(s->prefetch_stream);
+    pool_stream_release(s->device, 1, s->own_stream);    // (an adopted stream belongs to the host: only the store's own goes back)
+    pool_stream_release(s->device, 1, s->prefetch_stream);
     delete s;
     return PS_OK;
 }
