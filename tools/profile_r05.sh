@@ -8,7 +8,6 @@ python -m pytest tests -m gpu -q > $OUT/pytest_gpu_full.log 2>&1; tail -2 $OUT/p
 python bench.py > $OUT/c2_bench_line.json 2> $OUT/c2_bench.err; cut -c1-300 $OUT/c2_bench_line.json
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/c2_bench_line_20steps.json 2> $OUT/c2_bench_20.err; cut -c1-300 $OUT/c2_bench_line_20steps.json
 bash tools/profile_round.sh r05 > $OUT/profile_round.log 2>&1; tail -5 $OUT/profile_round.log
-python tools/pmc_traffic.py gpurun_out/prof_r05 r05 > $OUT/pmc_traffic.txt 2>&1; cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 python tools/gpu_timeline.py 64 > $OUT/c2_gpu_timeline.txt 2>&1
 MULTI_HOT=1 python tools/gpu_timeline.py 8 > $OUT/c4_gpu_timeline.txt 2>&1
 PS_HOST_TIMING=1 python bench.py --sharded --steps 2000 --no-cpu --gather 0 --multi-hot 0 > $OUT/shard_n1_line.json 2> $OUT/shard.err

@@ -20,6 +20,8 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OU
 find $OUT -name "*.csv" | head -20
 python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# HBM bytes per launch of every kernel group from the two PMC passes (before the raw tables are dropped)
+python tools/pmc_traffic.py $OUT $TAG > $OUT/pmc_traffic.txt 2>&1; cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 # keep the merged output small: drop the raw per-dispatch tables
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 find $OUT -name "*counter_collection.csv" -size +2M -delete
