@@ -1317,8 +1317,9 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_keys_grid = 0;        // ps_tune_set("keys_grid", workgroups): grid bound of the multi-hot key kernel (0: 1024)
 int g_seq_long_grid = 0;        // ps_tune_set("seq_long_grid", workgroups): long-key workgroups of the sequential order (0: SEQ_LONG_GRID)
-int g_emb_short_grid = 4096;    // ps_tune_set("emb_short_grid", workgroups): grid of the embedding update's one-key-per-lane-group role
+int g_emb_short_grid = 2048;    // ps_tune_set("emb_short_grid", workgroups): grid of the embedding update's one-key-per-lane-group role (multi-hot step: 1024/2048 0.361, 4096 0.3645, 8192 0.372 ms; the single-hot step does not care)
 int g_seq_ablate = 0;    // measurement only (results wrong): 1 = the fold wave skips its LDS reads + adds, 2 = the loaders skip their global loads
 
 // The LDS-staged form of the single-hot gather that BASELINE.json's north_star names ("coalesced CSR gather with
@@ -1416,24 +1417,25 @@ __global__ __launch_bounds__(256) void k_emb_keys_seg(EmbFwdArgs a, const uint32
         for (int f = 0; f < a.F; ++f) { pb[f] = p; p += (ftotal[f] + (uint32_t)tile - 1) / (uint32_t)tile * (uint32_t)tile; }
     }
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nb = (int64_t)a.B * a.F;
-    int64_t bag = t / LANES;
-    const int l = (int)(t % LANES);
-    const bool live = bag < nb;
-    if (!live) bag = nb - 1;
-    const int f = (int)(bag % a.F);
-    const int64_t rn = a.row_base[f + 1] - a.row_base[f];
-    const int64_t p0 = a.offsets[bag], p1 = live ? a.offsets[bag + 1] : p0;
-    const int64_t dst = (int64_t)pb[f] + pre[bag] - p0;         // entry p of the bag goes to dst + p
-    for (int64_t p = p0 + l; p < p1; p += 2 * LANES) {
-        const int64_t q = p + LANES;
-        int64_t id0 = a.ids[p], id1 = a.ids[q < p1 ? q : p];
-        if (id0 < 0 || id0 >= rn) id0 = 0;
-        if (id1 < 0 || id1 >= rn) id1 = 0;
-        kp[dst + p] = (uint32_t)id0;
-        vp[dst + p] = (uint32_t)bag;
-        if (q < p1) { kp[dst + q] = (uint32_t)id1; vp[dst + q] = (uint32_t)bag; }
+    // grid-stride over the bags (round 5: a bounded grid -- 3328 small workgroups at configs[4]'s shape were more than the chip holds at
+    // once, and a kernel that is still being placed holds up the launches of the other streams behind it)
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nb * LANES; t += (int64_t)gridDim.x * 256) {
+        const int64_t bag = t / LANES;
+        const int l = (int)(t % LANES);
+        const int f = (int)(bag % a.F);
+        const int64_t rn = a.row_base[f + 1] - a.row_base[f];
+        const int64_t p0 = a.offsets[bag], p1 = a.offsets[bag + 1];
+        const int64_t dst = (int64_t)pb[f] + pre[bag] - p0;         // entry p of the bag goes to dst + p
+        for (int64_t p = p0 + l; p < p1; p += 2 * LANES) {
+            const int64_t q = p + LANES;
+            int64_t id0 = a.ids[p], id1 = a.ids[q < p1 ? q : p];
+            if (id0 < 0 || id0 >= rn) id0 = 0;
+            if (id1 < 0 || id1 >= rn) id1 = 0;
+            kp[dst + p] = (uint32_t)id0;
+            vp[dst + p] = (uint32_t)bag;
+            if (q < p1) { kp[dst + q] = (uint32_t)id1; vp[dst + q] = (uint32_t)bag; }
+        }
     }
 }
 
@@ -1443,7 +1445,7 @@ int launch_emb_keys_seg(const EmbFwdArgs &a, const uint32_t *pre, const uint32_t
     if (nb <= 0) return PS_OK;
     EmbFwdArgs b = a;
     b.ts = stamp_next("emb_keys");
-    hipLaunchKernelGGL(k_emb_keys_seg<8>, dim3(cdiv(nb * 8, 256)), dim3(256), 0, st, b, pre, ftotal, tile, kp, vp);
+    hipLaunchKernelGGL(k_emb_keys_seg<8>, dim3(std::min<int64_t>(cdiv(nb * 8, 256), g_keys_grid > 0 ? g_keys_grid : 1024)), dim3(256), 0, st, b, pre, ftotal, tile, kp, vp);
     HIPCHK(hipGetLastError());
     return PS_OK;
 }

@@ -13,11 +13,13 @@ namespace {
 
 constexpr int RS_TPB = 256;
 #ifndef PS_RS_IPT
-#define PS_RS_IPT 16
+#define PS_RS_IPT 32        // round 5: 8192-pair tiles (was 16 = 4096).  Half as many, twice as large workgroups: every pass of the multi-hot
+                            // step's sort takes LONGER alone (scatter 39 -> 68 us) and the step is 10 us shorter (0.3766 -> 0.3664 ms) -- the kernels
+                            // beside it (forward GEMMs, per-key reduce) lose less to 416 resident workgroups than to 806 that are still being placed
 #endif
 constexpr int RS_IPT = PS_RS_IPT;       // keys per thread (tile = 256 x RS_IPT pairs); -DPS_RS_IPT=8 for A/B builds
-constexpr int RS_TILE = RS_TPB * RS_IPT;  // 4096 keys per workgroup
-constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 1024 consecutive keys per wave
+constexpr int RS_TILE = RS_TPB * RS_IPT;  // 8192 keys per workgroup
+constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 2048 consecutive keys per wave
 constexpr int RS_SB_LOG = 5, RS_SB = 1 << RS_SB_LOG;   // tiles per superblock (second level of the digit counts)
 
 // per-block digit histogram; counts is digit-major: counts[digit * nblk + blk].  DB = digit bits: 8 (256 buckets)
@@ -352,7 +354,9 @@ __global__ __launch_bounds__(BS_TPB) void k_bag_scan(const int64_t *__restrict__
     if (tid == 0) ftotal[f] = carry_s;
 }
 
+template <int IPT>
 __global__ __launch_bounds__(RS_TPB) void k_seg_hist(const uint32_t *__restrict__ keys, int shift, SegSortArgs s, unsigned long long *ts) {
+    constexpr int TILE = RS_TPB * IPT;          // this pass's tile (the padded layout's tile, RS_TILE, is a multiple of it)
     __shared__ uint32_t h[SG_ND];
     __shared__ uint32_t pb[65], cb[65];
     StampScope stamp(ts);
@@ -360,19 +364,19 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_hist(const uint32_t *__restrict_
 #pragma unroll
     for (int q = 0; q < SG_DPT; ++q) h[tid + q * RS_TPB] = 0;
     seg_bases(s, pb, cb);
-    const uint32_t bbase = blockIdx.x * (uint32_t)RS_TILE;
+    const uint32_t bbase = blockIdx.x * (uint32_t)TILE;
     if (bbase >= pb[s.F]) return;                          // (the grid is an upper bound)
     const int f = seg_field_of(pb, s.F, bbase);
     const uint32_t in_f = bbase - pb[f], nf = s.ftotal[f];
-    const uint32_t nvalid = nf > in_f ? (nf - in_f < (uint32_t)RS_TILE ? nf - in_f : (uint32_t)RS_TILE) : 0u;
-    uint32_t k[RS_IPT];
+    const uint32_t nvalid = nf > in_f ? (nf - in_f < (uint32_t)TILE ? nf - in_f : (uint32_t)TILE) : 0u;
+    uint32_t k[IPT];
 #pragma unroll
-    for (int j = 0; j < RS_IPT; ++j) {
+    for (int j = 0; j < IPT; ++j) {
         const uint32_t i = j * RS_TPB + tid;
         k[j] = keys[bbase + (i < nvalid ? i : 0)];
     }
 #pragma unroll
-    for (int j = 0; j < RS_IPT; ++j)
+    for (int j = 0; j < IPT; ++j)
         if ((uint32_t)(j * RS_TPB + tid) < nvalid) atomicAdd(&h[(k[j] >> shift) & (uint32_t)(SG_ND - 1)], 1u);
     __syncthreads();
 #pragma unroll
@@ -385,30 +389,31 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_hist(const uint32_t *__restrict_
 }
 
 // (ranking and staging as k_radix_scatter<false, true, .>; LAST: compact output, keys = rows of the concatenated table)
-template <bool LAST>
+template <bool LAST, int IPT>
 __global__ __launch_bounds__(RS_TPB) void k_seg_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                         uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int shift,
                                                         SegSortArgs s, unsigned long long *ts) {
     StampScope stamp(ts);
     constexpr uint32_t DMASK = SG_ND - 1;
+    constexpr int TILE = RS_TPB * IPT, WAVE_SPAN = TILE / 4;
     __shared__ uint32_t cur[4][SG_ND];
     __shared__ uint32_t gdelta[SG_ND];
     __shared__ uint32_t wtot[4];
-    __shared__ uint32_t sk[RS_TILE], sv[RS_TILE];
+    __shared__ uint32_t sk[TILE], sv[TILE];
     __shared__ uint32_t pb[65], cb[65];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 4 * SG_ND; i += RS_TPB) ((uint32_t *)cur)[i] = 0;
     seg_bases(s, pb, cb);
-    const uint32_t bbase = blockIdx.x * (uint32_t)RS_TILE;
+    const uint32_t bbase = blockIdx.x * (uint32_t)TILE;
     if (bbase >= pb[s.F]) return;
     const int f = seg_field_of(pb, s.F, bbase);
     const uint32_t in_f = bbase - pb[f], nf = s.ftotal[f];
-    const uint32_t nvalid = nf > in_f ? (nf - in_f < (uint32_t)RS_TILE ? nf - in_f : (uint32_t)RS_TILE) : 0u;
-    const int t0 = (int)(pb[f] / RS_TILE), ti = (int)blockIdx.x - t0;       // this field's first tile, my index among its tiles
-    const uint32_t wbase = (uint32_t)w * RS_WAVE_SPAN;                       // (inside the tile)
-    uint32_t k[RS_IPT], v[RS_IPT];
+    const uint32_t nvalid = nf > in_f ? (nf - in_f < (uint32_t)TILE ? nf - in_f : (uint32_t)TILE) : 0u;
+    const int t0 = (int)(pb[f] / TILE), ti = (int)blockIdx.x - t0;       // this field's first tile, my index among its tiles
+    const uint32_t wbase = (uint32_t)w * WAVE_SPAN;                       // (inside the tile)
+    uint32_t k[IPT], v[IPT];
 #pragma unroll
-    for (int j = 0; j < RS_IPT; ++j) {
+    for (int j = 0; j < IPT; ++j) {
         const uint32_t i = wbase + j * 64 + lane;
         const uint32_t ci = bbase + (i < nvalid ? i : 0);
         k[j] = kin[ci];
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_scatter(const uint32_t *__restri
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RS_IPT; ++j)
+    for (int j = 0; j < IPT; ++j)
         if (wbase + j * 64 + lane < nvalid) atomicAdd(&cur[w][(k[j] >> shift) & DMASK], 1u);
     // exclusive scan of the field's digit totals (digit bases inside the field) and of this tile's digit counts (local bases)
     uint32_t tsum = 0;
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_scatter(const uint32_t *__restri
     __syncthreads();
     const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int j = 0; j < RS_IPT; ++j) {
+    for (int j = 0; j < IPT; ++j) {
         const bool valid = wbase + j * 64 + lane < nvalid;
         const uint32_t d = (k[j] >> shift) & DMASK;
         uint64_t same = __ballot(valid);
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(RS_TPB) void k_seg_scatter(const uint32_t *__restri
     __syncthreads();
     const uint32_t rb = LAST ? (uint32_t)s.row_base[f] : 0u;
 #pragma unroll
-    for (int j = 0; j < RS_IPT; ++j) {
+    for (int j = 0; j < IPT; ++j) {
         const uint32_t lp = j * RS_TPB + tid;
         if (lp < nvalid) {
             const uint32_t key = sk[lp];
@@ -972,7 +977,7 @@ int g_mh_seg_sort = 1;      // ps_tune_set("mh_seg_sort", 0): multi-hot batches 
 int seg_sort_alloc(SegSortWs &ws, int64_t nnz_cap, int64_t nbags_cap, int F) {
     seg_sort_free(ws);
     ws.cap = nnz_cap + (int64_t)F * RS_TILE;               // every field padded to whole tiles
-    ws.ntile = (int)(ws.cap / RS_TILE) + 1;
+    ws.ntile = (int)(ws.cap / (RS_TILE / 2)) + 2;          // (tile counts of either pass: the second pass may use half-size tiles)
     ws.F = F;
     // (all or nothing: a partial workspace would make the caller skip the allocation next time and sort through null buffers)
     struct { uint32_t **p; size_t n; } want[] = {
@@ -1012,16 +1017,22 @@ int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipSt
 int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st, int which) {
     if (n + (int64_t)ws.F * RS_TILE > ws.cap) return ps_set_err(PS_E_BAD_ARG, "seg_sort_pairs: n=%lld > cap", (long long)n);
     if (n <= 0) return PS_OK;
-    const int grid = (int)cdiv(n, RS_TILE) + ws.F;         // upper bound on the tiles of the padded layout
+    // The two passes use different tiles over the same padded layout (fields padded to whole RS_TILE tiles).  The FIRST pass runs
+    // beside the previous step's backward (mh_presort): large tiles -- half as many resident workgroups cost that backward less
+    // (per-key reduce + Ftrl 98 -> 82 us).  The SECOND pass is on the step's own critical path beside the forward GEMMs: with
+    // 8192-pair tiles its scatter took 69 us instead of 39 and the sort chain, not the FC chain, ended the forward phase.
+    constexpr int IPT2 = RS_IPT >= 32 ? RS_IPT / 2 : RS_IPT;
+    const int grid1 = (int)cdiv(n, RS_TILE) + ws.F;         // upper bounds on the tiles of the padded layout
+    const int grid2 = (int)cdiv(n, RS_TPB * IPT2) + ws.F * (RS_IPT / IPT2);
     SegSortArgs a{ws.F, ws.ftotal, row_base_dev, ws.ftot, ws.tcounts};
     if (which & 1) {
-    hipLaunchKernelGGL(k_seg_hist, dim3(grid), dim3(RS_TPB), 0, st, ws.kp, 0, a, stamp_next("radix_hist"));
-    hipLaunchKernelGGL(k_seg_scatter<false>, dim3(grid), dim3(RS_TPB), 0, st, ws.kp, ws.vp, ws.kq, ws.vq, 0, a, stamp_next("radix_scatter"));
+    hipLaunchKernelGGL((k_seg_hist<RS_IPT>), dim3(grid1), dim3(RS_TPB), 0, st, ws.kp, 0, a, stamp_next("radix_hist"));
+    hipLaunchKernelGGL((k_seg_scatter<false, RS_IPT>), dim3(grid1), dim3(RS_TPB), 0, st, ws.kp, ws.vp, ws.kq, ws.vq, 0, a, stamp_next("radix_scatter"));
     }
     a.ftot = ws.ftot + (size_t)ws.F * SG_ND;
     if (which & 2) {
-    hipLaunchKernelGGL(k_seg_hist, dim3(grid), dim3(RS_TPB), 0, st, ws.kq, SG_DB, a, stamp_next("radix_hist"));
-    hipLaunchKernelGGL(k_seg_scatter<true>, dim3(grid), dim3(RS_TPB), 0, st, ws.kq, ws.vq, keys_out, vals_out, SG_DB, a, stamp_next("radix_scatter"));
+    hipLaunchKernelGGL((k_seg_hist<IPT2>), dim3(grid2), dim3(RS_TPB), 0, st, ws.kq, SG_DB, a, stamp_next("radix_hist"));
+    hipLaunchKernelGGL((k_seg_scatter<true, IPT2>), dim3(grid2), dim3(RS_TPB), 0, st, ws.kq, ws.vq, keys_out, vals_out, SG_DB, a, stamp_next("radix_scatter"));
     }
     HIPCHK(hipGetLastError());
     return PS_OK;

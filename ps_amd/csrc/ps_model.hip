@@ -402,6 +402,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // ... and the partition by FIELD costs no radix pass (round 4, kernels_sort.hip k_bag_scan): a column scan of the bag lengths, the
     // key kernel writes (id, bag) at the entry's place among its field's entries, two 9-bit passes sort every field on its own
     bool seg_sort = false, presort = false;
+    const bool mh_late_ok = g_mh_presort == 3 && m->dev_ok && !c.use_graph && !(nfc == 1 && s->fc[0].N == 1);
     if (keys_early) {
         if (m->seg_fits < 0) {          // (the tables' shapes do not change: decided once)
             std::vector<int64_t> rows_f((size_t)c.F);
@@ -439,7 +440,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         if (presort) {
             Prof pf(m, "emb_sort");
             PSCHK(seg_sort_pairs(m->seg, m->cur_nnz, s->emb.row_base_dev, m->ws.keys_alt, m->ws.vals_alt, side_stream(m, 0), 1));
-            PSCHK(fork(m, st, side_stream(m, 0)));      // the previous step's backward reads what the second pass overwrites
+            // The previous step's backward reads what the second pass overwrites.  mh_presort = 3 holds the second pass behind a
+            // spinner that this step's first forward GEMM releases -- on the training stream, behind that backward: the order is
+            // already there, and an event recorded on the training stream between the embedding update and the next gather made
+            // the gather start 19-23 us after the update's end instead of 4 (tools/gpu_timeline.py, round 5).
+            if (!mh_late_ok) PSCHK(fork(m, st, side_stream(m, 0)));
         }
         e.key_out = nullptr; e.ent_bag = nullptr;
     }
@@ -491,7 +496,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // mh_presort = 3: the sort's second half (second pass, run boundaries) is released by the first forward GEMM's START, like the
     // single-hot field sort: launched right behind the join it ran beside the gather (its histogram pass 37 us instead of 10) and
     // its 806-workgroup scatter was being placed when the first GEMM arrived -- that GEMM started 20 us after the gather's end
-    const bool mh_late = presort && g_mh_presort == 3 && m->dev_ok && !c.use_graph && !(nfc == 1 && s->fc[0].N == 1);
+    const bool mh_late = presort && mh_late_ok;
     auto enqueue_sort = [&]() -> int {
         // the sort only needs the row keys the gather just emitted: run it beside the FC chain
         hipStream_t ss = side_stream(m, 0);

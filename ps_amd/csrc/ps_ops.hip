@@ -281,6 +281,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "seg_fused") == 0) { g_seg_fused = value; return PS_OK; }
     if (strcmp(knob, "mh_presort") == 0) { g_mh_presort = value; return PS_OK; }
     if (strcmp(knob, "mh_prio") == 0) { g_mh_prio = value; return PS_OK; }
+    if (strcmp(knob, "keys_grid") == 0) { g_keys_grid = value; return PS_OK; }
     if (strcmp(knob, "slots_in_gather") == 0) { g_slots_in_gather = value; return PS_OK; }
     if (strcmp(knob, "shard_overlap") == 0) { g_shard_overlap = value; return PS_OK; }
     if (strcmp(knob, "radix_scan_free") == 0) { g_radix_scan_free = value; return PS_OK; }
@@ -291,7 +292,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "mh_ilp16") == 0) { g_mh_ilp16 = value; return PS_OK; }
     if (strcmp(knob, "seq_ablate") == 0) { g_seq_ablate = value; return PS_OK; }
     if (strcmp(knob, "seq_long_grid") == 0) { g_seq_long_grid = value; return PS_OK; }
-    if (strcmp(knob, "emb_short_grid") == 0) { g_emb_short_grid = value > 0 ? value : 4096; return PS_OK; }
+    if (strcmp(knob, "emb_short_grid") == 0) { g_emb_short_grid = value > 0 ? value : 2048; return PS_OK; }
     if (strcmp(knob, "gather_nt") == 0) { g_gather_nt = value; return PS_OK; }
     if (strcmp(knob, "gather_lds") == 0) {
 #if defined(PS_GEMM_LAB) && PS_GEMM_LAB
