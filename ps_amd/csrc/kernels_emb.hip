@@ -555,12 +555,31 @@ __device__ __forceinline__ UpdParams row_upd(const ARGS &a, uint32_t row) {
         if (a.fu.over_row[i] == row) g = a.fu.over_grp[i];
     return g ? a.fu.alt[g - 1] : a.upd;
 }
+// XCD-affine work order of the embedding backward.  The sorted entries run field by field, and an entry's delta row is the 64 bytes
+// of ITS field in its sample's row of dx: a contiguous eighth of the sorted entries touches the dx columns of ~F/8 + 1 fields -- 1-2 MB
+// of lines, resident in one XCD's 4 MB L2 -- where a round-robin deal makes every XCD's L2 fetch (and re-fetch, beside the streaming
+// W / state rows) all of dx, each 128-byte line once per half.  Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md: a matter
+// of speed only): the workgroups of one XCD take one contiguous eighth of the tiles (here) / of the keys by entry count
+// (k_emb_reduce_update).  Grids are multiples of 8 when a.xcd is set.
+__device__ __forceinline__ unsigned int emb_vblock(int xcd) {
+    return xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+}
+
+// the first key whose run starts at or behind entry p  (plain arguments: a lambda that captures the kernel's argument struct by
+// reference makes hipcc copy the whole struct to scratch -- 856 bytes per lane, the single-hot update 135 us instead of 17)
+__device__ __forceinline__ int64_t emb_key_at(const uint32_t *__restrict__ seg_id, const uint32_t *__restrict__ seg_start, int64_t nnz, int64_t nseg, int64_t p) {
+    if (p <= 0) return 0;
+    if (p >= nnz) return nseg;
+    const uint32_t u = seg_id[p];
+    return (int64_t)u + (seg_start[u] == (uint32_t)p ? 0 : 1);
+}
+
 template <int VEC, bool BAG>
 __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
     StampScope stamp(a.ts_partials);
     if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.skip && *a.skip) return;
-    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gt = (int64_t)emb_vblock(a.xcd) * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
     const int gpw = 64 / a.LPR;                         // lane groups per wave (groups never straddle waves)
     if (lane64 / a.LPR >= gpw) return;
@@ -598,7 +617,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_emb_super(EmbBwdArgs a) {
     StampScope stamp(a.ts_super);
     if (a.skip && *a.skip) return;
-    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gt = (int64_t)emb_vblock(a.xcd) * 256 + threadIdx.x;
     const int lane64 = (int)(gt & 63);
     const int gpw = 64 / a.LPR;
     if (lane64 / a.LPR >= gpw) return;
@@ -977,14 +996,26 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     // One lane group per key, GRID-STRIDE: the launcher cannot know the number of unique keys (it lives on the device) and
     // used to size the grid for the worst case, one key per entry -- at a multi-hot batch 50 k workgroups of which 40 k
     // found nothing to do; dispatching them was a sixth of the kernel.  Now a bounded grid walks the keys.
-    const int64_t gt = (int64_t)(blockIdx.x - (SEQ ? a.long_blocks : 0)) * 256 + threadIdx.x;
-    const int lane64 = (int)(gt & 63);
+    const int sb = (int)blockIdx.x - (SEQ ? a.long_blocks : 0);
+    const int lane64 = (int)(threadIdx.x & 63);
     const int gpw = 64 / a.LPR;
     if (lane64 / a.LPR >= gpw) return;
     const int part = lane64 % a.LPR;
     const int64_t nseg = (int64_t)*a.nseg;
-    const int64_t stride = (int64_t)a.short_blocks * 4 * gpw;      // lane groups in the short-key role's grid
-    for (int64_t u = (gt >> 6) * gpw + lane64 / a.LPR; u < nseg; u += stride) reduce_one_key<VEC, BAG, SEQ>(a, u, part);
+    // ONE call site of reduce_one_key (a second one made hipcc keep a private copy of the argument struct: 856 bytes of scratch per
+    // lane in the SEQ instantiation, the single-hot update 135 us instead of 17)
+    int64_t u = (((int64_t)sb * 4 + (threadIdx.x >> 6)) * gpw) + lane64 / a.LPR, uend = nseg;
+    int64_t stride = (int64_t)a.short_blocks * 4 * gpw;            // lane groups in the short-key role's grid
+    if (a.xcd) {
+        // the keys whose run starts in eighth x of the sorted entries, walked by the workgroups of XCD x (emb_vblock's comment)
+        const int x = (int)(blockIdx.x & 7u);
+        // (a.xcd = 2: eighths of the ENTRIES instead of eighths of the keys)
+        const int64_t u0 = a.xcd == 2 ? emb_key_at(a.seg_id, a.seg_start, a.nnz, nseg, a.nnz * x / 8) : nseg * x / 8;
+        uend = a.xcd == 2 ? emb_key_at(a.seg_id, a.seg_start, a.nnz, nseg, a.nnz * (x + 1) / 8) : nseg * (x + 1) / 8;
+        stride = (int64_t)(a.short_blocks >> 3) * 4 * gpw;
+        u = u0 + ((int64_t)(sb >> 3) * 4 + (threadIdx.x >> 6)) * gpw + lane64 / a.LPR;
+    }
+    for (; u < uend; u += stride) reduce_one_key<VEC, BAG, SEQ>(a, u, part);
 }
 
 
@@ -1317,6 +1348,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_emb_xcd = 1;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
 int g_keys_grid = 0;        // ps_tune_set("keys_grid", workgroups): grid bound of the multi-hot key kernel (0: 1024)
 int g_seq_long_grid = 0;        // ps_tune_set("seq_long_grid", workgroups): long-key workgroups of the sequential order (0: SEQ_LONG_GRID)
 int g_emb_short_grid = 2048;    // ps_tune_set("emb_short_grid", workgroups): grid of the embedding update's one-key-per-lane-group role (multi-hot step: 1024/2048 0.361, 4096 0.3645, 8192 0.372 ms; the single-hot step does not care)
@@ -1535,14 +1567,18 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     a.long_blocks = !a.seq_order ? 0 : a.long_list ? (g_seq_long_grid > 0 ? g_seq_long_grid : SEQ_LONG_GRID) : cdiv(a.nnz, SEQ_TILE);
     // the short-key role: enough workgroups to fill the chip a few times over, never more than one lane group per entry
     a.short_blocks = gr < g_emb_short_grid ? gr : g_emb_short_grid;
+    // XCD-affine order (emb_vblock): grids rounded up to multiples of 8 (surplus workgroups find nothing to do)
+    a.xcd = (g_emb_xcd && a.short_blocks >= 64 && a.long_blocks % 8 == 0) ? g_emb_xcd : 0;
+    if (a.xcd) a.short_blocks = (a.short_blocks + 7) & ~7;
+    const int gpx = a.xcd ? (gp + 7) & ~7 : gp;
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
     do {                                                                                       \
         if (a.seq_order) {                                                                     \
             hipLaunchKernelGGL((k_emb_reduce_update<V, BG, true>), dim3(a.long_blocks + a.short_blocks), dim3(256), 0, st, a); \
             break;                                                                             \
         }                                                                                      \
-        hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gp), dim3(256), 0, st, a);            \
-        if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gp), dim3(256), 0, st, a);  \
+        hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gpx), dim3(256), 0, st, a);            \
+        if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gpx), dim3(256), 0, st, a);  \
         hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(a.short_blocks), dim3(256), 0, st, a); \
     } while (0)
     if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }

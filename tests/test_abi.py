@@ -106,3 +106,24 @@ def test_the_product_never_touches_the_null_stream():
             if pat.search(code) and "null-stream-ok" not in line:      # (ps_dbg_stamps reads its stamps back AFTER the measurement)
                 bad.append("%s:%d: %s" % (os.path.basename(fn), n, line.strip()))
     assert not bad, "null-stream use in the product:\n" + "\n".join(bad)
+
+
+def test_hot_kernels_use_no_scratch():
+    """hipcc's kernel-resource-usage remarks, recorded by ps_amd/build.py for every translation unit.  Scratch in a hot kernel is a
+    silent 8x: an edit that gave an inlined function a second call site once made hipcc keep a private copy of the argument struct
+    of k_emb_reduce_update (856 bytes per lane; the embedding update went 17 -> 135 us, every test still green)."""
+    from ps_amd import build
+    build.build()
+    res = build.kernel_resources()
+    assert len(res) > 50, "no kernel-resource-usage record (ps_amd/build/*.resources.json)"
+    hot = ("k_gemm_nt", "k_gemm_tn", "k_emb_fwd", "k_emb_partials", "k_emb_super", "k_emb_reduce_updateILi4", "k_field_sort_segments",
+           "k_seg_hist", "k_seg_scatter", "k_seg_fused", "k_bag_scan", "k_emb_keys_seg", "k_last_bwdILb1", "k_dense_update",
+           "k_gather_rows", "k_push_apply", "k_plan_fused", "k_shard_keys", "k_radix_scatter", "k_radix_hist")
+    seen = set()
+    for name, r in res.items():
+        for h in hot:
+            if h in name:
+                seen.add(h)
+                assert r.get("scratch", 0) == 0 and r.get("vgpr_spill", 0) == 0, (name, r)
+        assert r.get("scratch", 0) <= 64, (name, r)          # (anywhere: a few spilled SGPRs at most)
+    assert len(seen) >= 15, sorted(seen)
