@@ -80,7 +80,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     hdr_t = _newest_header()
-    objs, relink = [], force or not os.path.exists(LIB)
+    objs, relink, todo = [], force or not os.path.exists(LIB), []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
@@ -88,14 +88,23 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(op)
         if force or not os.path.exists(op) or not os.path.exists(op + ".resources.json") or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
-            cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PS_AMD_EXTRA_FLAGS", "").split() + ["-c", sp, "-o", op]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-            _record_resources(op, r.stderr)
-            if r.returncode != 0:
-                raise subprocess.CalledProcessError(r.returncode, cmd)
-            relink = True
+            todo.append((sp, op))
+
+    def compile_one(job):
+        sp, op = job
+        cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PS_AMD_EXTRA_FLAGS", "").split() + ["-c", sp, "-o", op]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        _record_resources(op, r.stderr)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+
+    if todo:        # the translation units are independent: one hipcc per core
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+            list(ex.map(compile_one, todo))
+        relink = True
     if relink or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
