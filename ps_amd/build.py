@@ -32,7 +32,7 @@ def _newest_header():
     t = 0.0
     for d in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for f in os.listdir(d):
-            if f.endswith(".h"):
+            if f.endswith((".h", ".inc")):
                 t = max(t, os.path.getmtime(os.path.join(d, f)))
     return t
 

@@ -515,375 +515,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
 }
 
 #if PS_GEMM_LAB
-// ---------------------------------------------------------------------------------------------------------------
-// The same contraction on v_mfma_f32_16x16x4_f32 (round 3).  What the ablation builds showed about the 32x32x2 loop above:
-// MFMAs alone run at 96 % of the f32 MFMA rate; the fragment reads from LDS cost 23 % of it EVEN WHEN NO MFMA DEPENDS ON
-// THEM (PS_GEMM_ABLATE=64: same time as the full loop) and although LDS itself is at an eighth of its bandwidth
-// (tools/ubench/lds_read.hip: 256 B/clk for this pattern) -- every ds_read_b128 takes ~40 cycles out of the matrix pipe.
-// A 32x32x2 MFMA writes 16 result registers in its 64 cycles: back-to-back MFMAs keep the register file's write side busy
-// all the time, and every LDS return (4 registers) has to take its slots from them.  The 16x16x4 instruction has the same
-// rate (2048 flops in 32 cycles) and the same LDS volume per flop on a 2 x 2 block of accumulators, but writes HALF the
-// result registers per flop (4 per 2048 flops).  Tiles, LDS image, global traffic, pipeline: as gemm_nt_tile<PIPE = 1>.
-//   fragments: lane l reads the float4 at (row l % 16, k = 4 (l / 16) ..+3) of a 16-row block: MFMA c of a 16-wide k chunk
-//   multiplies component c, i.e. k = 4 (l / 16) + c from lane group l / 16 -- any fixed bijection of k serves both operands;
-//   result block: register r of lane l = C[4 (l / 16) + r][l % 16].
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt16(NtArgs a) {
-    constexpr int NTH = WM * WN * 64;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BKT + 4, ASZ = BM * LD, BSZ = BN * LD;
-    constexpr int RF4 = BKT / 4;
-    constexpr int A_F4 = (BM * RF4 + NTH - 1) / NTH, B_F4 = (BN * RF4 + NTH - 1) / NTH, NCH = A_F4 + B_F4;
-    constexpr int RA = 2 * TM, RB = 2 * TN;                    // 16-row blocks per wave
-    constexpr int NG = BKT / 16, MF = RA * RB * 4;             // k chunks per slab, MFMAs per chunk
-    __shared__ __attribute__((aligned(16))) float As[3 * ASZ];
-    __shared__ __attribute__((aligned(16))) float Bs[3 * BSZ];
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);
-    StampScope stamp(a.ts);
-    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.skip && *a.skip) return;
-    const int tn = (a.N + BN - 1) / BN;
-    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w / WN, wn = w % WN;
-    const int nk = (a.K + BKT - 1) / BKT;
-
-    float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];       // two register sets of operand chunks in flight (see gemm_nt_tile)
-    const float *pa[A_F4], *pb[B_F4];
-    int ca[A_F4], cb[B_F4];
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-        const int e = tid + i * NTH;
-        int r = m0 + (e / RF4 < BM ? e / RF4 : BM - 1);
-        r = r < a.a_rows ? r : a.a_rows - 1;
-        ca[i] = (e % RF4) * 4;
-        pa[i] = a.A + (size_t)r * a.lda;
-    }
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-        const int e = tid + i * NTH;
-        int r = n0 + (e / RF4 < BN ? e / RF4 : BN - 1);
-        r = r < a.b_rows ? r : a.b_rows - 1;
-        cb[i] = (e % RF4) * 4;
-        pb[i] = a.Bt + (size_t)r * a.ldb;
-    }
-    auto masked = [&](float4 v, int c) -> float4 {
-        const int m = c < a.K ? -1 : 0;
-        v.x = __int_as_float(__float_as_int(v.x) & m); v.y = __int_as_float(__float_as_int(v.y) & m);
-        v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
-        return v;
-    };
-    auto gload1 = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int c) {
-        const int k0 = kt2 * BKT;
-        if (c < A_F4) { const int cc = k0 + ca[c]; ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4)); }
-        else { const int i = c - A_F4; const int cc = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (cc < a.K ? cc : a.K - 4)); }
-    };
-    auto swrite1 = [&](int oa, int ob, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4], int c) {
-        const int k0 = kt2 * BKT;
-        if (c < A_F4) {
-            const int e = tid + c * NTH;
-            if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                *reinterpret_cast<float4 *>(__builtin_assume_aligned(As + oa + (e / RF4) * LD + (e % RF4) * 4, 16)) = masked(ra[c], k0 + ca[c]);
-        } else {
-            const int i = c - A_F4, e = tid + i * NTH;
-            if ((BN * RF4) % NTH == 0 || e < BN * RF4)
-                *reinterpret_cast<float4 *>(__builtin_assume_aligned(Bs + ob + (e / RF4) * LD + (e % RF4) * 4, 16)) = masked(rb[i], k0 + cb[i]);
-        }
-    };
-    f32x4 acc[RA][RB];
-#pragma unroll
-    for (int i = 0; i < RA; ++i)
-#pragma unroll
-        for (int j = 0; j < RB; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    const int arow = (wm * TM * 32 + (lane & 15)) * LD + (lane >> 4) * 4;
-    const int brow = (wn * TN * 32 + (lane & 15)) * LD + (lane >> 4) * 4;
-    float4 fa0[RA], fb0[RB], fa1[RA], fb1[RB];
-    auto fread = [&](float4 (&fa)[RA], float4 (&fb)[RB], int oa, int ob, int g) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) fa[i] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(As + oa + arow + i * 16 * LD + g * 16, 16));
-#pragma unroll
-        for (int j = 0; j < RB; ++j) fb[j] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(Bs + ob + brow + j * 16 * LD + g * 16, 16));
-    };
-    auto fmfma = [&](const float4 (&fa)[RA], const float4 (&fb)[RB], auto mc) {
-        constexpr int m = decltype(mc)::value, c = m / (RA * RB), t = m % (RA * RB), i = t / RB, j = t % RB;
-        const float x = c == 0 ? fa[i].x : c == 1 ? fa[i].y : c == 2 ? fa[i].z : fa[i].w;
-        const float y = c == 0 ? fb[j].x : c == 1 ? fb[j].y : c == 2 ? fb[j].z : fb[j].w;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[i][j], 0, 0, 0);
-    };
-#define PS_ORDER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-    auto slab = [&](auto p0c, auto fullc, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int kt2, int oca, int ocb, int ona, int onb, int owa, int owb) {
-        constexpr int P0 = decltype(p0c)::value;
-        constexpr bool FULL = decltype(fullc)::value;
-        static_for<NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value, P = (P0 + g) & 1;
-            PS_ORDER();
-            if constexpr (g + 1 < NG) { if constexpr (P == 0) fread(fa1, fb1, oca, ocb, g + 1); else fread(fa0, fb0, oca, ocb, g + 1); }
-            else if constexpr (FULL) { if constexpr (P == 0) fread(fa1, fb1, ona, onb, 0); else fread(fa0, fb0, ona, onb, 0); }
-            PS_ORDER();
-            static_for<MF>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                if constexpr (P == 0) fmfma(fa0, fb0, mc); else fmfma(fa1, fb1, mc);
-                if constexpr (FULL && g == 0) {
-                    constexpr int c0 = m * NCH / MF, c1 = (m + 1) * NCH / MF;
-                    if constexpr (c1 > c0) {
-                        PS_ORDER();
-                        static_for<c1 - c0>([&](auto cc) {
-                            constexpr int c = c0 + decltype(cc)::value;
-                            swrite1(owa, owb, kt2 + 2, ra, rb, c);
-                            gload1(kt2 + 4, ra, rb, c);
-                        });
-                        PS_ORDER();
-                    }
-                }
-            });
-        });
-        PS_ORDER();
-    };
-#undef PS_ORDER
-    constexpr auto I0 = std::integral_constant<int, 0>{};
-    constexpr auto I1 = std::integral_constant<int, NG & 1>{};
-    constexpr auto YES = std::integral_constant<bool, true>{};
-    constexpr auto NO = std::integral_constant<bool, false>{};
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) gload1(0, ra0, rb0, c);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) gload1(1, ra1, rb1, c);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { swrite1(0, 0, 0, ra0, rb0, c); gload1(2, ra0, rb0, c); }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { swrite1(ASZ, BSZ, 1, ra1, rb1, c); gload1(3, ra1, rb1, c); }
-    __syncthreads();
-    fread(fa0, fb0, 0, 0, 0);
-    int oca = 0, ocb = 0, ona = ASZ, onb = BSZ, owa = 2 * ASZ, owb = 2 * BSZ;
-    auto rotate = [&]() { const int ta = oca, tb = ocb; oca = ona; ocb = onb; ona = owa; onb = owb; owa = ta; owb = tb; };
-    int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {
-        slab(I0, YES, ra0, rb0, kt, oca, ocb, ona, onb, owa, owb);
-        __syncthreads();
-        rotate();
-        slab(I1, YES, ra1, rb1, kt + 1, oca, ocb, ona, onb, owa, owb);
-        __syncthreads();
-        rotate();
-    }
-    if (kt < nk) slab(I0, NO, ra0, rb0, kt, oca, ocb, ona, onb, owa, owb);
-
-    // epilogue: block (i, j), register r of lane l -> row 16 i + 4 (l / 16) + r, column 16 j + l % 16
-#pragma unroll
-    for (int i = 0; i < RA; ++i)
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int col = n0 + wn * TN * 32 + j * 16 + (lane & 15);
-            const int rbase = m0 + wm * TM * 32 + i * 16 + 4 * (lane >> 4);
-            float mk[4];
-            if (a.epi == EPI_MASK_POS) {                    // (loads up front from clamped addresses, see k_gemm_nt)
-                const int mc = col < a.mask_cols ? col : a.mask_cols - 1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mk[r] = a.mask[(size_t)(rbase + r < a.M ? rbase + r : a.M - 1) * a.ldmask + mc];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rbase + r;
-                float v = acc[i][j][r];
-                if (a.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
-                else if (a.epi == EPI_SIGMOID) v = sigmoid_clip_dev(v);
-                else if (a.epi == EPI_MASK_POS) v *= (col >= a.mask_cols || mk[r] > 0.f) ? 1.f : 0.f;
-                if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Two consecutive FcLayer.forward GEMMs in ONE launch (layer/FcLayer.java:74-91 twice): Y1 = relu(A0 W0'), Y2 = relu(Y1 W1').
-// The FC chain is local to a panel of 64 batch rows -- a tile of Y2 needs the whole row panel of Y1 and nothing else -- so
-// the second GEMM's tiles need not wait for the first GEMM to END, only for their own panel.  One launch of
-// tiles(Y1) + tiles(Y2) workgroups: a phase-2 workgroup waits (bounded) until its panel's phase-1 tiles have counted
-// themselves in, then runs the same tile code on the second problem.  Saves a launch boundary (~3.5 us on the training
-// stream) and overlaps the first GEMM's tail with the second's ramp.
-//   Coherence.  Each XCD has its own L2, not coherent with the others' for ordinary memory inside a kernel (DESIGN.md
-//   4.1.1): a hand-over through memory needs an L2 write-back + invalidate -- unless producer and consumer share the L2.
-//   MI355X deals the workgroups of a launch round-robin over the 8 XCDs (tools/ubench/xcc_probe.hip: XCC_ID == blockIdx % 8
-//   for a launch alone on the chip; inside the step the rotation starts where the previous launch left off, so it is
-//   (blockIdx + s) % 8 with one s per launch): workgroups with the same blockIdx % 8 share an XCD, and panel p's tiles of
-//   BOTH phases are given to class p % 8.  The producer's stores (write-through L1) are in that XCD's L2 when its counter
-//   increment is issued (s_waitcnt vmcnt(0) + barrier first), the consumer's loads miss its L1 (invalidated at kernel
-//   start, and nobody read those lines since) and hit the same L2.  Every workgroup checks that its class agrees on one
-//   XCC_ID for the launch and reports a disagreement (the host then stops using this kernel).
-//   Progress.  Workgroups are dispatched in blockIdx order and every phase-1 workgroup has a smaller index than every
-//   phase-2 one: a waiting consumer can only wait for workgroups that are already running or done.
-struct PairArgs {
-    NtArgs p1, p2;
-    int mt, tn1, tn2, lp_max;          // row panels, N tiles of each problem, panels per XCD (ceil(mt / 8))
-    unsigned int *ctr;                 // [mt] tiles of phase 1 finished per panel, ever (never reset)
-    unsigned int target;               // value ctr[p] reaches when this launch's phase 1 of panel p is complete
-    unsigned int *xcc_err;             // counts workgroups that found a workgroup of their class (blockIdx % 8) on another XCD
-    unsigned int *xcc_tag; unsigned int epoch;      // [8] per class: (epoch << 4) | XCC id of this launch
-};
-template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(WM * WN * 64) void k_fc_fwd_pair(PairArgs q) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BKT + 4;
-    __shared__ __attribute__((aligned(16))) float As[2 * BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LD];
-    if (q.p1.prio) __builtin_amdgcn_s_setprio(3);
-    StampScope stamp(q.p1.ts);
-    if (q.p1.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(q.p1.flag, q.p1.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (q.p1.skip && *q.p1.skip) return;
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    // same blockIdx % 8 => same XCD, within this launch (the dispatcher's round robin carries over from launch to launch,
-    // so WHICH XCD class x lands on differs per launch; that every workgroup of a class shares one is what is needed):
-    // the class's tag = (launch epoch, XCC id); whoever finds this epoch's tag with another id reports it.  Checked when
-    // the workgroup's tile is DONE: a returning atomic on one of 8 words from ~100 workgroups each is a queue of ~100
-    // memory-side round trips, and in front of the tile every workgroup's first barrier stood behind it (the pair took
-    // 48 us; phase 1 alone 28.5 against the plain launch's 20.4).
-    auto xcc_check = [&]() {
-        if (threadIdx.x != 0) return;
-        unsigned int xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned int mine = (q.epoch << 4) | (xcc & 0xFu);
-        const unsigned int old = atomicMax(q.xcc_tag + x, mine);
-        if ((old >> 4) == q.epoch && old != mine) atomicAdd(q.xcc_err, 1u);
-    };
-    const int n1 = q.lp_max * q.tn1;
-    if (j < n1) {                                            // ---- phase 1: a tile of Y1
-        const int p = (j / q.tn1) * 8 + x, nt = j % q.tn1;
-        if (p >= q.mt) return;
-        gemm_nt_tile<WM, WN, TM, TN, BKT, 1>(q.p1, p * BM, nt * BN, As, Bs);
-        __syncthreads();                                     // every wave's stores have been acknowledged by the L2 (vmcnt(0) + barrier)
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(q.ctr + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        xcc_check();
-        return;
-    }
-    const int j2 = j - n1;                                   // ---- phase 2: a tile of Y2, once its panel of Y1 is complete
-    const int p = (j2 / q.tn2) * 8 + x, nt = j2 % q.tn2;
-    if (p >= q.mt) return;
-    if (q.p1.ablate & 8) return;                             // (measurement only)
-    if (threadIdx.x == 0 && !(q.p1.ablate & 16)) (void)spin_bounded(q.ctr + p, q.target, q.p2.bound);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (an L1 invalidate: cheap; the L2 is the producers' own)
-    gemm_nt_tile<WM, WN, TM, TN, BKT, 1>(q.p2, p * BM, nt * BN, As, Bs);
-    xcc_check();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same contraction with the operand tiles DMA'd global -> LDS (global_load_lds_dwordx4 on gfx950: 16 bytes per lane
-// straight into LDS, no VGPR round trip, no ds_write): the k_gemm_nt above stages every slab through registers (4 float4
-// loads + 4 ds_write_b128 per thread and slab, two register sets in flight) and measures ~71 % of the f32 MFMA rate in
-// its steady state against ~87 % with the global loads ablated.  Here a slab is 2 + 2 load instructions per wave and
-// nothing else; three LDS stages keep two slabs in flight.
-//   LDS image of a 64 x 32 operand tile: 512 chunks of 16 bytes.  A wave-level load writes 64 consecutive chunks (the
-//   hardware adds lane * 16 to a wave-uniform base), so the image is "as loaded": chunk slot s holds row s / 8, and the
-//   row's k-chunk c sits at position c ^ (row & 7) -- each lane simply FETCHES the global chunk that belongs in its
-//   slot.  The XOR spreads the 8 rows that 8 consecutive lanes of a fragment read (same c, rows r .. r + 7) over the 8
-//   bank groups: ds_read_b128 without conflicts, no padding (which contiguous 16-byte lane writes could not produce).
-// K needs K % 4 == 0 (as above); a tail slab shorter than 32 loads and multiplies only its valid chunks.
-template <int NST>
-__global__ __launch_bounds__(256) void k_gemm_nt_lds(NtArgs a) {
-    static_assert(NST == 3, "three LDS stages (two slabs in flight)");
-    constexpr int BM = 64, BN = 64, BKT = 32;
-    // one object per stage: the compiler's wait-count pass then knows that a DMA into stage i cannot alias a ds_read of
-    // stage j (through one array with a runtime stage index it waits for EVERY outstanding DMA before every LDS read)
-    __shared__ __attribute__((aligned(16))) float As0[BM * BKT], As1[BM * BKT], As2[BM * BKT];
-    __shared__ __attribute__((aligned(16))) float Bs0[BN * BKT], Bs1[BN * BKT], Bs2[BN * BKT];
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);
-    StampScope stamp(a.ts);
-    if (a.flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.skip && *a.skip) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int tn = (a.N + BN - 1) / BN;
-    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int m0 = (wg / tn) * BM, n0 = (wg % tn) * BN;
-    // this thread's two chunk slots per operand: slot = (i * 4 + w) * 64 + lane -> (row, k-chunk)
-    const float *pa[2], *pb[2];
-    int kc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int slot = (i * 4 + w) * 64 + lane, row = slot >> 3;
-        kc[i] = ((slot & 7) ^ (row & 7)) * 4;               // first k of the chunk that belongs in this slot
-        int ra = m0 + row; ra = ra < a.a_rows ? ra : a.a_rows - 1;      // (rows beyond the operand: clamped, never stored)
-        int rb = n0 + row; rb = rb < a.b_rows ? rb : a.b_rows - 1;
-        pa[i] = a.A + (size_t)ra * a.lda + kc[i];
-        pb[i] = a.Bt + (size_t)rb * a.ldb + kc[i];
-    }
-    // K % 32 == 0 or 16 (the launcher's condition: K % 16 == 0): a half slab at the end loads and multiplies chunks 0-3 only
-    const int kfull = a.K / BKT, half = (a.K % BKT) ? 1 : 0;
-    auto issue = [&](float *Ast, float *Bst, int kt) {      // (every instruction has active lanes: the waits count instructions)
-        const int k0 = kt * BKT;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (kt < kfull || kc[i] < 16) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[i] + k0),
-                                                 (__attribute__((address_space(3))) void *)(Ast + (i * 4 + w) * 256), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k0),
-                                                 (__attribute__((address_space(3))) void *)(Bst + (i * 4 + w) * 256), 16, 0, 0);
-            }
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = lane >> 5;
-    const int aoff = arow * BKT, boff = brow * BKT, ax = arow & 7, bx = brow & 7;
-    auto mult = [&](const float *Ast, const float *Bst, int q) {
-        const int c = 2 * q + kh;
-        const float4 fa = *reinterpret_cast<const float4 *>(Ast + aoff + ((c ^ ax) << 2));
-        const float4 fb = *reinterpret_cast<const float4 *>(Bst + boff + ((c ^ bx) << 2));
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
-    };
-    const int nkt = kfull + half;
-    // One pipeline step: slab kt (in stage S) has landed once at most the 4 load instructions of slab kt + 1 are
-    // outstanding (a wave's loads retire in order); the barrier (no fence: the DMA waits are explicit) says every wave's
-    // part of slab kt is in LDS and every wave is past slab kt - 1, whose stage the next DMA overwrites.
-#define LDS_STEP(S_A, S_B, N_A, N_B)                                                                                   \
-    {                                                                                                                  \
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        if (kt + 2 < nkt) issue(N_A, N_B, kt + 2);                                                                     \
-        if (kt < kfull) { mult(S_A, S_B, 0); mult(S_A, S_B, 1); mult(S_A, S_B, 2); mult(S_A, S_B, 3); }                \
-        else { mult(S_A, S_B, 0); mult(S_A, S_B, 1); }                                                                 \
-        ++kt;                                                                                                          \
-    }
-    issue(As0, Bs0, 0);
-    if (nkt > 1) issue(As1, Bs1, 1);
-    int kt = 0;
-    while (kt < nkt) {
-        LDS_STEP(As0, Bs0, As2, Bs2)
-        if (kt >= nkt) break;
-        LDS_STEP(As1, Bs1, As0, Bs0)
-        if (kt >= nkt) break;
-        LDS_STEP(As2, Bs2, As1, Bs1)
-    }
-#undef LDS_STEP
-    // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
-    const int col = n0 + wn * 32 + (lane & 31);
-    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
-    float mk[16];
-    if (a.epi == EPI_MASK_POS) {
-        const int mc = col < a.mask_cols ? col : a.mask_cols - 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            mk[r] = a.mask[(size_t)(row < a.M ? row : a.M - 1) * a.ldmask + mc];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        float v = acc[r];
-        if (a.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
-        else if (a.epi == EPI_SIGMOID) v = sigmoid_clip_dev(v);
-        else if (a.epi == EPI_MASK_POS) v *= (col >= a.mask_cols || mk[r] > 0.f) ? 1.f : 0.f;
-        if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
-    }
-}
-
+#include "kernels_gemm_lab.inc"      // (the rejected variants of rounds 2-3: lab build only)
 #endif      // PS_GEMM_LAB
 
 struct TnArgs {

@@ -37,7 +37,7 @@ def test_product_never_touches_the_oracle():
     """The oracle is test infrastructure: nothing under ps_amd/ may import, link or call it."""
     for d, _, files in os.walk(os.path.join(ROOT, "ps_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")):
                 txt = open(os.path.join(d, f), errors="replace").read()
                 for pat in (r"#\s*include[^\n]*oracle", r"libps_oracle", r"^\s*from\s+oracle", r"^\s*import\s+oracle", r"\borc_[a-z_]+\s*\("):
                     assert not re.search(pat, txt, flags=re.M), (os.path.join(d, f), pat)
@@ -100,7 +100,7 @@ def test_the_product_never_touches_the_null_stream():
     bad = []
     pat = re.compile(r"\bhipMemset\s*\(|\bhipMemcpy\s*\(|\bhipMemcpy2D\s*\(|\bhipDeviceSynchronize\s*\(|hipStreamSynchronize\s*\(\s*(0|nullptr|NULL)\s*\)|"
                      r"hipMem(set|cpy)Async\s*\([^;]*,\s*(0|nullptr|NULL)\s*\)\s*\)?\s*;")
-    for fn in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+    for fn in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.inc"))):
         for n, line in enumerate(open(fn), 1):
             code = line.split("//")[0]
             if pat.search(code) and "null-stream-ok" not in line:      # (ps_dbg_stamps reads its stamps back AFTER the measurement)
