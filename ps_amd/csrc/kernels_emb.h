@@ -23,6 +23,7 @@ struct EmbFwdArgs {
     size_t table_bytes;        // size of W (decides the streaming hints)
     int nt;                    // bit 0: non-temporal row loads, bit 1: non-temporal output stores (set by the launcher)
     int LPR, gather_blocks;    // filled by the launcher
+    int order;                 // multi-hot (launcher): bit 0 workgroups of one XCD take neighbouring bags, bit 1 bags field-major (k_emb_fwd)
     unsigned long long *ts;    // stamp slot (ps_common.h) or nullptr, set by the launcher
     const unsigned int *end_wait; unsigned int end_val; WaitBound bound;   // the first workgroup ends only once *end_wait reached end_val
     const unsigned int *start_wait; unsigned int start_val;   // no workgroup starts before *start_wait reached start_val (the previous

@@ -116,7 +116,14 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
         }
         return;
     }
-    const int64_t bag = grp;
+    // a.order: bags FIELD-major and the workgroups of one XCD on one contiguous eighth of them -- an XCD's L2 then holds the hot rows of
+    // ~F/8 fields instead of every field's (the rows of a field are shared by its bags, not by a sample's)
+    int64_t bag = grp;
+    if (a.order) {
+        const unsigned int vb = (a.order & 1) ? (blockIdx.x & 7u) * ((unsigned)a.gather_blocks >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+        const int64_t bt = ((int64_t)vb * 256 + threadIdx.x) / a.LPR;
+        bag = (a.order & 2) ? (bt < nb ? (bt % a.B) * a.F + bt / a.B : nb) : bt;
+    }
     if (bag >= nb) return;
     const int b = (int)(bag / a.F), f = (int)(bag % a.F);
     const int64_t p0 = a.offsets[bag], p1 = a.offsets[bag + 1];
@@ -1349,6 +1356,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
 int g_emb_xcd = 1;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
+int g_fwd_order = 3;        // ps_tune_set("fwd_order", bits): multi-hot gather's bag order (EmbFwdArgs.order; 0: sample-major round robin -- 0.354 against 0.347 ms / step at configs[4]'s shape, the gather 47.8 -> 42.1 us)
 int g_keys_grid = 0;        // ps_tune_set("keys_grid", workgroups): grid bound of the multi-hot key kernel (0: 1024)
 int g_seq_long_grid = 0;        // ps_tune_set("seq_long_grid", workgroups): long-key workgroups of the sequential order (0: SEQ_LONG_GRID)
 int g_emb_short_grid = 2048;    // ps_tune_set("emb_short_grid", workgroups): grid of the embedding update's one-key-per-lane-group role (multi-hot step: 1024/2048 0.361, 4096 0.3645, 8192 0.372 ms; the single-hot step does not care)
@@ -1508,6 +1516,9 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     const int64_t nb = (int64_t)a.B * a.F;
     const int64_t groups = multi ? nb : (nb + GATHER_ILP - 1) / GATHER_ILP;
     a.gather_blocks = cdiv(groups * a.LPR, 256);
+    // (a table far beyond the Infinity Cache has no rows to keep in an L2: the order the 256 GB gather was tuned on stays)
+    a.order = (multi && !slot && a.gather_blocks >= 64 && a.table_bytes <= ((size_t)1 << 30)) ? g_fwd_order : 0;
+    if (a.order & 1) a.gather_blocks = (a.gather_blocks + 7) & ~7;
     const int dense_blocks = a.dense ? cdiv((int64_t)a.B * a.X, 256) : 0;
     const int grid = a.gather_blocks + dense_blocks;
     if (grid == 0) return PS_OK;
