@@ -500,18 +500,28 @@ __device__ __forceinline__ Vec<VEC> load_g(const EmbBwdArgs &a, uint32_t p, int 
 // order), but the loads are not: entries are fetched PS_EMB_ILP at a time -- 16 independent
 // index loads, then 16 independent row loads -- so a run costs ~2 memory latencies per 16
 // entries instead of 2 per entry (measured 30 us -> the latency chain was the whole kernel).
-#define PS_EMB_ILP 32
-template <int VEC, bool BAG>
+// Rows in flight per lane group (round 5: 32 -> 8 in the per-key reduce, 16 in the chunk partials).  Only the chunked order (multi-hot
+// batches) gets here with more than 16 entries, and there the kernels are bound by how many keys are in flight, not by one key's chain:
+// 32 rows per lane group cost k_emb_reduce_update 168 VGPRs (3 waves per SIMD), 16 cost 101 (4), 8 cost 71 (7).  At configs[4]'s shape
+// 32 / 16 / 8: per-key reduce + Ftrl 71 / 64 / 56 us, chunk partials 36 / 28 / 30 us, the step 0.348 / 0.337 / 0.334 ms.  Same adds in the
+// same order whatever the batch.
+#ifndef PS_EMB_ILP
+#define PS_EMB_ILP 8
+#endif
+#ifndef PS_EMB_ILP_PARTIALS
+#define PS_EMB_ILP_PARTIALS 16
+#endif
+template <int VEC, bool BAG, int ILP>
 __device__ __forceinline__ void run_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part, Vec<VEC> &acc, bool have) {
-    for (uint32_t k = s; k < e; k += PS_EMB_ILP) {
-        uint32_t ent[PS_EMB_ILP];
+    for (uint32_t k = s; k < e; k += ILP) {
+        uint32_t ent[ILP];
 #pragma unroll
-        for (int j = 0; j < PS_EMB_ILP; ++j) ent[j] = a.sorted_ent[k + j < e ? k + j : e - 1];
-        Vec<VEC> g[PS_EMB_ILP];
+        for (int j = 0; j < ILP; ++j) ent[j] = a.sorted_ent[k + j < e ? k + j : e - 1];
+        Vec<VEC> g[ILP];
 #pragma unroll
-        for (int j = 0; j < PS_EMB_ILP; ++j) g[j] = load_g<VEC, BAG>(a, ent[j], part);
+        for (int j = 0; j < ILP; ++j) g[j] = load_g<VEC, BAG>(a, ent[j], part);
 #pragma unroll
-        for (int j = 0; j < PS_EMB_ILP; ++j) {
+        for (int j = 0; j < ILP; ++j) {
             if (k + j < e) {
                 if (have) { VFOR(i) acc.at(i) = g[j].get(i) + acc.at(i); }
                 else { acc = g[j]; have = true; }
@@ -520,10 +530,10 @@ __device__ __forceinline__ void run_sum(const EmbBwdArgs &a, uint32_t s, uint32_
     }
 }
 
-template <int VEC, bool BAG>
+template <int VEC, bool BAG, int ILP>
 __device__ __forceinline__ Vec<VEC> chunk_sum(const EmbBwdArgs &a, uint32_t s, uint32_t e, int part) {
     Vec<VEC> acc = Vec<VEC>::zero();
-    run_sum<VEC, BAG>(a, s, e, part, acc, false);     // first touch: put :91; then addi :94
+    run_sum<VEC, BAG, ILP>(a, s, e, part, acc, false);     // first touch: put :91; then addi :94
     return acc;
 }
 
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
         if (s <= t1 && s < e0) {
             const uint32_t e = s + CH < e0 ? s + CH : e0;
             const size_t slot = (size_t)2 * c + (j == 0 ? 1 : 0);
-            chunk_sum<VEC, BAG>(a, s, e, part).store(a.partials + slot * a.D + part * VEC);
+            chunk_sum<VEC, BAG, PS_EMB_ILP_PARTIALS>(a, s, e, part).store(a.partials + slot * a.D + part * VEC);
         }
     }
     const uint32_t u1 = a.seg_id[t1];
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(256) void k_emb_partials(EmbBwdArgs a) {
         const uint32_t s1 = a.seg_start[u1], e1 = a.seg_start[u1 + 1];
         if (e1 - s1 > CH) {
             const uint32_t e = s1 + CH;  // < e1
-            chunk_sum<VEC, BAG>(a, s1, e, part).store(a.partials + ((size_t)2 * c + 1) * a.D + part * VEC);
+            chunk_sum<VEC, BAG, PS_EMB_ILP_PARTIALS>(a, s1, e, part).store(a.partials + ((size_t)2 * c + 1) * a.D + part * VEC);
         }
     }
 }
@@ -908,19 +918,16 @@ __device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_
         S = small_key<VEC, BAG, 1>(a, s0, n, part);
     } else if (n <= 4) {
         S = small_key<VEC, BAG, 4>(a, s0, n, part);
-    } else if (n <= 16) {
-        S = small_key<VEC, BAG, 16>(a, s0, n, part);
     } else if (SEQ) {
-        return;                                                 // n > SEQ_TILE: a long-key workgroup owns this key
+        if (n > 16) return;                                     // n > SEQ_TILE: a long-key workgroup owns this key
+        S = small_key<VEC, BAG, 16>(a, s0, n, part);
     } else if (n <= PS_EMB_ILP) {
-        // up to a whole chunk in registers: the kernel's duration is its slowest lane group, and a
-        // 17..32-entry key walked in two batches per pass was that group (8 dependent round trips)
-        S = small_key<VEC, BAG, PS_EMB_ILP>(a, s0, n, part);
+        S = small_key<VEC, BAG, PS_EMB_ILP>(a, s0, n, part);    // (one batch of loads, both passes from registers)
     } else if (n <= CH) {
-        S = chunk_sum<VEC, BAG>(a, s0, e0, part);
+        S = chunk_sum<VEC, BAG, PS_EMB_ILP>(a, s0, e0, part);
         VFOR(i) S.at(i) = div_rn(S.get(i), (float)n);
         if (a.grad_mode == PS_GRAD_COMPAT) {
-            run_sum<VEC, BAG>(a, s0, e0, part, S, true);
+            run_sum<VEC, BAG, PS_EMB_ILP>(a, s0, e0, part, S, true);
             VFOR(i) S.at(i) = div_rn(S.get(i), (float)(2 * n));
         }
     } else {
