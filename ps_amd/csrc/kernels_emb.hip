@@ -674,6 +674,45 @@ __global__ __launch_bounds__(256) void k_emb_super(EmbBwdArgs a) {
     }
 }
 
+// The same super partials from the sort's LIST of the runs above PS_EMB_CHUNK * PS_EMB_SUPER_MIN entries (a.long_list: run id, first
+// entry, end; *a.nlong of them) instead of a walk over every tile: a fixed small grid, workgroup i takes runs i, i + grid, ..., its lane
+// groups the run's super groups.  (The tile walk is 6 k workgroups of which a few dozen fold anything: 19 us on the multi-hot step's
+// main chain between the chunk partials and the per-key reduce.)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_super_list(EmbBwdArgs a) {
+    StampScope stamp(a.ts_super);
+    if (a.skip && *a.skip) return;
+    const int lane64 = (int)(threadIdx.x & 63);
+    const int gpw = 64 / a.LPR;
+    if (lane64 / a.LPR >= gpw) return;
+    const int part = lane64 % a.LPR;
+    const uint32_t grp = (threadIdx.x >> 6) * gpw + lane64 / a.LPR, ngrp = 4 * gpw;
+    const uint32_t CH = PS_EMB_CHUNK;
+    const uint32_t nl = *a.nlong;
+    for (uint32_t i = blockIdx.x; i < nl; i += gridDim.x) {
+        const uint32_t *ll = a.long_list + 3 * (size_t)i;
+        const uint32_t s0 = ll[1], e0 = ll[2];
+        const uint32_t nch = (e0 - s0 + CH - 1) / CH;
+        if (nch <= PS_EMB_SUPER_MIN) continue;
+        for (uint32_t j = grp * PS_EMB_SUPER; j < nch; j += ngrp * PS_EMB_SUPER) {
+            const uint32_t j1 = j + PS_EMB_SUPER < nch ? j + PS_EMB_SUPER : nch;
+            Vec<VEC> p[PS_EMB_SUPER];
+#pragma unroll
+            for (int k = 0; k < PS_EMB_SUPER; ++k) {
+                const uint32_t jj = j + k < j1 ? j + k : j1 - 1;
+                const uint32_t sc = s0 + jj * CH;
+                p[k] = Vec<VEC>::load(a.partials + ((size_t)2 * (sc / CH) + (jj == 0 ? 1 : 0)) * a.D + part * VEC);
+            }
+            Vec<VEC> acc = p[0];
+#pragma unroll
+            for (int k = 1; k < PS_EMB_SUPER; ++k)
+                if (j + k < j1) { VFOR(i2) acc.at(i2) = p[k].get(i2) + acc.at(i2); }
+            const uint32_t sj = s0 + j * CH;
+            acc.store(a.partials2 + ((size_t)2 * (sj / CH) + (j == 0 ? 1 : 0)) * a.D + part * VEC);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // per-key reduce (+ double-backward factor) (+ fused updater)
 // ---------------------------------------------------------------------------
@@ -1596,7 +1635,8 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
             break;                                                                             \
         }                                                                                      \
         hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gpx), dim3(256), 0, st, a);            \
-        if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gpx), dim3(256), 0, st, a);  \
+        if (a.long_runs && a.long_list) hipLaunchKernelGGL((k_emb_super_list<V>), dim3(128), dim3(256), 0, st, a); \
+        else if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gpx), dim3(256), 0, st, a);  \
         hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(a.short_blocks), dim3(256), 0, st, a); \
     } while (0)
     if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }

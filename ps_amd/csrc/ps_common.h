@@ -116,7 +116,7 @@ int seg_sort_tile();
 bool seg_sort_fits(const int64_t *rows_per_field, int F);
 int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipStream_t st);
 int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st, int which = 3);
-extern int g_mh_seg_sort, g_mh_presort, g_mh_prio, g_slots_in_gather, g_keys_grid, g_emb_xcd, g_fwd_order;
+extern int g_mh_seg_sort, g_mh_presort, g_mh_prio, g_slots_in_gather, g_keys_grid, g_emb_xcd, g_fwd_order, g_super_list;
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap);
 void sort_ws_free(SortWorkspace &ws);
 // Stable LSD radix sort of (key, val) pairs on `key_bits` low bits.
@@ -238,7 +238,8 @@ __device__ __forceinline__ void start_wait(const unsigned int *f, unsigned int v
 struct StampScope {
     unsigned long long *p;
     unsigned int always;            // the first `always` workgroups all report their end (the long-key role of the embedding update)
-    // start: workgroup 0 (dispatched first); end: the maximum over every 32nd workgroup and the last one -- one atomic
+    // start: workgroup 0 (dispatched first); end: the maximum over every 33rd workgroup (33, not 32: workgroup b runs on XCD b % 8, and the
+    // kernels that deal their work XCD by XCD would be sampled on XCD 7 only) and the last one -- one atomic
     // per workgroup on one address made a 7 000-workgroup launch 2.4x slower
     __device__ __forceinline__ explicit StampScope(unsigned long long *q, unsigned int all_below = 0) : p(q), always(all_below) {
         if (p && threadIdx.x == 0 && blockIdx.x == 0) p[0] = (unsigned long long)wall_clock64();
@@ -246,7 +247,7 @@ struct StampScope {
     __device__ __forceinline__ ~StampScope() {
         // (a large `always` range is sampled too, every 8th: 2048 long-key workgroups with an atomic each on this one word made the
         //  stamped embedding update 31 us instead of 18 -- the measurement, not the kernel)
-        if (p && threadIdx.x == 0 && ((blockIdx.x & 31u) == 31u || blockIdx.x == gridDim.x - 1 || (blockIdx.x < always && (always <= 256u || (blockIdx.x & 7u) == 7u))))
+        if (p && threadIdx.x == 0 && ((blockIdx.x % 33u) == 32u || blockIdx.x == gridDim.x - 1 || (blockIdx.x < always && (always <= 256u || (blockIdx.x & 7u) == 7u))))
             atomicMax(p + 1, (unsigned long long)wall_clock64());
     }
 };

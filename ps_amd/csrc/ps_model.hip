@@ -328,6 +328,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // Raised wave priority for the step's GEMMs and head (s_setprio, kernels_gemm.hip): where the critical path is the FC chain
 // (single-hot: fused and sharded step).  A multi-hot step is bound by its sort chain and the sum of its kernels, and the
 // priority takes from exactly those: 0.387 against 0.382 ms.
+int g_super_list = 1;   // ps_tune_set("super_list", 0): the chunked order's super partials by the walk over every tile (k_emb_super) instead of the sort's list of very long runs
 int g_mh_prio = 0;      // ps_tune_set("mh_prio", 1): raised wave priority for the GEMMs and the head of a MULTI-HOT step too (its sort chain left the critical path with mh_presort)
 static bool gemm_prio(const ps_model *m) { return g_main_prio && (m->cur_offsets == nullptr || g_mh_prio); }
 
@@ -541,9 +542,11 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
                 Prof pf(m, "emb_segments");
                 // (the list of long runs only where the sequential order will walk it)
                 const bool want_seq = c.emb_sum_order == PS_SUM_SEQUENTIAL || (c.emb_sum_order == PS_SUM_AUTO && !m->cur_offsets);
-                PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss, want_seq ? m->long_list : nullptr,
-                                     PS_EMB_SEQ_TILE));
-                m->long_list_valid = want_seq; m->nlong_ptr = m->nseg_dev + 1;
+                // (chunked order: the runs above PS_EMB_CHUNK * PS_EMB_SUPER_MIN entries, for k_emb_super_list)
+                const bool want_list = want_seq || g_super_list;
+                PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss, want_list ? m->long_list : nullptr,
+                                     want_seq ? PS_EMB_SEQ_TILE : PS_EMB_CHUNK * PS_EMB_SUPER_MIN));
+                m->long_list_valid = want_list; m->nlong_ptr = m->nseg_dev + 1;
             }
         }
         m->side0_pending = true;
