@@ -61,6 +61,25 @@ struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer 
     int prio;                          // raise the waves' priority (the fused step's main chain)
 };
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
+// FcLayer.forward x 2 (+ the head and the out = 1 layer's backward) of 16-row panels in one launch (kernels_panel.hip)
+#define PS_PANEL_ROWS 16
+struct FwdPanelArgs {
+    const float *X; int ldx;           // layer 0's input [B][ldx] (ones column and zero padding included)
+    int B, Kpad0, N0, N1;
+    const float *W0p, *W1p;            // the two layers' weights in fragment order (FcParams.Wp)
+    float *H1; int ld1;                // layer 0's output = layer 1's input [B][ld1] (its ones column is already there)
+    float *H2; int ld2;                // layer 1's output [B][ld2]
+    unsigned long long *ts;
+    unsigned int *flag; unsigned int flag_val;              // "this launch has started" (LaunchOpts.flag)
+    const unsigned int *wait_flag; unsigned int wait_val;   // workgroup 0 ends only once *wait_flag reached wait_val
+    int prio;
+    WaitBound bound;
+};
+int fwd_panel_shape_ok(int Kpad0, int N0, int N1);
+// q / h: the head + last layer's backward of the same rows in the launch (q->chunk must be PS_PANEL_ROWS; head_wgs workgroups
+// write a partial slab each, like k_last_bwd's grid), or nullptr
+int launch_fwd_panel(const FwdPanelArgs &a, const LastBwdArgs *q, const HeadArgs *h, int head_wgs, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);
+int launch_pack_w(const float *Wt, float *Wp, int N, int Kpad, hipStream_t st);      // Wp from Wt (init, load, set; the updates write both)
 int launch_head(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);   // loss_out NULL: no loss reduction
 int launch_loss_reduce(const HeadArgs &a, float *loss_out, float *gbar_out, int *skip, int force_no_skip, hipStream_t st);
 int launch_head_last_bwd(const HeadArgs &h, const LastBwdArgs &a, int nsplit, hipStream_t st, LaunchOpts *lo = nullptr);   // lo: stop_event
@@ -133,6 +152,7 @@ struct WideUpdArgs {
 };
 struct DenseLayer {
     float *W, *Wt, *S1, *S2;           // W' [K+1 rows][ldw], Wt [N rows][ldwt], state like W'
+    float *Wp;                         // Wt in MFMA-fragment order for k_fwd_panel (kernels_panel.hip; FcParams.Wp) or nullptr
     const float *part;                 // split-K partials [nsplit][..][ldp]
     int64_t part_stride;
     int K, N, ldw, ldwt, ldp, nsplit;

@@ -15,6 +15,10 @@
 #include "ps_common.h"
 #include "kernels_emb.h"
 
+#ifndef PS_GEMM_LAB
+#define PS_GEMM_LAB 0
+#endif
+
 namespace {
 
 template <int VEC> struct Vec;
@@ -188,13 +192,6 @@ __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
     s.store(a.out + (size_t)b * a.ld + (size_t)f * a.D + part * VEC);
 }
 
-// ---------------------------------------------------------------------------
-// head: wide LR + add + clipped sigmoid + cross-entropy term + delta_L
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoid_clip_d(float x) {
-    return (float)(0.001f + (double)(.999f - 0.001f) / (1.0 + exp(-(double)x)));
-}
-
 #ifdef PS_HEAD_TIMING
 __device__ unsigned long long g_head_t[256 * 8];
 extern "C" int ps_dbg_head_timing(unsigned long long *out) {
@@ -204,214 +201,22 @@ extern "C" int ps_dbg_head_timing(unsigned long long *out) {
 #else
 #define HEAD_T(k) do { } while (0)
 #endif
-// Eight lanes per sample, eight samples per wave: every load of the head is independent of the others (the out = 1
-// layer's dot product: 34 strided loads per lane at K = 257; the wide part: id -> weight for 26 fields, four per
-// lane) and the only serial pieces are two 3-step butterflies and the reference's sequential f32 sum of the F wide
-// weights (layer/LRLayer.java:73-84), done with shuffles inside the group.  (One WAVE per sample was as fast per
-// launch, but eight samples per wave is what lets a workgroup do the head of all the rows whose backward it owns.)
-// valid = false: the lanes take part in the shuffles with sample b clamped, and store nothing.
-// Returns delta_L * sigmoid' of the sample (every lane of the group holds it); 0 when there are no labels.
-__device__ __forceinline__ float head_one(const HeadArgs &a, int b, int lane, bool valid) {
-    const int l8 = lane & 7, gbase = lane & ~7;
-    // Load order, all branch-free so that the compiler's in-order s_waitcnt bookkeeping stays exact:
-    //   wide ids (F <= 32: the usual case; more fields fall back to the loop below) -> the row of the last layer's
-    //   input and its weights -> (ids arrived) the wide weights -> dot product -> wide sum.
-    // Every round trip overlaps the next one; the stores (touched marks, error count) wait until the end.
-    // (With the id -> weight chain issued as one block BEFORE the row loads the head was faster on cache-resident
-    // batches and slower on fresh ones: the row loads sat behind the wait for the ids.)
-    int64_t wid[4] = {0, 0, 0, 0};
-    float ww[4] = {0.f, 0.f, 0.f, 0.f};
-    bool wbad = false;
-    const bool wide_early = a.wide && a.F <= 32;
-    if (wide_early) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 8 * r + l8;
-            wid[r] = a.wide_ids[(size_t)b * a.F + (f < a.F ? f : a.F - 1)];
-        }
-    }
-    float zl;                                               // the last FcLayer's activation for this sample
-    if (a.a_last) {
-        // FcLayer.forward with out = 1 (layer/FcLayer.java:76-77): the group's 8 lanes read 128 contiguous bytes
-        // of the row per load, 8 loads per lane in flight (K <= 256: ONE memory round trip; scalar loads strided
-        // over the lanes, 34 per lane behind a runtime trip count, took 7.6 of the head's 11.5 us), butterfly sum
-        const float *__restrict__ x = a.a_last + (size_t)b * a.lda_last;
-        const float *__restrict__ wl = a.w_last;
-        const int k4 = a.k_last & ~3;
-        float acc = 0.f;
-        for (int kb = 0; kb < k4; kb += 256) {
-            float4 xv[8], wv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = kb + 32 * i + 4 * l8;
-                const int kk = k < k4 ? k : 0;
-                xv[i] = *reinterpret_cast<const float4 *>(x + kk);
-                wv[i] = *reinterpret_cast<const float4 *>(wl + kk);
-            }
-            if (kb == 0 && wide_early) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool bad = wid[r] < 0 || wid[r] >= a.wide_rows;
-                    wbad |= bad && 8 * r + l8 < a.F;
-                    if (bad) wid[r] = 0;
-                    ww[r] = a.wide_w[wid[r]];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (kb + 32 * i + 4 * l8 >= k4) xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                acc += xv[i].x * wv[i].x; acc += xv[i].y * wv[i].y; acc += xv[i].z * wv[i].z; acc += xv[i].w * wv[i].w;
-            }
-        }
-        for (int k = k4 + l8; k < a.k_last; k += 8) acc += x[k] * wl[k];       // <= 3 elements (the ones column)
-#pragma unroll
-        for (int off = 4; off; off >>= 1) acc += __shfl_xor(acc, off);
-        zl = a.last_sigmoid ? sigmoid_clip_d(acc) : acc;
-        if (valid && l8 == 0) a.zout[(size_t)b * a.ldz] = zl;
-    } else {
-        zl = a.zlast[(size_t)b * a.ldz];
-        if (wide_early) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool bad = wid[r] < 0 || wid[r] >= a.wide_rows;
-                wbad |= bad && 8 * r + l8 < a.F;
-                if (bad) wid[r] = 0;
-                ww[r] = a.wide_w[wid[r]];
-            }
-        }
-    }
-    if (wide_early) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (8 * r + l8 >= a.F) ww[r] = 0.f;
-    }
-    HEAD_T(4);
-    float p;
-    if (a.wide) {
-        // LRLayer.forward (layer/LRLayer.java:73-84): sum over the F wide ids, sequential, then + bias
-        float sumW = 0.f;
-        for (int j0 = 0; j0 < a.F; j0 += 32) {
-            float w[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                w[r] = ww[r];
-                const int f = j0 + 8 * r + l8;
-                if (!wide_early && f < a.F) {
-                    int64_t id = a.wide_ids[(size_t)b * a.F + f];
-                    if (id < 0 || id >= a.wide_rows) { if (valid) atomicAdd(a.err, 1); id = 0; }
-                    w[r] = a.wide_w[id];
-                    if (valid && a.touched && a.train) a.touched[id] = 1;   // LRLayer.weights.put (never cleared)
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = a.F - j0 - 8 * r;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {                                    // field order; the 8 shuffles are independent
-                    const float v = __shfl(w[r], gbase + j);
-                    if (j < n) sumW += v;
-                }
-            }
-        }
-        sumW += a.wide_bias[0];
-        if (wide_early && valid) {
-            if (wbad) atomicAdd(a.err, 1);
-            if (a.touched && a.train) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (8 * r + l8 < a.F) a.touched[wid[r]] = 1;   // LRLayer.weights.put (never cleared)
-            }
-        }
-        HEAD_T(5);
-        if (valid && l8 == 0) a.wide_z[b] = sumW;
-        const float z = zl + sumW;                          // AddLayer.forward l.add(r)
-        p = sigmoid_clip_d(z);
-    } else {
-        p = zl;                                             // last FcLayer already applied the sigmoid
-    }
-    HEAD_T(6);
-    if (valid && l8 == 0) a.P[b] = p;
-    if (!a.labels) return 0.f;
-    const float l = a.labels[b];
-    float d = (p - l) / (p * (1 - p));                      // loss/CrossEntropy.java:25
-    d *= p * (1 - p);                                       // Sigmoid.backward (activations/Sigmoid.java:18)
-    if (valid && l8 == 0) {
-        // loss/CrossEntropy.java:15 (FastMath.log ~ log; double math, cast to float)
-        a.terms[b] = (float)(-l * log((double)p) - ((1 - l) * log((double)(1 - p))));
-        a.dlast[(size_t)b * a.ldd] = d;
-    }
-    return d;
-}
+#include "kernels_head.inc"
 
 __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     const int b = blockIdx.x * 32 + (threadIdx.x >> 3);
     (void)head_one(a, b < a.B ? b : a.B - 1, threadIdx.x & 63, b < a.B);
 }
 
-// FcLayer.backward of the out = 1 layer in one pass over its input: delta_prev = W^T delta (* relu'),
-// dW/db partial sums over this workgroup's rows (reduced by k_dense_update like the split-K slabs).
-// HEAD: the head of the same rows runs first in the same launch (training step: head -> loss' -> this layer's
-// backward is a chain of three tiny kernels on the critical path; the rows' delta stays in LDS).
-#define HEAD_ROWS_MAX 1024
-#define LAST_ROWS 32
+// FcLayer.backward of the out = 1 layer (kernels_head.inc last_bwd_rows), optionally with the head of the same rows in front
+
 template <bool HEAD>
 __global__ __launch_bounds__(256) void k_last_bwd(LastBwdArgs a, HeadArgs h) {
     __shared__ float dsh[HEAD ? HEAD_ROWS_MAX : 1];
     if (a.prio) __builtin_amdgcn_s_setprio(3);       // main-chain kernel of the fused step (see k_gemm_nt)
     StampScope stamp(a.ts);
     if (!HEAD && a.skip && *a.skip) return;
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * a.chunk;
-    const int r1 = r0 + a.chunk < a.B ? r0 + a.chunk : a.B;
-    HEAD_T(0);
-    if (HEAD) {
-        for (int base = r0; base < r1; base += 32) {            // 32 rows per sweep: 8 lanes each
-            const int b = base + (tid >> 3);
-            const float d = head_one(h, b < r1 ? b : r1 - 1, tid & 63, b < r1);
-            if (b < r1 && (tid & 7) == 0) dsh[b - r0] = d;
-        }
-        HEAD_T(1);
-        __syncthreads();
-        HEAD_T(2);
-    }
-    const float *__restrict__ A = a.A;
-    const float *__restrict__ dl = a.dlast;
-    float *__restrict__ dp = a.dprev;
-    // (requesting the first LAST_ROWS x column before the head, to overlap the two round trips, measured slower:
-    // kernel span 12.9 -> 15.5 us)
-    // The ones column (k == K: db = the rows' delta summed in order, x = 1 exactly) needs no load of A at all: one thread adds
-    // it up from the deltas.  As one more trip of the loop below -- k = K .. Kp - 1 for 16 threads at K = 256 -- it was a
-    // second full memory round trip of the whole workgroup for one useful column (round 4).
-    if (tid == 255) {
-        float accb = 0.f;
-        for (int b = r0; b < r1; ++b) accb += 1.0f * (HEAD ? dsh[b - r0] : dl[(size_t)b * a.ldd]);
-        a.part[(size_t)blockIdx.x * a.part_stride + (size_t)a.K * a.ldpart] = accb;
-    }
-    for (int k = tid; k < a.K; k += 256) {
-        const bool in = true;
-        const float w = a.W[(size_t)k * a.ldw];
-        float acc = 0.f;
-        for (int b0 = r0; b0 < r1; b0 += LAST_ROWS) {
-            float x[LAST_ROWS], d[LAST_ROWS];
-#pragma unroll
-            for (int j = 0; j < LAST_ROWS; ++j) {               // a workgroup's usual 32 rows in ONE round trip
-                const int b = b0 + j < r1 ? b0 + j : r1 - 1;
-                x[j] = A[(size_t)b * a.lda + k];
-                d[j] = HEAD ? dsh[b - r0] : dl[(size_t)b * a.ldd];
-            }
-#pragma unroll
-            for (int j = 0; j < LAST_ROWS; ++j) {
-                if (b0 + j < r1) {
-                    acc += x[j] * d[j];                         // rows in order: the sequential batch sum
-                    if (k < a.dprev_cols) {
-                        float v = w * d[j];                     // weights.transpose().mmul(delta) with one output
-                        if (k < a.mask_cols) v *= x[j] > 0.f ? 1.f : 0.f;   // the previous layer's relu'
-                        dp[(size_t)(b0 + j) * a.ldp + k] = v;
-                    }
-                }
-            }
-        }
-        if (in) a.part[(size_t)blockIdx.x * a.part_stride + (size_t)k * a.ldpart] = acc;
-    }
-    HEAD_T(3);
+    last_bwd_rows<HEAD>(a, h, dsh, threadIdx.x, blockIdx.x);
 }
 
 // loss = sum(terms)/B, gbar = rowMeans(delta) ; sets the skip flag (model/DNN.java:58-63)
@@ -1308,6 +1113,23 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdArgs a) {
         const int nn = n0 + ty + 8 * j, kk = k0 + tx;
         if (nn < L.N && kk >= row_lo && kk <= row_hi) L.Wt[(size_t)nn * L.ldwt + kk] = tile[tx][ty + 8 * j];
     }
+#if PS_GEMM_LAB
+    if (L.Wp) {
+        // ... and the fragment-order copy k_fwd_panel streams (kernels_panel.hip): the tile is 2 x 2 fragments of 16 features x 16 k,
+        // one wave each -- lane (n % 16, (k % 16) / 4) holds four consecutive k of one feature, 1 KiB contiguous per wave
+        const int lane = threadIdx.x & 63, fr = threadIdx.x >> 6;
+        const int nl = (fr & 1) * 16 + (lane & 15), kl = (fr >> 1) * 16 + 4 * (lane >> 4);
+        const int nn = n0 + nl, kk = k0 + kl;
+        if (nn < L.N && kk < L.ldwt) {
+            float *dst = L.Wp + ((((size_t)(nn >> 4) * (L.ldwt >> 4) + (kk >> 4)) * 64 + lane) << 2);
+            if (kk >= row_lo && kk + 3 <= row_hi) *reinterpret_cast<float4 *>(dst) = make_float4(tile[kl][nl], tile[kl + 1][nl], tile[kl + 2][nl], tile[kl + 3][nl]);
+            else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) if (kk + m >= row_lo && kk + m <= row_hi) dst[m] = tile[kl + m][nl];
+            }
+        }
+    }
+#endif
 }
 
 // materialise the flat dense gradient (sum of split partials / B) without updating

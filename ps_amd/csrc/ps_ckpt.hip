@@ -223,7 +223,7 @@ extern "C" int ps_store_load(ps_store_t *s, const char *path) {
     if (rc != PS_OK || !io.ok)
         return ps_set_err(rc != PS_OK ? rc : PS_E_HIP, "%s: read error while loading; the store now holds a MIX of old and new tensors -- reload or recreate it", path);
     for (auto &f : s->fc)
-        if (f.present) PSCHK(launch_transpose_w(f.W, f.Wt, f.Kpad, f.ldw, f.N, s->stream));
+        if (f.present) { PSCHK(launch_transpose_w(f.W, f.Wt, f.Kpad, f.ldw, f.N, s->stream)); PSCHK(launch_pack_w(f.Wt, f.Wp, f.N, f.Kpad, s->stream)); }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->updaters = upd;
     s->global_step = h.global_step;

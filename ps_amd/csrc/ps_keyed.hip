@@ -162,7 +162,7 @@ extern "C" int ps_store_push_update(ps_store_t *s, int n, const char *const *key
             d.nlayers = 1; d.apply = 1; d.upd = make_upd_params(u);
             d.B = is_async ? 1 : m;                                    // KVStore.update: divi(sumCnt)
             DenseLayer &L = d.L[0];
-            L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+            L.W = p.W; L.Wt = p.Wt; L.Wp = p.Wp; L.S1 = p.S1; L.S2 = p.S2;
             L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad; L.ldp = p.N;
             L.part_stride = (int64_t)len; L.nsplit = is_async ? 1 : m;
             // a slab holds rows [row_lo, row_lo + row_cnt) only: shift the base so that row k lands on it

@@ -150,7 +150,7 @@ extern "C" int ps_dense_update(ps_store_t *s, int layer) {
         d.nlayers = 1; d.B = 1; d.apply = 1; d.flat_grad = p.pending; d.flat_div = (float)p.pending_cnt;
         d.upd = make_upd_params(u);
         DenseLayer &L = d.L[0];
-        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2; L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
+        L.W = p.W; L.Wt = p.Wt; L.Wp = p.Wp; L.S1 = p.S1; L.S2 = p.S2; L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = 0; L.elem_end = (int64_t)(p.K + 1) * p.N;
         PSCHK(launch_dense_update(d, s->stream));
         p.pending_cnt = 0;

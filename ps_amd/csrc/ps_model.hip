@@ -563,46 +563,6 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     // row exchanges, the gather) is then done, which is what the NEXT step's plan waits for on side chain 0
     bool fwd_flag_due = train && m->sh.active && m->dev_ok && !c.use_graph && !m->profile && m->multi_stream;
     m->fwd_flag_valid = false;
-    // FcLayer.forward x nfc
-    for (int l = 0; l < nfc; ++l) {
-        FcParams &p = s->fc[l];
-        float *out = l + 1 < nfc ? m->fc[l + 1].A : m->out_last;
-        const int ldo = l + 1 < nfc ? m->fc[l + 1].ldA : m->ld_last;
-        int epi = EPI_RELU;
-        if (l == nfc - 1) epi = c.kind == PS_MODEL_WIDEDEEP ? EPI_NONE : EPI_SIGMOID;   // FcLayer.java:58-62, WideDeepNN.java:128
-        static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
-        if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
-        // two consecutive hidden (relu) layers: ONE launch, the second layer's tiles start as their row panel of the first
-        // layer's output completes (kernels_gemm.hip k_fc_fwd_pair)
-        const bool pair = l + 2 < nfc && !s->fwd_pair_off && m->pair_ctr &&
-                          gemm_nt_fwd_pair_ok(B, p.N, s->fc[l + 1].N, p.Kpad, s->fc[l + 1].Kpad);
-        Prof pf(m, pair ? (l == 0 ? "fc_fwd01" : "fc_fwd_pair") : names[l]);
-        LaunchOpts lo;
-        // (sort_layer: which forward GEMM's start releases the field sort -- 0, the first; measurement knob)
-        const bool sort_here = sort_due && (l >= g_sort_layer || l + 1 >= nfc - 1);
-        if (sort_here || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
-        lo.prio = (train && gemm_prio(m)) ? 1 : 0;
-        if (pair) {
-            FcParams &p2 = s->fc[l + 1];
-            float *out2 = l + 2 < nfc ? m->fc[l + 2].A : m->out_last;
-            const int ldo2 = l + 2 < nfc ? m->fc[l + 2].ldA : m->ld_last;
-            PSCHK(gemm_nt_fwd_pair(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, p.Kpad, p2.Wt, p2.Kpad, p2.N, out2, ldo2, p2.Kpad, B,
-                                   m->pair_ctr, &m->pair_epoch, reinterpret_cast<unsigned int *>(s->err_dev) + 4, st, &lo, s->werr()));
-        } else
-        PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
-                      nullptr, 0, 0, nullptr, st, &lo, s->werr()));
-        if (lo.flag && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st));      // (an empty GEMM)
-        if (fwd_flag_due) {
-            fwd_flag_due = false; m->fwd_flag_valid = true;
-            if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, true));      // (the waiter after the launch that releases it)
-        }
-        if (sort_here) {        // the waiter is enqueued after the launch that releases it
-            PSCHK(enqueue_sort());
-            sort_due = false;
-        }
-        if (pair) ++l;          // (layer l + 1 went with this launch)
-    }
-    if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, false));      // (no GEMM carried the start flag: the sort at once)
     // LRLayer.forward + AddLayer.forward + loss
     HeadArgs h;
     memset(&h, 0, sizeof h);
@@ -624,7 +584,73 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     m->head_bwd_done = false;
     const FcParams &pl = s->fc[nfc - 1];
     FcBuf &bl = m->fc[nfc - 1];
-    if (train && pl.N == 1 && h.labels && head_last_bwd_fusable(cdiv(B, bl.nsplit))) {
+    // Two hidden (relu) layers of the built shape in front of the out = 1 layer: the FC forward chain of a 16-row panel is ONE
+    // launch (kernels_panel.hip), with the head and the out = 1 layer's backward of the same rows when this is a training step
+    // whose head workgroups own 16 rows too
+    const bool panel = g_fwd_panel && nfc == 3 && pl.N == 1 && s->fc[0].Wp && s->fc[1].Wp && !g_gemm_ablate &&
+                       fwd_panel_shape_ok(s->fc[0].Kpad, s->fc[0].N, s->fc[1].N) && m->fc[1].ldA == s->fc[1].Kpad;
+    const bool head_fusable = train && pl.N == 1 && h.labels && head_last_bwd_fusable(cdiv(B, bl.nsplit));
+    const bool panel_head = panel && head_fusable && g_fwd_panel >= 2 && cdiv(B, bl.nsplit) == PS_PANEL_ROWS;
+    // FcLayer.forward x nfc
+    for (int l = 0; l < nfc; ++l) {
+        FcParams &p = s->fc[l];
+        float *out = l + 1 < nfc ? m->fc[l + 1].A : m->out_last;
+        const int ldo = l + 1 < nfc ? m->fc[l + 1].ldA : m->ld_last;
+        int epi = EPI_RELU;
+        if (l == nfc - 1) epi = c.kind == PS_MODEL_WIDEDEEP ? EPI_NONE : EPI_SIGMOID;   // FcLayer.java:58-62, WideDeepNN.java:128
+        static const char *names[8] = {"fc_fwd0", "fc_fwd1", "fc_fwd2", "fc_fwd3", "fc_fwd4", "fc_fwd5", "fc_fwd6", "fc_fwd7"};
+        if (l == nfc - 1 && p.N == 1) break;      // the out = 1 layer is a per-sample dot product inside k_head
+        // two consecutive hidden (relu) layers: ONE launch, the second layer's tiles start as their row panel of the first
+        // layer's output completes (kernels_gemm.hip k_fc_fwd_pair)
+        const bool panel_l = panel && l == 0;
+        const bool pair = !panel_l && l + 2 < nfc && !s->fwd_pair_off && m->pair_ctr &&
+                          gemm_nt_fwd_pair_ok(B, p.N, s->fc[l + 1].N, p.Kpad, s->fc[l + 1].Kpad);
+        Prof pf(m, panel_l ? (panel_head ? "fwd_panel_head" : "fwd_panel") : pair ? (l == 0 ? "fc_fwd01" : "fc_fwd_pair") : names[l]);
+        LaunchOpts lo;
+        // (sort_layer: which forward GEMM's start releases the field sort -- 0, the first; measurement knob)
+        const bool sort_here = sort_due && (panel_l || l >= g_sort_layer || l + 1 >= nfc - 1);
+        if (sort_here || fwd_flag_due) { if (++m->fwd_epoch == 0) ++m->fwd_epoch; lo.flag = m->start_flag + 4; lo.flag_val = m->fwd_epoch; }
+        lo.prio = (train && gemm_prio(m)) ? 1 : 0;
+        if (panel_l) {
+            FwdPanelArgs pa;
+            memset(&pa, 0, sizeof pa);
+            pa.X = m->fc[0].A; pa.ldx = m->fc[0].ldA; pa.B = B; pa.Kpad0 = p.Kpad; pa.N0 = p.N; pa.N1 = s->fc[1].N;
+            pa.W0p = p.Wp; pa.W1p = s->fc[1].Wp;
+            pa.H1 = m->fc[1].A; pa.ld1 = m->fc[1].ldA; pa.H2 = m->fc[2].A; pa.ld2 = m->fc[2].ldA;
+            if (panel_head) {
+                LastBwdArgs q;
+                fill_last_bwd(m, q);
+                // (both side chains of the backward are released from the device when they can be -- dev_release() -- and the
+                //  launch then carries nothing: a launch with a stop event starts ~2 us later than a plain one)
+                lo.stop_event = m->head_ev = dev_release(m) ? nullptr : pick_event(m);
+                PSCHK(launch_fwd_panel(pa, &q, &h, bl.nsplit, st, &lo, s->werr()));
+                PSCHK(settle_event(m, lo));
+                m->head_bwd_done = true;
+            } else PSCHK(launch_fwd_panel(pa, nullptr, nullptr, 0, st, &lo, s->werr()));
+        } else if (pair) {
+            FcParams &p2 = s->fc[l + 1];
+            float *out2 = l + 2 < nfc ? m->fc[l + 2].A : m->out_last;
+            const int ldo2 = l + 2 < nfc ? m->fc[l + 2].ldA : m->ld_last;
+            PSCHK(gemm_nt_fwd_pair(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, p.Kpad, p2.Wt, p2.Kpad, p2.N, out2, ldo2, p2.Kpad, B,
+                                   m->pair_ctr, &m->pair_epoch, reinterpret_cast<unsigned int *>(s->err_dev) + 4, st, &lo, s->werr()));
+        } else
+        PSCHK(gemm_nt(m->fc[l].A, m->fc[l].ldA, B, p.Wt, p.Kpad, p.N, out, ldo, B, p.N, p.Kpad, epi,
+                      nullptr, 0, 0, nullptr, st, &lo, s->werr()));
+        if (lo.flag && !lo.launched) PSCHK(launch_flag_set(m->start_flag + 4, m->fwd_epoch, st));      // (an empty GEMM)
+        if (fwd_flag_due) {
+            fwd_flag_due = false; m->fwd_flag_valid = true;
+            if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, true));      // (the waiter after the launch that releases it)
+        }
+        if (sort_here) {        // the waiter is enqueued after the launch that releases it
+            PSCHK(enqueue_sort());
+            sort_due = false;
+        }
+        if (pair || panel_l) ++l;          // (layer l + 1 went with this launch)
+    }
+    if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, false));      // (no GEMM carried the start flag: the sort at once)
+    if (panel_head) {
+        // (went with the panel launch)
+    } else if (head_fusable) {
         // training: the head and the out = 1 layer's backward of the same rows in ONE launch (three tiny kernels
         // of the critical chain become one; the loss reduction leaves the chain altogether, see enqueue_backward)
         LastBwdArgs q;
@@ -746,7 +772,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
         DenseLayer &L = d.L[l];
-        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+        L.W = p.W; L.Wt = p.Wt; L.Wp = p.Wp; L.S1 = p.S1; L.S2 = p.S2;
         L.part = m->fc[l].part; L.part_stride = m->fc[l].part_stride; L.ldp = m->fc[l].ldp; L.nsplit = m->fc[l].nsplit;
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
@@ -1041,7 +1067,7 @@ static int enqueue_update(ps_model *m) {
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
         DenseLayer &L = d.L[l];
-        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+        L.W = p.W; L.Wt = p.Wt; L.Wp = p.Wp; L.S1 = p.S1; L.S2 = p.S2;
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }

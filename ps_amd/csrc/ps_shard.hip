@@ -940,7 +940,7 @@ int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st) {
     for (int l = 0; l < nfc; ++l) {
         FcParams &p = s->fc[l];
         DenseLayer &L = d.L[l];
-        L.W = p.W; L.Wt = p.Wt; L.S1 = p.S1; L.S2 = p.S2;
+        L.W = p.W; L.Wt = p.Wt; L.Wp = p.Wp; L.S1 = p.S1; L.S2 = p.S2;
         L.K = p.K; L.N = p.N; L.ldw = p.ldw; L.ldwt = p.Kpad;
         L.elem_begin = off; off += (int64_t)(p.K + 1) * p.N; L.elem_end = off;
     }

@@ -42,6 +42,7 @@ struct FcParams {
     int ldw = 0;             // round_up(N,16): row stride of W'
     float *W = nullptr;      // W'  [Kpad][ldw]   (reference layout [in][out] + bias row)
     float *Wt = nullptr;     // W'^T [N][Kpad]
+    float *Wp = nullptr;     // Wt in MFMA-fragment order [N/16][Kpad/16][64 lanes][4] for k_fwd_panel (N % 16 == 0 only; kernels_panel.hip)
     float *S1 = nullptr, *S2 = nullptr;  // updater state, W' layout
     // KVStore.sum of the layer-granular path (ps_fc_backward): flat [(K+1)][N] sum and its count, until ps_dense_update
     float *pending = nullptr; int pending_cnt = 0;

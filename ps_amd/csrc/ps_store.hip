@@ -293,7 +293,7 @@ extern "C" int ps_store_destroy(ps_store_t *s) {
     fr(s->emb.W); fr(s->emb.state); fr(s->emb.row_base_dev);
     fr(s->emb.owner_dev); fr(s->emb.local_dev); fr(s->emb.grow_base_dev);
     fr(s->wide.W); fr(s->wide.state); fr(s->wide.touched); fr(s->wide.bias); fr(s->wide.bias_state);
-    for (auto &f : s->fc) { fr(f.W); fr(f.Wt); fr(f.S1); fr(f.S2); fr(f.pending); }
+    for (auto &f : s->fc) { fr(f.W); fr(f.Wt); fr(f.Wp); fr(f.S1); fr(f.S2); fr(f.pending); }
     {
         ps_store::OpScratch &o = s->ops;
         sort_ws_free(o.ws);
@@ -600,11 +600,15 @@ extern "C" int ps_store_create_fc(ps_store_t *s, int layer, int in_dims, int out
     const size_t wn = (size_t)f.Kpad * f.ldw, wtn = (size_t)f.N * f.Kpad;
     PSCHK(store_dev_alloc(s, (void **)&f.W, sizeof(float) * wn, true));
     PSCHK(store_dev_alloc(s, (void **)&f.Wt, sizeof(float) * wtn, true));
+#if PS_GEMM_LAB
+    if (f.N % 16 == 0) PSCHK(store_dev_alloc(s, (void **)&f.Wp, sizeof(float) * wtn, true));      // (fragment order: kernels_panel.hip, lab build)
+#endif
     PSCHK(store_dev_alloc(s, (void **)&f.S1, sizeof(float) * wn, true));
     PSCHK(store_dev_alloc(s, (void **)&f.S2, sizeof(float) * wn, true));
     // layer/FcLayer.java:34-50: W ~ xavier(in+out), b ~ xavier(in+1)
     PSCHK(launch_init_dense(f.W, f.Wt, f.K, f.N, f.ldw, f.Kpad, s->seed, PS_TABLE_FC(layer), ps_xavier_scale(in_dims, out_dims),
                             PS_TABLE_FC(layer) + 1, ps_xavier_scale(in_dims, 1), s->stream));
+    PSCHK(launch_pack_w(f.Wt, f.Wp, f.N, f.Kpad, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     f.present = true;
     return PS_OK;
@@ -743,6 +747,7 @@ static int fc_io(ps_store *s, int layer, int bias, float *host, int cap, int *le
         for (int n2 = 0; n2 < f.N; ++n2) t[(size_t)n2 * krows + k] = host[(size_t)k * f.N + n2];
     HIPCHK(hipMemcpy2DAsync(f.Wt + (bias ? f.K : 0), sizeof(float) * f.Kpad, t.data(), sizeof(float) * krows,
                             sizeof(float) * krows, f.N, hipMemcpyHostToDevice, s->stream));
+    PSCHK(launch_pack_w(f.Wt, f.Wp, f.N, f.Kpad, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     return PS_OK;
 }

@@ -35,7 +35,7 @@ def batches(rng, n, B, F, X, V, WS):
     return out
 
 
-DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "dw_late": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
+DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "fwd_panel": 0, "dw_late": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
 
 
 def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):

@@ -45,3 +45,35 @@ def test_pipelined_gemm_loops_are_bit_identical(knob, plain, piped):
                 np.testing.assert_array_equal(a, b)
 
 
+
+
+def _close(a, b, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    tol = 2e-5 * (np.abs(b) + np.sqrt(np.mean(b * b)) + 1e-30)
+    bad = np.abs(a - b) > tol
+    assert not bad.any(), "%s: %d of %d beyond 2e-5 (|x| + rms), worst %.3g at |x| = %.3g" % (what, bad.sum(), bad.size, np.abs(a - b).max(), np.abs(b).flat[np.argmax(np.abs(a - b))])
+
+
+def test_row_panel_forward_matches_the_gemm_launches():
+    """k_fwd_panel (kernels_panel.hip; ps_tune_set("fwd_panel")): FcLayer.forward x 2 of a 16-row panel in one launch at configs[1]'s FC
+    shape (429 -> 512 -> 256 -> 1), weights streamed in fragment order (Wp, written by k_dense_update beside W' and Wt).  With and
+    without the head in the launch the step is bit-identical (the head's arithmetic is one function: kernels_head.inc head_one_t);
+    against the k_gemm_nt launches the products are summed in another order: tables, losses and P agree to f32 rounding over three
+    training steps, on a batch whose last panel is ragged."""
+    kind, F, D, X, fc, V, WS = "widedeep", 26, 16, 13, [512, 256, 1], 500, 997
+    for B in (4096, 1000):
+        rng = np.random.default_rng(B)
+        data = batches(rng, 3, B, F, X, V, WS)
+        gemm = run(kind, {"fwd_panel": 0}, False, data, F, D, X, fc, V, B, WS)
+        p1 = run(kind, {"fwd_panel": 1}, False, data, F, D, X, fc, V, B, WS)
+        p2 = run(kind, {"fwd_panel": 2}, False, data, F, D, X, fc, V, B, WS)
+        assert p1[0] == p2[0], "losses with / without the head in the launch: %s vs %s" % (p1[0], p2[0])
+        for a, b in zip(p1[1:], p2[1:]):
+            for x, y in zip(a if isinstance(a, list) else [a], b if isinstance(b, list) else [b]):
+                np.testing.assert_array_equal(x, y)
+        flat = lambda o: [np.asarray(x) for a in o[1:] for x in (a if isinstance(a, list) else [a])]
+        assert any(not np.array_equal(x, y) for x, y in zip(flat(p2), flat(gemm))), "the panel kernel did not run (every table has the GEMM launches' bits)"
+        _close(p2[0], gemm[0], "losses")
+        for i, (a, b) in enumerate(zip(p2[1:], gemm[1:])):
+            for j, (x, y) in enumerate(zip(a if isinstance(a, list) else [a], b if isinstance(b, list) else [b])):
+                _close(x, y, "output %d.%d at B = %d" % (i, j, B))
