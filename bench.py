@@ -413,26 +413,30 @@ def run_single(args):
     if args.sharded_leg:
         out["sharded_n1"] = sharded_n1_leg(args)
         try:
-            out["sharded_n1"]["projected_scaling_n8"] = project_n8(out["ms_per_step"], out["sharded_n1"]["ms_per_step"]["rccl_with_own_keys_in_place"])
+            out["sharded_n1"]["projected_scaling_n8"] = project_n8(out["ms_per_step"], out["sharded_n1"]["ms_per_step"]["rccl_with_own_keys_in_place"], cfg)
         except (KeyError, TypeError):
             pass
     return out
 
 
-def project_n8(fused_ms, rccl_n1_ms):
+def project_n8(fused_ms, rccl_n1_ms, cfg=None):
     """A PROJECTION, not a measurement (no multi-GPU node has run this code; DESIGN.md 6.2 has the reasoning): the 8-rank step =
     the N = 1 step with every collective through RCCL (launch + handshake of the four collectives included, the self parts moved at
     device bandwidth) + what real links add on the critical chain.  scaling = 8 x fused step / that."""
     link_gbs = 153.0                                   # one xGMI link (MI355X_MICROARCH.md); an all-to-all-v uses the 7 links in parallel
     rows_mb = grads_mb = 0.37                          # per peer and step at N = 8 (profiles/r04_rehearse_n8.log: 2.60 MB over 7 peers)
     a2a_us = 1e3 * (rows_mb + grads_mb) / link_gbs     # both sit on the critical chain
-    flat_mb = 2.21                                     # [fc | wide G | wide C | bias]
+    cfg = cfg or C2
+    dims = [cfg["F"] * cfg["D"] + cfg["X"]] + list(cfg["fc"])
+    dense = sum((dims[i] + 1) * dims[i + 1] for i in range(len(dims) - 1))
+    # [fc | wide bias g | 8 worker slots of (gbar_w, touched_w packed 24 bits to a float)]: 1.54 MB (rounds 2-4: [fc | wide G | wide C | bias] = 2.21 MB)
+    flat_mb = 4e-6 * (dense + 1 + 8 * (1 + (cfg["wide"] + 23) // 24))
     ring_us = 1e3 * 2.0 * (7.0 / 8.0) * flat_mb / link_gbs          # ring all-reduce, bandwidth term only
     slack_us = 18.0                                    # flat gradient ready -> the next step's first GEMM needs the replicated update (stamps), minus the update's 8 us
     exposed_us = max(0.0, ring_us - slack_us)
     step8 = rccl_n1_ms + 1e-3 * (a2a_us + exposed_us)
     return {"is_a_projection": True, "n1_step_through_rccl_ms": round(rccl_n1_ms, 5), "plus_link_time_rows_and_gradients_us": round(a2a_us, 2),
-            "all_reduce_ring_us": round(ring_us, 1), "of_which_exposed_us": round(exposed_us, 1), "projected_step_ms": round(step8, 5),
+            "all_reduce_mb": round(flat_mb, 3), "all_reduce_ring_us": round(ring_us, 1), "of_which_exposed_us": round(exposed_us, 1), "projected_step_ms": round(step8, 5),
             "fused_n1_ms": round(fused_ms, 5), "scaling_1_to_8": round(8.0 * fused_ms / step8, 2),
             "note": "bandwidth terms only for the links: RCCL's small-message latency between devices is unknown here and comes on top"}
 

@@ -146,9 +146,17 @@ struct WideUpdArgs {
     const float *gbar;
     UpdParams upd;
     const int *skip;
-    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C; 3 bias only
+    int mode;                          // 0 local update; 1 fill G/C for the all-reduce; 2 update from reduced G/C; 3 bias only;
+                                       // 6 / 7: the same two with the wide part as per-worker SLOTS (below) instead of dense G | C
     float *G, *C;                      // [rows] (+ G[2*rows] = bias gradient), contiguous G|C|bias
     int nworkers;
+    // Slot form of the sharded step's wide part (round 5): a worker's contribution to the dense vectors is one number and one bit per
+    // key -- G_w[k] = touched_w[k] * gbar_w, C_w[k] = touched_w[k] (compat mode: every touched key carries the batch's mean delta,
+    // SURVEY App. A.10) -- so the buffer that is all-reduced holds, per worker, [gbar_w | touched_w packed 24 bits to a float]: every
+    // worker fills its own slot and zeroes the others, the SUM is then an all-gather whatever order it adds in (x + 0 is exact; 24-bit
+    // integers are exact in f32), and every rank rebuilds G[k] = sum of gbar_w over the workers whose bit is set, in RANK order (the
+    // PS's arrival order: net/PServer.java:164-214), and C[k] = their number.  slots = [bias g | world x (1 + slot_words)].
+    float *slots; int slot_words, world, rank;
 };
 struct DenseLayer {
     float *W, *Wt, *S1, *S2;           // W' [K+1 rows][ldw], Wt [N rows][ldwt], state like W'

@@ -1144,7 +1144,44 @@ __device__ __forceinline__ void wide_update_body(const WideUpdArgs &a, const int
         else if (r == a.rows) a.G[2 * a.rows] = gb;          // wide.bias: every worker pushes it
         return;
     }
+    if (a.mode == 6) {
+        // sharded worker, before the all-reduce, slot form (WideUpdArgs.slots): r walks [bias | world x (gbar, words)]
+        const float gb = a.gbar[0];
+        const int64_t per = 1 + a.slot_words;
+        if (r == 0) { a.slots[0] = gb; return; }              // wide.bias: every worker pushes it (summed, / world at the update)
+        const int64_t q = r - 1;
+        if (q >= per * a.world) return;
+        const int w = (int)(q / per); const int64_t j = q % per;
+        float v = 0.f;                                        // another worker's slot: zero, so that the sum is that worker's own value
+        if (w == a.rank) {
+            if (j == 0) v = gb;
+            else {
+                const int64_t k0 = (j - 1) * 24;
+                uint32_t word = 0;
+#pragma unroll
+                for (int b = 0; b < 24; ++b) word |= (k0 + b < a.rows && a.touched[k0 + b < a.rows ? k0 + b : a.rows - 1]) ? (1u << b) : 0u;
+                v = (float)word;                              // (< 2^24: exact)
+            }
+        }
+        a.slots[1 + q] = v;
+        return;
+    }
     float g = a.gbar ? a.gbar[0] : 0.f;
+    if (a.mode == 7) {
+        // after the all-reduce, slot form: mean over the workers that touched the key, added in rank order
+        if (r < a.rows) {
+            const int64_t per = 1 + a.slot_words;
+            const float *sl = a.slots + 1;
+            const int64_t wi = 1 + r / 24; const int bit = (int)(r % 24);
+            float G = 0.f, c = 0.f;
+            for (int w = 0; w < a.world; ++w) {
+                const uint32_t word = (uint32_t)sl[w * per + wi];
+                if ((word >> bit) & 1u) { G += 1.f * sl[w * per]; c += 1.f; }
+            }
+            if (!(c > 0.f)) return;
+            g = div_rn(G, c);
+        } else if (r == a.rows) g = div_rn(a.slots[0], (float)a.nworkers);
+    }
     if (a.mode == 2) {
         // after the all-reduce: mean over the workers that touched the key
         if (r < a.rows) { const float c = a.C[r]; if (!(c > 0.f)) return; g = div_rn(a.G[r], c); }
@@ -1605,7 +1642,7 @@ int launch_wide_list(const WideListArgs &a, hipStream_t st) {
     return PS_OK;
 }
 
-int wide_update_blocks(const WideUpdArgs &a) { return cdiv(a.rows + 1, 256); }
+int wide_update_blocks(const WideUpdArgs &a) { return cdiv(a.mode == 6 ? 1 + (int64_t)(1 + a.slot_words) * a.world : a.rows + 1, 256); }
 int launch_wide_update(const WideUpdArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_wide_update, dim3(cdiv(a.rows + 1, 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());

@@ -980,6 +980,7 @@ int g_gemm_8w = 0;          // ps_tune_set("gemm_8w", 1): 8-wave 128 x 64 tiles 
 int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch between the counts and the scatter of every radix pass again
 int g_plan_mid = 1;         // ps_tune_set("plan_mid", 0): ps_shard_step's next plan head behind the running step's backward enqueue again (side chain 0; round 4)
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
+int g_wide_slots = 1;       // ps_tune_set("wide_slots", 0): the sharded step all-reduces the wide part as dense G | C vectors (rounds 2-4) instead of per-worker slots
 int g_fwd_panel = 0;        // ps_tune_set("fwd_panel", v), LAB build: 0 the FC forward as k_gemm_nt launches, 1 the two hidden layers of a 16-row panel in one launch (kernels_panel.hip), 2 with the head
 int g_sort_layer = 0;       // ps_tune_set("sort_layer", l): the single-hot field sort is released by forward GEMM l's start (0: the first)
 int g_sort_late = 0;        // ps_tune_set("sort_late", 1): the single-hot field sort behind the first delta GEMM's release instead of the first forward GEMM's

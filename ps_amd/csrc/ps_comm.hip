@@ -480,6 +480,18 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         HIPCHK(hipEventCreateWithFlags(&sh.done_ev, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sh.flat_ev, hipEventDisableTiming));
     }
+    if (!sh.blk_words && m->cfg.kind == PS_MODEL_WIDEDEEP && m->cfg.wide_grad_mode != PS_GRAD_INTENDED && g_wide_slots) {
+        // the wide part of the all-reduced buffer as per-worker slots (kernels_emb.h WideUpdArgs.slots): 1 + rows / 24 floats per
+        // worker instead of 2 x rows for all of them -- 2.21 -> 1.54 MB at configs[2]; fixed for the model's life, same on every
+        // rank (nranks and the table's rows are)
+        PSCHK(shard_ensure_state(m, nsh));          // (the flat buffer; the plan would allocate it a few lines further down)
+        const int64_t words = cdiv(s->wide.rows, 24), elems = m->dense_elems + 1 + (int64_t)nsh * (1 + words);
+        if (elems <= sh.flat_elems) {
+            sh.slot_world = nsh; sh.slot_rank = rank; sh.slot_words = words; sh.flat_elems = elems;
+            HIPCHK(hipMemsetAsync(sh.flat, 0, sizeof(float) * (size_t)elems, s->stream));
+        }
+    }
+    if (sh.slot_world && (sh.slot_world != nsh || sh.slot_rank != rank)) return ps_set_err(PS_E_STATE, "this model's steps began as rank %d of %d", sh.slot_rank, sh.slot_world);
     if (!sh.blk_words) {
         // a FULL block holds what one worker can ask one owner for at most: every id of a batch, or every row the owner has
         int64_t maxrows = 1;

@@ -278,7 +278,7 @@ extern int g_last_rows, g_sort_ablate, g_field_sort, g_ext_events;
 extern int g_gemm_nt_cfg, g_gemm_tn_cfg, g_gemm_xcd, g_gemm_ablate, g_gemm_tn_target;
 extern int g_seq_ablate, g_emb_short_grid, g_seq_long_grid;
 extern int g_gather_nt, g_gather_lds, g_plan_sort;
-extern int g_fwd_panel;
+extern int g_fwd_panel, g_wide_slots;
 extern int g_plan_fused, g_shard_sort_defer, g_sort_layer, g_plan_mid, g_seg_fused;
 extern int g_rccl_force, g_blk_factor, g_blk_cap, g_push_grouped_max_mb, g_comm_timing;
 extern int g_mh_ilp16;   // multi-hot gather: row loads in flight per 16-lane group (D = 64); 0 = default

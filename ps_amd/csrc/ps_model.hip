@@ -1009,6 +1009,9 @@ int enqueue_backward(ps_model *m, bool apply) {
         w.rows = s->wide.rows; w.touched = s->wide.touched; w.gbar = m->gbar_dev;
         w.mode = c.wide_grad_mode == PS_GRAD_INTENDED ? 5 : 1;
         w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
+        if (m->sh.slot_world) {         // (ps_shard_step: the wide part as per-worker slots, kernels_emb.h WideUpdArgs.slots)
+            w.mode = 6; w.slots = m->sh.flat + m->dense_elems; w.slot_words = (int)m->sh.slot_words; w.world = m->sh.slot_world; w.rank = m->sh.slot_rank;
+        }
         d.wide_blocks = wide_update_blocks(w);
     }
     if (tail_dev) {

@@ -310,6 +310,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "mh_seg_sort") == 0) { g_mh_seg_sort = value; return PS_OK; }
     if (strcmp(knob, "sort_layer") == 0) { g_sort_layer = value; return PS_OK; }
     if (strcmp(knob, "fwd_panel") == 0) { g_fwd_panel = value; return PS_OK; }
+    if (strcmp(knob, "wide_slots") == 0) { g_wide_slots = value; return PS_OK; }
     if (strcmp(knob, "shard_sort_defer") == 0) { g_shard_sort_defer = value; return PS_OK; }
     if (strcmp(knob, "rccl_force") == 0) { g_rccl_force = value; return PS_OK; }
     if (strcmp(knob, "comm_timing") == 0) { g_comm_timing = value; return PS_OK; }

@@ -410,6 +410,8 @@ int ensure_shard_state(ps_model *m, int nshards) {
 
 }  // namespace
 
+int shard_ensure_state(ps_model *m, int nshards) { return ensure_shard_state(m, nshards); }
+
 extern "C" int ps_store_set_stream(ps_store_t *s, void *hip_stream) {
     // Adopt the host framework's stream (e.g. torch.cuda.current_stream().cuda_stream) so the
     // kernels here and the RCCL collectives the host enqueues are ordered without host syncs.
@@ -949,6 +951,10 @@ int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st) {
         w.rows = s->wide.rows; w.W = s->wide.W; w.state = s->wide.state; w.touched = s->wide.touched;
         w.bias = s->wide.bias; w.bias_state = s->wide.bias_state; w.mode = 2; w.nworkers = nworkers;
         w.G = m->sh.flat + m->dense_elems; w.C = w.G + s->wide.rows;
+        if (m->sh.slot_world) {
+            if (nworkers != m->sh.slot_world) return ps_set_err(PS_E_BAD_ARG, "the wide slots hold %d workers, not %d", m->sh.slot_world, nworkers);
+            w.mode = 7; w.slots = m->sh.flat + m->dense_elems; w.slot_words = (int)m->sh.slot_words; w.world = m->sh.slot_world; w.rank = m->sh.slot_rank;
+        }
         PSCHK(store_resolve_updater(s, "wide.weights", &u));
         w.upd = make_upd_params(u);
         d.wide_blocks = wide_update_blocks(w);

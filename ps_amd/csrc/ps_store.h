@@ -197,6 +197,9 @@ struct ps_model {
         int64_t *lrb_dev = nullptr;   // [nshards][F+1] local row bases of every shard
         float *flat = nullptr;        // [dense_elems | wideG | wideC | wide bias g] for the all-reduce
         int64_t flat_elems = 0;
+        // slot form of the wide part (kernels_emb.h WideUpdArgs.slots): decided at the model's first ps_shard_step_begin, where the
+        // worker learns its rank -- flat = [dense_elems | wide bias g | world x (gbar_w, touched_w in 24-bit words)], flat_elems shrinks
+        int slot_world = 0, slot_rank = 0; int64_t slot_words = 0;
         int sbits = 0;
         int64_t U = 0;
         uint32_t *bitmap = nullptr, *word_prefix = nullptr, *blk_sum = nullptr; int64_t bm_words = 0;   // sort-free plan
@@ -311,6 +314,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels);
 int shard_plan_enqueue(ps_model *m, const ps_batch_t *batch, int nshards, hipStream_t st, bool readback, bool early = false,
                        bool order_after_main = false, bool hook = false);   // ps_shard.hip
 int shard_apply_flat(ps_model *m, int nworkers, hipStream_t st);
+int shard_ensure_state(ps_model *m, int nshards);      // the worker half's buffers (idempotent for one shard count)
 int shard_flush_deferred_flag(ps_model *m);       // ps_shard.hip
 bool shard_plan_hook_ok(const ps_model *m, const ps_batch_t *batch);     // ps_shard.hip: may this batch's plan head go through the hook
 int shard_step_begin_hook(ps_model *m);           // ps_comm.hip: the next step's plan head, called by ps_shard_forward_backward between forward and backward

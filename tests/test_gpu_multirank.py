@@ -182,7 +182,7 @@ def test_n_ranks_on_one_gpu(orc, world, is_async, pipelined):
     tol = 2e-5 * STEPS                   # same bound as the single-GPU step parity (FP32 GEMM order differs from the oracle's)
     touched = 0
     for r in range(world):
-        rows, W, b, wide, wbias, gstep = out[r]
+        rows, W, b, wide, wbias, gstep = out[r][:6]
         assert gstep == STEPS
         for (f, i), got in rows.items():
             assert i % world == r
@@ -306,8 +306,11 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False, 
             w = kv.get_rows(f, ids)
             for i, idv in enumerate(ids):
                 rows[(f, int(idv))] = w[i]
+        import ctypes as C
+        from ps_amd import native as N
+        st10 = (C.c_int64 * 10)(); N.check(N.lib().ps_shard_exchange_stats(gm.h, st10, 10))
         out[rank] = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)],
-                     kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step())
+                     kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step(), int(st10[4]))
         for g in gms:
             g.close()
         kv.close()
@@ -315,6 +318,39 @@ def native_rank_main(rank, world, shared, is_async, out, errs, pipelined=False, 
         import traceback
         errs.append((rank, traceback.format_exc()))
         shared.barrier.abort()
+
+
+@pytest.mark.parametrize("world,is_async", [(3, False), (4, True)])
+def test_wide_part_as_worker_slots_equals_dense_vectors(world, is_async):
+    """The all-reduced buffer's wide part as per-worker slots [gbar_w | touched_w, 24 bits to a float] (kernels_emb.h
+    WideUpdArgs.slots, the default) against rounds 2-4's dense G | C vectors (ps_tune_set("wide_slots", 0)): the sum of slots of which
+    all but one are zero is exact in any order, and every rank rebuilds G[k] in rank order -- the order this test's all-reduce adds
+    in -- so every table is bit-identical, with fewer floats on the wire (net/PServer.java:164-214: mean over the workers that
+    pushed the key)."""
+    from ps_amd import native as N
+    res = []
+    for slots in (0, 1):
+        N.lib().ps_tune_set(b"wide_slots", slots)
+        try:
+            shared = Shared(world)
+            out, errs = [None] * world, []
+            run_ranks(native_rank_main, [(r, world, shared, is_async, out, errs, "one") for r in range(world)])
+            assert not errs, "\n".join("rank %d:\n%s" % e for e in errs)
+            res.append(out)
+        finally:
+            N.lib().ps_tune_set(b"wide_slots", 1)
+    for r in range(world):
+        a, b = res[0][r], res[1][r]
+        for k in a[0]:
+            np.testing.assert_array_equal(a[0][k], b[0][k])
+        for i in (1, 2):
+            for x, y in zip(a[i], b[i]):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+        dense_elems = sum(x.size for x in a[1]) + sum(x.size for x in a[2])
+        assert a[6] == STEPS * 4 * (dense_elems + 2 * CFG["wide"] + 1), (a[6], dense_elems)
+        assert b[6] == STEPS * 4 * (dense_elems + 1 + world * (1 + (CFG["wide"] + 23) // 24)), (b[6], dense_elems)
+        assert b[6] < a[6]
 
 
 @pytest.mark.parametrize("world,is_async,pipelined", [(2, False, False), (4, False, True), (3, True, False), (2, True, True), (3, False, "one"), (2, True, "one"),
@@ -329,7 +365,7 @@ def test_library_driven_step_n_ranks_on_one_gpu(orc, world, is_async, pipelined)
     tol = 2e-5 * STEPS
     touched = 0
     for r in range(world):
-        rows, W, b, wide, wbias, gstep = out[r]
+        rows, W, b, wide, wbias, gstep = out[r][:6]
         assert gstep == STEPS
         for (f, i), got in rows.items():
             if (f, i) in emb:
