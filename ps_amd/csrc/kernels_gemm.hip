@@ -963,7 +963,9 @@ int gemm_nt_fwd_pair(const float *A, int lda, int a_rows, const float *W1t, int 
     q.target = *epoch * (unsigned int)q.tn1;
     q.xcc_err = xcc_err; q.xcc_tag = ctr + q.mt; q.epoch = *epoch & 0x0FFFFFFFu;      // (the 8 words behind the panel counters)
     const int grid = 8 * q.lp_max * (q.tn1 + q.tn2);
-    PS_LAUNCH_EV((k_fc_fwd_pair<2, 2, 1, 1, 32>), dim3(grid), dim3(256), 0, st, o.stop_event, q);
+    // (fwd_pair = 2, round 5: the product's slab loop -- 16-wide slabs, PIPE = 3 -- inside the pair)
+    if (g_fwd_pair == 2) PS_LAUNCH_EV((k_fc_fwd_pair<2, 2, 1, 1, 16, 3>), dim3(grid), dim3(256), 0, st, o.stop_event, q);
+    else PS_LAUNCH_EV((k_fc_fwd_pair<2, 2, 1, 1, 32>), dim3(grid), dim3(256), 0, st, o.stop_event, q);
     HIPCHK(hipGetLastError());
     if (lo) lo->launched = true;
 #endif
