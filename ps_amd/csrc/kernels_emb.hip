@@ -815,10 +815,20 @@ __device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_
 
 // SEQ: the reference's summation order for every key.  Blocks [0, a.long_blocks) are the long-key waves above,
 // the rest handle one key per lane group as before and leave keys above PS_EMB_CHUNK to them.
+#ifdef PS_EMB_TIMING      // (tools/emb_timing.sh: every workgroup's start and end, wall clock; the product build carries none)
+__device__ unsigned long long g_emb_t[8192 * 2];
+struct EmbWgTimer {
+    __device__ __forceinline__ EmbWgTimer() { if (threadIdx.x == 0 && blockIdx.x < 8192) g_emb_t[2 * blockIdx.x] = wall_clock64(); }
+    __device__ __forceinline__ ~EmbWgTimer() { if (threadIdx.x == 0 && blockIdx.x < 8192) g_emb_t[2 * blockIdx.x + 1] = wall_clock64(); }
+};
+#else
+struct EmbWgTimer {};
+#endif
 template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
     EndWait end_wait(a.end_wait, a.end_val, a.bound);       // (declared first: runs after the stamp's end; every return path)
+    EmbWgTimer wg_timer;
     // (no raised wave priority here: the dW GEMM and the dense update that run beside this kernel END the step's side
     //  chain -- with this kernel ahead of them the step got longer, 0.1530 against 0.1493 ms)
     StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);
@@ -873,6 +883,12 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         stride = (int64_t)(a.short_blocks >> 3) * 4 * gpw;
         u = u0 + ((int64_t)(sb >> 3) * 4 + (threadIdx.x >> 6)) * gpw + lane64 / a.LPR;
     }
+    // (Round 5, measured and taken out again: the bounds of the run two keys ahead and the row of the next key requested while a key is
+    //  reduced -- two of a key's four dependent round trips hidden for eight more VGPRs, 7 -> 6 waves per SIMD: the multi-hot step
+    //  0.328-0.335 against 0.326 ms.  So was PS_EMB_SUPER_MIN 128 -> 16 (no lane group walks more than 16 partials: the workgroups that
+    //  hold a 500..4000-entry key no longer end 25-35 us behind the median one, but k_emb_super_list then folds 570 runs instead of 78,
+    //  7 -> 18 us in front of this launch: 0.327 ms).  tools/emb_timing.sh: the median workgroup of this launch ends at 28 us of 64, and
+    //  moving its 230 MB of W / state in that time would take 8 TB/s -- the launch is within 1.5x of its HBM time.)
     for (; u < uend; u += stride) reduce_one_key<VEC, BAG, SEQ>(a, u, part);
 }
 
@@ -1774,3 +1790,9 @@ int launch_transpose_w(const float *W, float *Wt, int Kpad, int ldw, int N, hipS
     HIPCHK(hipGetLastError());
     return PS_OK;
 }
+
+#ifdef PS_EMB_TIMING
+extern "C" int ps_dbg_emb_timing(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_emb_t), sizeof(unsigned long long) * 8192 * 2) == hipSuccess ? 0 : -1;
+}
+#endif
