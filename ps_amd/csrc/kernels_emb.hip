@@ -567,6 +567,10 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
     if (a.fu.ngroups > 1) update_key<VEC>(a, row_upd(a, row), row, S, part);      // (a lane group's lanes share the row)
     else update_key<VEC>(a, a.upd, row, S, part);
 }
+// (Round 5, again, for the sequential order's short-key role only -- one key per lane group, so the row's W / state behind its gradient
+//  are a fourth dependent round trip: 105 -> 141 VGPRs, 4 -> 3 waves per SIMD, the embedding update 16 -> 21.9 us, the step 0.1332 ->
+//  0.1364 ms.  tools/ab_knobs.sh with seq_ablate says what bounds that launch in the step: without its long-key role 0.1339 ms, without its
+//  short-key role 0.1304 -- the 2048 short-key workgroups behind 1664 long-key ones, four waves per SIMD.)
 // (Round 4, measured and taken out again: requesting the row's W / state as soon as the row is known -- together with the key's
 // delta rows instead of behind the store of its gradient -- changes nothing for single-hot batches (0.1329 against 0.1331 ms / step,
 // A/B on one box: the long-key role decides that kernel) and costs the multi-hot step 35 us (0.390 -> 0.425 ms: twelve more
