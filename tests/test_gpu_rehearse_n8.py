@@ -134,6 +134,8 @@ def rank_process(rank, world, port, steps, q, snapshot=True, case="c2"):
                 snap["z"] = {f: kv.get_rows(f, ids, 1) for f in CHECK_FIELDS}; snap["n"] = {f: kv.get_rows(f, ids, 2) for f in CHECK_FIELDS}
             if rank == 0:
                 snap["fcW"] = [kv.get("fc%d.weights" % l) for l in range(3)]; snap["fcb"] = [kv.get("fc%d.bias" % l) for l in range(3)]
+                wid = np.arange(cfg["wide"])       # (w, z, n): Ftrl's w lags z and n by one update -- after step 1 the state is what moved
+                snap["wide"] = [kv.get_wide(wid, k) for k in range(3)]
         wk.run(bs[1:] + bs[:1], steps - 1)  # ... and the pipeline: begin of step t + 1 inside finish of step t
         kv.sync()
         if comm.err is not None: raise comm.err
@@ -186,11 +188,25 @@ def ps_semantics_after_one_step(orc, world):
     fc0 = [(kv.get("fc%d.weights" % l), kv.get("fc%d.bias" % l)) for l in range(3)]
     pushes = {f: [] for f in CHECK_FIELDS}
     dW = [None] * 3; db = [None] * 3
+    gbar, wmask = [], np.zeros(cfg["wide"], np.int64)
     for w in range(world):
         rng = np.random.default_rng(cfg["seed"] + 1000 * w)
         E, X, Y, Wd = synth_batch(cfg, rng)
         gm.forward({"E": E, "X": X, "Y": Y, "W": Wd})
         gm.backward()
+        # the worker's wide push (layer/LRLayer.java:106-117): every key it has touched gets rowMeans(delta) -- summed the way k_loss_reduce
+        # sums (1024 strided partial sums, a halving tree), / B
+        P = np.asarray(gm.p(cfg["B"]), f32); Yf = np.asarray(Y, f32).reshape(-1)
+        t = (P * (f32(1) - P)).astype(f32)
+        d = (((P - Yf).astype(f32) / t).astype(f32) * t).astype(f32)       # loss/CrossEntropy.java:25, activations/Sigmoid.java:18 (kernels_head.inc)
+        part = np.zeros(1024, f32)
+        for i in range(0, len(d), 1024):
+            seg = d[i:i + 1024]; part[:len(seg)] = (part[:len(seg)] + seg).astype(f32)
+        off = 512
+        while off:
+            part[:off] = (part[:off] + part[off:2 * off]).astype(f32); off >>= 1
+        gbar.append(f32(part[0] / f32(len(d))))
+        wmask[np.unique(Wd)] |= 1 << w
         for f in CHECK_FIELDS:
             pushes[f].append(gm.emb_grads(f))
         for l in range(3):
@@ -213,8 +229,20 @@ def ps_semantics_after_one_step(orc, world):
         gw = (dW[l] / f32(world)).astype(f32); gb = (db[l] / f32(world)).astype(f32)
         fc1.append((orc.adam_update(fc0[l][0], gw, np.zeros_like(gw), np.zeros_like(gw))[0],
                     orc.adam_update(fc0[l][1], gb, np.zeros_like(gb), np.zeros_like(gb))[0]))
+    # the wide table (w = z = n = 0 before the step): per key the mean, in worker order, over the workers that pushed it -- what the
+    # all-reduced worker slots are turned into (kernels_emb.h WideUpdArgs.slots) -- then one Ftrl step (update/FtrlUpdater.java:51-76)
+    wide1 = [np.zeros(cfg["wide"], f32) for _ in range(3)]
+    for m in np.unique(wmask):
+        if m == 0: continue
+        ws = [w for w in range(world) if (int(m) >> w) & 1]
+        G = gbar[ws[0]]
+        for w in ws[1:]: G = f32(gbar[w] + G)
+        g = f32(G / f32(len(ws)))
+        wzn = orc.ftrl_update(np.zeros(1, f32), np.array([g], f32), np.zeros(1, f32), np.zeros(1, f32))
+        for k in range(3): wide1[k][wmask == m] = wzn[k][0]
+    wbias1 = None
     gm.close(); kv.close()
-    return rows, W0, fc1
+    return rows, W0, fc1, wide1, wbias1
 
 
 def test_config2_full_size_eight_ranks_on_one_gpu(orc):
@@ -234,7 +262,7 @@ def test_config2_full_size_eight_ranks_on_one_gpu(orc):
         assert np.isfinite(i["loss"]) and 0.2 < i["loss"] < 20, i["loss"]
     assert all(i["digest"] == info[0]["digest"] for i in info), "replicated tensors differ across ranks"
     # step 1 against the parameter-server semantics, bit for bit
-    rows, W0, fc1 = ps_semantics_after_one_step(orc, world)
+    rows, W0, fc1, wide1, wbias1 = ps_semantics_after_one_step(orc, world)
     pushed = 0
     for r in CHECK_RANKS:
         got = info[r]["snap"]["rows"]
@@ -250,6 +278,10 @@ def test_config2_full_size_eight_ranks_on_one_gpu(orc):
     for l in range(3):
         np.testing.assert_array_equal(info[0]["snap"]["fcW"][l], fc1[l][0], err_msg="fc%d.weights after step 1" % l)
         np.testing.assert_array_equal(info[0]["snap"]["fcb"][l], fc1[l][1], err_msg="fc%d.bias after step 1" % l)
+    # the wide table and its bias after step 1 (replicated: rank 0's copy), every one of the 100 000 keys
+    assert (wide1[1] != 0).sum() > 50000 and (wide1[2] != 0).sum() > 50000
+    for k, what in enumerate(("w", "z", "n")):
+        np.testing.assert_array_equal(info[0]["snap"]["wide"][k], wide1[k], err_msg="wide table after step 1: %s" % what)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "rehearse_n8.log"), "w") as fo:
@@ -260,7 +292,7 @@ def test_config2_full_size_eight_ranks_on_one_gpu(orc):
                              r, i["loss"], "flags" if i["join_mode"] == 1 else "events", i["timeouts"], st[5] // n, st[6] // n, st[1] // n, st[7], st[9],
                              st[2] // n, st[3] // n, st[4] // n, st[8], i["seconds"]))
             fo.write("8 ranks x %d steps at configs[2] size: replicated tensors bit-identical; %d pushed rows of ranks %s and rank 0's FC tensors equal the "
-                     "PS semantics after step 1 bit for bit\n" % (steps + 1, pushed, list(CHECK_RANKS)))
+                     "PS semantics after step 1 bit for bit, and so do the (w, z, n) of all %d wide keys (rank-order mean over the workers that touched a key, Ftrl)\n" % (steps + 1, pushed, list(CHECK_RANKS), len(wide1[0])))
     except OSError:
         pass
 
