@@ -183,7 +183,10 @@ typedef struct ps_model_config {
     int64_t max_nnz;     /* largest number of ids per batch (B*F if single-hot) */
     int emb_grad_mode;   /* PS_GRAD_*                                         */
     int wide_grad_mode;  /* PS_GRAD_*                                         */
-    int use_graph;       /* 1: replay the step as a hipGraph                  */
+    int use_graph;       /* 1: replay the step as a hipGraph.  A graph bakes the batch's device pointers in: one instantiated graph per
+                            (pointers, B, nnz), at most 64 kept -- host batches (staged into the model's own buffers) and a few
+                            recycled device batches replay; a stream of ever-new device batches re-instantiates every step (~20 ms).
+                            Measured slower than the eager multi-stream step on MI355X: off by default. */
     int emb_sum_order;   /* PS_SUM_*: order in which a key's per-sample
                             gradients are added (layer/EmbeddingField.java:86-104) */
 } ps_model_config_t;
