@@ -410,6 +410,8 @@ def run_single(args):
     gm.close(); kv.close()
     if args.multi_hot:
         out["multi_hot"] = multi_hot_step(cfg)
+    if args.fused_adam:
+        out["fused_adam_hbm"] = fused_adam_roofline(args)
     if args.sharded_leg:
         out["sharded_n1"] = sharded_n1_leg(args)
         try:
@@ -555,6 +557,80 @@ def gather_roofline(kv, args):
     return res
 
 
+def fused_adam_roofline(args):
+    """BASELINE configs[3], "fused Adam, 1-GPU HBM-roofline run": DNN over ONE HBM-resident table of R rows x 64 (R = 320 M:
+    W + Adam M, V = 246 GB of the 288 GB), 2^22 uniformly random ids per step -- single-hot (EmbeddingField's own shape) and in
+    bags of 32.  What is graded is the fused backward (layer/EmbeddingField.java:86-104's per-key reduce) + AdamUpdater
+    (update/AdamUpdater.java:57-70) launch group of the training step, bracketed by HIP events on its own stream:
+    algorithmic bytes = nnz 4 D (delta rows) + U 6 * 4 D (W, M, V read and written once per unique key) + nnz 8."""
+    import ps_amd
+    R, D, X = args.adam_rows, 64, 13
+    res = []
+    for bag in (1, 32):
+        nnz = 1 << 22
+        B = nnz // bag
+        rng = np.random.default_rng(7 + bag)
+        kv = ps_amd.KVStore(0, 0x5EED)
+        try:
+            kv.create_embedding([R], D)
+        except Exception:
+            if R <= 64 * 1000 * 1000:
+                raise
+            kv.close()
+            R = 64 * 1000 * 1000                       # the 246 GB table did not fit beside what else is resident
+            kv = ps_amd.KVStore(0, 0x5EED)
+            kv.create_embedding([R], D)
+        gm = ps_amd.DNN.buildModel(1, D, X, [256, 64, 1], store=kv, max_batch=B, max_nnz=nnz)
+        batches, uniq = [], []
+        for _ in range(3):
+            ids = rng.integers(0, R, size=nnz).astype(np.int64)
+            uniq.append(int(np.unique(ids).size))
+            offsets = None if bag == 1 else (np.arange(B + 1) * bag).astype(np.int64)
+            E = ids.reshape(B, 1) if bag == 1 else ids
+            batches.append(ps_amd.DeviceBatch(kv, E, rng.standard_normal((B, X)).astype(np.float32),
+                                              (rng.random(B) < 0.25).astype(np.float32), None, offsets))
+        for i in range(4):
+            gm.train_async(batches[i % 3])
+        gm.sync()
+        gm.set_profile(True, only="emb_bwd_update")
+        n = 12
+        for i in range(n):
+            gm.train_async(batches[i % 3])
+        gm.sync()
+        rep = gm.profile_report()
+        gm.set_profile(False)
+        t0 = time.perf_counter()
+        for i in range(n):
+            gm.train_async(batches[i % 3])
+        gm.sync()
+        step_ms = 1e3 * (time.perf_counter() - t0) / n
+        loss = gm.train(batches[0])
+        cnt, ms = rep["emb_bwd_update"]
+        us = 1e3 * ms / max(cnt, 1)
+        U = float(np.mean(uniq))
+        algo = nnz * 4.0 * D + U * 6 * 4.0 * D + nnz * 8.0
+        gbs = algo / us / 1e3
+        res.append({"rows": R, "D": D, "table_plus_adam_state_GB": R * D * 4 * 3 / 1e9, "lookups": nnz, "bag": bag, "unique_keys": int(U),
+                    "kernel": "k_emb_reduce_update" + ("" if bag == 1 else " (+ k_emb_partials' tile walk in front of it)"),
+                    "launch_group_us": us, "algorithmic_bytes": algo, "achieved_GBs": gbs,
+                    "frac_of_8TBs": gbs / HBM_PEAK_GBS, "frac_of_6.29TBs_copy_ceiling": gbs / HBM_COPY_CEILING_GBS,
+                    "step_ms": step_ms, "final_loss": loss})
+        for b in batches:
+            b.close()
+        gm.close(); kv.close()
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for r in res:
+            g = pmc.get("fused_adam_hbm", {}).get("bag%d" % r["bag"])
+            if g:
+                r["traffic"] = g["hbm_bytes_per_launch"]
+                r["traffic_over_algorithmic"] = g["hbm_bytes_per_launch"] / r["algorithmic_bytes"]
+                r["traffic_source"] = "profiles/pmc_traffic.json (" + pmc["source"] + ")"
+    except (OSError, KeyError, ValueError):
+        pass
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -579,6 +655,8 @@ def main():
     ap.add_argument("--leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--gather", type=int, default=1)
     ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
+    ap.add_argument("--fused-adam", type=int, default=1, help="also report configs[3]'s fused backward + Adam on a 320 M-row HBM-resident table")
+    ap.add_argument("--adam-rows", type=int, default=320 * 1000 * 1000)      # W + M + V = 246 GB
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
     args = ap.parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -606,6 +684,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.leg == "sharded_n1":
         emit(leg_sharded_n1(args))
+        return
+    if args.leg == "fused_adam":              # the configs[3] fused-Adam leg alone (tools/profile_round.sh profiles it this way)
+        emit({"fused_adam_hbm": fused_adam_roofline(args)})
         return
     if args.gpus > 1 or world > 1 or args.sharded:
         from ps_amd import sharded
