@@ -264,6 +264,12 @@ int ps_model_get_p(ps_model_t *m, float *out, int cap);
  * n_out receives the count (call with NULL outputs to size). */
 int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out, float *grads_out,
                            int64_t cap_rows, int64_t *n_out);
+/* The gradients above exist after ps_model_backward (the split form) and after a sharded step (they are what is pushed).  A FUSED
+ * training step (ps_model_train) consumes every key's gradient in the registers it was reduced in -- KVStore.sum's map does not
+ * outlive update either (store/KVStore.java:268-276) -- unless the model was asked to keep them: on = 1 makes ps_model_train write
+ * them as well (nnz x D floats more per step), for parity tests.  Default 0; ps_model_get_emb_grads after a fused step of a model
+ * that does not keep them returns PS_E_BAD_ARG. */
+int ps_model_set_keep_grads(ps_model_t *m, int on);
 /* dense gradient of "fc<i>.weights" ([in][out]) / "fc<i>.bias" as given to the updater */
 int ps_model_get_fc_grad(ps_model_t *m, int layer, int bias, float *out, int cap);
 

@@ -306,7 +306,7 @@ class _Model:
     KIND = N.PS_MODEL_DNN
 
     def __init__(self, store, F, D, X, fc_dims, wide_size=0, max_batch=4096, max_nnz=0,
-                 emb_grad_mode=N.PS_GRAD_COMPAT, wide_grad_mode=N.PS_GRAD_COMPAT, use_graph=0, emb_sum_order=N.PS_SUM_AUTO):
+                 emb_grad_mode=N.PS_GRAD_COMPAT, wide_grad_mode=N.PS_GRAD_COMPAT, use_graph=0, emb_sum_order=N.PS_SUM_AUTO, keep_grads=False):
         self.store = store
         cfg = N.ps_model_config_t()
         cfg.kind = self.KIND
@@ -323,6 +323,8 @@ class _Model:
         N.check(N.lib().ps_model_create(store.h, C.byref(cfg), C.byref(h)))
         self._hcell = [h]               # (self.h reads it: the store destroys its models' handles through this cell too)
         store._adopt(self)
+        if keep_grads:                  # emb_grads() after a fused train(): parity tests (ps_native.h ps_model_set_keep_grads)
+            self.keep_grads(True)
         self._updater = {"default": AdamUpdater()}
 
     def close(self):
@@ -413,6 +415,9 @@ class _Model:
         out = np.empty(B, np.float32)
         N.check(N.lib().ps_model_get_p(self.h, _fp(out), B))
         return out
+
+    def keep_grads(self, on=True):
+        N.check(N.lib().ps_model_set_keep_grads(self.h, int(on)))
 
     def emb_grads(self, field):
         n = C.c_int64()

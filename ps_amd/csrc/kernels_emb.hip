@@ -832,7 +832,9 @@ template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
     EndWait end_wait(a.end_wait, a.end_val, a.bound);       // (declared first: runs after the stamp's end; every return path)
+#ifdef PS_EMB_TIMING
     EmbWgTimer wg_timer;
+#endif
     // (no raised wave priority here: the dW GEMM and the dense update that run beside this kernel END the step's side
     //  chain -- with this kernel ahead of them the step got longer, 0.1530 against 0.1493 ms)
     StampScope stamp(a.ts, (SEQ && a.long_list) ? (unsigned int)a.long_blocks : 0u);

@@ -1047,6 +1047,11 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
     }
     const int nblk = cdiv(n, RS_TILE);
     if (g_seg_fused && ws.seg_pub) {
+        // Under stream capture (cfg.use_graph) the launch's sequence number is frozen into the graph: a replay would find
+        // its own tags of the previous replay in pub[] and a look-back could read the previous batch's head counts
+        // (ADVICE r5).  A captured launch therefore zeroes the words itself -- the memset is a node of the same graph, in
+        // front of the kernel, and every replay starts from "no launch yet" whatever ran on the workspace before.
+        if (stream_is_capturing(st)) HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), st));
         if (ws.seg_seq == 0) HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), st));     // (tag 0 = no launch yet)
         if (++ws.seg_seq == 0) { HIPCHK(hipMemsetAsync(ws.seg_pub, 0, sizeof(unsigned long long) * (size_t)(ws.nblk + 1), st)); ++ws.seg_seq; }
         hipLaunchKernelGGL(k_seg_fused, dim3(nblk), dim3(RS_TPB), 0, st, keys_sorted, n, ws.seg_pub, ws.seg_seq, seg_start, seg_id, nseg_dev, stamp_next("seg_emit"));
@@ -1079,6 +1084,8 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
     const int npass = (key_bits + 7) / 8, digit_bits = (key_bits + npass - 1) / npass;
     FieldSortArgs a{keys, keys_base, B, F, NP, long_min, npass, digit_bits, sorted_keys, sorted_ents, seg_start, seg_id, nseg_dev,
                     long_list, pub, epoch, stamp_next("field_sort"), start_flag, start_val};
+    // (stream capture: the epoch is frozen into the graph -- every replay zeroes the look-back words first; build_segments' comment)
+    if (stream_is_capturing(st)) HIPCHK(hipMemsetAsync(pub, 0, sizeof(unsigned long long) * (size_t)F, st));
     const size_t lds = (size_t)NP * 16;
     static bool attr_set = false;
     if (!attr_set) {

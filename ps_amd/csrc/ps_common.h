@@ -48,6 +48,12 @@ struct RoctxRange {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// the stream is recording a hipGraph (ps_model.hip train_graph): kernel arguments are frozen, device memory is not
+static inline bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs == hipStreamCaptureStatusActive;
+}
 
 // ---------------------------------------------------------------------------
 // counter-based row init: +-U(0, scale) as a pure function of

@@ -974,7 +974,13 @@ int enqueue_backward(ps_model *m, bool apply) {
     // the reference's own summation order wherever the reference's input domain reaches (single-hot: n <= B)
     g.seq_order = (c.emb_sum_order == PS_SUM_SEQUENTIAL || (c.emb_sum_order == PS_SUM_AUTO && m->cur_offsets == nullptr)) ? 1 : 0;
     g.upd = emb_upd; g.fu = emb_fu;
-    g.grads_out = m->grads_out; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
+    // The per-key gradients as handed to the updater are an OUTPUT only of the split form (backward, then update), of the sharded
+    // step (they are what is pushed) and of a model that was asked to keep them (ps_model_set_keep_grads: parity tests).  The fused
+    // step consumes a key's gradient in the registers it was reduced in: KVStore.sum's map is cleared by update
+    // (store/KVStore.java:268-276), nothing of it outlives the step.  Writing it anyway cost nnz * 4 D bytes per step -- 1.07 GB
+    // beside 7.5 GB of algorithmic traffic on the 320 M-row table (configs[3]: 0.61 -> 0.69 of 8 TB/s without it).
+    m->grads_kept = m->keep_grads || !apply || m->sh.active;
+    g.grads_out = m->grads_kept ? m->grads_out : nullptr; g.uniq_row = m->uniq_row; g.uniq_cnt = m->uniq_cnt; g.skip = skip;
     // tail_dev: the dense update, on side chain 1, starts when the embedding update has STARTED (its first workgroup
     // raises start_flag[2]; the update's workgroups check that flag themselves, no spinner launch in front of it), a
     // flag-setter launch behind it raises start_flag[3], and the embedding update's first workgroup ENDS only once that
@@ -1264,6 +1270,9 @@ extern "C" int ps_model_get_emb_grads(ps_model_t *m, int field, int64_t *ids_out
     if (!m || !n_out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     ps_store *s = m->s;
     PSCHK(store_enter(s));
+    if (!m->grads_kept)
+        return ps_set_err(PS_E_BAD_ARG, "the last step was a fused training step of a model that does not keep its per-key gradients: "
+                                        "call ps_model_set_keep_grads(m, 1) first, or use ps_model_forward / ps_model_backward");
     HIPCHK(hipStreamSynchronize(s->stream));
     uint32_t nseg = 0;
     HIPCHK(hipMemcpyAsync(&nseg, m->nseg_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1324,6 +1333,18 @@ static int prof_collect(ps_model *m) {
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     m->prof_events.clear();
+    return PS_OK;
+}
+
+extern "C" int ps_model_set_keep_grads(ps_model_t *m, int on) {
+    if (!m) return ps_set_err(PS_E_BAD_ARG, "model is NULL");
+    PSCHK(store_enter(m->s));
+    if (m->keep_grads != (on != 0)) {           // (a captured step has the choice baked in)
+        HIPCHK(hipStreamSynchronize(m->s->stream));
+        for (auto &g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear();
+    }
+    m->keep_grads = on != 0;
     return PS_OK;
 }
 

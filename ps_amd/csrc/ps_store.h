@@ -180,6 +180,8 @@ struct ps_model {
     // per-kernel-group event timing (ps_model_set_profile)
     struct ProfEvent { const char *name; hipEvent_t a, b; };
     bool profile = false;
+    bool keep_grads = false;        // ps_model_set_keep_grads: the fused step also writes every key's gradient (grads_out / uniq_row / uniq_cnt) for ps_model_get_emb_grads
+    bool grads_kept = false;        // the last backward did
     std::string prof_filter;    // when set: only these kernel groups (comma-separated names) are bracketed
     std::vector<ProfEvent> prof_events;
     std::map<std::string, std::pair<long, double>> prof_acc;

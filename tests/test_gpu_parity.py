@@ -324,6 +324,38 @@ def test_fused_train_equals_split_form(orc, F, D, X, fc, V, B):
     assert a[4] == b[4] == 6
 
 
+@pytest.mark.gpu
+def test_fused_step_keeps_its_gradients_only_when_asked():
+    """ps_model_set_keep_grads (ps_native.h): the fused step consumes every key's gradient in registers (KVStore.sum's map does not
+    outlive update either, store/KVStore.java:268-276); emb_grads() after train() then fails loudly.  A model asked to keep them
+    hands out the same gradients the split form does, and the rows it trains are bit-identical either way."""
+    import ps_amd
+    F, D, X, fc, V, B = 4, 8, 3, [16, 1], 60, 96
+    out = []
+    for keep in (False, True):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, keep_grads=keep)
+        r2 = np.random.default_rng(11)
+        E, Xd, Y = data(r2, B, F, X, V, False)
+        d = {"E": E, "X": Xd, "Y": Y}
+        gm.forward(d); gm.backward()
+        split = [gm.emb_grads(f) for f in range(F)]                  # the split form always has them
+        gm.train(d)
+        if keep:
+            for f in range(F):
+                ids, g = gm.emb_grads(f)
+                np.testing.assert_array_equal(ids, split[f][0]); np.testing.assert_array_equal(g, split[f][1])
+        else:
+            with pytest.raises(ps_amd.native.PsError, match="keep_grads"):
+                gm.emb_grads(0)
+        gm.train(d)
+        out.append([kv.get_rows(f, np.arange(V)) for f in range(F)])
+        gm.close(); kv.close()
+    for x, y in zip(*out):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_ftrl_rows_bit_exact(orc):
     """Ftrl fused into the sparse scatter (config 5's updater) is bit-exact with the oracle,
     including the dw[0]==0 skip and w lagging z,n by one update."""
@@ -333,7 +365,7 @@ def test_ftrl_rows_bit_exact(orc):
     kv = ps_amd.KVStore(0, SEED)
     kv.create_embedding([V] * F, D)
     kv.set_updater("emF", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))
-    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, keep_grads=True)
     for step in range(4):
         E, Xd, Y = data(rng, B, F, X, V)
         uniq = [np.unique(E[:, f]) for f in range(F)]
@@ -379,7 +411,7 @@ def test_per_field_updaters_bit_exact(orc, form):
     kv.set_updater("emF0.2.0", ps_amd.FtrlUpdater(0.005, 1.0, 0.001, 0.001))      # row 2 of a "default" (Adam) field
     kv.set_updater("emF3.5.0", ps_amd.AdamUpdater(0.02, 0.8))                      # row 5 of the Simple field
     row_kind = {(0, 2): "ftrl", (3, 5): "adam2"}
-    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, keep_grads=True)
     for step in range(3):
         E, Xd, Y = data(rng, B, F, X, V)
         uniq = [np.unique(E[:, f]) for f in range(F)]

@@ -139,6 +139,38 @@ def test_graph_replay_is_bit_identical(kind, F, D, X, fc, V, B):
                 np.testing.assert_array_equal(x, y, err_msg=name)
 
 
+def test_graph_replay_multi_hot_look_back_words():
+    """build_segments' one-launch look-back (k_seg_fused) and the field sort's tag their per-workgroup words with a
+    launch number that a captured graph freezes.  Multi-hot batches above one 8192-pair tile, two resident batches (two graphs),
+    each replayed twice in a row, behind an eager forward that already advanced the number: the tables equal the eager step's."""
+    import ps_amd
+    F, D, X, fc, V, B = 3, 8, 2, [16, 1], 5000, 512
+    rng = np.random.default_rng(77)
+    data = []
+    for _ in range(2):
+        lens = np.clip(rng.poisson(10, size=B * F), 1, 40)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ids = rng.integers(0, V, size=int(offsets[-1])).astype(np.int64)
+        assert ids.size > 8192 + 1024
+        data.append((ids, rng.standard_normal((B, X)).astype(np.float32), (rng.random(B) < 0.3).astype(np.float32), None, offsets))
+    nnz_max = max(d[0].size for d in data)
+    res = []
+    for graph in (0, 1):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, max_nnz=nnz_max, use_graph=graph)
+        bs = [ps_amd.DeviceBatch(kv, *d) for d in data]
+        gm.forward({"E": data[1][0], "X": data[1][1], "Y": data[1][2], "offsets": data[1][4]})     # eager: the launch number moves on
+        losses = [gm.train(bs[i]) for i in (0, 0, 1, 1, 0, 1, 1, 0)]
+        res.append((losses, [kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(len(fc))]))
+        for b in bs:
+            b.close()
+        gm.close(); kv.close()
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_plan_epoch_wraps():
     """300 consecutive sharded steps (the plan's 8-bit epoch wraps after 255) == 300 fused steps, bit for bit."""
     import ps_amd

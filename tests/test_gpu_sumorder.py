@@ -100,7 +100,7 @@ def test_hot_keys_single_hot_use_the_reference_order(orc):
     Xd = rng.standard_normal((B, X)).astype(f32); Y = (rng.random(B) < 0.4).astype(f32)
     kv = ps_amd.KVStore(0, SEED)
     kv.create_embedding([V] * F, D)
-    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+    gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B, keep_grads=True)
     uniq = [np.unique(E[:, f]) for f in range(F)]
     w0 = [kv.get_rows(f, uniq[f]) for f in range(F)]
     gm.train({"E": E, "X": Xd, "Y": Y})
