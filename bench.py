@@ -239,7 +239,7 @@ def run_single(args):
             gm.train_async(batches[(5 + i) % nb])
         gm.sync()
         from_idle = {"steps": 20, "ms_per_step": 1e3 * (time.perf_counter() - t0i) / 20,
-                     "note": "5 steps, a wait, 20 timed steps behind a 0.3 s idle queue: the step on ramping clocks (round 4's headline was timed like this)"}
+                     "note": "5 steps, a 0.3 s idle queue, then 20 timed steps: the step on ramping clocks (round 4's headline sat behind 48 steps instead and read 0.1392 ms)"}
     # ---- priming (untimed, disclosed in config; the sharded line has primed the same way since round 2): the training job this line
     # stands for runs for millions of steps -- the timed region starts on the clocks it would run on
     for i in range(args.priming):

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libps_amd.so")
-SOURCES = ["kernels_sort.hip", "kernels_gemm.hip", "kernels_emb.hip", "kernels_panel.hip", "ps_store.hip", "ps_model.hip", "ps_ops.hip", "ps_layer_ops.hip", "ps_shard.hip", "ps_ingest.hip", "ps_eval.hip", "ps_ckpt.hip", "ps_comm.hip", "ps_keyed.hip"]
+SOURCES = ["kernels_sort.hip", "kernels_gemm.hip", "kernels_emb.hip", "ps_store.hip", "ps_model.hip", "ps_ops.hip", "ps_layer_ops.hip", "ps_shard.hip", "ps_ingest.hip", "ps_eval.hip", "ps_ckpt.hip", "ps_comm.hip", "ps_keyed.hip"]
 # -ffp-contract=off: the reference (JVM) rounds every float op separately;
 # the updater / reduce kernels must too, to stay bit-exact with the oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

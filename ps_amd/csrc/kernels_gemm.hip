@@ -17,6 +17,7 @@
 // the fragment reads stay simple: ds_read_b128 along k with a k-permutation
 // (per 8 k's: lanes 0-31 take k 0-3, lanes 32-63 take k 4-7).
 #include "ps_common.h"
+#include "kernels_emb.h"     // (FwdPanelArgs: the product build's stubs of the lab-only row-panel forward)
 #include <string.h>
 #include <strings.h>
 #include <stdlib.h>
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
 }
 
 #if PS_GEMM_LAB
-#include "kernels_gemm_lab.inc"      // (the rejected variants of rounds 2-3: lab build only)
+#include "lab/kernels_gemm_lab.inc"      // (the rejected variants of rounds 2-3: lab build only)
 #endif      // PS_GEMM_LAB
 
 struct TnArgs {
@@ -983,6 +984,16 @@ int g_radix_scan_free = 1;   // ps_tune_set("radix_scan_free", 0): a scan launch
 int g_plan_mid = 1;         // ps_tune_set("plan_mid", 0): ps_shard_step's next plan head behind the running step's backward enqueue again (side chain 0; round 4)
 int g_plan_early = 1;       // ps_tune_set("plan_early", 0): ps_shard_step's next plan in the running step's tail (main stream) again
 int g_wide_slots = 1;       // ps_tune_set("wide_slots", 0): the sharded step all-reduces the wide part as dense G | C vectors (rounds 2-4) instead of per-worker slots
+#if !PS_GEMM_LAB
+// the product build has no row-panel forward (csrc/lab/kernels_panel.hip: built, bit-checked, measured, not adopted -- lab build only)
+// and no fragment-order weights: ps_model.hip then takes the k_gemm_nt launches
+int fwd_panel_shape_ok(int, int, int) { return 0; }
+int launch_fwd_panel(const FwdPanelArgs &, const LastBwdArgs *, const HeadArgs *, int, hipStream_t, LaunchOpts *lo, unsigned int *) {
+    if (lo) lo->launched = false;
+    return ps_set_err(PS_E_UNSUPPORTED, "k_fwd_panel lives in the lab build (tools/gemm_lab_build.sh)");
+}
+int launch_pack_w(const float *, float *, int, int, hipStream_t) { return PS_OK; }
+#endif
 int g_fwd_panel = 0;        // ps_tune_set("fwd_panel", v), LAB build: 0 the FC forward as k_gemm_nt launches, 1 the two hidden layers of a 16-row panel in one launch (kernels_panel.hip), 2 with the head
 int g_sort_layer = 0;       // ps_tune_set("sort_layer", l): the single-hot field sort is released by forward GEMM l's start (0: the first)
 int g_sort_late = 0;        // ps_tune_set("sort_late", 1): the single-hot field sort behind the first delta GEMM's release instead of the first forward GEMM's

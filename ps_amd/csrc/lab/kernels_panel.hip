@@ -268,13 +268,6 @@ int launch_pack_w(const float *Wt, float *Wp, int N, int Kpad, hipStream_t st) {
     return PS_OK;
 }
 
-#else       // the product build: no panel kernel (ps_model.hip then takes the k_gemm_nt launches), no fragment-order weights
-
-int fwd_panel_shape_ok(int, int, int) { return 0; }
-int launch_fwd_panel(const FwdPanelArgs &, const LastBwdArgs *, const HeadArgs *, int, hipStream_t, LaunchOpts *lo, unsigned int *) {
-    if (lo) lo->launched = false;
-    return ps_set_err(PS_E_UNSUPPORTED, "k_fwd_panel lives in the lab build (tools/gemm_lab_build.sh)");
-}
-int launch_pack_w(const float *, float *, int, int, hipStream_t) { return PS_OK; }
-
+#else
+#error "lab/kernels_panel.hip is compiled into the measurement build only (tools/gemm_lab_build.sh, -DPS_GEMM_LAB=1)"
 #endif      // PS_GEMM_LAB

@@ -76,10 +76,12 @@ def main():
             n = short(row["Kernel_Name"])
             if role(n):
                 per[n].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-        print("\n== k_emb_reduce_update per instantiation, steady launches (the first 4 of each are warm-up) ==")
+        print("\n== k_emb_reduce_update per instantiation: launches 4..15 are the leg's bracketed pass (one stream at a time, what the bench line")
+        print("   reports); 0..3 warm-up and 16.. the step as it runs, beside the dW GEMMs and the dense update of the other two streams ==")
         for k, v in per.items():
-            w = v[4:] if len(v) > 8 else v
-            print("%-72s n %3d  avg %9.2f us  min %9.2f  max %9.2f" % (k, len(w), sum(w) / len(w), min(w), max(w)))
+            for name, w in (("bracketed pass", v[4:16]), ("beside the other streams", v[16:])):
+                if w:
+                    print("%-52s %-26s n %3d  avg %9.2f us  min %9.2f  max %9.2f" % (k, name, len(w), sum(w) / len(w), min(w), max(w)))
 
 
 if __name__ == "__main__":

@@ -9,12 +9,13 @@ set -e
 cd "$(dirname "$0")/.."
 python -m ps_amd.build >/dev/null
 mkdir -p ps_amd/build_lab
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPS_GEMM_LAB=1"
-# only the translation units that look at PS_GEMM_LAB are rebuilt (kernels_emb / ps_ops: the LDS-staged gather; kernels_panel, ps_store: the
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPS_GEMM_LAB=1 -Ips_amd/csrc ${PS_AMD_EXTRA_FLAGS:-}"
+# only the translation units that look at PS_GEMM_LAB are rebuilt (kernels_emb / ps_ops: the LDS-staged gather; lab/kernels_panel, ps_store: the
 # row-panel forward and its fragment-order weights); the rest are the product's objects
-for src in kernels_gemm ps_store kernels_emb ps_ops kernels_panel; do
+for src in kernels_gemm ps_store kernels_emb ps_ops; do
   /opt/rocm/bin/hipcc $FLAGS -c ps_amd/csrc/$src.hip -o ps_amd/build_lab/$src.o
 done
+/opt/rocm/bin/hipcc $FLAGS -c ps_amd/csrc/lab/kernels_panel.hip -o ps_amd/build_lab/kernels_panel.o      # (the lab-only sources live in csrc/lab/)
 objs=$(ls ps_amd/build/*.o | grep -v "/kernels_gemm.o" | grep -v "/ps_store.o" | grep -v "/kernels_emb.o" | grep -v "/ps_ops.o" | grep -v "/kernels_panel.o" | grep -v _ab)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ps_amd/lib/libps_amd_lab.so $objs ps_amd/build_lab/kernels_gemm.o ps_amd/build_lab/ps_store.o ps_amd/build_lab/kernels_emb.o ps_amd/build_lab/ps_ops.o ps_amd/build_lab/kernels_panel.o -ldl
 echo ps_amd/lib/libps_amd_lab.so
