@@ -416,12 +416,14 @@ def run_single(args):
         out["sharded_n1"] = sharded_n1_leg(args)
         try:
             out["sharded_n1"]["projected_scaling_n8"] = project_n8(out["ms_per_step"], out["sharded_n1"]["ms_per_step"]["rccl_with_own_keys_in_place"], cfg)
+            # the same arithmetic on the mapped-peer step (rows and gradients as stores into the peers' mapped memory, no RCCL launch on the chain)
+            out["sharded_n1"]["projected_scaling_n8_mapped_peer"] = project_n8(out["ms_per_step"], out["sharded_n1"]["ms_per_step"]["mapped_peer"], cfg, mapped=True)
         except (KeyError, TypeError):
             pass
     return out
 
 
-def project_n8(fused_ms, rccl_n1_ms, cfg=None):
+def project_n8(fused_ms, rccl_n1_ms, cfg=None, mapped=False):
     """A PROJECTION, not a measurement (no multi-GPU node has run this code; DESIGN.md 6.2 has the reasoning): the 8-rank step =
     the N = 1 step with every collective through RCCL (launch + handshake of the four collectives included, the self parts moved at
     device bandwidth) + what real links add on the critical chain.  scaling = 8 x fused step / that."""
@@ -440,7 +442,9 @@ def project_n8(fused_ms, rccl_n1_ms, cfg=None):
     return {"is_a_projection": True, "n1_step_through_rccl_ms": round(rccl_n1_ms, 5), "plus_link_time_rows_and_gradients_us": round(a2a_us, 2),
             "all_reduce_mb": round(flat_mb, 3), "all_reduce_ring_us": round(ring_us, 1), "of_which_exposed_us": round(exposed_us, 1), "projected_step_ms": round(step8, 5),
             "fused_n1_ms": round(fused_ms, 5), "scaling_1_to_8": round(8.0 * fused_ms / step8, 2),
-            "note": "bandwidth terms only for the links: RCCL's small-message latency between devices is unknown here and comes on top"}
+            "exchange": "rows and gradients as stores into the peers' mapped memory (one launch each + flags); id blocks and all-reduce through RCCL" if mapped else "every collective through RCCL",
+            "note": ("bandwidth terms only for the links: the flag round trip between devices (one xGMI write + a polling load) comes on top" if mapped else
+                     "bandwidth terms only for the links: RCCL's small-message latency between devices is unknown here and comes on top")}
 
 
 def multi_hot_step(cfg, steps=60):
@@ -506,7 +510,7 @@ def leg_sharded_n1(args):
     cfg["idgen"] = args.idgen
     steps = min(args.steps, 1000)
     ct = {}
-    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2), with_info=True, coll_times=ct)
+    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2, 3), with_info=True, coll_times=ct)
     return {"workload": "configs[2]'s sharded step on 1 GPU (1-rank table), batch %d; %d steps after 300 priming steps (268 + a wait + 32)" % (cfg["B"], steps),
             "ms_per_step": {k: round(v, 5) for k, v in res.items()},
             "wire_cost_ms_per_step": round(res["rccl_with_own_keys_in_place"] - res["device_copies"], 5),

@@ -504,6 +504,18 @@ int ps_comm_rccl_calls(const ps_comm_ops_t *ops, int64_t *out5);
  * order, a float all-reduce -- verified on the host.  PS_E_STATE names the
  * first wrong word.  bench.py runs it before the first timed step. */
 int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm);
+/* MAPPED PEER (ps_tune_set("mapped_peer", 1), or PS_MAPPED_PEER=1 in the environment; off by default): the two exchanges on
+ * the step's critical chain -- rows back (PServer.getList's reply, net/PServer.java:102-117) and gradients out (PSClient.push,
+ * net/PSClient.java:154-174) -- do not go through the table's all_to_all_v but through the peers' memory, mapped with
+ * hipIpcOpenMemHandle at the model's first ps_shard_step_begin (the handles travel through the table's all_gather; every rank
+ * must have asked for it and every mapping must succeed on every rank, otherwise all ranks stay on all_to_all_v): one launch
+ * per exchange stores every peer's part into that peer's buffer, raises this rank's flag there and waits -- bounded -- for the
+ * peers' flags here.  The id blocks and the all-reduce still use the table.  A wait that runs into its bound is reported like
+ * every other device-side wait: the next host-side check returns PS_E_STATE (a peer died: restart the ranks without the knob).
+ * Needs D % 4 == 0 and the sort-free owner push.  2: a 1-rank table too (its own part through the same launch; measurement).
+ * ps_shard_mapped_info: out5[0] 1 when this model's exchanges use it, [1] a rank's own part too, [2] / [3] launches so far
+ * (rows, gradients), [4] 1 when the flag words are fine-grained memory. */
+int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5);
 int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);
 /* The step in two halves.  _begin enqueues what reads no weight without a host wait: the plan, the exchange of the key
  * lists -- FIXED-SIZE blocks [count | overflow flag | owner-local rows | padding], one per peer, so the exchange needs

@@ -20,6 +20,9 @@
 // one process, N rank processes over gloo) to run N ranks on one GPU.
 #include <dlfcn.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
 
 #include <vector>
 
@@ -387,6 +390,245 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
     for (int i = 0; i < 8; ++i) { out8[i] = m->sh.coll_acc[i]; m->sh.coll_acc[i] = 0; }
     return PS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// MAPPED PEER (round 6): the two exchanges on the step's critical chain -- rows back (PServer.getList's reply,
+// net/PServer.java:102-117) and gradients out (PSClient.push, net/PSClient.java:154-174: fire and forget) -- as stores into
+// the peers' memory instead of grouped ncclSend / ncclRecv.  xGMI is point to point and every peer's HBM can be mapped
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle between the rank processes): ONE launch of this rank's own per exchange copies
+// every peer's part of the send buffer into that peer's receive buffer with 16-byte write-through stores (global_store_dwordx4
+// sc0 sc1: the bytes leave for the fabric, nothing stays dirty in an XCD's L2), every wave drains its stores (s_waitcnt
+// vmcnt(0): the writes are acknowledged), the launch's last workgroup raises this rank's flag in every peer's flag words and
+// then waits -- bounded, like every wait here -- until every peer's flag for this exchange is up in its own.  The next launch of
+// the stream (the forward's gather, the owner-side push) starts behind that kernel's end, so its start acquires what the peers
+// stored.  What RCCL costs here is not bandwidth (0.37 MB per peer) but 16-18 us of launch and handshake per grouped
+// send / recv (profiles/r05_rccl_env_sweep.txt); the id blocks and the all-reduce, both off the chain, stay RCCL's.
+//   * where a peer's rows land: the worker wrote its first cache slot of this owner's rows into the id block's header
+//     (PS_BLK_HDR word 2); where a worker's gradients land: region `worker` of the owner's receive buffer (per_peer rows each).
+//   * flags are epochs (the number of exchanges of that kind so far, the same on every rank): never reset, compared as
+//     (int)(flag - epoch) >= 0.  A buffer is not overwritten early: a peer stores the rows of step t+1 only after its own push
+//     of step t has run, which waited for this rank's gradients of step t, sent behind this rank's last read of the cache.
+//   * a wait that runs into its bound (a peer that died, a flag that never arrives) counts itself in the store's error words
+//     like every other bounded wait: the next host-side check returns PS_E_STATE, and bench.py's staged watchdog re-executes
+//     the ranks on the RCCL stage (ps_amd/sharded.py).
+// ps_tune_set("mapped_peer", 1): wanted wherever every rank can (N > 1, D % 4 == 0, the sort-free owner push, IPC works);
+// 2: a 1-rank table too, moving its own part through the same launch (bench.py's sharded_n1 `mapped_peer` mode).
+// ---------------------------------------------------------------------------
+int g_mapped_peer = getenv("PS_MAPPED_PEER") ? atoi(getenv("PS_MAPPED_PEER")) : 0;
+namespace {
+typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
+struct PeerPutArgs {
+    int npeers, rank, LPR, D, self;
+    const float *src;                            // rows grouped by destination peer, in peer order
+    uint32_t start[PS_MAX_MAPPED + 1];           // first row of peer p's part
+    float *dst[PS_MAX_MAPPED];                   // peer p's receive buffer (mapped)
+    long long dst_row[PS_MAX_MAPPED];            // first row there; < 0: hdr[p][2]
+    const uint32_t *hdr[PS_MAX_MAPPED];          // header of the id block peer p sent this rank
+    unsigned int *flag_peer[PS_MAX_MAPPED];      // peer p's flag word for (this kind, this rank)
+    const unsigned int *flag_mine;               // this rank's flag words of this kind, [p] raised by peer p
+    unsigned int epoch;
+    unsigned int *arrive;                        // workgroups of this launch that have drained their stores
+    WaitBound bound;
+    unsigned long long *ts;
+};
+__device__ __forceinline__ bool spin_bounded_sys(const unsigned int *f, unsigned int v, const WaitBound &b) {
+    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return false;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (b.ticks && (unsigned long long)wall_clock64() - t0 > b.ticks) {
+            if (b.err) {
+                atomicAdd(b.err, 1u);
+                __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicCAS(b.err + 2, 0u, b.code + 1000u);
+            }
+            break;
+        }
+    }
+    return true;
+}
+__global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
+    StampScope stamp(a.ts);
+    __shared__ int last_s;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / a.LPR;
+    const int part = (int)(t % a.LPR);
+    if (i < (int64_t)a.start[a.npeers]) {
+        int p = 0;
+        while (p + 1 < a.npeers && (uint32_t)i >= a.start[p + 1]) ++p;
+        if (p != a.rank || a.self) {
+            const long long r0 = a.dst_row[p] >= 0 ? a.dst_row[p] : (long long)a.hdr[p][2];
+            const mp_f32x4 v = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
+            float *q = a.dst[p] + (size_t)(r0 + (i - a.start[p])) * a.D + part * 4;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");       // write-through: nothing stays in this XCD's L2
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have been acknowledged by the memory they went to
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == gridDim.x - 1 ? 1 : 0;
+        if (last_s) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch of this kind: in stream order behind this one)
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // the last workgroup: every workgroup's stores have landed -- this rank's flag at every peer, then the peers' flags here
+    const int p = threadIdx.x;
+    if (p < a.npeers && (p != a.rank || a.self)) {
+        __hip_atomic_store(a.flag_peer[p], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        (void)spin_bounded_sys(a.flag_mine + p, a.epoch, a.bound);
+    }
+}
+
+void mapped_close(ps_model *m) {
+    ps_model::Shard::Mapped &mp = m->sh.mp;
+    for (int p = 0; p < PS_MAX_MAPPED; ++p) {
+        if (!mp.opened[p]) continue;
+        if (mp.cache[p]) (void)hipIpcCloseMemHandle(mp.cache[p]);
+        if (mp.grads[p]) (void)hipIpcCloseMemHandle(mp.grads[p]);
+        if (mp.flags[p]) (void)hipIpcCloseMemHandle(mp.flags[p]);
+        mp.opened[p] = false; mp.cache[p] = mp.grads[p] = nullptr; mp.flags[p] = nullptr;
+    }
+    mp.on = false;
+}
+
+// one record per rank in the set-up's all-gather
+struct MappedRec {
+    uint32_t ok, pid;
+    uint64_t cache, grads, flags, per_peer;         // the addresses as this rank sees them (a rank THREAD of the same process uses them as they are)
+    hipIpcMemHandle_t h_cache, h_grads, h_flags;
+    char pad[256 - 8 - 32 - 3 * sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(MappedRec) == 256, "one all-gather slot");
+
+// host-side helper of the set-up: all-gather `bytes` per rank through the table (device staging buffers of the caller)
+int mapped_gather(ps_store *s, const ps_comm_ops_t *comm, char *dev, const void *mine, void *all, size_t bytes) {
+    const int n = comm->nranks;
+    HIPCHK(hipMemcpyAsync(dev, mine, bytes, hipMemcpyHostToDevice, s->stream));
+    comm_select(comm, 0, false);
+    PSCHK(comm->all_gather(comm->ctx, dev, dev + bytes, bytes, s->stream));
+    HIPCHK(hipMemcpyAsync(all, dev + bytes, bytes * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PS_OK;
+}
+
+// Once per model, at its first begin, when EVERY rank asked for it (want_all: the agreement words).  Collective: every rank
+// makes the same calls whatever happens to it locally -- a rank that cannot (no IPC, an open that fails) says so in the
+// second all-gather and all ranks go on with the table's all-to-all-v.
+int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
+    ps_model::Shard &sh = m->sh;
+    ps_model::Shard::Mapped &mp = sh.mp;
+    ps_store *s = m->s;
+    if (mp.tried) return PS_OK;
+    mp.tried = true;
+    if (!want_all) return PS_OK;
+    const int n = comm->nranks, rank = comm->rank;
+    mp.nranks = n; mp.rank = rank;
+    mp.per_peer = std::min<int64_t>(m->nnz_cap, std::max<int64_t>(s->emb.total_rows, 1));
+    RtGuard rt_guard;
+    char *stage = nullptr;
+    std::vector<MappedRec> all((size_t)n);
+    MappedRec mine;
+    memset(&mine, 0, sizeof mine);
+    bool ok = true;
+    // this rank's flag words: fine-grained when the runtime gives that (a peer's store must be seen by a kernel that is running)
+    if (hipExtMallocWithFlags((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED, hipDeviceMallocFinegrained) == hipSuccess) mp.flags_fine = true;
+    else { (void)hipGetLastError(); if (hipMalloc((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED) != hipSuccess) { (void)hipGetLastError(); mp.flags_local = nullptr; ok = false; } }
+    if (hipMalloc((void **)&mp.arrive, sizeof(unsigned int) * 2) != hipSuccess) { (void)hipGetLastError(); mp.arrive = nullptr; ok = false; }
+    if (hipMalloc((void **)&stage, sizeof(MappedRec) * (size_t)(n + 1)) != hipSuccess) { (void)hipGetLastError(); return ps_set_err(PS_E_HIP, "mapped peer: staging buffer"); }
+    if (mp.flags_local) HIPCHK(hipMemsetAsync(mp.flags_local, 0, sizeof(unsigned int) * 2 * PS_MAX_MAPPED, s->stream));
+    if (mp.arrive) HIPCHK(hipMemsetAsync(mp.arrive, 0, sizeof(unsigned int) * 2, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    mine.pid = (uint32_t)getpid();
+    mine.cache = (uint64_t)(uintptr_t)sh.x_cache; mine.grads = (uint64_t)(uintptr_t)sh.x_recv_grads; mine.flags = (uint64_t)(uintptr_t)mp.flags_local;
+    mine.per_peer = (uint64_t)mp.per_peer;
+    if (ok && n > 1) {
+        if (hipIpcGetMemHandle(&mine.h_cache, sh.x_cache) != hipSuccess || hipIpcGetMemHandle(&mine.h_grads, sh.x_recv_grads) != hipSuccess ||
+            hipIpcGetMemHandle(&mine.h_flags, mp.flags_local) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+    }
+    mine.ok = ok ? 1u : 0u;
+    int rc = mapped_gather(s, comm, stage, &mine, all.data(), sizeof(MappedRec));
+    if (rc != PS_OK) { (void)hipFree(stage); return rc; }
+    bool all_ok = true;
+    for (int p = 0; p < n; ++p) all_ok = all_ok && all[(size_t)p].ok != 0;
+    uint32_t opened_ok = 1;
+    if (all_ok) {
+        for (int p = 0; p < n && opened_ok; ++p) {
+            const MappedRec &r = all[(size_t)p];
+            mp.peer_per_peer[p] = (int64_t)r.per_peer;
+            if (p == rank || r.pid == mine.pid) {           // this rank itself, or a rank thread of this process: the addresses as they are
+                mp.cache[p] = (float *)(uintptr_t)r.cache; mp.grads[p] = (float *)(uintptr_t)r.grads; mp.flags[p] = (unsigned int *)(uintptr_t)r.flags;
+                continue;
+            }
+            void *pc = nullptr, *pg = nullptr, *pf = nullptr;
+            if (hipIpcOpenMemHandle(&pc, r.h_cache, hipIpcMemLazyEnablePeerAccess) != hipSuccess || hipIpcOpenMemHandle(&pg, r.h_grads, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
+                hipIpcOpenMemHandle(&pf, r.h_flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError();
+                opened_ok = 0;
+            }
+            mp.cache[p] = (float *)pc; mp.grads[p] = (float *)pg; mp.flags[p] = (unsigned int *)pf; mp.opened[p] = true;
+        }
+    } else opened_ok = 0;
+    // second round: did every rank get every mapping?
+    std::vector<uint32_t> oks((size_t)n * 64);
+    uint32_t mine_ok[64];
+    memset(mine_ok, 0, sizeof mine_ok);
+    mine_ok[0] = opened_ok;
+    rc = mapped_gather(s, comm, stage, mine_ok, oks.data(), sizeof mine_ok);
+    (void)hipFree(stage);
+    if (rc != PS_OK) { mapped_close(m); return rc; }
+    bool every = true;
+    for (int p = 0; p < n; ++p) every = every && oks[(size_t)p * 64] != 0;
+    if (!every) { mapped_close(m); return PS_OK; }
+    mp.on = true;
+    mp.self = n == 1;
+    return PS_OK;
+}
+
+// one exchange: kind 0 rows back (src grouped by requesting worker), 1 gradients out (src grouped by owner)
+int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n + 1] */, const uint32_t *const *hdr, bool self, hipStream_t st) {
+    ps_model::Shard::Mapped &mp = m->sh.mp;
+    const int n = mp.nranks, D = m->cfg.D;
+    PeerPutArgs a;
+    memset(&a, 0, sizeof a);
+    a.npeers = n; a.rank = mp.rank; a.LPR = D / 4; a.D = D; a.self = (self || mp.self) ? 1 : 0;
+    a.src = src;
+    for (int p = 0; p <= n; ++p) a.start[p] = (uint32_t)pre[p];
+    for (int p = 0; p < n; ++p) {
+        a.dst[p] = kind == 0 ? mp.cache[p] : mp.grads[p];
+        a.dst_row[p] = kind == 0 ? -1 : (long long)mp.rank * (long long)mp.peer_per_peer[p];
+        a.hdr[p] = hdr ? hdr[p] : nullptr;
+        a.flag_peer[p] = mp.flags[p] + (size_t)kind * PS_MAX_MAPPED + mp.rank;
+    }
+    a.flag_mine = mp.flags_local + (size_t)kind * PS_MAX_MAPPED;
+    if (++mp.epoch[kind] == 0) ++mp.epoch[kind];
+    a.epoch = mp.epoch[kind];
+    a.arrive = mp.arrive + kind;
+    a.bound = wait_bound(m->s->werr(), 120u + (unsigned int)kind);
+    a.ts = stamp_next(kind == 0 ? "peer_put_rows" : "peer_put_grads");
+    const int64_t rows = pre[n];
+    hipLaunchKernelGGL(k_peer_put, dim3((unsigned int)std::max<int64_t>(1, cdiv(rows * a.LPR, 256))), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    ++mp.puts[kind];
+    return PS_OK;
+}
+}  // namespace
+
+// [0] 1 when this model's rows / gradient exchanges go through mapped peer memory, [1] 1 when a rank's own part does too (a 1-rank
+// table under mapped_peer = 2), [2] / [3] put launches so far (rows, gradients), [4] 1 when the flag words are fine-grained memory
+extern "C" int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5) {
+    if (!m || !out5) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    const ps_model::Shard::Mapped &mp = m->sh.mp;
+    out5[0] = mp.on ? 1 : 0; out5[1] = mp.self ? 1 : 0; out5[2] = mp.puts[0]; out5[3] = mp.puts[1]; out5[4] = mp.flags_fine ? 1 : 0;
+    return PS_OK;
+}
+void shard_mapped_release(ps_model *m) {        // (ps_model_destroy)
+    mapped_close(m);
+    if (m->sh.mp.flags_local) (void)hipFree(m->sh.mp.flags_local);
+    if (m->sh.mp.arrive) (void)hipFree(m->sh.mp.arrive);
+    m->sh.mp.flags_local = nullptr; m->sh.mp.arrive = nullptr;
+}
+
 int g_blk_factor = 2;       // ps_tune_set("blk_factor", f): a wire block holds f * nnz_cap / nranks rows (0: always full-size blocks)
 int g_blk_cap = 0;          // ps_tune_set("blk_cap", rows): the wire block's capacity outright (tests: force the overflow exchange)
 namespace {
@@ -401,8 +643,8 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const uint32_t *__restrict_
         uint32_t ovf = 0;
         for (int o = 0; o < nranks; ++o) ovf |= (owner_start[o + 1] - owner_start[o] > blk_cap) ? 1u : 0u;
         const uint32_t cnt = owner_start[u + 1] - owner_start[u];
-        blk[(size_t)u * blk_words] = cnt; blk[(size_t)u * blk_words + 1] = ovf;
-        if (full != blk) { full[(size_t)u * full_words] = cnt; full[(size_t)u * full_words + 1] = ovf; }
+        blk[(size_t)u * blk_words] = cnt; blk[(size_t)u * blk_words + 1] = ovf; blk[(size_t)u * blk_words + 2] = owner_start[u];      // (2: the worker's first cache slot of this owner's rows)
+        if (full != blk) { full[(size_t)u * full_words] = cnt; full[(size_t)u * full_words + 1] = ovf; full[(size_t)u * full_words + 2] = owner_start[u]; }
     }
     if (u >= (int64_t)owner_start[nranks]) return;
     int o = 0;
@@ -521,8 +763,11 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
             uint32_t *agree_dev = nullptr;
             { RtGuard rt_guard; HIPCHK(hipMalloc((void **)&agree_dev, sizeof(uint32_t) * 4 * (size_t)(nsh + 1))); }
             std::vector<uint32_t> agree((size_t)4 * (nsh + 1));
-            agree[0] = (uint32_t)blk_words; agree[1] = (uint32_t)full_words; agree[2] = (uint32_t)ov_want; agree[3] = PS_BLK_HDR;
+            // (bit 1 of the mode word: this rank wants, and could do, the rows / gradient exchanges over mapped peer memory)
+            const bool mp_want = g_mapped_peer && m->cfg.D % 4 == 0 && (nsh > 1 || g_mapped_peer == 2) && shard_push_grouped_ok(s, nsh);
+            agree[0] = (uint32_t)blk_words; agree[1] = (uint32_t)full_words; agree[2] = (uint32_t)ov_want | (mp_want ? 2u : 0u); agree[3] = PS_BLK_HDR;
             int arc = PS_OK;
+            bool mp_all = true;
             if (hipMemcpyAsync(agree_dev, agree.data(), 16, hipMemcpyHostToDevice, s->stream) != hipSuccess) arc = ps_set_err(PS_E_HIP, "upload of the agreement words failed");
             if (arc == PS_OK) { comm_select(comm, 0, false); arc = comm->all_gather(comm->ctx, agree_dev, agree_dev + 4, 16, s->stream); }
             if (arc == PS_OK && (hipMemcpyAsync(agree.data() + 4, agree_dev + 4, 16 * (size_t)nsh, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
@@ -534,8 +779,10 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
                 if (a[0] != (uint32_t)blk_words || a[1] != (uint32_t)full_words || a[3] != PS_BLK_HDR)
                     return ps_set_err(PS_E_BAD_ARG, "rank %d exchanges id blocks of %u / %u words, this rank (%d) of %lld / %lld: the ranks' models differ in "
                                       "max_batch / max_nnz (or blk_factor)", r, a[0], a[1], rank, (long long)blk_words, (long long)full_words);
-                ov_want = std::min<int>(ov_want, (int)a[2]);
+                ov_want = std::min<int>(ov_want, (int)(a[2] & 1u));
+                mp_all = mp_all && (a[2] & 2u) != 0;
             }
+            sh.mp.want_all = mp_all;
         }
         {
             RtGuard rt_guard;
@@ -579,6 +826,8 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
         // grouped or sorted owner-side push: decided once per model (push_grouped_max_mb is a mutable knob; a finish that
         // re-evaluated it could find the sorted push's list unallocated -- ADVICE r4)
         if (sh.push_grouped < 0) sh.push_grouped = shard_push_grouped_ok(s, nsh) ? 1 : 0;
+        // rows and gradients over mapped peer memory: set up once, behind the buffers it maps (collective: every rank asked for it)
+        if (!sh.mp.tried) PSCHK(mapped_setup(m, comm, sh.mp.want_all));
         if (!sh.push_grouped) PSCHK(size_once(s, &sh.x_recv_rows, &sh.x_recv_rows_cap, rmax + 1, sizeof(uint32_t)));   // (the sorted push's list)
     }
     // (overlap mode without an early plan -- the first step, a store that fell back to events: the plan's kernels go to side
@@ -728,7 +977,8 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     const float *grads_p[PS_PUSH_MAX_PEERS];
     for (int p = 0; p < nsh; ++p) {
         rows_p[p] = (ovf ? sh.x_recv_full[set] + (size_t)p * sh.full_words : sh.x_recv_blk[set] + (size_t)p * sh.blk_words) + PS_BLK_HDR;
-        grads_p[p] = sh.x_recv_grads + (size_t)rcpre[p] * D;
+        // (mapped peer: worker p's gradients land in region p of the receive buffer -- a sender cannot know the other workers' counts)
+        grads_p[p] = sh.x_recv_grads + (size_t)(sh.mp.on ? (int64_t)p * sh.mp.per_peer : rcpre[p]) * D;
     }
     // (own keys: the FULL block this rank packed for itself -- complete whatever the wire block holds)
     if (alias) { rows_p[rank] = sh.x_send_full[set] + (size_t)rank * sh.full_words + PS_BLK_HDR; grads_p[rank] = m->grads_out + (size_t)scpre[rank] * D; }
@@ -747,9 +997,17 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         PSCHK(shard_serve_pull_lists(s, rows_p, rc.data(), nsh, sh.x_rows_out, &lo, &gsl));
         if (lo.wait && lo.launched) sh.slot_ev = nullptr;        // (else ps_shard_forward_backward waits for the event)
     }
+    int crc;
+    if (sh.mp.on) {
+        // mapped peer: every worker's rows straight into its cache, at the slot its id block's header names
+        const uint32_t *hdr[PS_PUSH_MAX_PEERS];
+        for (int p = 0; p < nsh; ++p) hdr[p] = rows_p[p] - PS_BLK_HDR;
+        crc = timed_coll(m, 1, st, [&]() { return mapped_put(m, 0, sh.x_rows_out, rcpre.data(), hdr, !alias, st); });
+    } else {
     comm_select(comm, 0, alias);
-    int crc = timed_coll(m, 1, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st); });
+    crc = timed_coll(m, 1, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st); });
     comm_select(comm, 0, false);
+    }
     PSCHK(crc);
     // train on the cache (this rank's own rows straight from the gather's output)
     sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
@@ -801,9 +1059,13 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         PSCHK(brc);
     }
     // push: the per-key gradients to their owners
+    if (sh.mp.on) {
+        crc = timed_coll(m, 2, st, [&]() { return mapped_put(m, 1, m->grads_out, scpre.data(), nullptr, !alias, st); });
+    } else {
     comm_select(comm, 0, alias);
     crc = timed_coll(m, 2, st, [&]() { return comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st); });
     comm_select(comm, 0, false);
+    }
     PSCHK(crc);
     if (sh.push_grouped == 1) {
         LaunchOpts lo;

@@ -220,6 +220,7 @@ extern "C" int ps_model_destroy(ps_model_t *m) {
     }
     if (m->sh.x_ev) (void)hipEventDestroy(m->sh.x_ev);
     if (m->sh.done_ev) (void)hipEventDestroy(m->sh.done_ev);
+    shard_mapped_release(m);        // (before the buffers the peers map are freed)
     fr(m->sh.x_recv_rows); fr(m->sh.x_rows_out); fr(m->sh.x_recv_grads); fr(m->sh.x_cache);
     for (auto &b : m->fc) { fr(b.A); fr(b.dOut); fr(b.part); }
     fr(m->out_last); fr(m->dx); fr(m->P); fr(m->wide_z); fr(m->terms); fr(m->loss_dev); fr(m->gbar_dev); fr(m->skip_dev);

@@ -270,8 +270,9 @@ __global__ __launch_bounds__(256) void k_plan_fused(PlanFusedArgs a) {
         __syncthreads();
         if (tid < a.nshards) {
             const uint32_t cnt = os_s[tid + 1] - os_s[tid];
-            a.blk[(size_t)tid * a.blk_words] = cnt; a.blk[(size_t)tid * a.blk_words + 1] = ovf_s;
-            if (a.full != a.blk) { a.full[(size_t)tid * a.full_words] = cnt; a.full[(size_t)tid * a.full_words + 1] = ovf_s; }
+            // (word 2: this worker's first cache slot of owner tid's rows -- the mapped-peer pull stores them there, ps_comm.hip)
+            a.blk[(size_t)tid * a.blk_words] = cnt; a.blk[(size_t)tid * a.blk_words + 1] = ovf_s; a.blk[(size_t)tid * a.blk_words + 2] = os_s[tid];
+            if (a.full != a.blk) { a.full[(size_t)tid * a.full_words] = cnt; a.full[(size_t)tid * a.full_words + 1] = ovf_s; a.full[(size_t)tid * a.full_words + 2] = os_s[tid]; }
         }
     }
 }

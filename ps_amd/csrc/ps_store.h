@@ -121,7 +121,9 @@ void pool_stream_release(int device, int cls, hipStream_t st);
 int store_settle(ps_store *s);             // the pending join alone (an event wait on the store's stream)
 // may this store's models join their streams by device-side flags?  (g_dev_wait, no timeout so far, one live model on the device)
 #define PS_MAX_DEVICES 64
-#define PS_BLK_HDR 2        // header words of an id block: [count | overflow flag of the sending worker]
+#define PS_MAX_MAPPED 32       // (= PS_PUSH_MAX_PEERS = PS_COMM_MAX_RANKS)
+#define PS_BLK_HDR 4        // header words of an id block: [count | overflow flag of the sending worker | where the sending worker wants this
+                            // owner's rows in its cache (first slot: its owner_start[owner]) -- the mapped-peer pull stores them there | 0]
 #include <atomic>
 extern std::atomic<int> g_models_on_device[PS_MAX_DEVICES];
 bool dev_waits_ok(const ps_store *s);
@@ -281,6 +283,26 @@ struct ps_model {
         // slots_due (round 5, ps_tune_set("slots_in_gather")): the plan's slot kernel did not get a launch of its own (behind a spinner on side
         // chain 0, a flag setter behind it): the NEXT owner-side gather's launch computes the slots in extra workgroups (ps_shard.hip)
         bool slots_due = false; const uint32_t *slots_keys = nullptr; int64_t slots_nnz = 0;
+        // Round 6: rows and gradients over MAPPED PEER MEMORY (ps_comm.hip, "mapped peer"): every rank maps every peer's row cache,
+        // gradient receive buffer and flag words (hipIpcOpenMemHandle; the handles travel in one all-gather at the model's first
+        // begin) and the two exchanges on the step's critical chain become ONE launch each of this rank's own -- 16-byte
+        // write-through stores into the peers' buffers, a flag per peer behind the drained stores, then a bounded wait for the
+        // peers' flags -- instead of a grouped ncclSend / ncclRecv (16-18 us of launch and handshake each, profiles/r05_rccl_env_sweep.txt).
+        // mp_on: agreed by all ranks (the minimum of what each wanted and could do).  mp_self: a 1-rank table moves its own part the
+        // same way (measurement: the `mapped_peer` mode of bench.py's sharded_n1 leg).
+        struct Mapped {
+            bool on = false, self = false, tried = false, want_all = false;
+            int nranks = 0, rank = 0;
+            float *cache[PS_MAX_MAPPED] = {}, *grads[PS_MAX_MAPPED] = {};       // peer p's x_cache / x_recv_grads as mapped here (own: the local pointers)
+            unsigned int *flags[PS_MAX_MAPPED] = {};                            // peer p's flag words [2 kinds][PS_MAX_MAPPED] (own: flags_local)
+            bool opened[PS_MAX_MAPPED] = {};                                    // cache / grads / flags of peer p came from hipIpcOpenMemHandle
+            unsigned int *flags_local = nullptr; bool flags_fine = false;       // this rank's flag words (fine-grained when the runtime gives it)
+            unsigned int *arrive = nullptr;                                     // [2] arrival counters of the put launches' workgroups
+            unsigned int epoch[2] = {0, 0};                                     // exchanges of either kind so far (the same on every rank)
+            int64_t per_peer = 0;                                               // rows of one worker's region in this rank's x_recv_grads
+            int64_t peer_per_peer[PS_MAX_MAPPED] = {};                          // ... and in peer p's (shards differ by a row per field)
+            int64_t puts[2] = {0, 0};                                           // launches so far (ps_shard_mapped_info)
+        } mp;
     } sh;
     // host batches: pinned staging + two device slots on a copy stream (stage_batch)
     struct HostStage {
@@ -328,6 +350,8 @@ int shard_push_reserve(ps_store *s, int npeers);   // ps_shard.hip
 bool shard_push_grouped_ok(const ps_store *s, int npeers);
 // the slot kernel's arguments when it rides on the gather's launch (Shard::slots_due); keys == NULL: none
 struct GatherSlots { const uint32_t *keys; int64_t nnz; const uint32_t *bitmap, *word_prefix; uint32_t *slot; const unsigned int *wait; unsigned int wait_val; };
+void shard_mapped_release(ps_model *m);     // ps_comm.hip: unmap the peers' buffers, free the flag words
+extern int g_mapped_peer;
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
                            LaunchOpts *lo, const GatherSlots *gs = nullptr);       // lo: wait (an END wait of the gather's launch)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,

@@ -906,8 +906,14 @@ def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info
         if "=" in kv_:
             L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
     res, info = {}, None
-    names = {0: "device_copies", 1: "rccl_everything_off_the_wire", 2: "rccl_with_own_keys_in_place"}
+    names = {0: "device_copies", 1: "rccl_everything_off_the_wire", 2: "rccl_with_own_keys_in_place", 3: "mapped_peer"}
     for force in modes:
+        # mode 3 (round 6): rows and gradients through the mapped-peer launch (this rank's own part stored by the same kernel that would
+        # store the peers', own flag raised and awaited) with the id blocks and the all-reduce through RCCL as in mode 2
+        mapped = force == 3
+        if mapped:
+            force = 2
+            L.ps_tune_set(b"mapped_peer", 2)
         rng = np.random.default_rng(cfg["seed"])
         kv = ps_amd.KVStore(device, cfg["seed"])
         kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"])
@@ -916,24 +922,32 @@ def sharded_n1_modes(cfg, synth_batch, device, steps, modes=(0, 1, 2), with_info
         L.ps_tune_set(b"rccl_force", force)
         try:
             wk = NativeWorker([gm], 1, 0)
+            if force:
+                wk.selfcheck()
+            wk.run(bs, 4)               # (the model's first begin decides whether its exchanges are mapped: while the knob is set)
         finally:
             L.ps_tune_set(b"rccl_force", 0)
-        if force:
-            wk.selfcheck()
-        wk.run(bs, 268)
+            L.ps_tune_set(b"mapped_peer", 0)
+        if mapped:
+            mp5 = (C.c_int64 * 5)()
+            N.check(L.ps_shard_mapped_info(gm.h, mp5))
+            if not mp5[0]:
+                raise RuntimeError("the mapped-peer mode did not come up on a 1-rank table")
+        wk.run(bs, 264)
         kv.sync()
         wk.run(bs, 32)
         kv.sync()
         t0 = time.perf_counter()
         wk.run(bs, steps)
         kv.sync()
-        res[names[force]] = 1e3 * (time.perf_counter() - t0) / steps
+        name = names[3] if mapped else names[force]
+        res[name] = 1e3 * (time.perf_counter() - t0) / steps
         if force and with_info:
             info = rccl_info(wk)
         if coll_times is not None:
             ct = collective_times(wk, lambda n: wk.run(bs, n), kv, gm, steps=100)
             if ct:
-                coll_times[names[force]] = {k: v["avg_us"] for k, v in ct.items()}
+                coll_times[name] = {k: v["avg_us"] for k, v in ct.items()}
         wk.close()
         for b in bs:
             b.close()

@@ -142,9 +142,12 @@ def rank_process(rank, world, port, is_async, device_batches, q, opts=None):
         st10 = (C.c_int64 * 10)()
         N.check(L.ps_shard_exchange_stats(gm.h, st10, 10))
         xstats = [int(x) for x in st10]
+        mp5 = (C.c_int64 * 5)()
+        N.check(L.ps_shard_mapped_info(gm.h, mp5))
+        mapped = [int(x) for x in mp5]
         res = (rows, [kv.get("fc%d.weights" % l) for l in range(3)], [kv.get("fc%d.bias" % l) for l in range(3)],
                kv.get_wide(np.arange(CFG["wide"])), kv.get("wide.bias"), kv.global_step(), mode, why.value.decode(), dict(comm.calls),
-               int(L.ps_store_wait_timeouts(kv.h)), xstats)
+               int(L.ps_store_wait_timeouts(kv.h)), xstats, mapped)
         dist.barrier()
         gm.close(); kv.close()
         dist.destroy_process_group()
@@ -183,7 +186,7 @@ def test_one_process_per_rank_on_one_gpu(orc, world, is_async, device_batches):
     tol = 2e-5 * STEPS                   # the bound of the single-GPU step parity (FP32 GEMM order differs from the oracle's)
     touched = 0
     for r in range(world):
-        rows, W, b, wide, wbias, gstep, mode, why, calls, timeouts, xstats = out[r]
+        rows, W, b, wide, wbias, gstep, mode, why, calls, timeouts, xstats, _mapped = out[r]
         assert gstep == STEPS and timeouts == 0
         assert mode == 1 and why == "", "one model per process: the joins must be device-side flags (%r)" % why
         # per step: the fixed-size id-block exchange, rows back, gradients out; one all-reduce; no count all-gather any more --
@@ -265,6 +268,39 @@ def test_own_keys_in_place_overflowing_blocks_and_the_sorted_push(is_async):
                 assert calls["all_to_all_v"] == 3 * STEPS + 1 + xstats[8], calls   # one more exchange per overflowing step
             else:
                 assert xstats[8] == 0 and calls["all_to_all_v"] == 3 * STEPS + 1, (name, xstats, calls)
+
+
+_REF = {}
+
+
+def _ref(world, is_async):
+    if (world, is_async) not in _REF:
+        _REF[(world, is_async)] = run_processes(world, is_async, True)
+    return _REF[(world, is_async)]
+
+
+@pytest.mark.parametrize("world,is_async,opts", [
+    (2, False, dict(own_in_place=True)), (3, True, dict(own_in_place=True)), (8, False, dict(own_in_place=True)),
+    (3, False, dict()),                                                    # a rank's own part through the mapped path too
+    (3, False, dict(own_in_place=True, tune={"blk_cap": 2}))])             # lists that outgrow their wire blocks: headers of the FULL blocks
+def test_rows_and_gradients_over_mapped_peer_memory(world, is_async, opts):
+    """ps_tune_set("mapped_peer", 1) (round 6; net/PSClient.java:154-174's fire-and-forget push, net/PServer.java:102-117's reply): the
+    rank PROCESSES map each other's row cache, gradient receive buffer and flag words (hipIpcOpenMemHandle; the handles travel through
+    the table's all_gather) and the two exchanges on the critical chain are one launch each of stores into the peers' memory + flags.
+    The tables equal the plain run's, bit for bit; the table's all_to_all_v only carried the id blocks; no wait ran into its bound."""
+    ref = _ref(world, is_async)
+    o = dict(opts)
+    o["tune"] = dict(o.get("tune") or {}, mapped_peer=1, spin_timeout_ms=30000)
+    got = run_processes(world, is_async, True, o)
+    for r in range(world):
+        _same(ref[r], got[r], "mapped peer, rank %d of %d" % (r, world))
+        calls, timeouts, xstats, mapped = got[r][8], got[r][9], got[r][10], got[r][11]
+        assert timeouts == 0 and xstats[0] == STEPS
+        assert mapped[0] == 1 and mapped[2] == STEPS and mapped[3] == STEPS, mapped          # one put launch per exchange and step
+        assert calls["all_to_all_v"] == STEPS + 1 + xstats[8], calls                          # id blocks (+ full-size ones) + the selfcheck's
+        assert calls["all_gather"] == 4, calls                                                # selfcheck, block sizes, handles, "every mapping worked"
+        if "blk_cap" in o["tune"]:
+            assert xstats[8] > 0
 
 
 def test_ranks_with_different_block_sizes_fail_together():

@@ -838,6 +838,56 @@ def test_library_driven_step_n1_equals_fused_step():
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
 
 
+def test_mapped_peer_one_rank_equals_fused_step():
+    """ps_tune_set("mapped_peer", 2) on a 1-rank table: the rows / gradient exchanges of ps_shard_step run as the mapped-peer launch
+    (this rank's own part stored through the same kernel into its own cache / receive region, own flag raised and awaited) -- the mode
+    bench.py's sharded_n1 leg times as `mapped_peer`.  120 pipelined steps leave the fused step's tables, bit for bit."""
+    import ctypes as C
+    import ps_amd
+    from ps_amd import native as N
+    from ps_amd.sharded import NativeWorker
+    F, D, X, fc, V, B, WS = 5, 8, 3, [16, 8, 1], 400, 256, 31
+    rng = np.random.default_rng(14)
+    data_ = []
+    for _ in range(6):
+        E, Xd, Y = data(rng, B, F, X, V, True)
+        data_.append((E, Xd, Y, E % WS))
+    res = []
+    for mapped in (0, 2):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B)
+        bs = [ps_amd.DeviceBatch(kv, *d) for d in data_]
+        info = [0] * 5
+        if mapped:
+            N.lib().ps_tune_set(b"mapped_peer", mapped)
+            try:
+                wk = NativeWorker([gm], 1, 0)
+                wk.run(bs, 120)
+            finally:
+                N.lib().ps_tune_set(b"mapped_peer", 0)
+            kv.sync()
+            mp5 = (C.c_int64 * 5)()
+            N.check(N.lib().ps_shard_mapped_info(gm.h, mp5))
+            info = [int(x) for x in mp5]
+            wk.close()
+        else:
+            for i in range(120):
+                gm.train_async(bs[i % len(bs)])
+            kv.sync()
+        res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(3)],
+                    kv.get_wide(np.arange(WS)), kv.get("wide.bias"), kv.global_step(), info, int(N.lib().ps_store_wait_timeouts(kv.h))))
+        for b in bs:
+            b.close()
+        gm.close(); kv.close()
+    a, b = res
+    assert b[5][0] == 1 and b[5][1] == 1 and b[5][2] == 120 and b[5][3] == 120, b[5]
+    assert a[6] == 0 and b[6] == 0 and a[4] == b[4] == 120
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
+
+
 def test_simple_updater_rows_and_dense():
     """update/SimpleUpdater.java:20-22 (w += g * -eta) on embedding rows and FC tensors: bit-exact given the gradients."""
     import ps_amd

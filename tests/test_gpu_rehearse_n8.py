@@ -54,7 +54,7 @@ def c4_batch(cfg, rng):
     return ids, rng.standard_normal((B, cfg["X"])).astype(f32), (rng.random(B) < 0.25).astype(f32), W, offsets
 
 
-def rank_process(rank, world, port, steps, q, snapshot=True, case="c2"):
+def rank_process(rank, world, port, steps, q, snapshot=True, case="c2", tune=None):
     try:
         sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
         import ctypes as C, hashlib, time
@@ -75,6 +75,8 @@ def rank_process(rank, world, port, steps, q, snapshot=True, case="c2"):
         else:
             gm = ps_amd.WideDeepNN.buildModel(cfg["F"], cfg["D"], cfg["X"], cfg["fc"], cfg["wide"], store=kv, max_batch=cfg["B"])
         L = N.lib()
+        for k_, v_ in (tune or {}).items():          # (mapped_peer: rows and gradients through the peers' mapped memory, ps_native.h)
+            N.check(L.ps_tune_set(k_.encode(), int(v_)))
 
         class GlooOps:
             """ps_comm_ops_t over gloo, host staged; own keys in place: the self part of a receive buffer is poisoned"""
@@ -143,23 +145,24 @@ def rank_process(rank, world, port, steps, q, snapshot=True, case="c2"):
         st = (C.c_int64 * 10)(); N.check(L.ps_shard_exchange_stats(gm.h, st, 10))
         why = C.create_string_buffer(256)
         mode = L.ps_store_join_mode(kv.h, why, 256)
+        mp5 = (C.c_int64 * 5)(); N.check(L.ps_shard_mapped_info(gm.h, mp5))
         h = hashlib.sha256()
         for l in range(3): h.update(kv.get("fc%d.weights" % l).tobytes()); h.update(kv.get("fc%d.bias" % l).tobytes())
         h.update(kv.get_wide(np.arange(cfg["wide"])).tobytes())
         dist.barrier()
         q.put((rank, "ok", dict(loss=float(loss), digest=h.hexdigest(), stats=[int(x) for x in st], join_mode=mode, why=why.value.decode(),
-                                timeouts=int(L.ps_store_wait_timeouts(kv.h)), seconds=time.time() - t0, snap=snap)))
+                                timeouts=int(L.ps_store_wait_timeouts(kv.h)), seconds=time.time() - t0, snap=snap, mapped=[int(x) for x in mp5])))
         gm.close(); kv.close(); dist.destroy_process_group()
     except BaseException:       # noqa: BLE001
         import traceback
         q.put((rank, "fail", traceback.format_exc()))
 
 
-def run_ranks(world, steps, snapshot=True, timeout=600, case="c2"):
+def run_ranks(world, steps, snapshot=True, timeout=600, case="c2", tune=None):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=rank_process, args=(r, world, port, steps, q, snapshot, case), daemon=True) for r in range(world)]
+    ps = [ctx.Process(target=rank_process, args=(r, world, port, steps, q, snapshot, case, tune), daemon=True) for r in range(world)]
     for p in ps: p.start()
     try:
         res = [q.get(timeout=timeout) for _ in ps]
@@ -245,14 +248,20 @@ def ps_semantics_after_one_step(orc, world):
     return rows, W0, fc1, wide1, wbias1
 
 
-def test_config2_full_size_eight_ranks_on_one_gpu(orc):
+MAPPED = {"mapped_peer": 1, "spin_timeout_ms": 30000}       # (eight processes share one GPU: a peer's launch may be a time slice away)
+
+
+@pytest.mark.parametrize("mapped", [False, True])
+def test_config2_full_size_eight_ranks_on_one_gpu(orc, mapped):
+    """mapped: the rows / gradient exchanges as stores into the seven peer PROCESSES' mapped memory (round 6) -- the same bits"""
     world, steps = 8, 4
-    res = run_ranks(world, steps, timeout=330)
+    res = run_ranks(world, steps, timeout=330, tune=MAPPED if mapped else None)
     bad = [r for r in res if r[1] != "ok"]
     assert not bad, "\n".join("rank %d:\n%s" % (r[0], r[2]) for r in bad)
     info = [r[2] for r in res]
     # the pipeline ran clean on every rank
     for r, i in enumerate(info):
+        assert i["mapped"][0] == (1 if mapped else 0) and (not mapped or (i["mapped"][2] == steps + 1 and i["mapped"][3] == steps + 1)), i["mapped"]
         assert i["timeouts"] == 0 and i["join_mode"] == 1 and i["why"] == "", (r, i["why"], i["timeouts"])
         st = i["stats"]
         assert st[0] == steps + 1 and st[8] == 0, st                       # steps counted; no list outgrew its wire block
@@ -284,7 +293,7 @@ def test_config2_full_size_eight_ranks_on_one_gpu(orc):
         np.testing.assert_array_equal(info[0]["snap"]["wide"][k], wide1[k], err_msg="wide table after step 1: %s" % what)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "rehearse_n8.log"), "w") as fo:
+        with open(os.path.join(ROOT, "gpurun_out", "rehearse_n8%s.log" % ("_mapped" if mapped else "")), "w") as fo:
             for r, i in enumerate(info):
                 st = i["stats"]; n = st[0]
                 fo.write("rank %d: loss %.5f  joins %s  timeouts %d  per step: %d keys requested, %d served, id blocks %d B (wire block %d words, full %d), rows %d B, "
@@ -354,13 +363,15 @@ def ps_async_semantics_after_one_step(orc, world):
     return rows, W0, fc1, nnz
 
 
-def test_config4_full_size_eight_ranks_async_ftrl_on_one_gpu(orc):
+@pytest.mark.parametrize("mapped", [False, True])
+def test_config4_full_size_eight_ranks_async_ftrl_on_one_gpu(orc, mapped):
     world, steps = 8, 3
-    res = run_ranks(world, steps, timeout=380, case="c4")
+    res = run_ranks(world, steps, timeout=380, case="c4", tune=MAPPED if mapped else None)
     bad = [r for r in res if r[1] != "ok"]
     assert not bad, "\n".join("rank %d:\n%s" % (r[0], r[2]) for r in bad)
     info = [r[2] for r in res]
     for r, i in enumerate(info):
+        assert i["mapped"][0] == (1 if mapped else 0) and (not mapped or (i["mapped"][2] == steps + 1 and i["mapped"][3] == steps + 1)), i["mapped"]
         assert i["timeouts"] == 0 and i["join_mode"] == 1 and i["why"] == "", (r, i["why"], i["timeouts"])
         st = i["stats"]
         assert st[0] == steps + 1 and st[8] == 0, st                       # steps counted; no list outgrew its wire block
@@ -389,7 +400,7 @@ def test_config4_full_size_eight_ranks_async_ftrl_on_one_gpu(orc):
         np.testing.assert_array_equal(info[0]["snap"]["fcb"][l], fc1[l][1], err_msg="fc%d.bias after step 1" % l)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "rehearse_c4_n8.log"), "w") as fo:
+        with open(os.path.join(ROOT, "gpurun_out", "rehearse_c4_n8%s.log" % ("_mapped" if mapped else "")), "w") as fo:
             for r, i in enumerate(info):
                 st = i["stats"]; n = st[0]
                 fo.write("rank %d: loss %.5f  joins %s  timeouts %d  per step: %d keys requested, %d served, id blocks %d B (wire block %d words, full %d), rows %d B, "
