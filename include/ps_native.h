@@ -513,7 +513,9 @@ int ps_comm_selfcheck(ps_store_t *s, const ps_comm_ops_t *comm);
  * peers' flags here.  The id blocks and the all-reduce still use the table.  A wait that runs into its bound is reported like
  * every other device-side wait: the next host-side check returns PS_E_STATE (a peer died: restart the ranks without the knob).
  * Needs D % 4 == 0 and the sort-free owner push.  2: a 1-rank table too (its own part through the same launch; measurement).
- * ps_shard_mapped_info: out5[0] 1 when this model's exchanges use it, [1] a rank's own part too, [2] / [3] launches so far
+ * The set-up ends with a wire check of its own (three rounds of both exchanges on a pattern that names round, sender, receiver, row
+ * and column, verified by a kernel of the receiving rank): a wrong word on any rank and every rank stays on all_to_all_v.
+ * ps_shard_mapped_info: out5[0] 1 when this model's exchanges use it (-1: the wire check failed), [1] a rank's own part too, [2] / [3] launches so far
  * (rows, gradients), [4] 1 when the flag words are fine-grained memory. */
 int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5);
 int ps_shard_step(ps_model_t *m, const ps_batch_t *batch, const ps_comm_ops_t *comm, int is_async, float *loss);

@@ -450,23 +450,37 @@ __device__ __forceinline__ bool spin_bounded_sys(const unsigned int *f, unsigned
 __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     StampScope stamp(a.ts);
     __shared__ int last_s;
+    // every peer's destination once per workgroup (lane-indexed argument arrays are memory loads: three dependent ones per thread otherwise)
+    __shared__ uint32_t start_s[PS_MAX_MAPPED + 1];
+    __shared__ float *dst_s[PS_MAX_MAPPED];
+    {
+        const int p = threadIdx.x;
+        if (p <= a.npeers) start_s[p] = a.start[p];
+        if (p < a.npeers) {
+            const long long r0 = a.dst_row[p] >= 0 ? a.dst_row[p] : ((p != a.rank || a.self) ? (long long)a.hdr[p][2] : 0ll);
+            dst_s[p] = a.dst[p] + (size_t)r0 * a.D;
+        }
+    }
+    __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / a.LPR;
     const int part = (int)(t % a.LPR);
-    if (i < (int64_t)a.start[a.npeers]) {
+    if (i < (int64_t)start_s[a.npeers]) {
         int p = 0;
-        while (p + 1 < a.npeers && (uint32_t)i >= a.start[p + 1]) ++p;
+        while (p + 1 < a.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
         if (p != a.rank || a.self) {
-            const long long r0 = a.dst_row[p] >= 0 ? a.dst_row[p] : (long long)a.hdr[p][2];
             const mp_f32x4 v = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
-            float *q = a.dst[p] + (size_t)(r0 + (i - a.start[p])) * a.D + part * 4;
+            float *q = dst_s[p] + (size_t)(i - start_s[p]) * a.D + part * 4;
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");       // write-through: nothing stays in this XCD's L2
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have been acknowledged by the memory they went to
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // RELAXED on purpose: the payload went out write-through and has been acknowledged (the vmcnt drain above), so there is nothing
+        // for a release to write back -- an acq_rel here is a buffer_wbl2 + buffer_inv PER WORKGROUP (measured: the launch 22 us instead
+        // of 6).  The counter itself lives in L2 (device-scope atomic); whoever reads grid - 1 knows every workgroup's stores have landed.
+        const unsigned int old = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = old == gridDim.x - 1 ? 1 : 0;
         if (last_s) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch of this kind: in stream order behind this one)
     }
@@ -475,9 +489,35 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     // the last workgroup: every workgroup's stores have landed -- this rank's flag at every peer, then the peers' flags here
     const int p = threadIdx.x;
     if (p < a.npeers && (p != a.rank || a.self)) {
-        __hip_atomic_store(a.flag_peer[p], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.flag_peer[p], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (sc0 sc1 store; issued behind the counter's answer)
         (void)spin_bounded_sys(a.flag_mine + p, a.epoch, a.bound);
     }
+}
+
+int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre, const uint32_t *const *hdr, bool self, hipStream_t st);
+
+// The set-up's wire check (every rank, collectively, before the first step may trust the path -- it has never run between two
+// DEVICES on the development box): three rounds of both kinds of put with a pattern that names (round, sender, receiver, row,
+// column), each round verified by a KERNEL of the receiving rank (the next launch on the stream, like the step's consumers: a
+// host copy would not read through the caches the step reads through).  A round that changes every word also shows a stale
+// line of the round before.
+__device__ __forceinline__ uint32_t mp_pattern(uint32_t round, uint32_t from, uint32_t to, uint32_t row, uint32_t col) {
+    uint32_t x = round * 0x9E3779B1u ^ (from * 0x85EBCA77u + to * 0xC2B2AE3Du) ^ (row * 0x27D4EB2Fu + col * 0x165667B1u);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    return x | 1u;
+}
+__global__ __launch_bounds__(256) void k_mapped_fill(uint32_t *src, int rows_per_peer, int D, int npeers, uint32_t rank, uint32_t round) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)npeers * rows_per_peer * D) return;
+    const uint32_t col = (uint32_t)(t % D), row = (uint32_t)((t / D) % rows_per_peer), to = (uint32_t)(t / ((int64_t)D * rows_per_peer));
+    src[t] = mp_pattern(round, rank, to, row, col);
+}
+__global__ __launch_bounds__(256) void k_mapped_check(const uint32_t *recv, int64_t region_rows, int rows_per_peer, int D, int npeers, uint32_t rank, uint32_t round, int skip, unsigned int *bad) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)npeers * rows_per_peer * D) return;
+    const uint32_t col = (uint32_t)(t % D), row = (uint32_t)((t / D) % rows_per_peer), from = (uint32_t)(t / ((int64_t)D * rows_per_peer));
+    if ((int)from == skip) return;
+    if (recv[((size_t)from * region_rows + row) * D + col] != mp_pattern(round, from, rank, row, col)) atomicAdd(bad, 1u);
 }
 
 void mapped_close(ps_model *m) {
@@ -575,13 +615,52 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     memset(mine_ok, 0, sizeof mine_ok);
     mine_ok[0] = opened_ok;
     rc = mapped_gather(s, comm, stage, mine_ok, oks.data(), sizeof mine_ok);
-    (void)hipFree(stage);
-    if (rc != PS_OK) { mapped_close(m); return rc; }
+    if (rc != PS_OK) { (void)hipFree(stage); mapped_close(m); return rc; }
     bool every = true;
     for (int p = 0; p < n; ++p) every = every && oks[(size_t)p * 64] != 0;
-    if (!every) { mapped_close(m); return PS_OK; }
+    if (!every) { (void)hipFree(stage); mapped_close(m); return PS_OK; }
     mp.on = true;
     mp.self = n == 1;
+    // ---- the wire check (see k_mapped_fill): R rows per peer, region p of the receive buffers = what peer p stored ----
+    {
+        const int D = m->cfg.D;
+        const int64_t R = std::max<int64_t>(1, std::min<int64_t>(512, std::min<int64_t>(m->nnz_cap / n, mp.per_peer)));
+        uint32_t *src = nullptr, *hdr_dev = nullptr; unsigned int *bad = nullptr;
+        bool alloc_ok = hipMalloc((void **)&src, sizeof(uint32_t) * (size_t)n * R * D) == hipSuccess && hipMalloc((void **)&hdr_dev, sizeof(uint32_t) * 4 * (size_t)n) == hipSuccess &&
+                        hipMalloc((void **)&bad, sizeof(unsigned int)) == hipSuccess;
+        unsigned int nbad = 0;
+        if (alloc_ok) {
+            std::vector<uint32_t> hdr_h((size_t)4 * n, 0u);
+            for (int p = 0; p < n; ++p) hdr_h[(size_t)4 * p + 2] = (uint32_t)(rank * R);       // "store my rows from your slot rank * R on"
+            std::vector<int64_t> pre((size_t)n + 1);
+            for (int p = 0; p <= n; ++p) pre[(size_t)p] = (int64_t)p * R;
+            const uint32_t *hdr[PS_MAX_MAPPED];
+            for (int p = 0; p < n; ++p) hdr[p] = hdr_dev + 4 * (size_t)p;
+            hipError_t e = hipMemcpyAsync(hdr_dev, hdr_h.data(), sizeof(uint32_t) * 4 * (size_t)n, hipMemcpyHostToDevice, s->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(unsigned int), s->stream);
+            const unsigned int grid = (unsigned int)cdiv((int64_t)n * R * D, 256);
+            for (uint32_t round = 1; round <= 3 && e == hipSuccess; ++round)
+                for (int kind = 0; kind < 2; ++kind) {
+                    hipLaunchKernelGGL(k_mapped_fill, dim3(grid), dim3(256), 0, s->stream, src, (int)R, D, n, (uint32_t)rank, round * 2 + kind);
+                    if (mapped_put(m, kind, (const float *)src, pre.data(), hdr, true, s->stream) != PS_OK) { e = hipErrorUnknown; break; }
+                    hipLaunchKernelGGL(k_mapped_check, dim3(grid), dim3(256), 0, s->stream, (const uint32_t *)(kind == 0 ? sh.x_cache : sh.x_recv_grads),
+                                       kind == 0 ? R : mp.per_peer, (int)R, D, n, (uint32_t)rank, round * 2 + kind, -1, bad);
+                }
+            if (e == hipSuccess) e = hipMemcpyAsync(&nbad, bad, sizeof nbad, hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (e != hipSuccess) { (void)hipGetLastError(); nbad = 0xFFFFFFFFu; }
+            if (store_check_bad_ids(s) == PS_E_STATE) nbad = 0xFFFFFFFFu;         // (a put's wait ran into its bound)
+        } else { (void)hipGetLastError(); nbad = 0xFFFFFFFFu; }
+        (void)hipFree(src); (void)hipFree(hdr_dev); (void)hipFree(bad);
+        mp.selfcheck_bad = nbad; mp.checked = true;
+        memset(mine_ok, 0, sizeof mine_ok);
+        mine_ok[0] = nbad == 0 ? 1u : 0u;
+        rc = mapped_gather(s, comm, stage, mine_ok, oks.data(), sizeof mine_ok);
+        (void)hipFree(stage);
+        if (rc != PS_OK) { mapped_close(m); return rc; }
+        for (int p = 0; p < n; ++p) every = every && oks[(size_t)p * 64] != 0;
+        if (!every) { mapped_close(m); mp.selfcheck_failed = true; return PS_OK; }
+    }
     return PS_OK;
 }
 
@@ -619,7 +698,8 @@ int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n
 extern "C" int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5) {
     if (!m || !out5) return ps_set_err(PS_E_BAD_ARG, "null argument");
     const ps_model::Shard::Mapped &mp = m->sh.mp;
-    out5[0] = mp.on ? 1 : 0; out5[1] = mp.self ? 1 : 0; out5[2] = mp.puts[0]; out5[3] = mp.puts[1]; out5[4] = mp.flags_fine ? 1 : 0;
+    // (the set-up's wire check launches 6 puts of its own: not counted)
+    out5[0] = mp.on ? 1 : mp.selfcheck_failed ? -1 : 0; out5[1] = mp.self ? 1 : 0; out5[2] = mp.puts[0] - (mp.checked ? 3 : 0); out5[3] = mp.puts[1] - (mp.checked ? 3 : 0); out5[4] = mp.flags_fine ? 1 : 0;
     return PS_OK;
 }
 void shard_mapped_release(ps_model *m) {        // (ps_model_destroy)

@@ -302,6 +302,7 @@ struct ps_model {
             int64_t per_peer = 0;                                               // rows of one worker's region in this rank's x_recv_grads
             int64_t peer_per_peer[PS_MAX_MAPPED] = {};                          // ... and in peer p's (shards differ by a row per field)
             int64_t puts[2] = {0, 0};                                           // launches so far (ps_shard_mapped_info)
+            unsigned int selfcheck_bad = 0; bool selfcheck_failed = false, checked = false;   // the set-up's wire check: wrong words seen here | some rank saw some
         } mp;
     } sh;
     // host batches: pinned staging + two device slots on a copy stream (stage_batch)

@@ -549,14 +549,19 @@ class NativeWorker:
 # ---------------------------------------------------------------------------
 # A multi-GPU run that wedges costs the driver its whole timeout and yields nothing.  The bench therefore runs in STAGES,
 # each more conservative than the one before, and a watchdog thread moves on when a stage makes no progress:
-#   stage 0  the default: device-side joins, key lists + all-reduce on side streams with their own communicators
-#   stage 1  events only (dev_wait = 0, end_wait = 0), everything on the training stream with ONE communicator
-#   stage 2  the torch.distributed wire (ShardedWorker), the library only runs the device-side halves
+#   stage 0  rows and gradients over MAPPED PEER MEMORY (round 6: one launch of stores + flags per exchange instead of a grouped
+#            ncclSend / ncclRecv; ps_native.h ps_shard_mapped_info), everything else as stage 1.  Its set-up checks the wire on
+#            patterns and every rank falls back to RCCL's all-to-all-v together when any mapping or any word fails (the line says so)
+#   stage 1  rounds 3-5's default: every collective through RCCL, device-side joins, key lists + all-reduce on side streams with
+#            their own communicators
+#   stage 2  events only (dev_wait = 0, end_wait = 0), everything on the training stream with ONE communicator
+#   stage 3  the torch.distributed wire (ShardedWorker), the library only runs the device-side halves
 # "Moving on" = the process replaces itself (os.execve) with the same command line and PS_BENCH_STAGE + 1: a hung
 # collective or a spinning stream cannot be recovered from inside the process.  Every rank does this on its own
 # watchdog; they meet again in init_process_group on the next stage's rendezvous port.  The stage a line was measured
 # on is in config["stage"], the reason for leaving the earlier ones in config["stage_history"].
-STAGES = ["default (device-side joins, 3 communicators, key lists + all-reduce on side streams)",
+STAGES = ["rows + gradients over mapped peer memory (hipIpc; stores + flags), id blocks + all-reduce through RCCL (device-side joins, 3 communicators)",
+          "every collective through RCCL (device-side joins, 3 communicators, key lists + all-reduce on side streams)",
           "events only, one communicator, one stream (dev_wait=0, end_wait=0, shard_overlap=0)",
           "torch.distributed wire (ShardedWorker)"]
 
@@ -629,9 +634,10 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     for kv_ in os.environ.get("PS_TUNE", "").split(","):      # measurement knobs (bench.py applies them itself on the fused path)
         if "=" in kv_:
             L.ps_tune_set(kv_.split("=")[0].encode(), int(kv_.split("=")[1]))
-    if stage >= 1:
+    if stage >= 2:
         for k in (b"dev_wait", b"end_wait", b"shard_overlap"):
             L.ps_tune_set(k, 0)
+    L.ps_tune_set(b"mapped_peer", 1 if (stage == 0 and not os.environ.get("PS_BENCH_NO_MAPPED")) else 0)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -650,7 +656,7 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     kv = ps_amd.KVStore(local, cfg["seed"])
     kv.create_embedding([cfg["V"]] * cfg["F"], cfg["D"], shard=rank, nshards=world)
     overlap = bool(getattr(args, "overlap", 1))
-    native = bool(getattr(args, "native", 1)) and stage < 2
+    native = bool(getattr(args, "native", 1)) and stage < 3
     threaded = False
     wire_check = None
     rccl = None
@@ -729,6 +735,12 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     worker_run(3)
     kv.sync(); torch.cuda.synchronize()
     dist.barrier()
+    mapped = None
+    if native:
+        mp5 = (C.c_int64 * 5)()
+        N.check(L.ps_shard_mapped_info(gms[0].h, mp5))
+        mapped = {"active": mp5[0] == 1, "wire_check": "failed on some rank: every rank went back to RCCL's all-to-all-v" if mp5[0] < 0 else ("ok" if mp5[0] == 1 else "not run"),
+                  "flag_words_fine_grained": bool(mp5[4])}
     # priming (untimed, on top of --warmup): the first few hundred steps run ~30% slower while the communicators' buffers
     # and the host's clocks settle; keep that out of the timed region
     prim = max(args.warmup, 1) + int(getattr(args, "priming", 300))
@@ -845,6 +857,9 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
                        "exchange_driver": "libps_amd (ps_shard_step, RCCL via dlopen)" if native else "torch.distributed",
                        "stage": stage, "stage_name": STAGES[stage], "stage_history": os.environ.get("PS_BENCH_STAGE_HISTORY", ""),
                        "world_size": world, "rccl": rccl, "wire_selfcheck": wire_check,
+                       # rows and gradients: stores into the peers' mapped memory (stage 0) or RCCL's grouped send / recv
+                       "rows_and_gradients": ("mapped peer memory (hipIpc, stores + flags)" if (mapped and mapped["active"]) else "RCCL all-to-all-v") if native else "torch.distributed",
+                       "mapped_peer": mapped,
                        "stream_joins": "device-side flags" if join_mode == 1 else "events (%s)" % why.value.decode(),
                        "device_wait_timeouts": timeouts,
                        "prefetch_next_key_lists": overlap, "prefetch_thread": threaded,
