@@ -412,6 +412,8 @@ def run_single(args):
         out["multi_hot"] = multi_hot_step(cfg)
     if args.fused_adam:
         out["fused_adam_hbm"] = fused_adam_roofline(args)
+    if args.ingest_fed:
+        out["ingest_fed"] = ingest_fed_leg(cfg, out["value"])
     if args.sharded_leg:
         out["sharded_n1"] = sharded_n1_leg(args)
         try:
@@ -561,6 +563,68 @@ def gather_roofline(kv, args):
     return res
 
 
+def ingest_fed_leg(cfg, resident_examples_per_s, epochs=3):
+    """configs[1] trained STRAIGHT FROM libsvm TEXT (data/DataSet.java:77-100's reader threads, data/LibsvmParser.java:13-25,
+    CTR.java:47-68) through ps_ingest_*: CTR-shaped lines (label + 26 `idx:1` + 13 `idx:val`) held in memory, parsed by
+    min(nproc, 96) host threads into a ring of pinned batches, one H2D copy per batch, the same fused step on the batches as they
+    arrive.  Reported beside the resident number: the headline's inputs are in HBM when its timed region starts; this is the rate
+    when they are not."""
+    import ps_amd
+    F, X, B, V = cfg["F"], cfg["X"], cfg["B"], cfg["V"]
+    rng = np.random.default_rng(cfg["seed"] + 77)
+    nlines, nbatch = 4 * B, 96
+    E, Xd, Y, _ = synth_batch(cfg, rng, B=nlines)
+    lines = np.array([(str(int(Y[i])) + " " + " ".join("%d:1" % v for v in E[i]) + " " + " ".join("%d:%.6f" % (F + 1 + j, Xd[i, j]) for j in range(X))).encode()
+                      for i in range(nlines)], dtype=object)
+    # 96 batches of lines drawn from those 16 384 (the text, not the arrays, is what the leg starts from)
+    text = b"\n".join(lines[rng.integers(0, nlines, size=nbatch * B)]) + b"\n"
+    threads = max(1, min(os.cpu_count() or 1, 96))
+    kv = ps_amd.KVStore(0, cfg["seed"])
+    kv.create_embedding([V] * F, cfg["D"])
+    gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], X, cfg["fc"], cfg["wide"], store=kv, max_batch=B)
+    ds = ps_amd.DataSet(kv, text, F, X, B, wide_size=cfg["wide"], threads=threads)
+    assert ds.lines() == nbatch * B
+    # the pipeline alone (parse + H2D, nothing trains): what the host side can deliver
+    for _ in ds:
+        pass
+    ds.reset()
+    t0 = time.perf_counter()
+    k = 0
+    for _ in ds:
+        k += 1
+    pipe_dt = time.perf_counter() - t0
+    ds.reset()
+    st0 = ds.stats()
+    # training from the pipeline
+    for b in ds:                                    # one epoch of warm-up
+        gm.train_async(b)
+    gm.sync(); ds.reset()
+    t0 = time.perf_counter()
+    steps = 0
+    for _ in range(epochs):
+        for b in ds:
+            gm.train_async(b); steps += 1
+        ds.reset()
+    gm.sync()
+    dt = time.perf_counter() - t0
+    st1 = ds.stats()
+    loss = gm.train(ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)))
+    ds.close(); gm.close(); kv.close()
+    thread_s_per_line = (st1["parse_seconds"] - st0["parse_seconds"]) / max(st1["lines"] - st0["lines"], 1)
+    block = B * (F * 8 * (2 if cfg["wide"] else 1) + X * 4 + 4)
+    fed = B * steps / dt
+    out = {"workload": "configs[1] from libsvm text in memory: %d lines (%.1f MB), %d parser threads, ring of pinned batches, one H2D copy per batch" % (nbatch * B, len(text) / 1e6, threads),
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "examples_per_s": fed,
+           "resident_examples_per_s": resident_examples_per_s, "fed_over_resident": fed / resident_examples_per_s,
+           "pipeline_alone_lines_per_s": k * B / pipe_dt,
+           "parser": {"threads": threads, "thread_us_per_line": 1e6 * thread_s_per_line, "lines_per_s_all_threads": threads / thread_s_per_line,
+                      "text_MB_per_s_all_threads": threads / thread_s_per_line * len(text) / (nbatch * B) / 1e6},
+           "h2d_bytes_per_step": block, "h2d_GBs_at_this_rate": block * steps / dt / 1e9, "final_loss": loss}
+    stages = {"parser threads": out["parser"]["lines_per_s_all_threads"], "pipeline alone (parse + copy)": out["pipeline_alone_lines_per_s"], "resident step": resident_examples_per_s}
+    out["bounded_by"] = min(stages, key=stages.get) if fed < 0.9 * resident_examples_per_s else "nothing on the host: within 10 % of the resident step"
+    return out
+
+
 def fused_adam_roofline(args):
     """BASELINE configs[3], "fused Adam, 1-GPU HBM-roofline run": DNN over ONE HBM-resident table of R rows x 64 (R = 320 M:
     W + Adam M, V = 246 GB of the 288 GB), 2^22 uniformly random ids per step -- single-hot (EmbeddingField's own shape) and in
@@ -659,6 +723,7 @@ def main():
     ap.add_argument("--leg", default="", help=argparse.SUPPRESS)
     ap.add_argument("--gather", type=int, default=1)
     ap.add_argument("--multi-hot", type=int, default=1, help="also report the configs[4] shape (multi-hot bags, FTRL) on this GPU")
+    ap.add_argument("--ingest-fed", type=int, default=1, help="also train configs[1] straight from libsvm text through ps_ingest_* (examples/s beside the resident number)")
     ap.add_argument("--fused-adam", type=int, default=1, help="also report configs[3]'s fused backward + Adam on a 320 M-row HBM-resident table")
     ap.add_argument("--adam-rows", type=int, default=320 * 1000 * 1000)      # W + M + V = 246 GB
     ap.add_argument("--gather-rows", type=int, default=1000 * 1000 * 1000)   # BASELINE configs[3]: 1e9 rows x 64 f32 = 256 GB
@@ -688,6 +753,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.leg == "sharded_n1":
         emit(leg_sharded_n1(args))
+        return
+    if args.leg == "ingest_fed":              # (resident rate: the round's driver number, for the ratio only)
+        emit({"ingest_fed": ingest_fed_leg(dict(C2, zipf=args.zipf, idgen=args.idgen), 30.4e6)})
         return
     if args.leg == "fused_adam":              # the configs[3] fused-Adam leg alone (tools/profile_round.sh profiles it this way)
         emit({"fused_adam_hbm": fused_adam_roofline(args)})

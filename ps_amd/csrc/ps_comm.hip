@@ -415,6 +415,7 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
 // 2: a 1-rank table too, moving its own part through the same launch (bench.py's sharded_n1 `mapped_peer` mode).
 // ---------------------------------------------------------------------------
 int g_mapped_peer = getenv("PS_MAPPED_PEER") ? atoi(getenv("PS_MAPPED_PEER")) : 0;
+int g_mapped_grid = 64;     // ps_tune_set("mapped_grid", workgroups): the put launches' largest grid
 namespace {
 typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
 struct PeerPutArgs {
@@ -462,17 +463,32 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
         }
     }
     __syncthreads();
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = t / a.LPR;
-    const int part = (int)(t % a.LPR);
-    if (i < (int64_t)start_s[a.npeers]) {
-        int p = 0;
-        while (p + 1 < a.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
-        if (p != a.rank || a.self) {
-            const mp_f32x4 v = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
-            float *q = dst_s[p] + (size_t)(i - start_s[p]) * a.D + part * 4;
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");       // write-through: nothing stays in this XCD's L2
+    // A SMALL grid walks the 16-byte parts (PUT_ILP loads in flight per thread, then their stores): the launch ends with one
+    // returned atomic per workgroup on ONE address, and those serialise at the memory side -- one workgroup per 256 parts (725 of
+    // them at configs[2]) made the launch 16 us, the copy itself is ~2.
+    constexpr int PUT_ILP = 4;
+    const int64_t total = (int64_t)start_s[a.npeers] * a.LPR, T = (int64_t)gridDim.x * 256;
+    for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += T * PUT_ILP) {
+        mp_f32x4 v[PUT_ILP];
+        float *q[PUT_ILP];
+#pragma unroll
+        for (int j = 0; j < PUT_ILP; ++j) {
+            const int64_t t = t0 + (int64_t)j * T;
+            q[j] = nullptr;
+            if (t < total) {
+                const int64_t i = t / a.LPR;
+                const int part = (int)(t % a.LPR);
+                int p = 0;
+                while (p + 1 < a.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
+                if (p != a.rank || a.self) {
+                    v[j] = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
+                    q[j] = dst_s[p] + (size_t)(i - start_s[p]) * a.D + part * 4;
+                }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < PUT_ILP; ++j)
+            if (q[j]) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q[j]), "v"(v[j]) : "memory");       // write-through: nothing stays in this XCD's L2
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have been acknowledged by the memory they went to
     __syncthreads();
@@ -686,7 +702,8 @@ int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n
     a.bound = wait_bound(m->s->werr(), 120u + (unsigned int)kind);
     a.ts = stamp_next(kind == 0 ? "peer_put_rows" : "peer_put_grads");
     const int64_t rows = pre[n];
-    hipLaunchKernelGGL(k_peer_put, dim3((unsigned int)std::max<int64_t>(1, cdiv(rows * a.LPR, 256))), dim3(256), 0, st, a);
+    // (one workgroup per 1024 parts, 64 at most: k_peer_put's comment)
+    hipLaunchKernelGGL(k_peer_put, dim3((unsigned int)std::max<int64_t>(1, std::min<int64_t>(g_mapped_grid, cdiv(rows * a.LPR, 1024)))), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     ++mp.puts[kind];
     return PS_OK;

@@ -23,6 +23,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -232,6 +233,58 @@ void index_lines(const char *d, size_t len, int offset, int step, std::vector<si
     }
 }
 
+// The same index by chunks of the text (round 6: the serial walk was what bounded the host parser at 64 threads -- 131 072 lines,
+// 52 MB: 6 ms of memchr in front of 4 ms of parsing).  A chunk owns the lines that START inside it; the raw number of a chunk's
+// first line is the number of newlines in front of the chunk -- a prefix over per-chunk counts -- so offset / step select the same
+// raw lines as the serial walk, and the chunks' lists concatenate in order.
+void index_lines_parallel(const char *d, size_t len, int offset, int step, std::vector<size_t> *starts, std::vector<size_t> *ends, Pool *pool) {
+    const size_t CH = (size_t)4 << 20;
+    const int64_t nch = (int64_t)((len + CH - 1) / CH);
+    if (!pool || nch < 4) { index_lines(d, len, offset, step, starts, ends); return; }
+    std::vector<int64_t> nl((size_t)nch + 1, 0);
+    pool->run(nch, 1, [&](int64_t b, int64_t e) {
+        for (int64_t c = b; c < e; ++c) {
+            const size_t lo = (size_t)c * CH, hi = std::min(len, lo + CH);
+            int64_t k = 0;
+            for (const char *q = d + lo; (q = (const char *)memchr(q, '\n', (size_t)(d + hi - q))) != nullptr; ++q) ++k;
+            nl[(size_t)c + 1] = k;
+        }
+    });
+    for (int64_t c = 0; c < nch; ++c) nl[(size_t)c + 1] += nl[(size_t)c];
+    std::vector<std::vector<size_t>> st((size_t)nch), en((size_t)nch);
+    pool->run(nch, 1, [&](int64_t b, int64_t e) {
+        for (int64_t c = b; c < e; ++c) {
+            const size_t lo = (size_t)c * CH, hi = std::min(len, lo + CH);
+            size_t pos = lo;
+            int64_t g = nl[(size_t)c];                       // raw number of the line that contains byte lo
+            if (lo > 0 && d[lo - 1] != '\n') {               // ... which started in an earlier chunk: skip to the first start in here
+                const char *q = (const char *)memchr(d + lo, '\n', hi - lo);
+                if (!q) continue;                            // (no line starts in this chunk)
+                pos = (size_t)(q - d) + 1; ++g;
+            }
+            while (pos < hi) {                               // lines that START in [lo, hi); they may end beyond hi
+                const char *q = (const char *)memchr(d + pos, '\n', len - pos);
+                const size_t end = q ? (size_t)(q - d) : len;
+                if (g >= offset && (g - offset) % step == 0) {
+                    bool blank = true;
+                    for (size_t i = pos; i < end; ++i)
+                        if (d[i] != ' ' && d[i] != '\t' && d[i] != '\r') { blank = false; break; }
+                    if (!blank) { st[(size_t)c].push_back(pos); en[(size_t)c].push_back(end); }
+                }
+                ++g;
+                pos = end + 1;
+            }
+        }
+    });
+    size_t tot = 0;
+    for (auto &v : st) tot += v.size();
+    starts->reserve(tot); ends->reserve(tot);
+    for (int64_t c = 0; c < nch; ++c) {
+        starts->insert(starts->end(), st[(size_t)c].begin(), st[(size_t)c].end());
+        ends->insert(ends->end(), en[(size_t)c].begin(), en[(size_t)c].end());
+    }
+}
+
 int check_cfg(const ps_ingest_config_t *c) {
     if (!c || c->F < 0 || c->X < 0 || c->F + c->X <= 0 || c->batch <= 0 || c->offset < 0 || c->step < 1 || c->wide_size < 0)
         return ps_set_err(PS_E_BAD_ARG, "bad ingest config");
@@ -281,23 +334,33 @@ extern "C" int ps_libsvm_parse(const char *text, size_t len, const ps_ingest_con
     if (!text || !n_parsed || first_line < 0 || max_lines < 0 || (cfg->F > 0 && !ids) || (cfg->X > 0 && !dense) || !labels)
         return ps_set_err(PS_E_BAD_ARG, "null argument");
     std::vector<size_t> st, en;
-    index_lines(text, len, cfg->offset, cfg->step, &st, &en);
+    const int nt = cfg->threads > 1 ? cfg->threads : 1;
+    Pool *pool = nt > 1 ? new Pool(nt) : nullptr;
+    index_lines_parallel(text, len, cfg->offset, cfg->step, &st, &en, pool);
     int64_t n = (int64_t)st.size() - first_line;
     if (n < 0) n = 0;
     if (n > max_lines) n = max_lines;
     *n_parsed = n;
-    if (n == 0) return PS_OK;
-    const int nt = cfg->threads > 1 ? cfg->threads : 1;
-    if (nt > 1) {
-        Pool pool(nt);
-        return parse_range(text, st, en, first_line, n, *cfg, ids, dense, labels, wide_ids, &pool);
-    }
-    return parse_range(text, st, en, first_line, n, *cfg, ids, dense, labels, wide_ids, nullptr);
+    int rc = PS_OK;
+    if (n > 0) rc = parse_range(text, st, en, first_line, n, *cfg, ids, dense, labels, wide_ids, pool);
+    delete pool;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------
-// the pipeline: parse batch k+1 into pinned memory and copy it to HBM while batch k trains
+// the pipeline: a RING of batches between the text and the training stream
 // ---------------------------------------------------------------------------
+// Round 6.  Rounds 2-5 filled ONE batch at a time: a pool parsed its 4096 lines 64 at a chunk, then four H2D copies, then a
+// stream wait -- wake-up of the pool, parse, copies and wait in series per batch: 12.7 M lines/s on 64 threads while the
+// resident step consumes 30 M examples/s (VERDICT r5 missing #4).  Now the unit of parallel work is a BATCH:
+//   * `threads` parser threads each take the next unparsed batch and parse all of it into that batch's slot of a ring of
+//     pinned blocks [ids | wide ids | dense | labels] -- no HIP call, no shared state but two counters;
+//   * ONE copier thread (the only one that talks to HIP) takes the parsed batches in order: waits until the kernels that read
+//     the slot's previous batch are done (an event the training thread recorded), ONE hipMemcpyAsync of the whole block, waits
+//     for it, marks the batch ready;
+//   * ps_ingest_next hands out batch b when it is ready and gives batch b - 2's slot back to the parsers (its consumers were
+//     enqueued before this call: "valid until the call after the next one").
+// The ring holds RING batches (2 x threads, 4..64): that many batches may be in flight between the parsers and the step.
 struct ps_ingest {
     ps_store *s = nullptr;
     ps_ingest_config_t cfg{};
@@ -306,125 +369,145 @@ struct ps_ingest {
     void *map = nullptr; size_t map_len = 0;          // mmap of a file
     std::vector<char> copy;                           // or a private copy of the caller's memory
     std::vector<size_t> st, en;
-    int64_t next_line = 0;
-    Pool *pool = nullptr;
     hipStream_t copy_stream = nullptr;
+    size_t off_ids = 0, off_wide = 0, off_dense = 0, off_labels = 0, block = 0;     // layout of a slot's block
     struct Slot {
-        int64_t *ids_h = nullptr, *wide_h = nullptr; float *dense_h = nullptr, *labels_h = nullptr;     // pinned
-        int64_t *ids_d = nullptr, *wide_d = nullptr; float *dense_d = nullptr, *labels_d = nullptr;     // HBM
-        hipEvent_t copied = nullptr;                  // the slot's H2D copies are done (copy stream)
+        char *host = nullptr, *dev = nullptr;         // pinned | HBM
         hipEvent_t consumed = nullptr;                // the kernels that read the slot were enqueued before this (store stream)
         bool consumed_recorded = false;
         int B = 0;
         int rc = PS_OK;
         char err[256] = "";
-        bool pending = false;                         // a fill was requested and has not finished
-    } slot[2];
-    // ONE persistent filler thread (parse + H2D of one slot at a time).  Not a thread per fill: HIP calls from
-    // short-lived threads raced with the training thread's launches (measured: occasional wrong batches).
-    std::thread filler;
+    };
+    std::vector<Slot> slot;
+    int ring = 0;
+    int64_t nbatches = 0;
+    // progress, all under mu: batch b may be PARSED into its slot once free_upto > b; it is parsed when parsed[b % ring] == b,
+    // in HBM when ready_upto > b
     std::mutex mu;
-    std::condition_variable cv_req, cv_done;
-    int req = -1;
-    bool stop = false;
-    int cur = 0;                                      // slot the next ps_ingest_next hands out
-    bool primed = false;
+    std::condition_variable cv_free, cv_parsed, cv_ready;
+    int64_t next_parse = 0, free_upto = 0, ready_upto = 0, cur = 0;
+    std::vector<int64_t> parsed;
+    std::vector<std::thread> parsers;
+    std::thread copier;
+    bool running = false, stop = false;
     double parse_s = 0; int64_t parsed_lines = 0, parsed_bytes = 0;
 };
 
 namespace {
 
-void ingest_copy(ps_ingest *g, int k);
-
-void ingest_fill(ps_ingest *g, int k) {               // runs on the slot's worker thread
-    ps_ingest::Slot &S = g->slot[k];
+void parser_loop(ps_ingest *g) {
     const ps_ingest_config_t &c = g->cfg;
-    S.rc = PS_OK;
-    int64_t n = (int64_t)g->st.size() - g->next_line;
-    if (n > c.batch) n = c.batch;
-    if (n < 0) n = 0;
-    const int64_t first = g->next_line;
-    g->next_line += n;
-    S.B = (int)n;
-    if (n == 0) return;
-    (void)hipSetDevice(g->s->device);
-    const auto t0 = std::chrono::steady_clock::now();
-    S.rc = parse_range(g->data, g->st, g->en, first, n, c, S.ids_h, S.dense_h, S.labels_h, S.wide_h, g->pool);
-    g->parse_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    g->parsed_lines += n;
-    g->parsed_bytes += (int64_t)(g->en[first + n - 1] - g->st[first]);
-    if (S.rc != PS_OK) { snprintf(S.err, sizeof S.err, "%s", ps_last_error()); return; }
-    ingest_copy(g, k);
-}
-
-void ingest_copy(ps_ingest *g, int k) {
-    ps_ingest::Slot &S = g->slot[k];
-    const ps_ingest_config_t &c = g->cfg;
-    const int64_t n = S.B;
-    if (n == 0 || S.rc != PS_OK) return;
-    hipStream_t st = g->copy_stream;
-    hipError_t e = hipSuccess;
-    // Everything is host-synchronised HERE, in the background: wait until the kernels that read this slot's
-    // previous batch are done, copy, and wait for the copies to land.  The training thread then needs no
-    // cross-stream event at all (cross-thread event waits proved unreliable: occasional stale batches).
-    if (S.consumed_recorded) e = hipEventSynchronize(S.consumed);
-    if (e == hipSuccess && c.F > 0) e = hipMemcpyAsync(S.ids_d, S.ids_h, sizeof(int64_t) * n * c.F, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && c.F > 0 && c.wide_size > 0) e = hipMemcpyAsync(S.wide_d, S.wide_h, sizeof(int64_t) * n * c.F, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && c.X > 0) e = hipMemcpyAsync(S.dense_d, S.dense_h, sizeof(float) * n * c.X, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(S.labels_d, S.labels_h, sizeof(float) * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { S.rc = PS_E_HIP; snprintf(S.err, sizeof S.err, "ingest H2D: %s", hipGetErrorString(e)); }
-}
-
-void ingest_wait(ps_ingest *g, int k) {
-    std::unique_lock<std::mutex> l(g->mu);
-    g->cv_done.wait(l, [&] { return !g->slot[k].pending; });
-}
-
-void filler_loop(ps_ingest *g) {
     for (;;) {
-        int k;
+        int64_t b;
         {
             std::unique_lock<std::mutex> l(g->mu);
-            g->cv_req.wait(l, [&] { return g->stop || g->req >= 0; });
+            b = g->next_parse;
+            if (b >= g->nbatches) return;
+            ++g->next_parse;
+            g->cv_free.wait(l, [&] { return g->stop || g->free_upto > b; });
             if (g->stop) return;
-            k = g->req; g->req = -1;
         }
-        ingest_fill(g, k);
+        ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
+        const int64_t first = b * c.batch;
+        int64_t n = (int64_t)g->st.size() - first;
+        if (n > c.batch) n = c.batch;
+        const auto t0 = std::chrono::steady_clock::now();
+        S.B = (int)n;
+        S.rc = parse_range(g->data, g->st, g->en, first, n, c, (int64_t *)(S.host + g->off_ids), (float *)(S.host + g->off_dense),
+                           (float *)(S.host + g->off_labels), c.wide_size > 0 ? (int64_t *)(S.host + g->off_wide) : nullptr, nullptr);
+        if (S.rc != PS_OK) snprintf(S.err, sizeof S.err, "%s", ps_last_error());
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         {
             std::lock_guard<std::mutex> l(g->mu);
-            g->slot[k].pending = false;
+            g->parsed[(size_t)(b % g->ring)] = b;
+            g->parse_s += dt; g->parsed_lines += n; g->parsed_bytes += (int64_t)(g->en[(size_t)(first + n - 1)] - g->st[(size_t)first]);
         }
-        g->cv_done.notify_all();
+        g->cv_parsed.notify_all();
     }
 }
 
-void ingest_start(ps_ingest *g, int k) {
-    ingest_wait(g, k);
-    ingest_wait(g, k ^ 1);                            // one fill at a time (they share next_line and the pool)
-    if (!g->filler.joinable()) g->filler = std::thread(filler_loop, g);
+void copier_loop(ps_ingest *g) {
+    (void)hipSetDevice(g->s->device);
+    for (int64_t b = 0; b < g->nbatches; ++b) {
+        ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
+        {
+            std::unique_lock<std::mutex> l(g->mu);
+            g->cv_parsed.wait(l, [&] { return g->stop || g->parsed[(size_t)(b % g->ring)] == b; });
+            if (g->stop) return;
+        }
+        if (S.rc == PS_OK && S.B > 0) {
+            // host-synchronised HERE, in the background: the kernels that read this slot's previous batch are done, the block is
+            // copied, the copy has landed -- the training thread needs no cross-stream event (cross-thread event WAITS proved
+            // unreliable in round 2: occasional stale batches)
+            hipError_t e = hipSuccess;
+            if (S.consumed_recorded) e = hipEventSynchronize(S.consumed);
+            // (a short last batch: the arrays keep their full-batch offsets inside the block, the tail of each is not copied)
+            const ps_ingest_config_t &c = g->cfg;
+            if (S.B == c.batch) {
+                if (e == hipSuccess) e = hipMemcpyAsync(S.dev, S.host, g->block, hipMemcpyHostToDevice, g->copy_stream);
+            } else {
+                const size_t n = (size_t)S.B;
+                if (e == hipSuccess && c.F > 0) e = hipMemcpyAsync(S.dev + g->off_ids, S.host + g->off_ids, sizeof(int64_t) * n * c.F, hipMemcpyHostToDevice, g->copy_stream);
+                if (e == hipSuccess && c.F > 0 && c.wide_size > 0) e = hipMemcpyAsync(S.dev + g->off_wide, S.host + g->off_wide, sizeof(int64_t) * n * c.F, hipMemcpyHostToDevice, g->copy_stream);
+                if (e == hipSuccess && c.X > 0) e = hipMemcpyAsync(S.dev + g->off_dense, S.host + g->off_dense, sizeof(float) * n * c.X, hipMemcpyHostToDevice, g->copy_stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(S.dev + g->off_labels, S.host + g->off_labels, sizeof(float) * n, hipMemcpyHostToDevice, g->copy_stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(g->copy_stream);
+            if (e != hipSuccess) { S.rc = PS_E_HIP; snprintf(S.err, sizeof S.err, "ingest H2D: %s", hipGetErrorString(e)); }
+        }
+        {
+            std::lock_guard<std::mutex> l(g->mu);
+            g->ready_upto = b + 1;
+        }
+        g->cv_ready.notify_all();
+    }
+}
+
+void ingest_stop(ps_ingest *g) {                      // join every thread of the running epoch (open / reset / destroy)
     {
         std::lock_guard<std::mutex> l(g->mu);
-        g->slot[k].pending = true;
-        g->req = k;
+        g->stop = true;
     }
-    g->cv_req.notify_one();
+    g->cv_free.notify_all(); g->cv_parsed.notify_all(); g->cv_ready.notify_all();
+    for (auto &t : g->parsers) if (t.joinable()) t.join();
+    g->parsers.clear();
+    if (g->copier.joinable()) g->copier.join();
+    if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    g->running = false; g->stop = false;
+}
+
+void ingest_rewind(ps_ingest *g) {
+    ingest_stop(g);
+    g->next_parse = 0; g->free_upto = g->ring; g->ready_upto = 0; g->cur = 0;
+    for (auto &v : g->parsed) v = -1;
+    g->nbatches = ((int64_t)g->st.size() + g->cfg.batch - 1) / g->cfg.batch;
+}
+
+void ingest_start(ps_ingest *g) {
+    if (g->running) return;
+    g->running = true;
+    const int nt = g->cfg.threads > 1 ? g->cfg.threads : 1;
+    for (int i = 0; i < nt; ++i) g->parsers.emplace_back(parser_loop, g);
+    g->copier = std::thread(copier_loop, g);
 }
 
 int ingest_alloc(ps_ingest *g) {
     const ps_ingest_config_t &c = g->cfg;
     const size_t nb = (size_t)c.batch;
-    for (int k = 0; k < 2; ++k) {
-        ps_ingest::Slot &S = g->slot[k];
-        HIPCHK(hipHostMalloc((void **)&S.ids_h, sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&S.wide_h, sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&S.dense_h, sizeof(float) * nb * (c.X > 0 ? c.X : 1), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&S.labels_h, sizeof(float) * nb, hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&S.ids_d, sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1)));
-        HIPCHK(hipMalloc((void **)&S.wide_d, sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1)));
-        HIPCHK(hipMalloc((void **)&S.dense_d, sizeof(float) * nb * (c.X > 0 ? c.X : 1)));
-        HIPCHK(hipMalloc((void **)&S.labels_d, sizeof(float) * nb));
-        HIPCHK(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    g->off_ids = 0;
+    g->off_wide = up(g->off_ids + sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1));
+    g->off_dense = up(g->off_wide + sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1));
+    g->off_labels = up(g->off_dense + sizeof(float) * nb * (c.X > 0 ? c.X : 1));
+    g->block = up(g->off_labels + sizeof(float) * nb);
+    const int nt = c.threads > 1 ? c.threads : 1;
+    g->ring = std::max(4, std::min(64, 2 * nt));
+    g->slot.resize((size_t)g->ring);
+    g->parsed.assign((size_t)g->ring, -1);
+    for (auto &S : g->slot) {
+        HIPCHK(hipHostMalloc((void **)&S.host, g->block, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&S.dev, g->block));
         HIPCHK(hipEventCreateWithFlags(&S.consumed, hipEventDisableTiming));
     }
     HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
@@ -433,14 +516,14 @@ int ingest_alloc(ps_ingest *g) {
 
 int ingest_open(ps_ingest *g) {
     g->st.clear(); g->en.clear();
-    index_lines(g->data, g->len, g->cfg.offset, g->cfg.step, &g->st, &g->en);
-    g->next_line = 0; g->cur = 0; g->primed = false;
+    if (g->cfg.threads > 1) {
+        Pool pool(std::min(g->cfg.threads, 16));
+        index_lines_parallel(g->data, g->len, g->cfg.offset, g->cfg.step, &g->st, &g->en, &pool);
+    } else {
+        index_lines(g->data, g->len, g->cfg.offset, g->cfg.step, &g->st, &g->en);
+    }
+    ingest_rewind(g);
     return PS_OK;
-}
-
-void ingest_quiesce(ps_ingest *g) {
-    ingest_wait(g, 0); ingest_wait(g, 1);
-    if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
 }
 
 }  // namespace
@@ -454,7 +537,6 @@ extern "C" int ps_ingest_create(ps_store_t *s, const ps_ingest_config_t *cfg, ps
     g->s = s; g->cfg = *cfg;
     const int rc = ingest_alloc(g);
     if (rc != PS_OK) { ps_ingest_destroy(g); return rc; }
-    if (cfg->threads > 1) g->pool = new Pool(cfg->threads);
     *out = g;
     return PS_OK;
 }
@@ -462,35 +544,21 @@ extern "C" int ps_ingest_create(ps_store_t *s, const ps_ingest_config_t *cfg, ps
 extern "C" int ps_ingest_destroy(ps_ingest_t *g) {
     if (!g) return PS_OK;
     (void)hipSetDevice(g->s->device);
-    ingest_quiesce(g);
-    if (g->filler.joinable()) {
-        { std::lock_guard<std::mutex> l(g->mu); g->stop = true; }
-        g->cv_req.notify_all();
-        g->filler.join();
-    }
-    for (int k = 0; k < 2; ++k) {
-        ps_ingest::Slot &S = g->slot[k];
-        if (S.ids_h) (void)hipHostFree(S.ids_h);
-        if (S.wide_h) (void)hipHostFree(S.wide_h);
-        if (S.dense_h) (void)hipHostFree(S.dense_h);
-        if (S.labels_h) (void)hipHostFree(S.labels_h);
-        if (S.ids_d) (void)hipFree(S.ids_d);
-        if (S.wide_d) (void)hipFree(S.wide_d);
-        if (S.dense_d) (void)hipFree(S.dense_d);
-        if (S.labels_d) (void)hipFree(S.labels_d);
-        if (S.copied) (void)hipEventDestroy(S.copied);
+    ingest_stop(g);
+    for (auto &S : g->slot) {
+        if (S.host) (void)hipHostFree(S.host);
+        if (S.dev) (void)hipFree(S.dev);
         if (S.consumed) (void)hipEventDestroy(S.consumed);
     }
     if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
     if (g->map) munmap(g->map, g->map_len);
-    delete g->pool;
     delete g;
     return PS_OK;
 }
 
 extern "C" int ps_ingest_open_file(ps_ingest_t *g, const char *path) {
     if (!g || !path) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    ingest_quiesce(g);
+    ingest_stop(g);
     if (g->map) { munmap(g->map, g->map_len); g->map = nullptr; }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return ps_set_err(PS_MISSING, "cannot open %s", path);
@@ -509,7 +577,7 @@ extern "C" int ps_ingest_open_file(ps_ingest_t *g, const char *path) {
 
 extern "C" int ps_ingest_open_memory(ps_ingest_t *g, const char *text, size_t len) {
     if (!g || (!text && len)) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    ingest_quiesce(g);
+    ingest_stop(g);
     g->copy.assign(text, text + len);
     g->data = g->copy.data(); g->len = len;
     return ingest_open(g);
@@ -527,36 +595,49 @@ extern "C" int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out) {
     if (!g || !out) return ps_set_err(PS_E_BAD_ARG, "null argument");
     if (!g->data && g->len == 0 && g->st.empty()) return ps_set_err(PS_E_STATE, "ps_ingest_open_* first");
     HIPCHK(hipSetDevice(g->s->device));
-    if (!g->primed) { ingest_start(g, g->cur); g->primed = true; }
-    ps_ingest::Slot &S = g->slot[g->cur];
-    ingest_wait(g, g->cur);
+    const int64_t b = g->cur;
+    if (b >= g->nbatches) return ps_set_err(PS_MISSING, "end of data");
+    ingest_start(g);
+    // batch b - 2 goes back to the parsers: its consumers were enqueued on the store's stream before this call; the copier waits
+    // (host side) for this event before it overwrites the slot's HBM block
+    if (b >= 2) {
+        ps_ingest::Slot &R = g->slot[(size_t)((b - 2) % g->ring)];
+        HIPCHK(hipEventRecord(R.consumed, g->s->stream));
+        R.consumed_recorded = true;
+        {
+            std::lock_guard<std::mutex> l(g->mu);
+            g->free_upto = b - 2 + g->ring + 1;
+        }
+        g->cv_free.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> l(g->mu);
+        g->cv_ready.wait(l, [&] { return g->ready_upto > b; });
+    }
+    ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
     if (S.rc != PS_OK) return ps_set_err(S.rc, "%s", S.err);
-    if (S.B == 0) return ps_set_err(PS_MISSING, "end of data");
-    // the filler thread already waited for the copies to land: the batch is in HBM
     memset(out, 0, sizeof *out);
     out->B = S.B;
-    out->ids = S.ids_d; out->offsets = nullptr; out->dense = g->cfg.X > 0 ? S.dense_d : nullptr;
-    out->labels = S.labels_d; out->wide_ids = g->cfg.wide_size > 0 ? S.wide_d : nullptr;
+    out->ids = (int64_t *)(S.dev + g->off_ids); out->offsets = nullptr; out->dense = g->cfg.X > 0 ? (float *)(S.dev + g->off_dense) : nullptr;
+    out->labels = (float *)(S.dev + g->off_labels); out->wide_ids = g->cfg.wide_size > 0 ? (int64_t *)(S.dev + g->off_wide) : nullptr;
     out->on_device = 1;
-    g->cur ^= 1;
-    // the slot being refilled was handed out by the previous call: its consumer kernels were enqueued on the
-    // store's stream before this call; the filler waits (host side) for this event before overwriting it
-    HIPCHK(hipEventRecord(g->slot[g->cur].consumed, g->s->stream));
-    g->slot[g->cur].consumed_recorded = true;
-    ingest_start(g, g->cur);
+    g->cur = b + 1;
     return PS_OK;
 }
 
 extern "C" int ps_ingest_reset(ps_ingest_t *g) {
     if (!g) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    ingest_quiesce(g);
-    g->next_line = 0; g->cur = 0; g->primed = false;
+    // (the blocks handed out last may still be read by kernels in flight: the next epoch's copies into them wait for the store's stream)
+    HIPCHK(hipSetDevice(g->s->device));
+    ingest_rewind(g);
+    for (auto &S : g->slot) { HIPCHK(hipEventRecord(S.consumed, g->s->stream)); S.consumed_recorded = true; }
     return PS_OK;
 }
 
+// parse_seconds: THREAD-seconds the parser threads spent parsing (divide by the threads for wall time); lines and text bytes parsed
 extern "C" int ps_ingest_stats(ps_ingest_t *g, double *parse_seconds, int64_t *lines, int64_t *bytes) {
     if (!g) return ps_set_err(PS_E_BAD_ARG, "null argument");
-    ingest_quiesce(g);
+    std::lock_guard<std::mutex> l(g->mu);
     if (parse_seconds) *parse_seconds = g->parse_s;
     if (lines) *lines = g->parsed_lines;
     if (bytes) *bytes = g->parsed_bytes;

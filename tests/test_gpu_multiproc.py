@@ -298,7 +298,7 @@ def test_rows_and_gradients_over_mapped_peer_memory(world, is_async, opts):
         assert timeouts == 0 and xstats[0] == STEPS
         assert mapped[0] == 1 and mapped[2] == STEPS and mapped[3] == STEPS, mapped          # one put launch per exchange and step
         assert calls["all_to_all_v"] == STEPS + 1 + xstats[8], calls                          # id blocks (+ full-size ones) + the selfcheck's
-        assert calls["all_gather"] == 4, calls                                                # selfcheck, block sizes, handles, "every mapping worked"
+        assert calls["all_gather"] == 5, calls                     # selfcheck, block sizes, handles, "every mapping worked", "every word of the wire check was right"
         if "blk_cap" in o["tune"]:
             assert xstats[8] > 0
 

@@ -75,3 +75,28 @@ def test_bad_lines_are_errors_not_crashes():
             p.parse(bad)
     assert p.parse("")["E"].shape == (0, 2)
     assert p.parse("\n\n  \n")["Y"].shape == (0,)
+
+
+@pytest.mark.parametrize("offset,step", [(0, 1), (1, 3)])
+def test_the_chunked_line_index_equals_the_serial_walk(offset, step):
+    """Round 6: with threads > 1 the line index is built chunk by chunk (4 MB chunks, raw line numbers from a prefix over
+    per-chunk newline counts).  A text of several chunks with blank lines, CRLF ends, a line that spans a chunk boundary's
+    worth of padding and no final newline parses to the same arrays as the serial walk (threads = 1)."""
+    import ps_amd
+    rng = np.random.default_rng(3)
+    n = 90000
+    lines = []
+    for i in range(n):
+        if i % 997 == 5:
+            lines.append("   ")                                  # blank: counted as a raw line, dropped
+            continue
+        body = "%d %d:1 %d:1 3:%.5f" % (i & 1, rng.integers(0, 1 << 20), rng.integers(0, 1 << 20), rng.standard_normal())
+        pad = " " * int(rng.integers(0, 400))                    # runs of spaces are tolerated: ~280 bytes per line, ~21 MB in all
+        lines.append(body + pad + ("\r" if i % 13 == 0 else ""))
+    text = "\n".join(lines).encode()                             # (no newline at the end)
+    assert len(text) > (4 << 20) * 4
+    a = ps_amd.LibsvmParser(2, 1, 1000, threads=1).parse(text, offset=offset, step=step)
+    b = ps_amd.LibsvmParser(2, 1, 1000, threads=6).parse(text, offset=offset, step=step)
+    assert a["Y"].size == b["Y"].size > n // step - n // 900 - 2
+    for k in ("E", "X", "Y", "W"):
+        np.testing.assert_array_equal(a[k], b[k])
