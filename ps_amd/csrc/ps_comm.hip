@@ -415,7 +415,6 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
 // 2: a 1-rank table too, moving its own part through the same launch (bench.py's sharded_n1 `mapped_peer` mode).
 // ---------------------------------------------------------------------------
 int g_mapped_peer = getenv("PS_MAPPED_PEER") ? atoi(getenv("PS_MAPPED_PEER")) : 0;
-int g_mapped_grid = 64;     // ps_tune_set("mapped_grid", workgroups): the put launches' largest grid
 namespace {
 typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
 struct PeerPutArgs {
@@ -425,10 +424,9 @@ struct PeerPutArgs {
     float *dst[PS_MAX_MAPPED];                   // peer p's receive buffer (mapped)
     long long dst_row[PS_MAX_MAPPED];            // first row there; < 0: hdr[p][2]
     const uint32_t *hdr[PS_MAX_MAPPED];          // header of the id block peer p sent this rank
-    unsigned int *flag_peer[PS_MAX_MAPPED];      // peer p's flag word for (this kind, this rank)
-    const unsigned int *flag_mine;               // this rank's flag words of this kind, [p] raised by peer p
+    unsigned int *flag_peer[PS_MAX_MAPPED];      // peer p's PS_PUT_WGS flag words for (this kind, this rank): one per workgroup of this launch
+    const unsigned int *flag_mine;               // this rank's flag words of this kind: [p][PS_PUT_WGS] raised by peer p's workgroups
     unsigned int epoch;
-    unsigned int *arrive;                        // workgroups of this launch that have drained their stores
     WaitBound bound;
     unsigned long long *ts;
 };
@@ -448,33 +446,35 @@ __device__ __forceinline__ bool spin_bounded_sys(const unsigned int *f, unsigned
     }
     return true;
 }
+// The launch is ALWAYS PS_PUT_WGS workgroups (every rank polls that many words per peer).  What the launch costs is a chain of
+// memory round trips, not bytes (3 MB per exchange at configs[2]) -- so the chain is kept short:
+//   source loads (one batch of PUT_ILP per thread in flight; the header word that says where a peer wants its rows is requested
+//   in front of them and needed only behind them) -> write-through stores, drained -> THIS workgroup's flag word at every peer
+//   (no arrival counter: a returned atomic per workgroup on one address serialises at the memory side, and a "last workgroup"
+//   adds a round trip) -> workgroup 0 polls the peers' PS_PUT_WGS words each.
+// First version (one workgroup per 256 parts, acq_rel counter, flags by the last workgroup): 22 us per exchange on one GPU, as
+// slow as the grouped ncclSend / ncclRecv it replaces; relaxed counter 16; 64 workgroups 14.5; this one: see DESIGN.md 6.
+#define PS_PUT_WGS 128
 __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     StampScope stamp(a.ts);
-    __shared__ int last_s;
-    // every peer's destination once per workgroup (lane-indexed argument arrays are memory loads: three dependent ones per thread otherwise)
     __shared__ uint32_t start_s[PS_MAX_MAPPED + 1];
     __shared__ float *dst_s[PS_MAX_MAPPED];
-    {
-        const int p = threadIdx.x;
-        if (p <= a.npeers) start_s[p] = a.start[p];
-        if (p < a.npeers) {
-            const long long r0 = a.dst_row[p] >= 0 ? a.dst_row[p] : ((p != a.rank || a.self) ? (long long)a.hdr[p][2] : 0ll);
-            dst_s[p] = a.dst[p] + (size_t)r0 * a.D;
-        }
-    }
+    const int tid = threadIdx.x;
+    long long r0 = 0;
+    if (tid <= a.npeers) start_s[tid] = a.start[tid];
+    if (tid < a.npeers) r0 = a.dst_row[tid] >= 0 ? a.dst_row[tid] : ((tid != a.rank || a.self) ? (long long)a.hdr[tid][2] : 0ll);      // (requested now, used behind the first loads)
     __syncthreads();
-    // A SMALL grid walks the 16-byte parts (PUT_ILP loads in flight per thread, then their stores): the launch ends with one
-    // returned atomic per workgroup on ONE address, and those serialise at the memory side -- one workgroup per 256 parts (725 of
-    // them at configs[2]) made the launch 16 us, the copy itself is ~2.
-    constexpr int PUT_ILP = 4;
-    const int64_t total = (int64_t)start_s[a.npeers] * a.LPR, T = (int64_t)gridDim.x * 256;
-    for (int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += T * PUT_ILP) {
+    constexpr int PUT_ILP = 8;
+    const int64_t total = (int64_t)start_s[a.npeers] * a.LPR, T = (int64_t)PS_PUT_WGS * 256;
+    bool first = true;
+    for (int64_t t0 = (int64_t)blockIdx.x * 256 + tid; first || t0 < total; t0 += T * PUT_ILP) {
         mp_f32x4 v[PUT_ILP];
-        float *q[PUT_ILP];
+        int64_t off[PUT_ILP];
+        int pp[PUT_ILP];
 #pragma unroll
         for (int j = 0; j < PUT_ILP; ++j) {
             const int64_t t = t0 + (int64_t)j * T;
-            q[j] = nullptr;
+            pp[j] = -1;
             if (t < total) {
                 const int64_t i = t / a.LPR;
                 const int part = (int)(t % a.LPR);
@@ -482,31 +482,34 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
                 while (p + 1 < a.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
                 if (p != a.rank || a.self) {
                     v[j] = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
-                    q[j] = dst_s[p] + (size_t)(i - start_s[p]) * a.D + part * 4;
+                    off[j] = (i - start_s[p]) * a.D + part * 4;
+                    pp[j] = p;
                 }
             }
         }
+        if (first) {                                   // every peer's destination, once per workgroup
+            if (tid < a.npeers) dst_s[tid] = a.dst[tid] + (size_t)r0 * a.D;
+            __syncthreads();
+            first = false;
+        }
 #pragma unroll
         for (int j = 0; j < PUT_ILP; ++j)
-            if (q[j]) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q[j]), "v"(v[j]) : "memory");       // write-through: nothing stays in this XCD's L2
+            if (pp[j] >= 0) {
+                float *q = dst_s[pp[j]] + off[j];
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v[j]) : "memory");       // write-through: nothing stays in this XCD's L2
+            }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have been acknowledged by the memory they went to
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // RELAXED on purpose: the payload went out write-through and has been acknowledged (the vmcnt drain above), so there is nothing
-        // for a release to write back -- an acq_rel here is a buffer_wbl2 + buffer_inv PER WORKGROUP (measured: the launch 22 us instead
-        // of 6).  The counter itself lives in L2 (device-scope atomic); whoever reads grid - 1 knows every workgroup's stores have landed.
-        const unsigned int old = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = old == gridDim.x - 1 ? 1 : 0;
-        if (last_s) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch of this kind: in stream order behind this one)
-    }
-    __syncthreads();
-    if (!last_s) return;
-    // the last workgroup: every workgroup's stores have landed -- this rank's flag at every peer, then the peers' flags here
-    const int p = threadIdx.x;
-    if (p < a.npeers && (p != a.rank || a.self)) {
-        __hip_atomic_store(a.flag_peer[p], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (sc0 sc1 store; issued behind the counter's answer)
-        (void)spin_bounded_sys(a.flag_mine + p, a.epoch, a.bound);
+    // this workgroup's word at every peer: sc0 sc1 stores, issued behind the barrier = behind every wave's drain
+    if (tid < a.npeers && (tid != a.rank || a.self))
+        __hip_atomic_store(a.flag_peer[tid] + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x != 0) return;
+    // workgroup 0, done with its own part: every peer's PS_PUT_WGS words for this exchange (bounded; the next launch of the stream
+    // starts behind this kernel's end and acquires what the peers stored)
+    for (int idx = tid; idx < a.npeers * PS_PUT_WGS; idx += 256) {
+        const int p = idx / PS_PUT_WGS;
+        if (p != a.rank || a.self) (void)spin_bounded_sys(a.flag_mine + idx, a.epoch, a.bound);
     }
 }
 
@@ -588,12 +591,10 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     memset(&mine, 0, sizeof mine);
     bool ok = true;
     // this rank's flag words: fine-grained when the runtime gives that (a peer's store must be seen by a kernel that is running)
-    if (hipExtMallocWithFlags((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED, hipDeviceMallocFinegrained) == hipSuccess) mp.flags_fine = true;
-    else { (void)hipGetLastError(); if (hipMalloc((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED) != hipSuccess) { (void)hipGetLastError(); mp.flags_local = nullptr; ok = false; } }
-    if (hipMalloc((void **)&mp.arrive, sizeof(unsigned int) * 2) != hipSuccess) { (void)hipGetLastError(); mp.arrive = nullptr; ok = false; }
+    if (hipExtMallocWithFlags((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS, hipDeviceMallocFinegrained) == hipSuccess) mp.flags_fine = true;
+    else { (void)hipGetLastError(); if (hipMalloc((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS) != hipSuccess) { (void)hipGetLastError(); mp.flags_local = nullptr; ok = false; } }
     if (hipMalloc((void **)&stage, sizeof(MappedRec) * (size_t)(n + 1)) != hipSuccess) { (void)hipGetLastError(); return ps_set_err(PS_E_HIP, "mapped peer: staging buffer"); }
-    if (mp.flags_local) HIPCHK(hipMemsetAsync(mp.flags_local, 0, sizeof(unsigned int) * 2 * PS_MAX_MAPPED, s->stream));
-    if (mp.arrive) HIPCHK(hipMemsetAsync(mp.arrive, 0, sizeof(unsigned int) * 2, s->stream));
+    if (mp.flags_local) HIPCHK(hipMemsetAsync(mp.flags_local, 0, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     mine.pid = (uint32_t)getpid();
     mine.cache = (uint64_t)(uintptr_t)sh.x_cache; mine.grads = (uint64_t)(uintptr_t)sh.x_recv_grads; mine.flags = (uint64_t)(uintptr_t)mp.flags_local;
@@ -693,17 +694,16 @@ int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n
         a.dst[p] = kind == 0 ? mp.cache[p] : mp.grads[p];
         a.dst_row[p] = kind == 0 ? -1 : (long long)mp.rank * (long long)mp.peer_per_peer[p];
         a.hdr[p] = hdr ? hdr[p] : nullptr;
-        a.flag_peer[p] = mp.flags[p] + (size_t)kind * PS_MAX_MAPPED + mp.rank;
+        a.flag_peer[p] = mp.flags[p] + ((size_t)kind * PS_MAX_MAPPED + mp.rank) * PS_PUT_WGS;
     }
-    a.flag_mine = mp.flags_local + (size_t)kind * PS_MAX_MAPPED;
+    a.flag_mine = mp.flags_local + (size_t)kind * PS_MAX_MAPPED * PS_PUT_WGS;
     if (++mp.epoch[kind] == 0) ++mp.epoch[kind];
     a.epoch = mp.epoch[kind];
-    a.arrive = mp.arrive + kind;
     a.bound = wait_bound(m->s->werr(), 120u + (unsigned int)kind);
     a.ts = stamp_next(kind == 0 ? "peer_put_rows" : "peer_put_grads");
     const int64_t rows = pre[n];
-    // (one workgroup per 1024 parts, 64 at most: k_peer_put's comment)
-    hipLaunchKernelGGL(k_peer_put, dim3((unsigned int)std::max<int64_t>(1, std::min<int64_t>(g_mapped_grid, cdiv(rows * a.LPR, 1024)))), dim3(256), 0, st, a);
+    (void)rows;
+    hipLaunchKernelGGL(k_peer_put, dim3(PS_PUT_WGS), dim3(256), 0, st, a);       // (always: every rank polls PS_PUT_WGS words per peer)
     HIPCHK(hipGetLastError());
     ++mp.puts[kind];
     return PS_OK;
@@ -722,8 +722,7 @@ extern "C" int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5) {
 void shard_mapped_release(ps_model *m) {        // (ps_model_destroy)
     mapped_close(m);
     if (m->sh.mp.flags_local) (void)hipFree(m->sh.mp.flags_local);
-    if (m->sh.mp.arrive) (void)hipFree(m->sh.mp.arrive);
-    m->sh.mp.flags_local = nullptr; m->sh.mp.arrive = nullptr;
+    m->sh.mp.flags_local = nullptr;
 }
 
 int g_blk_factor = 2;       // ps_tune_set("blk_factor", f): a wire block holds f * nnz_cap / nranks rows (0: always full-size blocks)

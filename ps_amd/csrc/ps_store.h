@@ -294,10 +294,9 @@ struct ps_model {
             bool on = false, self = false, tried = false, want_all = false;
             int nranks = 0, rank = 0;
             float *cache[PS_MAX_MAPPED] = {}, *grads[PS_MAX_MAPPED] = {};       // peer p's x_cache / x_recv_grads as mapped here (own: the local pointers)
-            unsigned int *flags[PS_MAX_MAPPED] = {};                            // peer p's flag words [2 kinds][PS_MAX_MAPPED] (own: flags_local)
+            unsigned int *flags[PS_MAX_MAPPED] = {};                            // peer p's flag words [2 kinds][PS_MAX_MAPPED senders][PS_PUT_WGS] (own: flags_local)
             bool opened[PS_MAX_MAPPED] = {};                                    // cache / grads / flags of peer p came from hipIpcOpenMemHandle
             unsigned int *flags_local = nullptr; bool flags_fine = false;       // this rank's flag words (fine-grained when the runtime gives it)
-            unsigned int *arrive = nullptr;                                     // [2] arrival counters of the put launches' workgroups
             unsigned int epoch[2] = {0, 0};                                     // exchanges of either kind so far (the same on every rank)
             int64_t per_peer = 0;                                               // rows of one worker's region in this rank's x_recv_grads
             int64_t peer_per_peer[PS_MAX_MAPPED] = {};                          // ... and in peer p's (shards differ by a row per field)
@@ -352,7 +351,7 @@ bool shard_push_grouped_ok(const ps_store *s, int npeers);
 // the slot kernel's arguments when it rides on the gather's launch (Shard::slots_due); keys == NULL: none
 struct GatherSlots { const uint32_t *keys; int64_t nnz; const uint32_t *bitmap, *word_prefix; uint32_t *slot; const unsigned int *wait; unsigned int wait_val; };
 void shard_mapped_release(ps_model *m);     // ps_comm.hip: unmap the peers' buffers, free the flag words
-extern int g_mapped_peer, g_mapped_grid;
+extern int g_mapped_peer;
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
                            LaunchOpts *lo, const GatherSlots *gs = nullptr);       // lo: wait (an END wait of the gather's launch)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,

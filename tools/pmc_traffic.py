@@ -56,6 +56,12 @@ for g, v in sorted(acc.items()):
     rec["hbm_bytes_per_launch"] = rec["read_bytes"] + rec["write_bytes"]
     for name in g.split("|"):
         out["groups"][name] = rec
+try:        # (keys other tools keep in the same file: tools/adam_profile.py's "fused_adam_hbm")
+    old = json.load(open("profiles/pmc_traffic.json"))
+    for k, v in old.items():
+        out.setdefault(k, v)
+except (OSError, ValueError):
+    pass
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 for g, r in out["groups"].items():
     print("%-24s read %8.2f MB  write %8.2f MB" % (g, r["read_bytes"] / 1e6, r["write_bytes"] / 1e6))
