@@ -415,10 +415,12 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
 // 2: a 1-rank table too, moving its own part through the same launch (bench.py's sharded_n1 `mapped_peer` mode).
 // ---------------------------------------------------------------------------
 int g_mapped_peer = getenv("PS_MAPPED_PEER") ? atoi(getenv("PS_MAPPED_PEER")) : 0;
+int g_mapped_ablate = 0;    // measurement only (results wrong): PeerPutArgs.ablate
 namespace {
 typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
 struct PeerPutArgs {
     int npeers, rank, LPR, D, self;
+    int ablate;                                  // measurement only (ps_tune_set("mapped_ablate")): 1 no stores, 2 plain stores, 4 no flags / no wait, 8 no source loads
     const float *src;                            // rows grouped by destination peer, in peer order
     uint32_t start[PS_MAX_MAPPED + 1];           // first row of peer p's part
     float *dst[PS_MAX_MAPPED];                   // peer p's receive buffer (mapped)
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
                 int p = 0;
                 while (p + 1 < a.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
                 if (p != a.rank || a.self) {
-                    v[j] = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
+                    if (!(a.ablate & 8)) v[j] = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
                     off[j] = (i - start_s[p]) * a.D + part * 4;
                     pp[j] = p;
                 }
@@ -496,11 +498,14 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
         for (int j = 0; j < PUT_ILP; ++j)
             if (pp[j] >= 0) {
                 float *q = dst_s[pp[j]] + off[j];
+                if (a.ablate & 1) continue;
+                if (a.ablate & 2) { *reinterpret_cast<mp_f32x4 *>(q) = v[j]; continue; }
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v[j]) : "memory");       // write-through: nothing stays in this XCD's L2
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have been acknowledged by the memory they went to
     __syncthreads();
+    if (a.ablate & 4) return;
     // this workgroup's word at every peer: sc0 sc1 stores, issued behind the barrier = behind every wave's drain
     if (tid < a.npeers && (tid != a.rank || a.self))
         __hip_atomic_store(a.flag_peer[tid] + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -688,7 +693,7 @@ int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n
     PeerPutArgs a;
     memset(&a, 0, sizeof a);
     a.npeers = n; a.rank = mp.rank; a.LPR = D / 4; a.D = D; a.self = (self || mp.self) ? 1 : 0;
-    a.src = src;
+    a.src = src; a.ablate = g_mapped_ablate;
     for (int p = 0; p <= n; ++p) a.start[p] = (uint32_t)pre[p];
     for (int p = 0; p < n; ++p) {
         a.dst[p] = kind == 0 ? mp.cache[p] : mp.grads[p];

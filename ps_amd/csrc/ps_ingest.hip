@@ -355,9 +355,10 @@ extern "C" int ps_libsvm_parse(const char *text, size_t len, const ps_ingest_con
 // resident step consumes 30 M examples/s (VERDICT r5 missing #4).  Now the unit of parallel work is a BATCH:
 //   * `threads` parser threads each take the next unparsed batch and parse all of it into that batch's slot of a ring of
 //     pinned blocks [ids | wide ids | dense | labels] -- no HIP call, no shared state but two counters;
-//   * ONE copier thread (the only one that talks to HIP) takes the parsed batches in order: waits until the kernels that read
-//     the slot's previous batch are done (an event the training thread recorded), ONE hipMemcpyAsync of the whole block, waits
-//     for it, marks the batch ready;
+//   * a COPIER thread takes the parsed batches in order: waits until the kernels that read the slot's previous batch are done (an
+//     event the training thread recorded), ONE hipMemcpyAsync of the whole block, an event behind it -- and goes on to the next
+//     batch; a COMPLETER thread waits for those events in order and marks the batches ready.  (One thread that copied AND waited
+//     was the pipeline's limit: 167 us per batch, 24 M lines/s, with the parsers at 138 M -- first measurement of this round.)
 //   * ps_ingest_next hands out batch b when it is ready and gives batch b - 2's slot back to the parsers (its consumers were
 //     enqueued before this call: "valid until the call after the next one").
 // The ring holds RING batches (2 x threads, 4..64): that many batches may be in flight between the parsers and the step.
@@ -374,6 +375,7 @@ struct ps_ingest {
     struct Slot {
         char *host = nullptr, *dev = nullptr;         // pinned | HBM
         hipEvent_t consumed = nullptr;                // the kernels that read the slot were enqueued before this (store stream)
+        hipEvent_t copied = nullptr;                  // the slot's H2D copy has landed (copy stream)
         bool consumed_recorded = false;
         int B = 0;
         int rc = PS_OK;
@@ -385,11 +387,11 @@ struct ps_ingest {
     // progress, all under mu: batch b may be PARSED into its slot once free_upto > b; it is parsed when parsed[b % ring] == b,
     // in HBM when ready_upto > b
     std::mutex mu;
-    std::condition_variable cv_free, cv_parsed, cv_ready;
-    int64_t next_parse = 0, free_upto = 0, ready_upto = 0, cur = 0;
+    std::condition_variable cv_free, cv_parsed, cv_issued, cv_ready;
+    int64_t next_parse = 0, free_upto = 0, issued_upto = 0, ready_upto = 0, cur = 0;
     std::vector<int64_t> parsed;
     std::vector<std::thread> parsers;
-    std::thread copier;
+    std::thread copier, completer;
     bool running = false, stop = false;
     double parse_s = 0; int64_t parsed_lines = 0, parsed_bytes = 0;
 };
@@ -453,7 +455,28 @@ void copier_loop(ps_ingest *g) {
                 if (e == hipSuccess && c.X > 0) e = hipMemcpyAsync(S.dev + g->off_dense, S.host + g->off_dense, sizeof(float) * n * c.X, hipMemcpyHostToDevice, g->copy_stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(S.dev + g->off_labels, S.host + g->off_labels, sizeof(float) * n, hipMemcpyHostToDevice, g->copy_stream);
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(g->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(S.copied, g->copy_stream);
+            if (e != hipSuccess) { S.rc = PS_E_HIP; snprintf(S.err, sizeof S.err, "ingest H2D: %s", hipGetErrorString(e)); }
+        }
+        {
+            std::lock_guard<std::mutex> l(g->mu);
+            g->issued_upto = b + 1;
+        }
+        g->cv_issued.notify_all();
+    }
+}
+
+void completer_loop(ps_ingest *g) {
+    (void)hipSetDevice(g->s->device);
+    for (int64_t b = 0; b < g->nbatches; ++b) {
+        ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
+        {
+            std::unique_lock<std::mutex> l(g->mu);
+            g->cv_issued.wait(l, [&] { return g->stop || g->issued_upto > b; });
+            if (g->stop) return;
+        }
+        if (S.rc == PS_OK && S.B > 0) {
+            const hipError_t e = hipEventSynchronize(S.copied);
             if (e != hipSuccess) { S.rc = PS_E_HIP; snprintf(S.err, sizeof S.err, "ingest H2D: %s", hipGetErrorString(e)); }
         }
         {
@@ -469,17 +492,18 @@ void ingest_stop(ps_ingest *g) {                      // join every thread of th
         std::lock_guard<std::mutex> l(g->mu);
         g->stop = true;
     }
-    g->cv_free.notify_all(); g->cv_parsed.notify_all(); g->cv_ready.notify_all();
+    g->cv_free.notify_all(); g->cv_parsed.notify_all(); g->cv_issued.notify_all(); g->cv_ready.notify_all();
     for (auto &t : g->parsers) if (t.joinable()) t.join();
     g->parsers.clear();
     if (g->copier.joinable()) g->copier.join();
+    if (g->completer.joinable()) g->completer.join();
     if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
     g->running = false; g->stop = false;
 }
 
 void ingest_rewind(ps_ingest *g) {
     ingest_stop(g);
-    g->next_parse = 0; g->free_upto = g->ring; g->ready_upto = 0; g->cur = 0;
+    g->next_parse = 0; g->free_upto = g->ring; g->issued_upto = 0; g->ready_upto = 0; g->cur = 0;
     for (auto &v : g->parsed) v = -1;
     g->nbatches = ((int64_t)g->st.size() + g->cfg.batch - 1) / g->cfg.batch;
 }
@@ -490,6 +514,7 @@ void ingest_start(ps_ingest *g) {
     const int nt = g->cfg.threads > 1 ? g->cfg.threads : 1;
     for (int i = 0; i < nt; ++i) g->parsers.emplace_back(parser_loop, g);
     g->copier = std::thread(copier_loop, g);
+    g->completer = std::thread(completer_loop, g);
 }
 
 int ingest_alloc(ps_ingest *g) {
@@ -509,6 +534,7 @@ int ingest_alloc(ps_ingest *g) {
         HIPCHK(hipHostMalloc((void **)&S.host, g->block, hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&S.dev, g->block));
         HIPCHK(hipEventCreateWithFlags(&S.consumed, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
     }
     HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
     return PS_OK;
@@ -549,6 +575,7 @@ extern "C" int ps_ingest_destroy(ps_ingest_t *g) {
         if (S.host) (void)hipHostFree(S.host);
         if (S.dev) (void)hipFree(S.dev);
         if (S.consumed) (void)hipEventDestroy(S.consumed);
+        if (S.copied) (void)hipEventDestroy(S.copied);
     }
     if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
     if (g->map) munmap(g->map, g->map_len);

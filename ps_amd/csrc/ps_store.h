@@ -351,7 +351,7 @@ bool shard_push_grouped_ok(const ps_store *s, int npeers);
 // the slot kernel's arguments when it rides on the gather's launch (Shard::slots_due); keys == NULL: none
 struct GatherSlots { const uint32_t *keys; int64_t nnz; const uint32_t *bitmap, *word_prefix; uint32_t *slot; const unsigned int *wait; unsigned int wait_val; };
 void shard_mapped_release(ps_model *m);     // ps_comm.hip: unmap the peers' buffers, free the flag words
-extern int g_mapped_peer;
+extern int g_mapped_peer, g_mapped_ablate;
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
                            LaunchOpts *lo, const GatherSlots *gs = nullptr);       // lo: wait (an END wait of the gather's launch)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
