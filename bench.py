@@ -596,14 +596,12 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=3):
     ds.reset()
     st0 = ds.stats()
     # training from the pipeline
-    for b in ds:                                    # one epoch of warm-up
-        gm.train_async(b)
+    ds.train(gm)                                    # one epoch of warm-up (ps_ingest_train: CTR.java:84-100's loop, in C)
     gm.sync(); ds.reset()
     t0 = time.perf_counter()
     steps = 0
     for _ in range(epochs):
-        for b in ds:
-            gm.train_async(b); steps += 1
+        steps += ds.train(gm)
         ds.reset()
     gm.sync()
     dt = time.perf_counter() - t0
@@ -620,8 +618,13 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=3):
            "parser": {"threads": threads, "thread_us_per_line": 1e6 * thread_s_per_line, "lines_per_s_all_threads": threads / thread_s_per_line,
                       "text_MB_per_s_all_threads": threads / thread_s_per_line * len(text) / (nbatch * B) / 1e6},
            "h2d_bytes_per_step": block, "h2d_GBs_at_this_rate": block * steps / dt / 1e9, "final_loss": loss}
-    stages = {"parser threads": out["parser"]["lines_per_s_all_threads"], "pipeline alone (parse + copy)": out["pipeline_alone_lines_per_s"], "resident step": resident_examples_per_s}
-    out["bounded_by"] = min(stages, key=stages.get) if fed < 0.9 * resident_examples_per_s else "nothing on the host: within 10 % of the resident step"
+    if fed >= 0.9 * resident_examples_per_s:
+        out["bounded_by"] = "nothing on the host: within 10 % of the resident step"
+    elif out["pipeline_alone_lines_per_s"] < 1.1 * fed:
+        out["bounded_by"] = "the pipeline (parse + H2D copy): it delivers no more on its own"
+    else:
+        out["bounded_by"] = ("the training thread: ps_ingest_next + the step's launches per batch take the host longer than the GPU takes for the step "
+                             "(the pipeline alone delivers %.1f M lines/s, the parsers %.0f M)" % (out["pipeline_alone_lines_per_s"] / 1e6, out["parser"]["lines_per_s_all_threads"] / 1e6))
     return out
 
 

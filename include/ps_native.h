@@ -378,6 +378,10 @@ int ps_ingest_lines(ps_ingest_t *g, int64_t *n_lines);
 int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out);
 int ps_ingest_reset(ps_ingest_t *g);
 int ps_ingest_stats(ps_ingest_t *g, double *parse_seconds, int64_t *lines, int64_t *bytes);
+/* CTR.java:84-100's loop (dataSet.next -> trainer.train until the source is dry) for one reader and one model: up to
+ * max_batches batches (< 0: to the end of the data) trained as they arrive, no host wait in between; *trained = their
+ * number.  PS_OK at the end of the data too. */
+int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batches, int64_t *trained);
 
 /* ---- shard checkpoint / resume (absent in the reference) --
  * One file per shard: the store's arrays raw (embedding rows + updater state

@@ -588,6 +588,12 @@ class DataSet:
     def reset(self):
         N.check(N.lib().ps_ingest_reset(self.h))
 
+    def train(self, model, max_batches=-1):
+        """CTR.java:84-100's loop in C (ps_ingest_train): the batches trained as they arrive; returns how many."""
+        k = C.c_int64()
+        N.check(N.lib().ps_ingest_train(self.h, model.h, int(max_batches), C.byref(k)))
+        return k.value
+
     def stats(self):
         s, l, b = C.c_double(), C.c_int64(), C.c_int64()
         N.check(N.lib().ps_ingest_stats(self.h, C.byref(s), C.byref(l), C.byref(b)))

@@ -424,8 +424,7 @@ struct PeerPutArgs {
     const float *src;                            // rows grouped by destination peer, in peer order
     uint32_t start[PS_MAX_MAPPED + 1];           // first row of peer p's part
     float *dst[PS_MAX_MAPPED];                   // peer p's receive buffer (mapped)
-    long long dst_row[PS_MAX_MAPPED];            // first row there; < 0: hdr[p][2]
-    const uint32_t *hdr[PS_MAX_MAPPED];          // header of the id block peer p sent this rank
+    long long dst_row[PS_MAX_MAPPED];            // first row there
     unsigned int *flag_peer[PS_MAX_MAPPED];      // peer p's PS_PUT_WGS flag words for (this kind, this rank): one per workgroup of this launch
     const unsigned int *flag_mine;               // this rank's flag words of this kind: [p][PS_PUT_WGS] raised by peer p's workgroups
     unsigned int epoch;
@@ -461,10 +460,15 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     StampScope stamp(a.ts);
     __shared__ uint32_t start_s[PS_MAX_MAPPED + 1];
     __shared__ float *dst_s[PS_MAX_MAPPED];
+    __shared__ unsigned int *flag_s[PS_MAX_MAPPED];
     const int tid = threadIdx.x;
-    long long r0 = 0;
-    if (tid <= a.npeers) start_s[tid] = a.start[tid];
-    if (tid < a.npeers) r0 = a.dst_row[tid] >= 0 ? a.dst_row[tid] : ((tid != a.rank || a.self) ? (long long)a.hdr[tid][2] : 0ll);      // (requested now, used behind the first loads)
+    // every peer's destination once per workgroup, by ONE thread with a uniform index: scalar loads of the argument block.  (Indexed
+    // by the lane, an argument array is read with vector loads from the kernel-argument buffer -- with the header word behind a pointer
+    // loaded that way the launch's floor was 8 us with every load, store and flag switched off: tools/r06_put_ablate.py.)
+    if (tid == 0) {
+        for (int p = 0; p < a.npeers; ++p) { start_s[p] = a.start[p]; dst_s[p] = a.dst[p] + (size_t)a.dst_row[p] * a.D; flag_s[p] = a.flag_peer[p]; }
+        start_s[a.npeers] = a.start[a.npeers];
+    }
     __syncthreads();
     constexpr int PUT_ILP = 8;
     const int64_t total = (int64_t)start_s[a.npeers] * a.LPR, T = (int64_t)PS_PUT_WGS * 256;
@@ -489,11 +493,7 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
                 }
             }
         }
-        if (first) {                                   // every peer's destination, once per workgroup
-            if (tid < a.npeers) dst_s[tid] = a.dst[tid] + (size_t)r0 * a.D;
-            __syncthreads();
-            first = false;
-        }
+        first = false;
 #pragma unroll
         for (int j = 0; j < PUT_ILP; ++j)
             if (pp[j] >= 0) {
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     if (a.ablate & 4) return;
     // this workgroup's word at every peer: sc0 sc1 stores, issued behind the barrier = behind every wave's drain
     if (tid < a.npeers && (tid != a.rank || a.self))
-        __hip_atomic_store(a.flag_peer[tid] + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(flag_s[tid] + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (blockIdx.x != 0) return;
     // workgroup 0, done with its own part: every peer's PS_PUT_WGS words for this exchange (bounded; the next launch of the stream
     // starts behind this kernel's end and acquires what the peers stored)
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     }
 }
 
-int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre, const uint32_t *const *hdr, bool self, hipStream_t st);
+int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre, const int64_t *dst_row, bool self, hipStream_t st);
 
 // The set-up's wire check (every rank, collectively, before the first step may trust the path -- it has never run between two
 // DEVICES on the development box): three rounds of both kinds of put with a pattern that names (round, sender, receiver, row,
@@ -647,24 +647,19 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     {
         const int D = m->cfg.D;
         const int64_t R = std::max<int64_t>(1, std::min<int64_t>(512, std::min<int64_t>(m->nnz_cap / n, mp.per_peer)));
-        uint32_t *src = nullptr, *hdr_dev = nullptr; unsigned int *bad = nullptr;
-        bool alloc_ok = hipMalloc((void **)&src, sizeof(uint32_t) * (size_t)n * R * D) == hipSuccess && hipMalloc((void **)&hdr_dev, sizeof(uint32_t) * 4 * (size_t)n) == hipSuccess &&
+        uint32_t *src = nullptr; unsigned int *bad = nullptr;
+        bool alloc_ok = hipMalloc((void **)&src, sizeof(uint32_t) * (size_t)n * R * D) == hipSuccess &&
                         hipMalloc((void **)&bad, sizeof(unsigned int)) == hipSuccess;
         unsigned int nbad = 0;
         if (alloc_ok) {
-            std::vector<uint32_t> hdr_h((size_t)4 * n, 0u);
-            for (int p = 0; p < n; ++p) hdr_h[(size_t)4 * p + 2] = (uint32_t)(rank * R);       // "store my rows from your slot rank * R on"
-            std::vector<int64_t> pre((size_t)n + 1);
+            std::vector<int64_t> pre((size_t)n + 1), slot0((size_t)n, (int64_t)rank * R);       // "my rows go to your slots rank * R ..."
             for (int p = 0; p <= n; ++p) pre[(size_t)p] = (int64_t)p * R;
-            const uint32_t *hdr[PS_MAX_MAPPED];
-            for (int p = 0; p < n; ++p) hdr[p] = hdr_dev + 4 * (size_t)p;
-            hipError_t e = hipMemcpyAsync(hdr_dev, hdr_h.data(), sizeof(uint32_t) * 4 * (size_t)n, hipMemcpyHostToDevice, s->stream);
-            if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(unsigned int), s->stream);
+            hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned int), s->stream);
             const unsigned int grid = (unsigned int)cdiv((int64_t)n * R * D, 256);
             for (uint32_t round = 1; round <= 3 && e == hipSuccess; ++round)
                 for (int kind = 0; kind < 2; ++kind) {
                     hipLaunchKernelGGL(k_mapped_fill, dim3(grid), dim3(256), 0, s->stream, src, (int)R, D, n, (uint32_t)rank, round * 2 + kind);
-                    if (mapped_put(m, kind, (const float *)src, pre.data(), hdr, true, s->stream) != PS_OK) { e = hipErrorUnknown; break; }
+                    if (mapped_put(m, kind, (const float *)src, pre.data(), slot0.data(), true, s->stream) != PS_OK) { e = hipErrorUnknown; break; }
                     hipLaunchKernelGGL(k_mapped_check, dim3(grid), dim3(256), 0, s->stream, (const uint32_t *)(kind == 0 ? sh.x_cache : sh.x_recv_grads),
                                        kind == 0 ? R : mp.per_peer, (int)R, D, n, (uint32_t)rank, round * 2 + kind, -1, bad);
                 }
@@ -673,7 +668,7 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
             if (e != hipSuccess) { (void)hipGetLastError(); nbad = 0xFFFFFFFFu; }
             if (store_check_bad_ids(s) == PS_E_STATE) nbad = 0xFFFFFFFFu;         // (a put's wait ran into its bound)
         } else { (void)hipGetLastError(); nbad = 0xFFFFFFFFu; }
-        (void)hipFree(src); (void)hipFree(hdr_dev); (void)hipFree(bad);
+        (void)hipFree(src); (void)hipFree(bad);
         mp.selfcheck_bad = nbad; mp.checked = true;
         memset(mine_ok, 0, sizeof mine_ok);
         mine_ok[0] = nbad == 0 ? 1u : 0u;
@@ -687,7 +682,7 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
 }
 
 // one exchange: kind 0 rows back (src grouped by requesting worker), 1 gradients out (src grouped by owner)
-int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n + 1] */, const uint32_t *const *hdr, bool self, hipStream_t st) {
+int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n + 1] */, const int64_t *dst_row /* kind 0: [n] first row at every peer */, bool self, hipStream_t st) {
     ps_model::Shard::Mapped &mp = m->sh.mp;
     const int n = mp.nranks, D = m->cfg.D;
     PeerPutArgs a;
@@ -697,8 +692,7 @@ int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n
     for (int p = 0; p <= n; ++p) a.start[p] = (uint32_t)pre[p];
     for (int p = 0; p < n; ++p) {
         a.dst[p] = kind == 0 ? mp.cache[p] : mp.grads[p];
-        a.dst_row[p] = kind == 0 ? -1 : (long long)mp.rank * (long long)mp.peer_per_peer[p];
-        a.hdr[p] = hdr ? hdr[p] : nullptr;
+        a.dst_row[p] = kind == 0 ? (long long)dst_row[p] : (long long)mp.rank * (long long)mp.peer_per_peer[p];
         a.flag_peer[p] = mp.flags[p] + ((size_t)kind * PS_MAX_MAPPED + mp.rank) * PS_PUT_WGS;
     }
     a.flag_mine = mp.flags_local + (size_t)kind * PS_MAX_MAPPED * PS_PUT_WGS;
@@ -756,7 +750,7 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const uint32_t *__restrict_
 }
 // owner_start[0..n] of this rank's plan, the received blocks' counts and the OR of every worker's overflow flag -> pinned
 // host memory, then the epoch word (the host spins on it: a copy + event record + event wait woke the host 20-40 us late
-// in some processes, round 2).  host: [owner_start 0..n | received counts 0..n-1 | overflow | epoch]
+// in some processes, round 2).  host: [owner_start 0..n | received counts 0..n-1 | overflow | epoch | the workers' cache slots 0..n-1]
 // done_flag (round 5, or NULL): "the plan head in front of this launch on the list chain is done" for the device -- the plan's
 // tail on side chain 0 (slots, entry lists) waits for it (start_flag[7]); like k_flag_set it stands for the launches in front
 // of it on its stream, which have finished and released their writes.
@@ -771,6 +765,7 @@ __global__ void k_publish_counts(const uint32_t *__restrict__ owner_start, const
         // (this rank's own block is read where it was packed: its self part of the exchange need not have travelled)
         const uint32_t *b = (i == rank ? send_blk : recv_blk) + (size_t)i * blk_words;
         host[nranks + 1 + i] = b[0];
+        host[2 * nranks + 3 + i] = b[2];          // where worker i wants its rows from this owner (its first cache slot): the mapped-peer pull's destination
         if (b[1]) atomicOr(&ovf_s, 1u);
     }
     __syncthreads();
@@ -901,8 +896,8 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
                     s->bytes += 2 * (int64_t)sizeof(uint32_t) * full_words * nsh;
                 } else { sh.x_send_full[k] = sh.x_send_blk[k]; sh.x_recv_full[k] = sh.x_recv_blk[k]; }
             }
-            HIPCHK(hipHostMalloc((void **)&sh.counts_host, sizeof(uint32_t) * (size_t)(2 * nsh + 3) + 64, hipHostMallocDefault));
-            memset(sh.counts_host, 0, sizeof(uint32_t) * (size_t)(2 * nsh + 3) + 64);
+            HIPCHK(hipHostMalloc((void **)&sh.counts_host, sizeof(uint32_t) * (size_t)(3 * nsh + 3) + 64, hipHostMallocDefault));
+            memset(sh.counts_host, 0, sizeof(uint32_t) * (size_t)(3 * nsh + 3) + 64);
             HIPCHK(hipStreamSynchronize(s->stream));
         }
         sh.blk_words = blk_words; sh.full_words = full_words; sh.blk_cap = blk_cap; sh.full_cap = full_cap; sh.has_full = has_full;
@@ -1101,9 +1096,13 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     int crc;
     if (sh.mp.on) {
         // mapped peer: every worker's rows straight into its cache, at the slot its id block's header names
-        const uint32_t *hdr[PS_PUSH_MAX_PEERS];
-        for (int p = 0; p < nsh; ++p) hdr[p] = rows_p[p] - PS_BLK_HDR;
-        crc = timed_coll(m, 1, st, [&]() { return mapped_put(m, 0, sh.x_rows_out, rcpre.data(), hdr, !alias, st); });
+        // (the slot came in the id block's header and reached the host with the counts: k_publish_counts)
+        int64_t slot0[PS_PUSH_MAX_PEERS];
+        for (int p = 0; p < nsh; ++p) {
+            slot0[p] = (int64_t)sh.counts_host[2 * nsh + 3 + p];
+            if (slot0[p] + rc[p] > m->nnz_cap) return ps_set_err(PS_E_STATE, "worker %d wants %lld rows from slot %lld on: beyond a cache of %lld rows", p, (long long)rc[p], (long long)slot0[p], (long long)m->nnz_cap);
+        }
+        crc = timed_coll(m, 1, st, [&]() { return mapped_put(m, 0, sh.x_rows_out, rcpre.data(), slot0, !alias, st); });
     } else {
     comm_select(comm, 0, alias);
     crc = timed_coll(m, 1, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st); });

@@ -402,14 +402,17 @@ void parser_loop(ps_ingest *g) {
     const ps_ingest_config_t &c = g->cfg;
     for (;;) {
         int64_t b;
+        bool last;
         {
+            // a thread takes a batch only once that batch's slot is free: a freed slot then wakes ONE sleeper (taking first and waiting
+            // afterwards had all 96 threads wake at every release -- the training thread shares the mutex and the cores with them)
             std::unique_lock<std::mutex> l(g->mu);
-            b = g->next_parse;
-            if (b >= g->nbatches) return;
-            ++g->next_parse;
-            g->cv_free.wait(l, [&] { return g->stop || g->free_upto > b; });
-            if (g->stop) return;
+            g->cv_free.wait(l, [&] { return g->stop || g->next_parse >= g->nbatches || g->free_upto > g->next_parse; });
+            if (g->stop || g->next_parse >= g->nbatches) return;
+            b = g->next_parse++;
+            last = g->next_parse >= g->nbatches;
         }
+        if (last) g->cv_free.notify_all();             // (nothing left to take: the sleepers leave)
         ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
         const int64_t first = b * c.batch;
         int64_t n = (int64_t)g->st.size() - first;
@@ -635,7 +638,7 @@ extern "C" int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out) {
             std::lock_guard<std::mutex> l(g->mu);
             g->free_upto = b - 2 + g->ring + 1;
         }
-        g->cv_free.notify_all();
+        g->cv_free.notify_one();
     }
     {
         std::unique_lock<std::mutex> l(g->mu);
@@ -669,4 +672,24 @@ extern "C" int ps_ingest_stats(ps_ingest_t *g, double *parse_seconds, int64_t *l
     if (lines) *lines = g->parsed_lines;
     if (bytes) *bytes = g->parsed_bytes;
     return PS_OK;
+}
+
+// CTR.java:84-100's epoch loop (dataSet.next -> trainer.train until the source is dry) for one reader and one model, in C: up to
+// max_batches batches (< 0: to the end of the data) of the pipeline trained without a host wait in between (ps_model_train
+// with loss = NULL); *trained receives their number.  PS_OK at the end of the data too (ps_ingest_reset rewinds).
+extern "C" int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batches, int64_t *trained) {
+    if (!g || !m) return ps_set_err(PS_E_BAD_ARG, "null argument");
+    int64_t k = 0;
+    int rc = PS_OK;
+    while (max_batches < 0 || k < max_batches) {
+        ps_batch_t b;
+        rc = ps_ingest_next(g, &b);
+        if (rc == PS_MISSING) { rc = PS_OK; break; }
+        if (rc != PS_OK) break;
+        rc = ps_model_train(m, &b, nullptr);
+        if (rc != PS_OK) break;
+        ++k;
+    }
+    if (trained) *trained = k;
+    return rc;
 }

@@ -167,6 +167,7 @@ SIGNATURES = {
     "ps_store_wait_timeouts": (C.c_int64, [_vp]),
     "ps_model_time_steps": (_i, [_vp, C.POINTER(ps_batch_t), _i, _pd]),
     "ps_model_set_keep_grads": (_i, [_vp, _i]),
+    "ps_ingest_train": (_i, [_vp, _vp, _i64, _pi64]),
     "ps_shard_mapped_info": (_i, [_vp, _pi64]),
     "ps_model_set_profile": (_i, [_vp, _i]),
     "ps_model_set_profile_filter": (_i, [_vp, _cp]),

@@ -94,3 +94,43 @@ def test_two_readers_split_the_file_like_datasource_offset_step(orc):
         np.testing.assert_array_equal(np.concatenate(got), E.astype(np.int64))
         ds.close()
     kv.close()
+
+
+def test_the_epoch_loop_in_c_and_a_ring_that_wraps():
+    """ps_ingest_train (CTR.java:84-100's loop in C) over three epochs of 41 batches through a ring of 4 slots (threads = 1: every
+    slot is reused ten times per epoch, every reuse waits for the kernels that read it) == the same batches handed over one by
+    one as host batches, bit for bit."""
+    import ps_amd
+    rng = np.random.default_rng(8)
+    F, D, X, fc, V, B = 5, 8, 3, [16, 1], 300, 64
+    n = 41 * B - 17                                              # a short last batch
+    lines = [" ".join([str(int(rng.random() < 0.4))] + ["%d:1" % int(rng.integers(0, V)) for _ in range(F)] +
+                      ["%d:%.5f" % (F + 1 + j, rng.standard_normal()) for j in range(X)]) for _ in range(n)]
+    text = "\n".join(lines).encode()
+    parsed = ps_amd.LibsvmParser(F, X).parse(text)
+    res = []
+    for mode in ("host", "c loop, 1 parser thread", "c loop, 7 parser threads"):
+        kv = ps_amd.KVStore(0, SEED)
+        kv.create_embedding([V] * F, D)
+        gm = ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B)
+        if mode == "host":
+            for _ in range(3):
+                for s in range(0, n, B):
+                    gm.train_async(ps_amd.Batch(parsed["E"][s:s + B], parsed["X"][s:s + B], parsed["Y"][s:s + B]))
+        else:
+            ds = ps_amd.DataSet(kv, text, F, X, B, threads=1 if "1 parser" in mode else 7)
+            for ep in range(3):
+                if ep == 1:                                      # an epoch in two calls
+                    assert ds.train(gm, 10) == 10 and ds.train(gm) == 31
+                else:
+                    assert ds.train(gm) == 41
+                assert ds.train(gm) == 0                         # dry: nothing trained, no error
+                ds.reset()
+            ds.close()
+        kv.sync()
+        res.append(([kv.get_rows(f, np.arange(V)) for f in range(F)], [kv.get("fc%d.weights" % i) for i in range(2)], kv.global_step()))
+        gm.close(); kv.close()
+    for got in res[1:]:
+        assert got[2] == res[0][2] == 3 * 41
+        for a, b in zip(res[0][0] + res[0][1], got[0] + got[1]):
+            np.testing.assert_array_equal(a, b)
