@@ -416,6 +416,7 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
 // ---------------------------------------------------------------------------
 int g_mapped_peer = getenv("PS_MAPPED_PEER") ? atoi(getenv("PS_MAPPED_PEER")) : 0;
 int g_mapped_ablate = 0;    // measurement only (results wrong): PeerPutArgs.ablate
+int g_mapped_fuse = 1;      // ps_tune_set("mapped_fuse", 0): the rows exchange as a put launch behind the gather again (first form of round 6)
 namespace {
 typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
 struct PeerPutArgs {
@@ -431,22 +432,6 @@ struct PeerPutArgs {
     WaitBound bound;
     unsigned long long *ts;
 };
-__device__ __forceinline__ bool spin_bounded_sys(const unsigned int *f, unsigned int v, const WaitBound &b) {
-    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return false;
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (b.ticks && (unsigned long long)wall_clock64() - t0 > b.ticks) {
-            if (b.err) {
-                atomicAdd(b.err, 1u);
-                __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicCAS(b.err + 2, 0u, b.code + 1000u);
-            }
-            break;
-        }
-    }
-    return true;
-}
 // The launch is ALWAYS PS_PUT_WGS workgroups (every rank polls that many words per peer).  What the launch costs is a chain of
 // memory round trips, not bytes (3 MB per exchange at configs[2]) -- so the chain is kept short:
 //   source loads (one batch of PUT_ILP per thread in flight; the header word that says where a peer wants its rows is requested
@@ -455,7 +440,6 @@ __device__ __forceinline__ bool spin_bounded_sys(const unsigned int *f, unsigned
 //   adds a round trip) -> workgroup 0 polls the peers' PS_PUT_WGS words each.
 // First version (one workgroup per 256 parts, acq_rel counter, flags by the last workgroup): 22 us per exchange on one GPU, as
 // slow as the grouped ncclSend / ncclRecv it replaces; relaxed counter 16; 64 workgroups 14.5; this one: see DESIGN.md 6.
-#define PS_PUT_WGS 128
 __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     StampScope stamp(a.ts);
     __shared__ uint32_t start_s[PS_MAX_MAPPED + 1];
@@ -598,6 +582,8 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     // this rank's flag words: fine-grained when the runtime gives that (a peer's store must be seen by a kernel that is running)
     if (hipExtMallocWithFlags((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS, hipDeviceMallocFinegrained) == hipSuccess) mp.flags_fine = true;
     else { (void)hipGetLastError(); if (hipMalloc((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS) != hipSuccess) { (void)hipGetLastError(); mp.flags_local = nullptr; ok = false; } }
+    if (hipMalloc((void **)&mp.arrive, sizeof(unsigned int) * 4) != hipSuccess) { (void)hipGetLastError(); mp.arrive = nullptr; ok = false; }
+    else HIPCHK(hipMemsetAsync(mp.arrive, 0, sizeof(unsigned int) * 4, s->stream));
     if (hipMalloc((void **)&stage, sizeof(MappedRec) * (size_t)(n + 1)) != hipSuccess) { (void)hipGetLastError(); return ps_set_err(PS_E_HIP, "mapped peer: staging buffer"); }
     if (mp.flags_local) HIPCHK(hipMemsetAsync(mp.flags_local, 0, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -721,7 +707,8 @@ extern "C" int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5) {
 void shard_mapped_release(ps_model *m) {        // (ps_model_destroy)
     mapped_close(m);
     if (m->sh.mp.flags_local) (void)hipFree(m->sh.mp.flags_local);
-    m->sh.mp.flags_local = nullptr;
+    if (m->sh.mp.arrive) (void)hipFree(m->sh.mp.arrive);
+    m->sh.mp.flags_local = nullptr; m->sh.mp.arrive = nullptr;
 }
 
 int g_blk_factor = 2;       // ps_tune_set("blk_factor", f): a wire block holds f * nnz_cap / nranks rows (0: always full-size blocks)
@@ -1079,6 +1066,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     // (own keys: the FULL block this rank packed for itself -- complete whatever the wire block holds)
     if (alias) { rows_p[rank] = sh.x_send_full[set] + (size_t)rank * sh.full_words + PS_BLK_HDR; grads_p[rank] = m->grads_out + (size_t)scpre[rank] * D; }
     // getList: the owner gathers the requested rows, rows back
+    bool rows_fused = false;
     {   // (the gather's launch also holds the join with side chain 0 -- "this step's slots are written" -- for the forward
         //  behind it: a wait on an event that fired long ago still costs the training stream ~3.5 us, round 2)
         LaunchOpts lo;
@@ -1090,11 +1078,33 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             gsl.wait = m->start_flag + 7; gsl.wait_val = sh.plan_epoch;
             sh.slots_due = false;
         }
-        PSCHK(shard_serve_pull_lists(s, rows_p, rc.data(), nsh, sh.x_rows_out, &lo, &gsl));
+        // mapped peer, fused (round 6): the gather's own stores go into the workers' caches and its last workgroup exchanges the
+        // flags -- the put launch (one more kernel start + boundary on the chain, ~8 us whatever it moves: tools/r06_put_ablate.py) is gone
+        GatherPut gput;
+        memset(&gput, 0, sizeof gput);
+        if (sh.mp.on && g_mapped_fuse && nrecv > 0 && D % 4 == 0) {
+            ps_model::Shard::Mapped &mp = sh.mp;
+            rows_fused = true;
+            gput.on = 1; gput.rank = rank; gput.self = (!alias || mp.self) ? 1 : 0;
+            for (int p = 0; p < nsh; ++p) {
+                const int64_t slot0 = (int64_t)sh.counts_host[2 * nsh + 3 + p];
+                if (slot0 + rc[p] > m->nnz_cap) return ps_set_err(PS_E_STATE, "worker %d wants %lld rows from slot %lld on: beyond a cache of %lld rows", p, (long long)rc[p], (long long)slot0, (long long)m->nnz_cap);
+                gput.dst[p] = mp.cache[p] + (size_t)slot0 * D;
+                gput.flag_peer[p] = mp.flags[p] + ((size_t)0 * PS_MAX_MAPPED + rank) * PS_PUT_WGS;
+            }
+            gput.flag_mine = mp.flags_local;
+            if (++mp.epoch[0] == 0) ++mp.epoch[0];
+            gput.epoch = mp.epoch[0];
+            gput.arrive = mp.arrive;
+            ++mp.puts[0];
+        }
+        PSCHK(shard_serve_pull_lists(s, rows_p, rc.data(), nsh, sh.x_rows_out, &lo, &gsl, rows_fused ? &gput : nullptr));
         if (lo.wait && lo.launched) sh.slot_ev = nullptr;        // (else ps_shard_forward_backward waits for the event)
     }
-    int crc;
-    if (sh.mp.on) {
+    int crc = PS_OK;
+    if (rows_fused) {
+        // (nothing: the gather did it)
+    } else if (sh.mp.on) {
         // mapped peer: every worker's rows straight into its cache, at the slot its id block's header names
         // (the slot came in the id block's header and reached the host with the counts: k_publish_counts)
         int64_t slot0[PS_PUSH_MAX_PEERS];
@@ -1111,7 +1121,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     PSCHK(crc);
     // train on the cache (this rank's own rows straight from the gather's output)
     sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
-    if (alias && sc[rank] > 0) {
+    if (alias && sc[rank] > 0 && !(rows_fused && sh.mp.self)) {      // (fused + a 1-rank table's self mode: the own rows went to the cache too)
         sh.alt_lo = (uint32_t)scpre[rank]; sh.alt_hi = (uint32_t)scpre[rank + 1];
         sh.alt_W = reinterpret_cast<const float *>(reinterpret_cast<intptr_t>(sh.x_rows_out) + (intptr_t)sizeof(float) * D * ((intptr_t)rcpre[rank] - (intptr_t)scpre[rank]));
     }

@@ -217,6 +217,23 @@ __device__ __forceinline__ bool spin_bounded(const unsigned int *f, unsigned int
     }
     return true;
 }
+// the same wait on a word a PEER DEVICE stores to (mapped peer memory, ps_comm.hip): system-scope loads
+__device__ __forceinline__ bool spin_bounded_sys(const unsigned int *f, unsigned int v, const WaitBound &b) {
+    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return false;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (b.ticks && (unsigned long long)wall_clock64() - t0 > b.ticks) {
+            if (b.err) {
+                atomicAdd(b.err, 1u);
+                __hip_atomic_store(b.err + 1, b.code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicCAS(b.err + 2, 0u, b.code + 1000u);
+            }
+            break;
+        }
+    }
+    return true;
+}
 // "This launch does not END before another chain has reached X": the first workgroup, done with its work, holds its
 // slot until the flag is there (normally long since) -- the join costs the waiting chain no launch of its own.  What
 // the other chain wrote is read by the NEXT launch of this stream (its start acquires).

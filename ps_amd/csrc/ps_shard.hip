@@ -301,7 +301,7 @@ struct PeerLists {
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W, PeerLists pl, int64_t n,
                                                      int D, int LPR, int64_t total_rows, float *__restrict__ out, int *err, unsigned long long *ts,
-                                                     const unsigned int *end_wait, unsigned int end_val, WaitBound bound, GatherSlots gs, int gather_blocks) {
+                                                     const unsigned int *end_wait, unsigned int end_val, WaitBound bound, GatherSlots gs, int gather_blocks, GatherPut gp) {
     EndWait end_wait_scope(end_wait, end_val, bound);
     StampScope stamp_scope(ts);
     if ((int)blockIdx.x >= gather_blocks) {
@@ -316,13 +316,60 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ W
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / LPR;
     const int part = (int)(t % LPR);
-    if (i >= n) return;
-    int p = 0;
-    while (p + 1 < pl.npeers && (uint32_t)i >= pl.start[p + 1]) ++p;
-    int64_t r = pl.rows_p[p][i - pl.start[p]];
-    if (r >= total_rows) { if (part == 0) atomicAdd(err, 1); r = 0; }
-    if (VEC == 4) *reinterpret_cast<float4 *>(out + (size_t)i * D + part * 4) = *reinterpret_cast<const float4 *>(W + (size_t)r * D + part * 4);
-    else out[(size_t)i * D + part] = W[(size_t)r * D + part];
+    if (!gp.on) {
+        if (i >= n) return;
+        int p = 0;
+        while (p + 1 < pl.npeers && (uint32_t)i >= pl.start[p + 1]) ++p;
+        int64_t r = pl.rows_p[p][i - pl.start[p]];
+        if (r >= total_rows) { if (part == 0) atomicAdd(err, 1); r = 0; }
+        if (VEC == 4) *reinterpret_cast<float4 *>(out + (size_t)i * D + part * 4) = *reinterpret_cast<const float4 *>(W + (size_t)r * D + part * 4);
+        else out[(size_t)i * D + part] = W[(size_t)r * D + part];
+        return;
+    }
+    // ---- mapped peer, fused (VEC == 4 only: the launcher checks): worker p's rows go straight into its cache ----
+    typedef float gp_f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t start_s[PS_PUSH_MAX_PEERS + 1];
+    __shared__ const uint32_t *rows_s[PS_PUSH_MAX_PEERS];
+    __shared__ float *dst_s[PS_PUSH_MAX_PEERS];
+    __shared__ int last_s;
+    if (threadIdx.x == 0) {             // one thread, uniform index: scalar loads of the argument block (k_peer_put's comment)
+        for (int p = 0; p < pl.npeers; ++p) { start_s[p] = pl.start[p]; rows_s[p] = pl.rows_p[p]; dst_s[p] = gp.dst[p]; }
+        start_s[pl.npeers] = pl.start[pl.npeers];
+    }
+    __syncthreads();
+    if (i < n) {
+        int p = 0;
+        while (p + 1 < pl.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
+        int64_t r = rows_s[p][i - start_s[p]];
+        if (r >= total_rows) { if (part == 0) atomicAdd(err, 1); r = 0; }
+        const gp_f32x4 v = *reinterpret_cast<const gp_f32x4 *>(W + (size_t)r * D + part * 4);
+        if (p != gp.rank || gp.self) {
+            float *q = dst_s[p] + (size_t)(i - start_s[p]) * D + part * 4;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");      // write-through, like k_peer_put's
+        } else {
+            *reinterpret_cast<gp_f32x4 *>(out + (size_t)i * D + part * 4) = v;      // this rank's own rows: read in place by its forward
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (relaxed: the payload is write-through and drained -- nothing for a release to write back; ps_comm.hip k_peer_put)
+        const unsigned int old = __hip_atomic_fetch_add(gp.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == (unsigned int)gather_blocks - 1u ? 1 : 0;
+        if (last_s) __hip_atomic_store(gp.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // the last gather workgroup: every workgroup's rows have landed -- this rank's PS_PUT_WGS words at every peer (the same words a
+    // put launch's workgroups raise one by one: a peer polls them all, whichever form its sender used), then the peers' words here
+    for (int idx = threadIdx.x; idx < pl.npeers * PS_PUT_WGS; idx += 256) {
+        const int p = idx / PS_PUT_WGS;
+        if (p != gp.rank || gp.self) __hip_atomic_store(gp.flag_peer[p] + (idx - p * PS_PUT_WGS), gp.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int idx = threadIdx.x; idx < pl.npeers * PS_PUT_WGS; idx += 256) {
+        const int p = idx / PS_PUT_WGS;
+        if (p != gp.rank || gp.self) (void)spin_bounded_sys(gp.flag_mine + idx, gp.epoch, bound);
+    }
 }
 
 }  // namespace
@@ -733,7 +780,7 @@ extern "C" int ps_shard_plan(ps_model_t *m, const ps_batch_t *batch, int nshards
 }
 
 // PServer.getList for key lists that lie grouped by requesting worker (rows_p[p]: counts[p] owner-local rows)
-int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev, LaunchOpts *lo, const GatherSlots *gs) {
+int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev, LaunchOpts *lo, const GatherSlots *gs, const GatherPut *gp) {
     if (lo) lo->launched = false;
     if (!s->emb.W) return ps_set_err(PS_MISSING, "no embedding tables");
     if (npeers < 1 || npeers > PS_PUSH_MAX_PEERS) return ps_set_err(PS_E_BAD_ARG, "1..%d workers", PS_PUSH_MAX_PEERS);
@@ -755,14 +802,18 @@ int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int
         return PS_OK;
     }
     const int D = s->emb.D, vec = D % 4 == 0 ? 4 : 1, LPR = D / vec;
+    GatherPut gp0;
+    memset(&gp0, 0, sizeof gp0);
+    if (gp && gp->on && vec == 4) gp0 = *gp;
+    else if (gp && gp->on) return ps_set_err(PS_E_UNSUPPORTED, "the fused mapped-peer gather needs D %% 4 == 0");
     const unsigned int *ew = lo ? lo->wait : nullptr;
     const unsigned int ev = lo ? lo->wait_val : 0u;
     const WaitBound wb = wait_bound(s->werr(), 104);
     const int gb = (int)cdiv(n * LPR, 256), sb = slots ? (int)cdiv(g0.nnz, 256) : 0;
     if (vec == 4)
-        hipLaunchKernelGGL(k_gather_rows<4>, dim3(gb + sb), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb, g0, gb);
+        hipLaunchKernelGGL(k_gather_rows<4>, dim3(gb + sb), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb, g0, gb, gp0);
     else
-        hipLaunchKernelGGL(k_gather_rows<1>, dim3(gb + sb), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb, g0, gb);
+        hipLaunchKernelGGL(k_gather_rows<1>, dim3(gb + sb), dim3(256), 0, s->stream, s->emb.W, pl, n, D, LPR, s->emb.total_rows, rows_out_dev, s->err_dev, stamp_next("gather_rows"), ew, ev, wb, g0, gb, gp0);
     HIPCHK(hipGetLastError());
     if (lo) lo->launched = true;
     return PS_OK;

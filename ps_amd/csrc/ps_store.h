@@ -297,6 +297,7 @@ struct ps_model {
             unsigned int *flags[PS_MAX_MAPPED] = {};                            // peer p's flag words [2 kinds][PS_MAX_MAPPED senders][PS_PUT_WGS] (own: flags_local)
             bool opened[PS_MAX_MAPPED] = {};                                    // cache / grads / flags of peer p came from hipIpcOpenMemHandle
             unsigned int *flags_local = nullptr; bool flags_fine = false;       // this rank's flag words (fine-grained when the runtime gives it)
+            unsigned int *arrive = nullptr;                                     // the fused gather's workgroups that have drained their stores
             unsigned int epoch[2] = {0, 0};                                     // exchanges of either kind so far (the same on every rank)
             int64_t per_peer = 0;                                               // rows of one worker's region in this rank's x_recv_grads
             int64_t peer_per_peer[PS_MAX_MAPPED] = {};                          // ... and in peer p's (shards differ by a row per field)
@@ -349,11 +350,22 @@ int enqueue_backward(ps_model *m, bool apply);
 int shard_push_reserve(ps_store *s, int npeers);   // ps_shard.hip
 bool shard_push_grouped_ok(const ps_store *s, int npeers);
 // the slot kernel's arguments when it rides on the gather's launch (Shard::slots_due); keys == NULL: none
+#define PS_PUT_WGS 128      // flag words per (exchange kind, sending rank): one per workgroup of a put launch (ps_comm.hip)
+// mapped peer, fused form (ps_comm.hip): the owner-side gather stores worker p's rows straight into that worker's cache -- no
+// x_rows_out round trip, no put launch -- and its last workgroup raises this rank's flag words at every peer and waits for theirs
+struct GatherPut {
+    int on, rank, self;
+    float *dst[PS_MAX_MAPPED];                  // worker p's cache at the slot its id block named
+    unsigned int *flag_peer[PS_MAX_MAPPED];     // peer p's PS_PUT_WGS flag words for (rows, this rank)
+    const unsigned int *flag_mine;              // this rank's: [p][PS_PUT_WGS]
+    unsigned int epoch;
+    unsigned int *arrive;                       // gather workgroups that have drained their stores
+};
 struct GatherSlots { const uint32_t *keys; int64_t nnz; const uint32_t *bitmap, *word_prefix; uint32_t *slot; const unsigned int *wait; unsigned int wait_val; };
 void shard_mapped_release(ps_model *m);     // ps_comm.hip: unmap the peers' buffers, free the flag words
-extern int g_mapped_peer, g_mapped_ablate;
+extern int g_mapped_peer, g_mapped_ablate, g_mapped_fuse;
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
-                           LaunchOpts *lo, const GatherSlots *gs = nullptr);       // lo: wait (an END wait of the gather's launch)
+                           LaunchOpts *lo, const GatherSlots *gs = nullptr, const GatherPut *gp = nullptr);       // lo: wait (an END wait of the gather's launch)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
                            int is_async, bool bump_step, LaunchOpts *lo);
 int finish_step(ps_model *m, float *loss);

@@ -282,6 +282,8 @@ def _ref(world, is_async):
 @pytest.mark.parametrize("world,is_async,opts", [
     (2, False, dict(own_in_place=True)), (3, True, dict(own_in_place=True)), (8, False, dict(own_in_place=True)),
     (3, False, dict()),                                                    # a rank's own part through the mapped path too
+    (3, True, dict(own_in_place=True, tune={"mapped_fuse": 0})),           # the rows as a put launch behind the gather (the unfused form)
+    (4, False, dict(tune={"mapped_fuse": 0})),
     (3, False, dict(own_in_place=True, tune={"blk_cap": 2}))])             # lists that outgrow their wire blocks: headers of the FULL blocks
 def test_rows_and_gradients_over_mapped_peer_memory(world, is_async, opts):
     """ps_tune_set("mapped_peer", 1) (round 6; net/PSClient.java:154-174's fire-and-forget push, net/PServer.java:102-117's reply): the
