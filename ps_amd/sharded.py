@@ -637,7 +637,8 @@ def _run_bench(args, cfg, synth_batch, stage, wd):
     if stage >= 2:
         for k in (b"dev_wait", b"end_wait", b"shard_overlap"):
             L.ps_tune_set(k, 0)
-    L.ps_tune_set(b"mapped_peer", 1 if (stage == 0 and not os.environ.get("PS_BENCH_NO_MAPPED")) else 0)
+    # (PS_MAPPED_PEER=2: a one-GPU run moves its own part through the mapped path too -- timelines of the mode on a one-GPU box)
+    L.ps_tune_set(b"mapped_peer", int(os.environ.get("PS_MAPPED_PEER", "1")) if (stage == 0 and not os.environ.get("PS_BENCH_NO_MAPPED")) else 0)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
