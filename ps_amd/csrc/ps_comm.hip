@@ -416,11 +416,13 @@ extern "C" int ps_shard_collective_times(ps_model_t *m, double *out8) {
 // ---------------------------------------------------------------------------
 int g_mapped_peer = getenv("PS_MAPPED_PEER") ? atoi(getenv("PS_MAPPED_PEER")) : 0;
 int g_mapped_ablate = 0;    // measurement only (results wrong): PeerPutArgs.ablate
+int g_mapped_lists = 1;     // ps_tune_set("mapped_lists", 0): the id blocks and the flat reduction stay on the table (RCCL) under mapped_peer
 int g_mapped_fuse = 1;      // ps_tune_set("mapped_fuse", 0): the rows exchange as a put launch behind the gather again (first form of round 6)
 namespace {
 typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
 struct PeerPutArgs {
     int npeers, rank, LPR, D, self;
+    int bcast;                                   // every peer gets the SAME rows (the flat gradient): source row = row inside the peer's part
     int ablate;                                  // measurement only (ps_tune_set("mapped_ablate")): 1 no stores, 2 plain stores, 4 no flags / no wait, 8 no source loads
     const float *src;                            // rows grouped by destination peer, in peer order
     uint32_t start[PS_MAX_MAPPED + 1];           // first row of peer p's part
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
                 int p = 0;
                 while (p + 1 < a.npeers && (uint32_t)i >= start_s[p + 1]) ++p;
                 if (p != a.rank || a.self) {
-                    if (!(a.ablate & 8)) v[j] = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)i * a.D + part * 4);
+                    if (!(a.ablate & 8)) v[j] = *reinterpret_cast<const mp_f32x4 *>(a.src + (size_t)(a.bcast ? i - start_s[p] : i) * a.D + part * 4);
                     off[j] = (i - start_s[p]) * a.D + part * 4;
                     pp[j] = p;
                 }
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(256) void k_peer_put(PeerPutArgs a) {
     }
 }
 
-int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre, const int64_t *dst_row, bool self, hipStream_t st);
+int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre, int rowD, int win, const int64_t *dst_row, bool bcast, bool self, hipStream_t st);
 
 // The set-up's wire check (every rank, collectively, before the first step may trust the path -- it has never run between two
 // DEVICES on the development box): three rounds of both kinds of put with a pattern that names (round, sender, receiver, row,
@@ -530,12 +532,18 @@ __global__ __launch_bounds__(256) void k_mapped_check(const uint32_t *recv, int6
 
 void mapped_close(ps_model *m) {
     ps_model::Shard::Mapped &mp = m->sh.mp;
+    typedef ps_model::Shard::Mapped MP;
     for (int p = 0; p < PS_MAX_MAPPED; ++p) {
-        if (!mp.opened[p]) continue;
-        if (mp.cache[p]) (void)hipIpcCloseMemHandle(mp.cache[p]);
-        if (mp.grads[p]) (void)hipIpcCloseMemHandle(mp.grads[p]);
-        if (mp.flags[p]) (void)hipIpcCloseMemHandle(mp.flags[p]);
-        mp.opened[p] = false; mp.cache[p] = mp.grads[p] = nullptr; mp.flags[p] = nullptr;
+        if (mp.opened[p])
+            for (int w = 0; w < MP::NWIN; ++w) {
+                void *q = mp.win[w][p];
+                if (!q) continue;
+                bool dup = false;                       // (the full-size blocks ARE the wire blocks when a model has no separate ones)
+                for (int w2 = 0; w2 < w; ++w2) dup = dup || mp.win[w2][p] == q;
+                if (!dup) (void)hipIpcCloseMemHandle(q);
+            }
+        for (int w = 0; w < MP::NWIN; ++w) mp.win[w][p] = nullptr;
+        mp.opened[p] = false;
     }
     mp.on = false;
 }
@@ -543,11 +551,12 @@ void mapped_close(ps_model *m) {
 // one record per rank in the set-up's all-gather
 struct MappedRec {
     uint32_t ok, pid;
-    uint64_t cache, grads, flags, per_peer;         // the addresses as this rank sees them (a rank THREAD of the same process uses them as they are)
-    hipIpcMemHandle_t h_cache, h_grads, h_flags;
-    char pad[256 - 8 - 32 - 3 * sizeof(hipIpcMemHandle_t)];
+    uint64_t per_peer, flat_rows;
+    uint64_t addr[ps_model::Shard::Mapped::NWIN];         // the addresses as this rank sees them (a rank THREAD of the same process uses them as they are)
+    hipIpcMemHandle_t h[ps_model::Shard::Mapped::NWIN];
+    char pad[640 - 8 - 16 - 8 * ps_model::Shard::Mapped::NWIN - ps_model::Shard::Mapped::NWIN * sizeof(hipIpcMemHandle_t)];
 };
-static_assert(sizeof(MappedRec) == 256, "one all-gather slot");
+static_assert(sizeof(MappedRec) == 640, "one all-gather slot");
 
 // host-side helper of the set-up: all-gather `bytes` per rank through the table (device staging buffers of the caller)
 int mapped_gather(ps_store *s, const ps_comm_ops_t *comm, char *dev, const void *mine, void *all, size_t bytes) {
@@ -579,42 +588,50 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     MappedRec mine;
     memset(&mine, 0, sizeof mine);
     bool ok = true;
+    typedef ps_model::Shard::Mapped MP;
+    const size_t flag_bytes = sizeof(unsigned int) * (size_t)MP::NKIND * PS_MAX_MAPPED * PS_PUT_WGS;
     // this rank's flag words: fine-grained when the runtime gives that (a peer's store must be seen by a kernel that is running)
-    if (hipExtMallocWithFlags((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS, hipDeviceMallocFinegrained) == hipSuccess) mp.flags_fine = true;
-    else { (void)hipGetLastError(); if (hipMalloc((void **)&mp.flags_local, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS) != hipSuccess) { (void)hipGetLastError(); mp.flags_local = nullptr; ok = false; } }
+    if (hipExtMallocWithFlags((void **)&mp.flags_local, flag_bytes, hipDeviceMallocFinegrained) == hipSuccess) mp.flags_fine = true;
+    else { (void)hipGetLastError(); if (hipMalloc((void **)&mp.flags_local, flag_bytes) != hipSuccess) { (void)hipGetLastError(); mp.flags_local = nullptr; ok = false; } }
     if (hipMalloc((void **)&mp.arrive, sizeof(unsigned int) * 4) != hipSuccess) { (void)hipGetLastError(); mp.arrive = nullptr; ok = false; }
     else HIPCHK(hipMemsetAsync(mp.arrive, 0, sizeof(unsigned int) * 4, s->stream));
+    // every rank's flat gradient [fc | wide ...] lands here, one slab per (step parity, rank): the sum is then taken HERE, in rank order
+    mp.flat_rows = (sh.flat_elems + 3) / 4;
+    if (hipMalloc((void **)&mp.flat_recv, sizeof(float) * 4 * (size_t)mp.flat_rows * 2 * (size_t)n) != hipSuccess) { (void)hipGetLastError(); mp.flat_recv = nullptr; ok = false; }
     if (hipMalloc((void **)&stage, sizeof(MappedRec) * (size_t)(n + 1)) != hipSuccess) { (void)hipGetLastError(); return ps_set_err(PS_E_HIP, "mapped peer: staging buffer"); }
-    if (mp.flags_local) HIPCHK(hipMemsetAsync(mp.flags_local, 0, sizeof(unsigned int) * 2 * PS_MAX_MAPPED * PS_PUT_WGS, s->stream));
+    if (mp.flags_local) HIPCHK(hipMemsetAsync(mp.flags_local, 0, flag_bytes, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    void *local[MP::NWIN] = {sh.x_cache, sh.x_recv_grads, sh.x_recv_blk[0], sh.x_recv_blk[1], sh.x_recv_full[0], sh.x_recv_full[1], mp.flat_recv, mp.flags_local};
     mine.pid = (uint32_t)getpid();
-    mine.cache = (uint64_t)(uintptr_t)sh.x_cache; mine.grads = (uint64_t)(uintptr_t)sh.x_recv_grads; mine.flags = (uint64_t)(uintptr_t)mp.flags_local;
-    mine.per_peer = (uint64_t)mp.per_peer;
-    if (ok && n > 1) {
-        if (hipIpcGetMemHandle(&mine.h_cache, sh.x_cache) != hipSuccess || hipIpcGetMemHandle(&mine.h_grads, sh.x_recv_grads) != hipSuccess ||
-            hipIpcGetMemHandle(&mine.h_flags, mp.flags_local) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+    mine.per_peer = (uint64_t)mp.per_peer; mine.flat_rows = (uint64_t)mp.flat_rows;
+    for (int w = 0; w < MP::NWIN; ++w) {
+        mine.addr[w] = (uint64_t)(uintptr_t)local[w];
+        if (!local[w]) ok = false;
+        else if (ok && n > 1 && hipIpcGetMemHandle(&mine.h[w], local[w]) != hipSuccess) { (void)hipGetLastError(); ok = false; }
     }
     mine.ok = ok ? 1u : 0u;
     int rc = mapped_gather(s, comm, stage, &mine, all.data(), sizeof(MappedRec));
     if (rc != PS_OK) { (void)hipFree(stage); return rc; }
     bool all_ok = true;
-    for (int p = 0; p < n; ++p) all_ok = all_ok && all[(size_t)p].ok != 0;
+    for (int p = 0; p < n; ++p) all_ok = all_ok && all[(size_t)p].ok != 0 && all[(size_t)p].flat_rows == (uint64_t)mp.flat_rows;
     uint32_t opened_ok = 1;
     if (all_ok) {
         for (int p = 0; p < n && opened_ok; ++p) {
             const MappedRec &r = all[(size_t)p];
             mp.peer_per_peer[p] = (int64_t)r.per_peer;
             if (p == rank || r.pid == mine.pid) {           // this rank itself, or a rank thread of this process: the addresses as they are
-                mp.cache[p] = (float *)(uintptr_t)r.cache; mp.grads[p] = (float *)(uintptr_t)r.grads; mp.flags[p] = (unsigned int *)(uintptr_t)r.flags;
+                for (int w = 0; w < MP::NWIN; ++w) mp.win[w][p] = (void *)(uintptr_t)r.addr[w];
                 continue;
             }
-            void *pc = nullptr, *pg = nullptr, *pf = nullptr;
-            if (hipIpcOpenMemHandle(&pc, r.h_cache, hipIpcMemLazyEnablePeerAccess) != hipSuccess || hipIpcOpenMemHandle(&pg, r.h_grads, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
-                hipIpcOpenMemHandle(&pf, r.h_flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-                (void)hipGetLastError();
-                opened_ok = 0;
+            mp.opened[p] = true;
+            for (int w = 0; w < MP::NWIN && opened_ok; ++w) {
+                int same = -1;                              // (a buffer that serves as two windows -- no separate full-size blocks -- is opened once)
+                for (int w2 = 0; w2 < w; ++w2) if (r.addr[w2] == r.addr[w]) same = w2;
+                if (same >= 0) { mp.win[w][p] = mp.win[same][p]; continue; }
+                void *q = nullptr;
+                if (hipIpcOpenMemHandle(&q, r.h[w], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened_ok = 0; q = nullptr; }
+                mp.win[w][p] = q;
             }
-            mp.cache[p] = (float *)pc; mp.grads[p] = (float *)pg; mp.flags[p] = (unsigned int *)pf; mp.opened[p] = true;
         }
     } else opened_ok = 0;
     // second round: did every rank get every mapping?
@@ -629,6 +646,7 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     if (!every) { (void)hipFree(stage); mapped_close(m); return PS_OK; }
     mp.on = true;
     mp.self = n == 1;
+    mp.with_lists = g_mapped_lists != 0;
     // ---- the wire check (see k_mapped_fill): R rows per peer, region p of the receive buffers = what peer p stored ----
     {
         const int D = m->cfg.D;
@@ -638,14 +656,15 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
                         hipMalloc((void **)&bad, sizeof(unsigned int)) == hipSuccess;
         unsigned int nbad = 0;
         if (alloc_ok) {
-            std::vector<int64_t> pre((size_t)n + 1), slot0((size_t)n, (int64_t)rank * R);       // "my rows go to your slots rank * R ..."
+            std::vector<int64_t> pre((size_t)n + 1), slot0((size_t)n, (int64_t)rank * R), grow((size_t)n);       // "my rows go to your slots rank * R ..."
+            for (int p = 0; p < n; ++p) grow[(size_t)p] = (int64_t)rank * mp.peer_per_peer[p];
             for (int p = 0; p <= n; ++p) pre[(size_t)p] = (int64_t)p * R;
             hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned int), s->stream);
             const unsigned int grid = (unsigned int)cdiv((int64_t)n * R * D, 256);
             for (uint32_t round = 1; round <= 3 && e == hipSuccess; ++round)
                 for (int kind = 0; kind < 2; ++kind) {
                     hipLaunchKernelGGL(k_mapped_fill, dim3(grid), dim3(256), 0, s->stream, src, (int)R, D, n, (uint32_t)rank, round * 2 + kind);
-                    if (mapped_put(m, kind, (const float *)src, pre.data(), slot0.data(), true, s->stream) != PS_OK) { e = hipErrorUnknown; break; }
+                    if (mapped_put(m, kind, (const float *)src, pre.data(), D, kind == 0 ? MP::W_CACHE : MP::W_GRADS, kind == 0 ? slot0.data() : grow.data(), false, true, s->stream) != PS_OK) { e = hipErrorUnknown; break; }
                     hipLaunchKernelGGL(k_mapped_check, dim3(grid), dim3(256), 0, s->stream, (const uint32_t *)(kind == 0 ? sh.x_cache : sh.x_recv_grads),
                                        kind == 0 ? R : mp.per_peer, (int)R, D, n, (uint32_t)rank, round * 2 + kind, -1, bad);
                 }
@@ -667,30 +686,70 @@ int mapped_setup(ps_model *m, const ps_comm_ops_t *comm, bool want_all) {
     return PS_OK;
 }
 
-// one exchange: kind 0 rows back (src grouped by requesting worker), 1 gradients out (src grouped by owner)
-int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n + 1] */, const int64_t *dst_row /* kind 0: [n] first row at every peer */, bool self, hipStream_t st) {
+// one exchange of `kind`: peer p's part of src (rows [pre[p], pre[p + 1]) of rowD floats; bcast: the same pre[1] rows for every peer) into
+// window `win` of peer p from row dst_row[p] on
+int mapped_put(ps_model *m, int kind, const float *src, const int64_t *pre /* [n + 1] */, int rowD, int win, const int64_t *dst_row /* [n] */, bool bcast, bool self, hipStream_t st) {
     ps_model::Shard::Mapped &mp = m->sh.mp;
-    const int n = mp.nranks, D = m->cfg.D;
+    static const char *names[] = {"peer_put_rows", "peer_put_grads", "peer_put_blocks", "peer_put_full_blocks", "peer_put_flat"};
+    const int n = mp.nranks;
     PeerPutArgs a;
     memset(&a, 0, sizeof a);
-    a.npeers = n; a.rank = mp.rank; a.LPR = D / 4; a.D = D; a.self = (self || mp.self) ? 1 : 0;
+    a.npeers = n; a.rank = mp.rank; a.LPR = rowD / 4; a.D = rowD; a.self = (self || mp.self) ? 1 : 0; a.bcast = bcast ? 1 : 0;
     a.src = src; a.ablate = g_mapped_ablate;
     for (int p = 0; p <= n; ++p) a.start[p] = (uint32_t)pre[p];
     for (int p = 0; p < n; ++p) {
-        a.dst[p] = kind == 0 ? mp.cache[p] : mp.grads[p];
-        a.dst_row[p] = kind == 0 ? (long long)dst_row[p] : (long long)mp.rank * (long long)mp.peer_per_peer[p];
-        a.flag_peer[p] = mp.flags[p] + ((size_t)kind * PS_MAX_MAPPED + mp.rank) * PS_PUT_WGS;
+        a.dst[p] = (float *)mp.win[win][p];
+        a.dst_row[p] = (long long)dst_row[p];
+        a.flag_peer[p] = mp.flags(p) + ((size_t)kind * PS_MAX_MAPPED + mp.rank) * PS_PUT_WGS;
     }
     a.flag_mine = mp.flags_local + (size_t)kind * PS_MAX_MAPPED * PS_PUT_WGS;
     if (++mp.epoch[kind] == 0) ++mp.epoch[kind];
     a.epoch = mp.epoch[kind];
     a.bound = wait_bound(m->s->werr(), 120u + (unsigned int)kind);
-    a.ts = stamp_next(kind == 0 ? "peer_put_rows" : "peer_put_grads");
-    const int64_t rows = pre[n];
-    (void)rows;
-    hipLaunchKernelGGL(k_peer_put, dim3(PS_PUT_WGS), dim3(256), 0, st, a);       // (always: every rank polls PS_PUT_WGS words per peer)
+    a.ts = stamp_next(names[kind]);
+    hipLaunchKernelGGL(k_peer_put, dim3(PS_PUT_WGS), dim3(256), 0, st, a);       // (always PS_PUT_WGS workgroups: every rank polls that many words per peer)
     HIPCHK(hipGetLastError());
     ++mp.puts[kind];
+    return PS_OK;
+}
+
+// the id blocks of a step (fixed size: one block per peer) -- wire blocks on the list chain, full-size ones in front of the gather
+int mapped_put_blocks(ps_model *m, bool full, int set, bool self, hipStream_t st) {
+    ps_model::Shard &sh = m->sh;
+    typedef ps_model::Shard::Mapped MP;
+    const int n = sh.mp.nranks;
+    const int64_t rows = (full ? sh.full_words : sh.blk_words) / 4;        // 16-byte "rows" (the blocks are 64-byte multiples)
+    int64_t pre[PS_MAX_MAPPED + 1], drow[PS_MAX_MAPPED];
+    for (int p = 0; p <= n; ++p) pre[p] = (int64_t)p * rows;
+    for (int p = 0; p < n; ++p) drow[p] = (int64_t)sh.mp.rank * rows;
+    return mapped_put(m, full ? MP::K_FULL : MP::K_BLK, (const float *)(full ? sh.x_send_full[set] : sh.x_send_blk[set]), pre, 4,
+                      (full ? MP::W_FULL0 : MP::W_BLK0) + set, drow, false, self, st);
+}
+
+// flat[i] = slab_0[i] + slab_1[i] + ... in RANK order (the PS's arrival order, net/PServer.java:164-214) -- a ring's order is its own
+__global__ __launch_bounds__(256) void k_flat_sum(float *__restrict__ flat, const float *__restrict__ slabs, int64_t slab_floats, int n, int64_t elems, unsigned long long *ts) {
+    StampScope stamp(ts);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    float s = slabs[i];
+    for (int p = 1; p < n; ++p) s = s + slabs[(size_t)p * slab_floats + i];
+    flat[i] = s;
+}
+// the dense + wide reduction without a collective: every rank stores its flat gradient into every rank's slab of this step's
+// parity (its own included), then sums the slabs it holds
+int mapped_flat_reduce(ps_model *m, hipStream_t st) {
+    ps_model::Shard &sh = m->sh;
+    ps_model::Shard::Mapped &mp = sh.mp;
+    typedef ps_model::Shard::Mapped MP;
+    const int n = mp.nranks;
+    const int64_t parity = (int64_t)((mp.epoch[MP::K_FLAT] + 1u) & 1u);
+    int64_t pre[PS_MAX_MAPPED + 1], drow[PS_MAX_MAPPED];
+    for (int p = 0; p <= n; ++p) pre[p] = (int64_t)p * mp.flat_rows;
+    for (int p = 0; p < n; ++p) drow[p] = (parity * n + mp.rank) * mp.flat_rows;
+    PSCHK(mapped_put(m, MP::K_FLAT, sh.flat, pre, 4, MP::W_FLAT, drow, true, true, st));
+    hipLaunchKernelGGL(k_flat_sum, dim3((unsigned int)cdiv(sh.flat_elems, 256)), dim3(256), 0, st, sh.flat, mp.flat_recv + (size_t)parity * n * mp.flat_rows * 4, mp.flat_rows * 4, n,
+                       sh.flat_elems, stamp_next("flat_sum"));
+    HIPCHK(hipGetLastError());
     return PS_OK;
 }
 }  // namespace
@@ -701,14 +760,16 @@ extern "C" int ps_shard_mapped_info(const ps_model_t *m, int64_t *out5) {
     if (!m || !out5) return ps_set_err(PS_E_BAD_ARG, "null argument");
     const ps_model::Shard::Mapped &mp = m->sh.mp;
     // (the set-up's wire check launches 6 puts of its own: not counted)
-    out5[0] = mp.on ? 1 : mp.selfcheck_failed ? -1 : 0; out5[1] = mp.self ? 1 : 0; out5[2] = mp.puts[0] - (mp.checked ? 3 : 0); out5[3] = mp.puts[1] - (mp.checked ? 3 : 0); out5[4] = mp.flags_fine ? 1 : 0;
+    out5[0] = mp.on ? 1 : mp.selfcheck_failed ? -1 : 0; out5[1] = mp.self ? 1 : 0; out5[2] = mp.puts[0] - (mp.checked ? 3 : 0); out5[3] = mp.puts[1] - (mp.checked ? 3 : 0);
+    if (mp.on && mp.with_lists) out5[1] |= 2;       // (bit 1: the id blocks and the flat reduction go this way too) out5[4] = mp.flags_fine ? 1 : 0;
     return PS_OK;
 }
 void shard_mapped_release(ps_model *m) {        // (ps_model_destroy)
     mapped_close(m);
     if (m->sh.mp.flags_local) (void)hipFree(m->sh.mp.flags_local);
     if (m->sh.mp.arrive) (void)hipFree(m->sh.mp.arrive);
-    m->sh.mp.flags_local = nullptr; m->sh.mp.arrive = nullptr;
+    if (m->sh.mp.flat_recv) (void)hipFree(m->sh.mp.flat_recv);
+    m->sh.mp.flags_local = nullptr; m->sh.mp.arrive = nullptr; m->sh.mp.flat_recv = nullptr;
 }
 
 int g_blk_factor = 2;       // ps_tune_set("blk_factor", f): a wire block holds f * nnz_cap / nranks rows (0: always full-size blocks)
@@ -941,7 +1002,11 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     {   // the id exchange: fixed size, no host wait.  (Own keys in place: this rank's own block stays where it was packed.)
         std::vector<int64_t> fixed((size_t)nsh, sh.blk_words);
         comm_select(comm, (use_side || ov) ? 1 : 0, comm_own_in_place(comm));
-        int rc = timed_coll(m, 0, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_send_blk[set], fixed.data(), sh.x_recv_blk[set], fixed.data(), sizeof(uint32_t), st); });
+        int rc;
+        if (sh.mp.on && sh.mp.with_lists)        // mapped peer: this rank's blocks straight into the peers' receive sets (no RCCL call in the step)
+            rc = timed_coll(m, 0, st, [&]() { return mapped_put_blocks(m, false, set, !comm_own_in_place(comm), st); });
+        else
+            rc = timed_coll(m, 0, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_send_blk[set], fixed.data(), sh.x_recv_blk[set], fixed.data(), sizeof(uint32_t), st); });
         comm_select(comm, 0, false);
         PSCHK(rc);
     }
@@ -1041,7 +1106,9 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     if (ovf) {
         std::vector<int64_t> fixed((size_t)nsh, sh.full_words);
         comm_select(comm, 0, alias);
-        int xrc = timed_coll(m, 0, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_send_full[set], fixed.data(), sh.x_recv_full[set], fixed.data(), sizeof(uint32_t), st); });
+        int xrc;
+        if (sh.mp.on && sh.mp.with_lists) xrc = timed_coll(m, 0, st, [&]() { return mapped_put_blocks(m, true, set, !alias, st); });
+        else xrc = timed_coll(m, 0, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_send_full[set], fixed.data(), sh.x_recv_full[set], fixed.data(), sizeof(uint32_t), st); });
         comm_select(comm, 0, false);
         PSCHK(xrc);
         sh.stat[7] += 1;
@@ -1089,8 +1156,8 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             for (int p = 0; p < nsh; ++p) {
                 const int64_t slot0 = (int64_t)sh.counts_host[2 * nsh + 3 + p];
                 if (slot0 + rc[p] > m->nnz_cap) return ps_set_err(PS_E_STATE, "worker %d wants %lld rows from slot %lld on: beyond a cache of %lld rows", p, (long long)rc[p], (long long)slot0, (long long)m->nnz_cap);
-                gput.dst[p] = mp.cache[p] + (size_t)slot0 * D;
-                gput.flag_peer[p] = mp.flags[p] + ((size_t)0 * PS_MAX_MAPPED + rank) * PS_PUT_WGS;
+                gput.dst[p] = mp.cache(p) + (size_t)slot0 * D;
+                gput.flag_peer[p] = mp.flags(p) + ((size_t)ps_model::Shard::Mapped::K_ROWS * PS_MAX_MAPPED + rank) * PS_PUT_WGS;
             }
             gput.flag_mine = mp.flags_local;
             if (++mp.epoch[0] == 0) ++mp.epoch[0];
@@ -1112,7 +1179,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             slot0[p] = (int64_t)sh.counts_host[2 * nsh + 3 + p];
             if (slot0[p] + rc[p] > m->nnz_cap) return ps_set_err(PS_E_STATE, "worker %d wants %lld rows from slot %lld on: beyond a cache of %lld rows", p, (long long)rc[p], (long long)slot0[p], (long long)m->nnz_cap);
         }
-        crc = timed_coll(m, 1, st, [&]() { return mapped_put(m, 0, sh.x_rows_out, rcpre.data(), slot0, !alias, st); });
+        crc = timed_coll(m, 1, st, [&]() { return mapped_put(m, ps_model::Shard::Mapped::K_ROWS, sh.x_rows_out, rcpre.data(), D, ps_model::Shard::Mapped::W_CACHE, slot0, false, !alias, st); });
     } else {
     comm_select(comm, 0, alias);
     crc = timed_coll(m, 1, st, [&]() { return comm->all_to_all_v(comm->ctx, sh.x_rows_out, rc.data(), sh.x_cache, sc.data(), sizeof(float) * (size_t)D, st); });
@@ -1170,7 +1237,9 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     }
     // push: the per-key gradients to their owners
     if (sh.mp.on) {
-        crc = timed_coll(m, 2, st, [&]() { return mapped_put(m, 1, m->grads_out, scpre.data(), nullptr, !alias, st); });
+        int64_t grow[PS_PUSH_MAX_PEERS];          // region `rank` of every owner's receive buffer
+        for (int p = 0; p < nsh; ++p) grow[p] = (int64_t)rank * sh.mp.peer_per_peer[p];
+        crc = timed_coll(m, 2, st, [&]() { return mapped_put(m, ps_model::Shard::Mapped::K_GRADS, m->grads_out, scpre.data(), D, ps_model::Shard::Mapped::W_GRADS, grow, false, !alias, st); });
     } else {
     comm_select(comm, 0, alias);
     crc = timed_coll(m, 2, st, [&]() { return comm->all_to_all_v(comm->ctx, m->grads_out, sc.data(), sh.x_recv_grads, rc.data(), sizeof(float) * (size_t)D, st); });
@@ -1198,7 +1267,11 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     // the dense + wide reduction and the replicated update: on side chain 1 + the side communicator (behind the flat
     // gradient's kernel and the next step's id exchange, beside the push), or in line
     hipStream_t fs = ov2 ? m->side[1] : st;
-    if (comm_wired(comm)) {
+    if (sh.mp.on && sh.mp.with_lists) {
+        // mapped peer: every rank's flat gradient into every rank's slab, summed locally in rank order (mapped_flat_reduce)
+        crc = timed_coll(m, 3, fs, [&]() { return mapped_flat_reduce(m, fs); });
+        PSCHK(crc);
+    } else if (comm_wired(comm)) {
         comm_select(comm, ov2 ? 2 : 0, false);
         crc = timed_coll(m, 3, fs, [&]() { return comm->all_reduce_sum_f32(comm->ctx, sh.flat, sh.flat_elems, fs); });
         comm_select(comm, 0, false);

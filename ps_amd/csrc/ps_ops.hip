@@ -286,6 +286,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "mapped_peer") == 0) { g_mapped_peer = value; return PS_OK; }
     if (strcmp(knob, "mapped_ablate") == 0) { g_mapped_ablate = value; return PS_OK; }
     if (strcmp(knob, "mapped_fuse") == 0) { g_mapped_fuse = value; return PS_OK; }
+    if (strcmp(knob, "mapped_lists") == 0) { g_mapped_lists = value; return PS_OK; }
     if (strcmp(knob, "super_list") == 0) { g_super_list = value; return PS_OK; }
     if (strcmp(knob, "fwd_order") == 0) { g_fwd_order = value; return PS_OK; }
     if (strcmp(knob, "slots_in_gather") == 0) { g_slots_in_gather = value; return PS_OK; }

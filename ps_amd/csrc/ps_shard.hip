@@ -449,7 +449,7 @@ int ensure_shard_state(ps_model *m, int nshards) {
     PSCHK(store_dev_alloc(s, (void **)&sh.send_rows, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(store_dev_alloc(s, (void **)&sh.owner_start, sizeof(uint32_t) * (size_t)(nshards + 2), true));
     sh.flat_elems = m->dense_elems + (m->cfg.kind == PS_MODEL_WIDEDEEP ? 2 * s->wide.rows + 1 : 0);
-    PSCHK(store_dev_alloc(s, (void **)&sh.flat, sizeof(float) * (size_t)sh.flat_elems, true));
+    PSCHK(store_dev_alloc(s, (void **)&sh.flat, sizeof(float) * (size_t)(sh.flat_elems + 4), true));      // (+4: the mapped-peer reduction reads it in 16-byte rows)
     HIPCHK(hipHostMalloc((void **)&sh.owner_start_host, sizeof(uint32_t) * (size_t)(nshards + 2), hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&sh.plan_ev, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(s->stream));

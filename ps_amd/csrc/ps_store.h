@@ -293,16 +293,25 @@ struct ps_model {
         struct Mapped {
             bool on = false, self = false, tried = false, want_all = false;
             int nranks = 0, rank = 0;
-            float *cache[PS_MAX_MAPPED] = {}, *grads[PS_MAX_MAPPED] = {};       // peer p's x_cache / x_recv_grads as mapped here (own: the local pointers)
-            unsigned int *flags[PS_MAX_MAPPED] = {};                            // peer p's flag words [2 kinds][PS_MAX_MAPPED senders][PS_PUT_WGS] (own: flags_local)
-            bool opened[PS_MAX_MAPPED] = {};                                    // cache / grads / flags of peer p came from hipIpcOpenMemHandle
-            unsigned int *flags_local = nullptr; bool flags_fine = false;       // this rank's flag words (fine-grained when the runtime gives it)
+            // the peers' buffers this rank stores into, as mapped here (win[w][rank]: the local pointer): the row cache, the gradient
+            // receive buffer, the received id blocks (two sets, wire and full size), the flat-gradient slabs, the flag words
+            enum { W_CACHE = 0, W_GRADS, W_BLK0, W_BLK1, W_FULL0, W_FULL1, W_FLAT, W_FLAGS, NWIN };
+            void *win[NWIN][PS_MAX_MAPPED] = {};
+            bool opened[PS_MAX_MAPPED] = {};                                    // peer p's windows came from hipIpcOpenMemHandle
+            // exchange kinds (each its own flag words and epoch: two kinds may be in flight on two streams)
+            enum { K_ROWS = 0, K_GRADS, K_BLK, K_FULL, K_FLAT, NKIND };
+            unsigned int *flags_local = nullptr; bool flags_fine = false;       // this rank's flag words [NKIND][PS_MAX_MAPPED senders][PS_PUT_WGS] (fine-grained when the runtime gives it)
             unsigned int *arrive = nullptr;                                     // the fused gather's workgroups that have drained their stores
-            unsigned int epoch[2] = {0, 0};                                     // exchanges of either kind so far (the same on every rank)
+            unsigned int epoch[NKIND] = {};                                     // exchanges of each kind so far (the same on every rank)
             int64_t per_peer = 0;                                               // rows of one worker's region in this rank's x_recv_grads
             int64_t peer_per_peer[PS_MAX_MAPPED] = {};                          // ... and in peer p's (shards differ by a row per field)
-            int64_t puts[2] = {0, 0};                                           // launches so far (ps_shard_mapped_info)
+            float *flat_recv = nullptr; int64_t flat_rows = 0;                  // [2 parities][nranks][flat_rows x 4 floats]: every rank's flat gradient, summed here in RANK order
+            bool with_lists = false;                                            // the id blocks and the flat reduction go this way too (no RCCL call in the step)
+            int64_t puts[NKIND] = {};                                           // launches so far (ps_shard_mapped_info)
             unsigned int selfcheck_bad = 0; bool selfcheck_failed = false, checked = false;   // the set-up's wire check: wrong words seen here | some rank saw some
+            float *cache(int p) const { return (float *)win[W_CACHE][p]; }
+            float *grads(int p) const { return (float *)win[W_GRADS][p]; }
+            unsigned int *flags(int p) const { return (unsigned int *)win[W_FLAGS][p]; }
         } mp;
     } sh;
     // host batches: pinned staging + two device slots on a copy stream (stage_batch)
@@ -363,7 +372,7 @@ struct GatherPut {
 };
 struct GatherSlots { const uint32_t *keys; int64_t nnz; const uint32_t *bitmap, *word_prefix; uint32_t *slot; const unsigned int *wait; unsigned int wait_val; };
 void shard_mapped_release(ps_model *m);     // ps_comm.hip: unmap the peers' buffers, free the flag words
-extern int g_mapped_peer, g_mapped_ablate, g_mapped_fuse;
+extern int g_mapped_peer, g_mapped_ablate, g_mapped_fuse, g_mapped_lists;
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
                            LaunchOpts *lo, const GatherSlots *gs = nullptr, const GatherPut *gp = nullptr);       // lo: wait (an END wait of the gather's launch)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,

@@ -284,6 +284,8 @@ def _ref(world, is_async):
     (3, False, dict()),                                                    # a rank's own part through the mapped path too
     (3, True, dict(own_in_place=True, tune={"mapped_fuse": 0})),           # the rows as a put launch behind the gather (the unfused form)
     (4, False, dict(tune={"mapped_fuse": 0})),
+    (3, False, dict(own_in_place=True, tune={"mapped_lists": 0})),         # id blocks and the flat reduction stay on the table
+    (2, True, dict(tune={"mapped_lists": 0, "blk_cap": 2})),
     (3, False, dict(own_in_place=True, tune={"blk_cap": 2}))])             # lists that outgrow their wire blocks: headers of the FULL blocks
 def test_rows_and_gradients_over_mapped_peer_memory(world, is_async, opts):
     """ps_tune_set("mapped_peer", 1) (round 6; net/PSClient.java:154-174's fire-and-forget push, net/PServer.java:102-117's reply): the
@@ -299,7 +301,12 @@ def test_rows_and_gradients_over_mapped_peer_memory(world, is_async, opts):
         calls, timeouts, xstats, mapped = got[r][8], got[r][9], got[r][10], got[r][11]
         assert timeouts == 0 and xstats[0] == STEPS
         assert mapped[0] == 1 and mapped[2] == STEPS and mapped[3] == STEPS, mapped          # one put launch per exchange and step
-        assert calls["all_to_all_v"] == STEPS + 1 + xstats[8], calls                          # id blocks (+ full-size ones) + the selfcheck's
+        if o["tune"].get("mapped_lists", 1):
+            # NOTHING of the step goes through the table: id blocks and the flat reduction (summed in rank order, like the table's) are
+            # stores into the peers' memory too -- one all_to_all_v and one all_reduce remain, the selfcheck's
+            assert calls["all_to_all_v"] == 1 and calls["all_reduce"] == 1 and (mapped[1] & 2), (calls, mapped)
+        else:
+            assert calls["all_to_all_v"] == STEPS + 1 + xstats[8] and calls["all_reduce"] == STEPS + 1, calls      # id blocks (+ full-size ones) + the selfcheck's
         assert calls["all_gather"] == 5, calls                     # selfcheck, block sizes, handles, "every mapping worked", "every word of the wire check was right"
         if "blk_cap" in o["tune"]:
             assert xstats[8] > 0
