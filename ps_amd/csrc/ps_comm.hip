@@ -1015,6 +1015,7 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, st, sh.owner_start, sh.x_recv_blk[set], sh.x_send_blk[set], nsh, rank, sh.blk_words,
                        sh.counts_host, sh.x_epoch, stamp_next("publish_counts"), (sh.tail_due && sh.head_on_list) ? m->start_flag + 7 : (unsigned int *)nullptr, sh.plan_epoch);
     HIPCHK(hipGetLastError());
+    sh.x_stream = st;
     if (mode == BEGIN_HEAD_HOOK) {
         if (!sh.tail_due) return ps_set_err(PS_E_STATE, "the hooked plan head left no tail");
         return PS_OK;       // (the tail: BEGIN_TAIL, behind the running step's backward)
@@ -1051,13 +1052,21 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     static const bool host_timing = getenv("PS_HOST_TIMING") != nullptr;
     struct HostTimer {
         bool on; double t0, wait = 0;
+        double lap_t = 0, seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // where the enqueue time goes: gather | forward + hook + backward | next begin | gradients | push | flat
+        void lap(int k) { if (!on) return; const double t = now(); seg[k] += t - lap_t; lap_t = t; }
         static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
         explicit HostTimer(bool o) : on(o), t0(o ? now() : 0) {}
         ~HostTimer() {
             if (!on) return;
-            static thread_local double sum_all = 0, sum_wait = 0; static thread_local long calls = 0;
+            static thread_local double sum_all = 0, sum_wait = 0, sum_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; static thread_local long calls = 0;
             sum_all += now() - t0; sum_wait += wait;
-            if (++calls % 1000 == 0) { fprintf(stderr, "[ps_shard_step] host: %.1f us per step enqueueing, %.1f us waiting for the counts\n", (sum_all - sum_wait) / 1000, sum_wait / 1000); sum_all = sum_wait = 0; }
+            for (int k = 0; k < 8; ++k) sum_seg[k] += seg[k];
+            if (++calls % 1000 == 0) {
+                fprintf(stderr, "[ps_shard_step] host: %.1f us per step enqueueing, %.1f us waiting for the counts  [gather + rows %.1f | forward, plan head, backward %.1f | next begin %.1f | gradients %.1f | push %.1f | flat %.1f]\n",
+                        (sum_all - sum_wait) / 1000, sum_wait / 1000, sum_seg[0] / 1000, sum_seg[1] / 1000, sum_seg[2] / 1000, sum_seg[3] / 1000, sum_seg[4] / 1000, sum_seg[5] / 1000);
+                sum_all = sum_wait = 0;
+                for (int k = 0; k < 8; ++k) sum_seg[k] = 0;
+            }
         }
     } host_timer(host_timing);
     const double wait_t0 = host_timing ? HostTimer::now() : 0;
@@ -1066,14 +1075,16 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         int64_t spins = 0;
         while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != sh.x_epoch) {
             if (++spins > (1ll << 22)) {                 // ~seconds: the kernel never ran -- surface the stream's error instead of hanging
-                HIPCHK(hipStreamSynchronize(sh.x_side ? s->prefetch_stream : sh.x_ov ? m->side[0] : st));
+                // (the stream the counts' publication was enqueued on: the LIST chain since round 5 -- this named side chain 0 until round 6, so a
+                //  slow exchange, e.g. eight rank processes sharing one GPU, was reported as lost after ~0.3 s of spinning)
+                HIPCHK(hipStreamSynchronize(sh.x_stream ? sh.x_stream : st));
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != sh.x_epoch) return ps_set_err(PS_E_STATE, "the counts of the exchange never arrived");
                 break;
             }
             __builtin_ia32_pause();
         }
     }
-    if (host_timing) host_timer.wait = HostTimer::now() - wait_t0;
+    if (host_timing) { host_timer.wait = HostTimer::now() - wait_t0; host_timer.lap_t = HostTimer::now(); }
     if (sh.x_side) HIPCHK(hipStreamWaitEvent(st, sh.x_ev, 0));
     const bool was_side = sh.x_side;
     m->dev_ok = dev_waits_ok(s);
@@ -1186,6 +1197,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     comm_select(comm, 0, false);
     }
     PSCHK(crc);
+    host_timer.lap(0);
     // train on the cache (this rank's own rows straight from the gather's output)
     sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
     if (alias && sc[rank] > 0 && !(rows_fused && sh.mp.self)) {      // (fused + a 1-rank table's self mode: the own rows went to the cache too)
@@ -1214,6 +1226,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         sh.alt_W = nullptr; sh.alt_lo = sh.alt_hi = 0;
         if (frc != PS_OK) { (void)shard_flush_deferred_flag(m); return frc; }
     }
+    host_timer.lap(1);
     // (start_flag[5], "side chain 0's small kernels are done", may be deferred to the next plan's opening spinner: every
     //  return between here and that plan's enqueue raises it first -- the running step's last delta GEMM holds its slot
     //  until the flag is up)
@@ -1235,6 +1248,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
         (void)shard_flush_deferred_flag(m);          // (a no-op when the plan's spinner took it)
         PSCHK(brc);
     }
+    host_timer.lap(2);
     // push: the per-key gradients to their owners
     if (sh.mp.on) {
         int64_t grow[PS_PUSH_MAX_PEERS];          // region `rank` of every owner's receive buffer
@@ -1246,6 +1260,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
     comm_select(comm, 0, false);
     }
     PSCHK(crc);
+    host_timer.lap(3);
     if (sh.push_grouped == 1) {
         LaunchOpts lo;
         if (sh.tail_flag_due) { lo.flag = m->start_flag + 6; lo.flag_val = sh.pub_epoch; }
@@ -1264,6 +1279,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             HIPCHK(hipMemcpyAsync(sh.x_recv_grads + (size_t)rcpre[rank] * D, grads_p[rank], sizeof(float) * (size_t)rc[rank] * D, hipMemcpyDeviceToDevice, st));
         PSCHK(shard_apply_push(s, sh.x_recv_rows, sh.x_recv_grads, nrecv, nullptr, nsh, is_async, true));
     }
+    host_timer.lap(4);
     // the dense + wide reduction and the replicated update: on side chain 1 + the side communicator (behind the flat
     // gradient's kernel and the next step's id exchange, beside the push), or in line
     hipStream_t fs = ov2 ? m->side[1] : st;
@@ -1293,6 +1309,7 @@ extern "C" int ps_shard_step_finish_begin(ps_model_t *m, const ps_comm_ops_t *co
             sh.flat_pending = false;
         }
     }
+    host_timer.lap(5);
     if (was_side) {         // (two-model prefetch: this model's next begin, on the prefetch stream, must not overtake this step)
         HIPCHK(hipEventRecord(sh.done_ev, st));
         sh.done_recorded = true;

@@ -264,6 +264,7 @@ struct ps_model {
         float *x_cache = nullptr; int64_t x_cache_cap = 0;
         hipEvent_t x_ev = nullptr, done_ev = nullptr;   // begin's work is done | finish's work was enqueued
         bool x_begun = false, x_side = false, done_recorded = false;
+        hipStream_t x_stream = nullptr;                 // where the last counts' publication was enqueued (the host's wait falls back to a sync of it)
         // the NEXT step's plan enqueued on side chain 0 while this step trains (shard_plan_enqueue, early): its slot /
         // entry-list half still to be enqueued behind the counts' publication | epoch of "plan done" (start_flag word 7)
         bool tail_due = false;
