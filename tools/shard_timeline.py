@@ -10,7 +10,7 @@ per = starts[1] - starts[0]
 spans = np.diff([v[i, 0] for i in starts])
 med = np.median(spans)
 sel = [k for k in range(3, len(starts) - 1) if starts[k + 1] - starts[k] == per and abs(spans[k] - med) < 0.03 * med]
-print("%d launches, %d steps of %d stamped launches; span median %.1f us" % (len(nm), len(starts) - 1, per, med))
+print("%d launches, %d steps of %d stamped launches; span median %.1f us, mean %.1f, p10 %.1f, p90 %.1f, max %.1f" % (len(nm), len(starts) - 1, per, med, spans.mean(), np.percentile(spans, 10), np.percentile(spans, 90), spans.max()))
 T = np.mean([v[starts[k]:starts[k] + per + 1] - v[starts[k], 0] for k in sel], axis=0)
 order = np.argsort(T[:, 0], kind="stable")
 for i in order:
