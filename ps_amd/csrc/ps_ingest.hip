@@ -479,7 +479,14 @@ void completer_loop(ps_ingest *g) {
             if (g->stop) return;
         }
         if (S.rc == PS_OK && S.B > 0) {
-            const hipError_t e = hipEventSynchronize(S.copied);
+            // (polled: a blocking hipEventSynchronize here and the copier's calls share the runtime's locks with the training
+            //  thread's launches -- PS_INGEST_SYNC=1 is the blocking form, for the A/B)
+            static const bool blocking = getenv("PS_INGEST_SYNC") != nullptr;
+            hipError_t e = hipSuccess;
+            if (blocking) e = hipEventSynchronize(S.copied);
+            else {
+                while ((e = hipEventQuery(S.copied)) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(15));
+            }
             if (e != hipSuccess) { S.rc = PS_E_HIP; snprintf(S.err, sizeof S.err, "ingest H2D: %s", hipGetErrorString(e)); }
         }
         {
@@ -681,15 +688,23 @@ extern "C" int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batche
     if (!g || !m) return ps_set_err(PS_E_BAD_ARG, "null argument");
     int64_t k = 0;
     int rc = PS_OK;
+    // PS_INGEST_TIMING=1 (measurement): where the training thread's time goes, per batch: taking the batch | enqueueing the step
+    static const bool timing = getenv("PS_INGEST_TIMING") != nullptr;
+    double t_next = 0, t_train = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (max_batches < 0 || k < max_batches) {
         ps_batch_t b;
+        const double t0 = timing ? now() : 0;
         rc = ps_ingest_next(g, &b);
         if (rc == PS_MISSING) { rc = PS_OK; break; }
         if (rc != PS_OK) break;
+        const double t1 = timing ? now() : 0;
         rc = ps_model_train(m, &b, nullptr);
         if (rc != PS_OK) break;
+        if (timing) { t_next += t1 - t0; t_train += now() - t1; }
         ++k;
     }
+    if (timing && k > 0) fprintf(stderr, "[ps_ingest_train] %lld batches: %.1f us per batch taking it from the ring, %.1f us enqueueing its step\n", (long long)k, t_next / k, t_train / k);
     if (trained) *trained = k;
     return rc;
 }
