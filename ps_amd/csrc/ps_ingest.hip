@@ -362,6 +362,19 @@ extern "C" int ps_libsvm_parse(const char *text, size_t len, const ps_ingest_con
 //   * ps_ingest_next hands out batch b when it is ready and gives batch b - 2's slot back to the parsers (its consumers were
 //     enqueued before this call: "valid until the call after the next one").
 // The ring holds RING batches (2 x threads, 4..64): that many batches may be in flight between the parsers and the step.
+int g_ingest_compact = getenv("PS_INGEST_COMPACT") ? atoi(getenv("PS_INGEST_COMPACT")) : 1;      // 0: every batch crosses the link as int64 arrays (rounds 2-5)
+namespace {
+// ids[i] = ids32[i] (sign-extended), wide[i] = what the parser computes from the same id (parse_line: MatrixUtil.hash through a float when
+// ids_via_float -- (float)id is the parser's own float, the id came out of it -- else id % wide_size; fmodf is exact on both sides)
+__global__ __launch_bounds__(256) void k_ingest_expand(const int32_t *__restrict__ ids32, int64_t n, int64_t wide_size, int via_float, int64_t *__restrict__ ids, int64_t *__restrict__ wide) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = (int64_t)ids32[i];
+    ids[i] = id;
+    if (wide_size > 0) wide[i] = via_float ? (int64_t)fmodf((float)id, (float)wide_size) : id % wide_size;
+}
+}  // namespace
+
 struct ps_ingest {
     ps_store *s = nullptr;
     ps_ingest_config_t cfg{};
@@ -371,7 +384,7 @@ struct ps_ingest {
     std::vector<char> copy;                           // or a private copy of the caller's memory
     std::vector<size_t> st, en;
     hipStream_t copy_stream = nullptr;
-    size_t off_ids = 0, off_wide = 0, off_dense = 0, off_labels = 0, block = 0;     // layout of a slot's block
+    size_t off_ids = 0, off_wide = 0, off_dense = 0, off_labels = 0, off_ids32 = 0, block = 0;     // layout of a slot's block: [ids | wide ids | dense | labels | ids as int32]
     struct Slot {
         char *host = nullptr, *dev = nullptr;         // pinned | HBM
         hipEvent_t consumed = nullptr;                // the kernels that read the slot were enqueued before this (store stream)
@@ -379,6 +392,7 @@ struct ps_ingest {
         bool consumed_recorded = false;
         int B = 0;
         int rc = PS_OK;
+        bool compact = false;                         // every id of the batch fits an int32: only [dense | labels | ids32] crosses the link
         char err[256] = "";
     };
     std::vector<Slot> slot;
@@ -422,6 +436,19 @@ void parser_loop(ps_ingest *g) {
         S.rc = parse_range(g->data, g->st, g->en, first, n, c, (int64_t *)(S.host + g->off_ids), (float *)(S.host + g->off_dense),
                            (float *)(S.host + g->off_labels), c.wide_size > 0 ? (int64_t *)(S.host + g->off_wide) : nullptr, nullptr);
         if (S.rc != PS_OK) snprintf(S.err, sizeof S.err, "%s", ps_last_error());
+        // Two thirds of a batch's bytes are its ids as int64, twice (ids and wide ids = a function of the ids): when every id fits
+        // an int32 only [dense | labels | ids32] is copied (0.65 instead of 1.93 MB at configs[1]) and a kernel on the copy stream
+        // writes the two int64 arrays the step reads (k_ingest_expand).  H2D moved 22 GB/s alone and 10 GB/s beside a training step:
+        // it, not the parsers, bounded the pipeline (profiles/r06_ingest_*).
+        S.compact = false;
+        if (S.rc == PS_OK && c.F > 0 && g_ingest_compact) {
+            const int64_t *src = (const int64_t *)(S.host + g->off_ids);
+            int32_t *dst = (int32_t *)(S.host + g->off_ids32);
+            const int64_t cnt = n * c.F;
+            bool fits = true;
+            for (int64_t i = 0; i < cnt; ++i) { const int64_t v = src[i]; dst[i] = (int32_t)v; fits = fits && v == (int64_t)(int32_t)v; }
+            S.compact = fits;
+        }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         {
             std::lock_guard<std::mutex> l(g->mu);
@@ -449,8 +476,23 @@ void copier_loop(ps_ingest *g) {
             if (S.consumed_recorded) e = hipEventSynchronize(S.consumed);
             // (a short last batch: the arrays keep their full-batch offsets inside the block, the tail of each is not copied)
             const ps_ingest_config_t &c = g->cfg;
-            if (S.B == c.batch) {
-                if (e == hipSuccess) e = hipMemcpyAsync(S.dev, S.host, g->block, hipMemcpyHostToDevice, g->copy_stream);
+            if (S.compact) {
+                const size_t n = (size_t)S.B;
+                if (S.B == c.batch) {           // [dense | labels | ids32] lie back to back: one copy
+                    if (e == hipSuccess) e = hipMemcpyAsync(S.dev + g->off_dense, S.host + g->off_dense, g->off_ids32 + sizeof(int32_t) * n * c.F - g->off_dense, hipMemcpyHostToDevice, g->copy_stream);
+                } else {
+                    if (e == hipSuccess && c.X > 0) e = hipMemcpyAsync(S.dev + g->off_dense, S.host + g->off_dense, sizeof(float) * n * c.X, hipMemcpyHostToDevice, g->copy_stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(S.dev + g->off_labels, S.host + g->off_labels, sizeof(float) * n, hipMemcpyHostToDevice, g->copy_stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(S.dev + g->off_ids32, S.host + g->off_ids32, sizeof(int32_t) * n * c.F, hipMemcpyHostToDevice, g->copy_stream);
+                }
+                if (e == hipSuccess) {
+                    const int64_t cnt = (int64_t)n * c.F;
+                    hipLaunchKernelGGL(k_ingest_expand, dim3((unsigned int)((cnt + 255) / 256)), dim3(256), 0, g->copy_stream, (const int32_t *)(S.dev + g->off_ids32), cnt,
+                                       c.wide_size, c.ids_via_float, (int64_t *)(S.dev + g->off_ids), (int64_t *)(S.dev + g->off_wide));
+                    e = hipGetLastError();
+                }
+            } else if (S.B == c.batch) {
+                if (e == hipSuccess) e = hipMemcpyAsync(S.dev, S.host, g->off_ids32, hipMemcpyHostToDevice, g->copy_stream);
             } else {
                 const size_t n = (size_t)S.B;
                 if (e == hipSuccess && c.F > 0) e = hipMemcpyAsync(S.dev + g->off_ids, S.host + g->off_ids, sizeof(int64_t) * n * c.F, hipMemcpyHostToDevice, g->copy_stream);
@@ -535,7 +577,8 @@ int ingest_alloc(ps_ingest *g) {
     g->off_wide = up(g->off_ids + sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1));
     g->off_dense = up(g->off_wide + sizeof(int64_t) * nb * (c.F > 0 ? c.F : 1));
     g->off_labels = up(g->off_dense + sizeof(float) * nb * (c.X > 0 ? c.X : 1));
-    g->block = up(g->off_labels + sizeof(float) * nb);
+    g->off_ids32 = up(g->off_labels + sizeof(float) * nb);
+    g->block = up(g->off_ids32 + sizeof(int32_t) * nb * (c.F > 0 ? c.F : 1));
     const int nt = c.threads > 1 ? c.threads : 1;
     g->ring = std::max(4, std::min(64, 2 * nt));
     g->slot.resize((size_t)g->ring);

@@ -134,3 +134,30 @@ def test_the_epoch_loop_in_c_and_a_ring_that_wraps():
         assert got[2] == res[0][2] == 3 * 41
         for a, b in zip(res[0][0] + res[0][1], got[0] + got[1]):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("via_float", [True, False])
+def test_compact_and_full_size_batches_hold_the_same_arrays(via_float):
+    """Round 6: a batch whose ids all fit an int32 crosses the link as [dense | labels | ids32] and a kernel rebuilds the two int64
+    arrays (ids; wide ids = the parser's own function of the id, through a float or not); a batch with one id beyond int32 crosses
+    as the int64 arrays.  Both kinds, mixed in one epoch, equal the host parser's arrays bit for bit -- negative ids included."""
+    import ps_amd
+    rng = np.random.default_rng(21)
+    F, X, WS, B, n = 4, 2, 1000, 32, 32 * 6
+    ids = rng.integers(-5000, 1 << 24, size=(n, F))
+    ids[40, 2] = (1 << 40) + 12345                               # batch 1: beyond int32 -> the full-size copy
+    ids[100, 0] = -(1 << 33)                                     # batch 3 too
+    lines = [" ".join(["1"] + ["%d:1" % v for v in ids[i]] + ["%d:%.4f" % (F + 1 + j, rng.standard_normal()) for j in range(X)]) for i in range(n)]
+    text = "\n".join(lines).encode()
+    want = ps_amd.LibsvmParser(F, X, WS, ids_via_float=via_float).parse(text)
+    kv = ps_amd.KVStore(0, SEED)
+    ds = ps_amd.DataSet(kv, text, F, X, B, wide_size=WS, threads=3, ids_via_float=via_float)
+    seen = 0
+    for b in ds:
+        kv.sync()
+        np.testing.assert_array_equal(_down(kv, b.c.ids, (b.B, F), np.int64), want["E"][seen:seen + b.B])
+        np.testing.assert_array_equal(_down(kv, b.c.wide_ids, (b.B, F), np.int64), want["W"][seen:seen + b.B])
+        np.testing.assert_array_equal(_down(kv, b.c.dense, (b.B, X), f32), want["X"][seen:seen + b.B])
+        seen += b.B
+    assert seen == n
+    ds.close(); kv.close()
