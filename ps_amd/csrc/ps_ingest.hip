@@ -459,21 +459,28 @@ void parser_loop(ps_ingest *g) {
     }
 }
 
+static double ing_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void copier_loop(ps_ingest *g) {
     (void)hipSetDevice(g->s->device);
+    static const bool timing = getenv("PS_INGEST_TIMING") != nullptr;
+    double t_wait = 0, t_sync = 0, t_issue = 0;
     for (int64_t b = 0; b < g->nbatches; ++b) {
         ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
+        const double c0 = timing ? ing_now() : 0;
         {
             std::unique_lock<std::mutex> l(g->mu);
             g->cv_parsed.wait(l, [&] { return g->stop || g->parsed[(size_t)(b % g->ring)] == b; });
             if (g->stop) return;
         }
+        const double c1 = timing ? ing_now() : 0;
+        t_wait += c1 - c0;
         if (S.rc == PS_OK && S.B > 0) {
             // host-synchronised HERE, in the background: the kernels that read this slot's previous batch are done, the block is
             // copied, the copy has landed -- the training thread needs no cross-stream event (cross-thread event WAITS proved
             // unreliable in round 2: occasional stale batches)
             hipError_t e = hipSuccess;
             if (S.consumed_recorded) e = hipEventSynchronize(S.consumed);
+            if (timing) t_sync += ing_now() - c1;
             // (a short last batch: the arrays keep their full-batch offsets inside the block, the tail of each is not copied)
             const ps_ingest_config_t &c = g->cfg;
             if (S.compact) {
@@ -503,12 +510,15 @@ void copier_loop(ps_ingest *g) {
             if (e == hipSuccess) e = hipEventRecord(S.copied, g->copy_stream);
             if (e != hipSuccess) { S.rc = PS_E_HIP; snprintf(S.err, sizeof S.err, "ingest H2D: %s", hipGetErrorString(e)); }
         }
+        if (timing) t_issue += ing_now() - c1;
         {
             std::lock_guard<std::mutex> l(g->mu);
             g->issued_upto = b + 1;
         }
         g->cv_issued.notify_all();
     }
+    if (timing && g->nbatches > 0) fprintf(stderr, "[ingest copier] per batch: %.1f us waiting for the parsers, %.1f us in HIP calls (of which %.1f waiting for the slot's consumers)\n",
+                                          t_wait / g->nbatches, t_issue / g->nbatches, t_sync / g->nbatches);
 }
 
 void completer_loop(ps_ingest *g) {
