@@ -563,7 +563,7 @@ def gather_roofline(kv, args):
     return res
 
 
-def ingest_fed_leg(cfg, resident_examples_per_s, epochs=3):
+def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
     """configs[1] trained STRAIGHT FROM libsvm TEXT (data/DataSet.java:77-100's reader threads, data/LibsvmParser.java:13-25,
     CTR.java:47-68) through ps_ingest_*: CTR-shaped lines (label + 26 `idx:1` + 13 `idx:val`) held in memory, parsed by
     min(nproc, 96) host threads into a ring of pinned batches, one H2D copy per batch, the same fused step on the batches as they
@@ -572,11 +572,11 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=3):
     import ps_amd
     F, X, B, V = cfg["F"], cfg["X"], cfg["B"], cfg["V"]
     rng = np.random.default_rng(cfg["seed"] + 77)
-    nlines, nbatch = 4 * B, 96
+    nlines, nbatch = 4 * B, 512       # (an epoch of 96 batches measured the epoch boundary: threads restarted, every slot waiting for the previous epoch's kernels)
     E, Xd, Y, _ = synth_batch(cfg, rng, B=nlines)
     lines = np.array([(str(int(Y[i])) + " " + " ".join("%d:1" % v for v in E[i]) + " " + " ".join("%d:%.6f" % (F + 1 + j, Xd[i, j]) for j in range(X))).encode()
                       for i in range(nlines)], dtype=object)
-    # 96 batches of lines drawn from those 16 384 (the text, not the arrays, is what the leg starts from)
+    # 512 batches of lines drawn from those 16 384 (the text, not the arrays, is what the leg starts from)
     text = b"\n".join(lines[rng.integers(0, nlines, size=nbatch * B)]) + b"\n"
     threads = max(1, min(os.cpu_count() or 1, 96))
     kv = ps_amd.KVStore(0, cfg["seed"])
