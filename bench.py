@@ -578,7 +578,7 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
                       for i in range(nlines)], dtype=object)
     # 512 batches of lines drawn from those 16 384 (the text, not the arrays, is what the leg starts from)
     text = b"\n".join(lines[rng.integers(0, nlines, size=nbatch * B)]) + b"\n"
-    threads = max(1, min(os.cpu_count() or 1, 96))
+    threads = int(os.environ.get("PS_INGEST_THREADS", max(1, min(os.cpu_count() or 1, 96))))
     kv = ps_amd.KVStore(0, cfg["seed"])
     kv.create_embedding([V] * F, cfg["D"])
     gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], X, cfg["fc"], cfg["wide"], store=kv, max_batch=B)

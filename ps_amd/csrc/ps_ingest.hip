@@ -743,6 +743,7 @@ extern "C" int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batche
     int rc = PS_OK;
     // PS_INGEST_TIMING=1 (measurement): where the training thread's time goes, per batch: taking the batch | enqueueing the step
     static const bool timing = getenv("PS_INGEST_TIMING") != nullptr;
+    static const int lead = getenv("PS_INGEST_LEAD") ? atoi(getenv("PS_INGEST_LEAD")) : 0;
     double t_next = 0, t_train = 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (max_batches < 0 || k < max_batches) {
@@ -756,6 +757,7 @@ extern "C" int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batche
         if (rc != PS_OK) break;
         if (timing) { t_next += t1 - t0; t_train += now() - t1; }
         ++k;
+        if (lead > 0 && k % lead == 0) (void)hipStreamSynchronize(g->s->stream);       // (measurement: the host at most `lead` steps ahead of the GPU)
     }
     if (timing && k > 0) fprintf(stderr, "[ps_ingest_train] %lld batches: %.1f us per batch taking it from the ring, %.1f us enqueueing its step\n", (long long)k, t_next / k, t_train / k);
     if (trained) *trained = k;
