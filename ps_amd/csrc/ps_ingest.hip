@@ -474,7 +474,8 @@ void copier_loop(ps_ingest *g) {
         }
         const double c1 = timing ? ing_now() : 0;
         t_wait += c1 - c0;
-        if (S.rc == PS_OK && S.B > 0) {
+        static const bool nocopy = getenv("PS_INGEST_NOCOPY") != nullptr;        // (measurement only: the batches in HBM are not refreshed)
+        if (S.rc == PS_OK && S.B > 0 && !nocopy) {
             // host-synchronised HERE, in the background: the kernels that read this slot's previous batch are done, the block is
             // copied, the copy has landed -- the training thread needs no cross-stream event (cross-thread event WAITS proved
             // unreliable in round 2: occasional stale batches)
@@ -530,7 +531,8 @@ void completer_loop(ps_ingest *g) {
             g->cv_issued.wait(l, [&] { return g->stop || g->issued_upto > b; });
             if (g->stop) return;
         }
-        if (S.rc == PS_OK && S.B > 0) {
+        static const bool nocopy2 = getenv("PS_INGEST_NOCOPY") != nullptr;
+        if (S.rc == PS_OK && S.B > 0 && !nocopy2) {
             // (polled: a blocking hipEventSynchronize here and the copier's calls share the runtime's locks with the training
             //  thread's launches -- PS_INGEST_SYNC=1 is the blocking form, for the A/B)
             static const bool blocking = getenv("PS_INGEST_SYNC") != nullptr;
@@ -692,8 +694,8 @@ extern "C" int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out) {
     // (host side) for this event before it overwrites the slot's HBM block
     if (b >= 2) {
         ps_ingest::Slot &R = g->slot[(size_t)((b - 2) % g->ring)];
-        HIPCHK(hipEventRecord(R.consumed, g->s->stream));
-        R.consumed_recorded = true;
+        static const bool noevent = getenv("PS_INGEST_NOEVENT") != nullptr;      // (measurement only: unsafe)
+        if (!noevent) { HIPCHK(hipEventRecord(R.consumed, g->s->stream)); R.consumed_recorded = true; }
         {
             std::lock_guard<std::mutex> l(g->mu);
             g->free_upto = b - 2 + g->ring + 1;
