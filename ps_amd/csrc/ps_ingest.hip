@@ -746,7 +746,9 @@ extern "C" int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batche
     // PS_INGEST_TIMING=1 (measurement): where the training thread's time goes, per batch: taking the batch | enqueueing the step
     static const bool timing = getenv("PS_INGEST_TIMING") != nullptr;
     static const int lead = getenv("PS_INGEST_LEAD") ? atoi(getenv("PS_INGEST_LEAD")) : 0;
-    double t_next = 0, t_train = 0;
+    double t_next = 0, t_train = 0, t_sync = 0, gpu_ms = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timing && lead > 0) { (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventRecord(ev0, g->s->stream); }
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (max_batches < 0 || k < max_batches) {
         ps_batch_t b;
@@ -759,9 +761,21 @@ extern "C" int ps_ingest_train(ps_ingest_t *g, ps_model_t *m, int64_t max_batche
         if (rc != PS_OK) break;
         if (timing) { t_next += t1 - t0; t_train += now() - t1; }
         ++k;
-        if (lead > 0 && k % lead == 0) (void)hipStreamSynchronize(g->s->stream);       // (measurement: the host at most `lead` steps ahead of the GPU)
+        if (lead > 0 && k % lead == 0) {       // (measurement: the host at most `lead` steps ahead of the GPU; GPU time of every group of `lead` steps)
+            if (timing && ev0) {
+                (void)hipEventRecord(ev1, g->s->stream);
+                const double ts0 = now();
+                (void)hipEventSynchronize(ev1);
+                t_sync += now() - ts0;
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) gpu_ms += ms;
+                (void)hipEventRecord(ev0, g->s->stream);
+            } else (void)hipStreamSynchronize(g->s->stream);
+        }
     }
-    if (timing && k > 0) fprintf(stderr, "[ps_ingest_train] %lld batches: %.1f us per batch taking it from the ring, %.1f us enqueueing its step\n", (long long)k, t_next / k, t_train / k);
+    if (timing && k > 0) fprintf(stderr, "[ps_ingest_train] %lld batches: %.1f us per batch taking it from the ring, %.1f us enqueueing its step; groups of %d steps: GPU %.1f us per step between the group's events, host %.1f us per step waiting for the group\n",
+                                 (long long)k, t_next / k, t_train / k, lead, 1e3 * gpu_ms / k, t_sync / k);
+    if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
     if (trained) *trained = k;
     return rc;
 }
