@@ -16,6 +16,8 @@
 // out a ps_batch_t whose pointers are device pointers.  ps_libsvm_parse is the same parser as
 // a plain host function (no GPU) -- what the CPU tests pin against the restated reference.
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -412,8 +414,25 @@ struct ps_ingest {
 
 namespace {
 
+// PS_INGEST_PIN=1: the parser threads keep to the upper half of the CPUs this process may use (measured: 96 busy host threads slow
+// the fused step's launches on the GPU from 0.137 to 0.20-0.24 ms per step; kept away from the launching thread's half: 0.147 with 48 --
+// tools/r06_host_load_probe2.py, profiles/r06_host_load_probe.txt)
+void pin_parser_thread() {
+    static const bool pin = getenv("PS_INGEST_PIN") != nullptr;
+    if (!pin) return;
+    cpu_set_t have, want;
+    CPU_ZERO(&have); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return;
+    const int n = CPU_COUNT(&have);
+    int k = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &have)) { if (k >= n / 2) CPU_SET(c, &want); ++k; }
+    if (CPU_COUNT(&want) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof want, &want);
+}
+
 void parser_loop(ps_ingest *g) {
     const ps_ingest_config_t &c = g->cfg;
+    pin_parser_thread();
     for (;;) {
         int64_t b;
         bool last;
