@@ -114,6 +114,7 @@ struct EmbBwdArgs {
     const uint32_t *sorted_key, *sorted_ent, *seg_start, *seg_id, *nseg;
     const uint32_t *long_list;         // seq_order: (run id, first entry, end) of the runs above PS_EMB_SEQ_TILE entries, *nlong triples (or nullptr)
     const uint32_t *nlong;
+    const uint32_t *ftab;              // the field sort's table [F][first run, runs, first long run, long runs] (or nullptr): keys dealt to XCDs by FIELD PAIR
     unsigned long long *ts_partials, *ts_super;   // stamps of the chunked order's first two launches
     const uint32_t *out_slot;          // when set (sharded step, single-hot): grads_out / uniq_* index of a run = out_slot[its first entry]
     const uint32_t *ent_bag;           // nullptr => bag = entry

@@ -387,6 +387,26 @@ __device__ __forceinline__ unsigned int emb_vblock(int xcd) {
     return xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 }
 
+// XCD-affine order BY FIELD PAIR (a.xcd == 3, round 6).  An entry's delta row is the D floats of ITS field in its sample's row of dx; at
+// D = 16 two neighbouring fields share every 128-byte line.  Dealt by eighths of the keys (a.xcd == 1) the two halves of a line are consumed
+// under two L2s wherever an eighth ends inside a pair, and the long-key role took its runs in list order, any XCD: every delta line was
+// fetched about twice (PMC: 24.1 MB read for 16.6 algorithmic, profiles/r05_pmc_traffic.txt).  Now the runs -- short and long -- of fields
+// 2x, 2x + 1, 2x + 16, 2x + 17, ... belong to the workgroups of XCD x (block b runs on XCD b % 8: observed, a matter of speed only), from the
+// table the field sort leaves per field: [first run, runs, first long run, long runs].  t-th run (which = 0) / long run (which = 1) of XCD x:
+__device__ __forceinline__ bool emb_xcd_pick(const uint32_t *__restrict__ ftab, int F, int x, int which, uint32_t t, uint32_t &idx) {
+    for (int f0 = 2 * x; f0 < F; f0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int f = f0 + e;
+            if (f >= F) break;
+            const uint32_t base = ftab[4 * f + 2 * which], cnt = ftab[4 * f + 2 * which + 1];
+            if (t < cnt) { idx = base + t; return true; }
+            t -= cnt;
+        }
+    }
+    return false;
+}
+
 // the first key whose run starts at or behind entry p  (plain arguments: a lambda that captures the kernel's argument struct by
 // reference makes hipcc copy the whole struct to scratch -- 856 bytes per lane, the single-hot update 135 us instead of 17)
 __device__ __forceinline__ int64_t emb_key_at(const uint32_t *__restrict__ seg_id, const uint32_t *__restrict__ seg_start, int64_t nnz, int64_t nseg, int64_t p) {
@@ -847,7 +867,12 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         if (a.long_list) {
             // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
             const uint32_t nl = *a.nlong;
-            for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.long_blocks) {
+            const bool by_pair = a.xcd == 3;
+            const uint32_t step = by_pair ? (uint32_t)a.long_blocks >> 3 : (uint32_t)a.long_blocks;
+            for (uint32_t t = by_pair ? blockIdx.x >> 3 : blockIdx.x; ; t += step) {
+                uint32_t i = t;
+                if (by_pair) { if (!emb_xcd_pick(a.ftab, a.F, (int)(blockIdx.x & 7u), 1, t, i)) break; }     // the XCD's own field pairs' long runs
+                else if (i >= nl) break;
                 const uint32_t *ll = a.long_list + 3 * (size_t)i;        // (run id, first entry, end): one load level
                 long_key_run<VEC, BAG>(a, seq_lds, ll[0], ll[1], ll[2]);
                 __syncthreads();                               // the next run reuses the LDS buffers
@@ -895,7 +920,19 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
     //  hold a 500..4000-entry key no longer end 25-35 us behind the median one, but k_emb_super_list then folds 570 runs instead of 78,
     //  7 -> 18 us in front of this launch: 0.327 ms).  tools/emb_timing.sh: the median workgroup of this launch ends at 28 us of 64, and
     //  moving its 230 MB of W / state in that time would take 8 TB/s -- the launch is within 1.5x of its HBM time.)
-    for (; u < uend; u += stride) reduce_one_key<VEC, BAG, SEQ>(a, u, part);
+    if (SEQ && a.xcd == 3) {        // by field pair: u counts the runs of this XCD's fields (emb_xcd_pick)
+        u = ((int64_t)(sb >> 3) * 4 + (threadIdx.x >> 6)) * gpw + lane64 / a.LPR;
+        uend = (int64_t)1 << 40;
+    }
+    for (; u < uend; u += stride) {
+        int64_t key = u;
+        if (SEQ && a.xcd == 3) {
+            uint32_t k32;
+            if (!emb_xcd_pick(a.ftab, a.F, (int)(blockIdx.x & 7u), 0, (uint32_t)u, k32)) break;
+            key = k32;
+        }
+        reduce_one_key<VEC, BAG, SEQ>(a, key, part);
+    }
 }
 
 
@@ -1282,7 +1319,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
-int g_emb_xcd = 1;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
+int g_emb_xcd = 3;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
 int g_fwd_order = 3;        // ps_tune_set("fwd_order", bits): multi-hot gather's bag order (EmbFwdArgs.order; 0: sample-major round robin -- 0.354 against 0.347 ms / step at configs[4]'s shape, the gather 47.8 -> 42.1 us)
 int g_keys_grid = 0;        // ps_tune_set("keys_grid", workgroups): grid bound of the multi-hot key kernel (0: 1024)
 int g_seq_long_grid = 0;        // ps_tune_set("seq_long_grid", workgroups): long-key workgroups of the sequential order (0: SEQ_LONG_GRID)
@@ -1507,6 +1544,8 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     a.short_blocks = gr < g_emb_short_grid ? gr : g_emb_short_grid;
     // XCD-affine order (emb_vblock): grids rounded up to multiples of 8 (surplus workgroups find nothing to do)
     a.xcd = (g_emb_xcd && a.short_blocks >= 64 && a.long_blocks % 8 == 0) ? g_emb_xcd : 0;
+    // by field pair when the field sort left its table (single-hot batches; ps_tune_set("emb_xcd", 1 | 2): by eighths of the keys / entries again)
+    if (a.xcd == 3 && !(a.seq_order && a.long_list && a.ftab && a.F <= 64)) a.xcd = 1;
     if (a.xcd) a.short_blocks = (a.short_blocks + 7) & ~7;
     const int gpx = a.xcd ? (gp + 7) & ~7 : gp;
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \

@@ -857,6 +857,10 @@ __global__ __launch_bounds__(FS_TPB) void k_field_sort_segments(FieldSortArgs a)
     __syncthreads();
     FS_T(4);
     const uint32_t rbase = base_s[0], lbase = base_s[1];
+    if (tid == 0) {     // this field's runs and long runs: [rbase, rbase + nrun) of the runs, [lbase, lbase + nlong) of the long list (k_emb_reduce_update deals by field pair)
+        uint32_t *ft = reinterpret_cast<uint32_t *>(a.pub + PS_FS_TAB_OFF(a.F)) + 4 * (size_t)f;
+        ft[0] = rbase; ft[1] = nrun; ft[2] = lbase; ft[3] = nlong;
+    }
     const uint32_t pos0 = (uint32_t)f * (uint32_t)B;
     {
         uint32_t idx = before, li = lbefore;                 // idx = runs started before position r0

@@ -141,6 +141,7 @@ int build_segments(SortWorkspace &ws, const uint32_t *keys_sorted, int64_t n, ui
 // radix_sort_pairs(iota) + build_segments; nseg_dev[1] = number of long runs.  keys_base[f] (device) = first key of
 // field f's interval, key_bits = bits of the largest (key - keys_base[f]).  pub: F look-back words (zeroed once),
 // epoch: a value that differs from every earlier launch on the same pub (nonzero).
+#define PS_FS_TAB_OFF(F) (((F) + 1) & ~1)      // the field table starts this many 8-byte words behind pub (16-byte aligned)
 bool field_sort_fits(int B, int F);
 int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_bits, int B, int F, int long_min,
                         uint32_t *sorted_keys, uint32_t *sorted_ents, uint32_t *seg_start, uint32_t *seg_id,

@@ -160,7 +160,8 @@ extern "C" int ps_model_create(ps_store_t *s, const ps_model_config_t *cfg, ps_m
     PSCHK(model_alloc(m, (void **)&m->fs_keys, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->fs_ents, sizeof(uint32_t) * (size_t)(nc + 1), false));
     PSCHK(model_alloc(m, (void **)&m->long_list, sizeof(uint32_t) * 3 * (size_t)(nc / (PS_EMB_SEQ_TILE + 1) + 2), false));
-    PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)F, true));
+    // (behind the F look-back words: the field table [F][rbase, runs, lbase, long runs] the sort leaves for the embedding update -- PS_FS_TAB_OFF)
+    PSCHK(model_alloc(m, (void **)&m->fs_pub, sizeof(unsigned long long) * (size_t)PS_FS_TAB_OFF(F) + 16 * (size_t)F, true));
     PSCHK(model_alloc(m, (void **)&m->start_flag, sizeof(unsigned int) * 16, true));
     PSCHK(model_alloc(m, (void **)&m->pair_ctr, sizeof(unsigned int) * (size_t)(cdiv(B, 64) + 8), true));       // k_fc_fwd_pair: tiles done per row panel      // [0..7] flags, [8] the dense update's workgroup count
     PSCHK(model_alloc(m, (void **)&m->uniq_row, sizeof(uint32_t) * (size_t)(nc + 1), false));
@@ -967,6 +968,7 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.nseg = m->sh.active ? m->nseg_cur : m->nseg_dev;
     g.long_list = m->long_list_valid ? m->long_list : nullptr;
     g.nlong = m->nlong_ptr;
+    g.ftab = (m->long_list_valid && m->field_sorted) ? reinterpret_cast<const uint32_t *>(m->fs_pub + PS_FS_TAB_OFF(c.F)) : nullptr;
     g.out_slot = (m->sh.active && m->field_sorted) ? m->sh.slot : nullptr;     // (runs field by field, gradients in send order)
     g.ent_bag = (m->cur_offsets && m->sh.active) ? m->ent_bag : nullptr;     // fused path: sorted_ent already holds bags
     g.delta = m->dx; g.ldd = m->ldx; g.partials = m->partials; g.partials2 = m->partials2; g.W = s->emb.W; g.state = s->emb.state;
