@@ -134,6 +134,7 @@ struct EmbBwdArgs {
     unsigned long long *ts;
     unsigned int *flag; unsigned int flag_val;      // "this launch has started" for a device-side waiter (set by the launcher)
     const unsigned int *end_wait; unsigned int end_val; WaitBound bound;   // the last launch's first workgroup ends only once *end_wait reached end_val
+    int lxcd;                          // filled by the launcher: the long-key role takes the list XCD by XCD too (eighths)
     int xcd;                           // filled by the launcher: 1 = keys / tiles are dealt to workgroups XCD by XCD (kernels_emb.hip emb_vblock)
 };
 int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: flag (the first launch announces its

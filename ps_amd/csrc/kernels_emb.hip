@@ -868,11 +868,16 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
             // the sort listed the runs above SEQ_TILE entries (nseg[1] of them, any order)
             const uint32_t nl = *a.nlong;
             const bool by_pair = a.xcd == 3;
-            const uint32_t step = by_pair ? (uint32_t)a.long_blocks >> 3 : (uint32_t)a.long_blocks;
-            for (uint32_t t = by_pair ? blockIdx.x >> 3 : blockIdx.x; ; t += step) {
-                uint32_t i = t;
-                if (by_pair) { if (!emb_xcd_pick(a.ftab, a.F, (int)(blockIdx.x & 7u), 1, t, i)) break; }     // the XCD's own field pairs' long runs
-                else if (i >= nl) break;
+            // (a.xcd == 1 | 2, a.lxcd: the list lies field by field -- XCD x takes its x-th EIGHTH, the fields the short role's eighth x
+            //  roughly covers too: balanced, and only the pairs an eighth ends in are read under two L2s)
+            const bool by_eighth = a.xcd && !by_pair && a.lxcd;
+            const uint32_t x = blockIdx.x & 7u;
+            const uint32_t step = (by_pair || by_eighth) ? (uint32_t)a.long_blocks >> 3 : (uint32_t)a.long_blocks;
+            const uint32_t lo = by_eighth ? (uint32_t)((uint64_t)nl * x / 8) : 0u, hi = by_eighth ? (uint32_t)((uint64_t)nl * (x + 1) / 8) : nl;
+            for (uint32_t t = (by_pair || by_eighth) ? blockIdx.x >> 3 : blockIdx.x; ; t += step) {
+                uint32_t i = lo + t;
+                if (by_pair) { if (!emb_xcd_pick(a.ftab, a.F, (int)x, 1, t, i)) break; }     // the XCD's own field pairs' long runs
+                else if (i >= hi) break;
                 const uint32_t *ll = a.long_list + 3 * (size_t)i;        // (run id, first entry, end): one load level
                 long_key_run<VEC, BAG>(a, seq_lds, ll[0], ll[1], ll[2]);
                 __syncthreads();                               // the next run reuses the LDS buffers
@@ -1319,7 +1324,8 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
-int g_emb_xcd = 3;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
+int g_emb_lxcd = 1;         // ps_tune_set("emb_lxcd", 0): the long-key role takes the sort's list in order, any XCD (rounds 4-5)
+int g_emb_xcd = 1;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
 int g_fwd_order = 3;        // ps_tune_set("fwd_order", bits): multi-hot gather's bag order (EmbFwdArgs.order; 0: sample-major round robin -- 0.354 against 0.347 ms / step at configs[4]'s shape, the gather 47.8 -> 42.1 us)
 int g_keys_grid = 0;        // ps_tune_set("keys_grid", workgroups): grid bound of the multi-hot key kernel (0: 1024)
 int g_seq_long_grid = 0;        // ps_tune_set("seq_long_grid", workgroups): long-key workgroups of the sequential order (0: SEQ_LONG_GRID)
@@ -1546,6 +1552,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     a.xcd = (g_emb_xcd && a.short_blocks >= 64 && a.long_blocks % 8 == 0) ? g_emb_xcd : 0;
     // by field pair when the field sort left its table (single-hot batches; ps_tune_set("emb_xcd", 1 | 2): by eighths of the keys / entries again)
     if (a.xcd == 3 && !(a.seq_order && a.long_list && a.ftab && a.F <= 64)) a.xcd = 1;
+    a.lxcd = g_emb_lxcd;
     if (a.xcd) a.short_blocks = (a.short_blocks + 7) & ~7;
     const int gpx = a.xcd ? (gp + 7) & ~7 : gp;
 #define EMB_BWD_LAUNCH(V, BG)                                                                  \
