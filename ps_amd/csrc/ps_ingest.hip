@@ -112,10 +112,19 @@ bool parse_long_tok(const char *p, const char *e, int64_t *out) {
     return true;
 }
 
+// MatrixUtil.hash (util/MatrixUtil.java:27-33): fmodf(fe, (float)wideSize) on an id that went through a float.  fe is integral (a long cast
+// to float) and so is (float)wideSize: the float remainder of two integers IS the integer remainder, sign of the dividend -- C's % on the
+// two values as int64 -- and needs no libm call (fmodf was most of a line's parse time: 26 calls of ~30 ns).  Beyond 2^62 the cast would
+// overflow: fmodf itself.
+static inline int64_t wide_of(float fe, int64_t wide_size) {
+    const float ws = (float)wide_size;
+    if (fe > -4.0e18f && fe < 4.0e18f && ws < 4.0e18f) return (int64_t)fe % (int64_t)ws;
+    return (int64_t)fmodf(fe, ws);
+}
 struct LineOut { int64_t *ids; float *dense; float *label; int64_t *wide; };
 
 // one line -> one sample.  0 ok, else the 1-based column that failed (1 = label), -1 = too few columns
-int parse_line(const char *p, const char *e, const ps_ingest_config_t &c, const LineOut &o) {
+int parse_line_general(const char *p, const char *e, const ps_ingest_config_t &c, const LineOut &o) {
     while (e > p && (e[-1] == '\r' || e[-1] == ' ' || e[-1] == '\t')) --e;
     int col = 0;
     const int need = 1 + c.F + c.X;
@@ -138,7 +147,7 @@ int parse_line(const char *p, const char *e, const ps_ingest_config_t &c, const 
                 if (c.ids_via_float) {
                     const float fe = (float)idx;                               // E[j-1][i] = cols.get(j).getIdx()  (long -> float)
                     id = (int64_t)fe;
-                    if (c.wide_size > 0) w = (int64_t)fmodf(fe, (float)c.wide_size);   // MatrixUtil.hash (util/MatrixUtil.java:27-33)
+                    if (c.wide_size > 0) w = wide_of(fe, c.wide_size);   // MatrixUtil.hash (util/MatrixUtil.java:27-33)
                 } else if (c.wide_size > 0) {
                     w = idx % c.wide_size;
                 }
@@ -153,6 +162,78 @@ int parse_line(const char *p, const char *e, const ps_ingest_config_t &c, const 
         ++col;
     }
     return col == need ? 0 : -1;
+}
+
+
+// ---- the common line, in one pass ------------------------------------------------------------------------------------
+// Round 6: the pipeline needs ~22 parser threads at 0.7 us per line to feed a 135 us step, and that many busy host threads slow the
+// step's launches (profiles/r06_ingest_probes.txt).  A CTR line is 40 tokens of three shapes -- `label`, `idx:1`, `idx:-0.123456` --
+// so one forward scan handles it: digits into an integer, ':', an optional sign, digits, an optional fraction, a space.  The values
+// computed are parse_line_general's, operation for operation (same mantissa < 2^24 rule, same one IEEE division by a power of ten,
+// the same long -> float -> id path).  Anything else on the line -- an exponent, a ninth significant digit, a suffix, a tab, a
+// missing column, an index beyond 18 digits -- and the line is handed to parse_line_general untouched: errors keep their column numbers.
+// Returns 0 (parsed) or -2 (not this shape).
+#define PS_FAST_FLOAT(V)                                                                                   \
+    do {                                                                                                   \
+        bool neg_ = false;                                                                                 \
+        if (p < e && (*p == '-' || *p == '+')) { neg_ = *p == '-'; ++p; }                                  \
+        uint32_t m_ = 0; int nd_ = 0, fr_ = 0;                                                             \
+        while (p < e && (unsigned)(*p - '0') <= 9u) { m_ = m_ * 10u + (uint32_t)(*p - '0'); ++nd_; ++p; }  \
+        if (p < e && *p == '.') {                                                                          \
+            ++p;                                                                                           \
+            while (p < e && (unsigned)(*p - '0') <= 9u) { m_ = m_ * 10u + (uint32_t)(*p - '0'); ++nd_; ++fr_; ++p; } \
+        }                                                                                                  \
+        /* 8 digits: m_ < 10^8 fits; the general rule stops accumulating once m >= 2^24 BEFORE a digit: with <= 7 digits m stays below */ \
+        if (nd_ == 0 || nd_ > 7 || (p < e && *p != ' ')) return -2;                                        \
+        float v_ = (float)m_;                                                                              \
+        if (fr_ > 0) v_ = v_ / kPow10f[fr_];                                                               \
+        (V) = neg_ ? -v_ : v_;                                                                             \
+    } while (0)
+int parse_line_fast(const char *p, const char *e, const ps_ingest_config_t &c, const LineOut &o) {
+    float label;
+    PS_FAST_FLOAT(label);
+    const int ncol = c.F + c.X;
+    for (int col = 0; col < ncol; ++col) {
+        if (p >= e || *p != ' ') return -2;
+        while (p < e && *p == ' ') ++p;
+        bool ineg = false;
+        if (p < e && (*p == '-' || *p == '+')) { ineg = *p == '-'; ++p; }
+        uint64_t v = 0; int nd = 0;
+        while (p < e && (unsigned)(*p - '0') <= 9u) { v = v * 10u + (uint64_t)(*p - '0'); ++nd; ++p; }
+        if (nd == 0 || nd > 18 || p >= e || *p != ':') return -2;
+        ++p;
+        float val;
+        PS_FAST_FLOAT(val);
+        if (col < c.F) {
+            const int64_t idx = ineg ? -(int64_t)v : (int64_t)v;
+            int64_t id = idx, w = 0;
+            if (c.ids_via_float) {
+                const float fe = (float)idx;
+                id = (int64_t)fe;
+                if (c.wide_size > 0) w = wide_of(fe, c.wide_size);
+            } else if (c.wide_size > 0) {
+                w = idx % c.wide_size;
+            }
+            o.ids[col] = id;
+            if (o.wide) o.wide[col] = w;
+        } else {
+            o.dense[col - c.F] = val;
+        }
+    }
+    // (columns beyond 1 + F + X are ignored by the general parser too; trailing blanks were trimmed by the caller)
+    *o.label = label;
+    return 0;
+}
+#undef PS_FAST_FLOAT
+
+int g_ingest_fast = getenv("PS_INGEST_FAST") ? atoi(getenv("PS_INGEST_FAST")) : 1;     // 0: every line through parse_line_general (rounds 2-5)
+int parse_line(const char *p, const char *e, const ps_ingest_config_t &c, const LineOut &o) {
+    if (g_ingest_fast) {
+        const char *e2 = e;
+        while (e2 > p && (e2[-1] == '\r' || e2[-1] == ' ' || e2[-1] == '\t')) --e2;
+        if (parse_line_fast(p, e2, c, o) == 0) return 0;
+    }
+    return parse_line_general(p, e, c, o);
 }
 
 // ---- a small pool: run fn(i) for i in [0,n) on the pool's threads + the caller ----
