@@ -475,6 +475,7 @@ struct ps_ingest {
         bool consumed_recorded = false;
         int B = 0;
         int rc = PS_OK;
+        bool skipped = false;                         // (measurement knobs: this batch's copy was left out)
         bool compact = false;                         // every id of the batch fits an int32: only [dense | labels | ids32] crosses the link
         char err[256] = "";
     };
@@ -606,7 +607,10 @@ void copier_loop(ps_ingest *g) {
         }
         const double c1 = timing ? ing_now() : 0;
         t_wait += c1 - c0;
-        static const bool nocopy = getenv("PS_INGEST_NOCOPY") != nullptr;        // (measurement only: the batches in HBM are not refreshed)
+        static const bool nocopy_all = getenv("PS_INGEST_NOCOPY") != nullptr;        // (measurement only: the batches in HBM are not refreshed)
+        static const int copy_every = getenv("PS_INGEST_COPY_EVERY") ? atoi(getenv("PS_INGEST_COPY_EVERY")) : 1;      // (measurement only)
+        const bool nocopy = nocopy_all || (copy_every > 1 && b % copy_every != 0);
+        S.skipped = nocopy;
         if (S.rc == PS_OK && S.B > 0 && !nocopy) {
             // host-synchronised HERE, in the background: the kernels that read this slot's previous batch are done, the block is
             // copied, the copy has landed -- the training thread needs no cross-stream event (cross-thread event WAITS proved
@@ -638,8 +642,7 @@ void completer_loop(ps_ingest *g) {
             g->cv_issued.wait(l, [&] { return g->stop || g->issued_upto > b; });
             if (g->stop) return;
         }
-        static const bool nocopy2 = getenv("PS_INGEST_NOCOPY") != nullptr;
-        if (S.rc == PS_OK && S.B > 0 && !nocopy2) {
+        if (S.rc == PS_OK && S.B > 0 && !S.skipped) {
             // (polled: a blocking hipEventSynchronize here and the copier's calls share the runtime's locks with the training
             //  thread's launches -- PS_INGEST_SYNC=1 is the blocking form, for the A/B)
             static const bool blocking = getenv("PS_INGEST_SYNC") != nullptr;
@@ -684,8 +687,8 @@ void ingest_start(ps_ingest *g) {
     g->running = true;
     const int nt = g->cfg.threads > 1 ? g->cfg.threads : 1;
     for (int i = 0; i < nt; ++i) g->parsers.emplace_back(parser_loop, g);
-    static const bool threads_copy = getenv("PS_INGEST_COPIER") != nullptr;      // (the copier + completer threads of the first round-6 form, for the A/B)
-    g->inline_copy = !threads_copy;
+    static const bool inline_copy = getenv("PS_INGEST_INLINE") != nullptr;      // (measured: the training thread issuing the copies itself, 0.38 ms per step -- not the default)
+    g->inline_copy = inline_copy;
     if (!g->inline_copy) {
         g->copier = std::thread(copier_loop, g);
         g->completer = std::thread(completer_loop, g);
