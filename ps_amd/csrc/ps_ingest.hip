@@ -604,12 +604,22 @@ void copier_loop(ps_ingest *g) {
     static const bool timing = getenv("PS_INGEST_TIMING") != nullptr;
     double t_wait = 0, t_sync = 0, t_issue = 0;
     static const int group_max = getenv("PS_INGEST_GROUP") ? atoi(getenv("PS_INGEST_GROUP")) : 16;      // batches per H2D call at most (1: one call per batch)
+    static const int64_t low_water = getenv("PS_INGEST_LOW") ? atoi(getenv("PS_INGEST_LOW")) : 8;        // ... gathered while the consumer has this many batches ahead of it
     for (int64_t b = 0; b < g->nbatches; ++b) {
         ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
         const double c0 = timing ? ing_now() : 0;
         {
+            // wait for batch b -- and, while the consumer still has `low_water` batches in HBM ahead of it, for a whole group behind b: in the
+            // steady state batches are parsed one by one at the consumer's pace, and a copier that sends each as it appears sends groups of one
             std::unique_lock<std::mutex> l(g->mu);
-            g->cv_parsed.wait(l, [&] { return g->stop || g->parsed[(size_t)(b % g->ring)] == b; });
+            g->cv_parsed.wait(l, [&] {
+                if (g->stop) return true;
+                if (g->parsed[(size_t)(b % g->ring)] != b) return false;
+                if (group_max <= 1 || b - g->cur < low_water) return true;
+                int have = 1;
+                while (have < group_max && b + have < g->nbatches && (b + have) % g->ring != 0 && g->parsed[(size_t)((b + have) % g->ring)] == b + have) ++have;
+                return have >= group_max || b + have >= g->nbatches || (b + have) % g->ring == 0;
+            });
             if (g->stop) return;
         }
         const double c1 = timing ? ing_now() : 0;
@@ -915,7 +925,11 @@ extern "C" int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out) {
     out->ids = (int64_t *)(S.dev + g->off_ids); out->offsets = nullptr; out->dense = g->cfg.X > 0 ? (float *)(S.dev + g->off_dense) : nullptr;
     out->labels = (float *)(S.dev + g->off_labels); out->wide_ids = g->cfg.wide_size > 0 ? (int64_t *)(S.dev + g->off_wide) : nullptr;
     out->on_device = 1;
-    g->cur = b + 1;
+    {
+        std::lock_guard<std::mutex> l(g->mu);
+        g->cur = b + 1;
+    }
+    g->cv_parsed.notify_all();          // (the copier gathers groups while the consumer is far enough behind it: tell it where the consumer is)
     return PS_OK;
 }
 
