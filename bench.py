@@ -566,7 +566,7 @@ def gather_roofline(kv, args):
 def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
     """configs[1] trained STRAIGHT FROM libsvm TEXT (data/DataSet.java:77-100's reader threads, data/LibsvmParser.java:13-25,
     CTR.java:47-68) through ps_ingest_*: CTR-shaped lines (label + 26 `idx:1` + 13 `idx:val`) held in memory, parsed by
-    min(nproc, 96) host threads into a ring of pinned batches, one H2D copy per batch, the same fused step on the batches as they
+    min(nproc, 32) host threads into a ring of pinned batches, groups of batches per H2D copy, the same fused step on the batches as they
     arrive.  Reported beside the resident number: the headline's inputs are in HBM when its timed region starts; this is the rate
     when they are not."""
     import ps_amd
@@ -578,7 +578,7 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
                       for i in range(nlines)], dtype=object)
     # 512 batches of lines drawn from those 16 384 (the text, not the arrays, is what the leg starts from)
     text = b"\n".join(lines[rng.integers(0, nlines, size=nbatch * B)]) + b"\n"
-    threads = int(os.environ.get("PS_INGEST_THREADS", max(1, min(os.cpu_count() or 1, 96))))
+    threads = int(os.environ.get("PS_INGEST_THREADS", max(1, min(os.cpu_count() or 1, 32))))      # (32 feed the step with room to spare; 96 measured no better)
     kv = ps_amd.KVStore(0, cfg["seed"])
     kv.create_embedding([V] * F, cfg["D"])
     gm = ps_amd.WideDeepNN.buildModel(F, cfg["D"], X, cfg["fc"], cfg["wide"], store=kv, max_batch=B)
@@ -611,7 +611,7 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
     thread_s_per_line = (st1["parse_seconds"] - st0["parse_seconds"]) / max(st1["lines"] - st0["lines"], 1)
     block = B * (F * 8 * (2 if cfg["wide"] else 1) + X * 4 + 4)
     fed = B * steps / dt
-    out = {"workload": "configs[1] from libsvm text in memory: %d lines (%.1f MB), %d parser threads, ring of pinned batches, one H2D copy per batch" % (nbatch * B, len(text) / 1e6, threads),
+    out = {"workload": "configs[1] from libsvm text in memory: %d lines (%.1f MB), %d parser threads, ring of pinned batches, groups of batches per H2D copy" % (nbatch * B, len(text) / 1e6, threads),
            "steps": steps, "ms_per_step": 1e3 * dt / steps, "examples_per_s": fed,
            "resident_examples_per_s": resident_examples_per_s, "fed_over_resident": fed / resident_examples_per_s,
            "pipeline_alone_lines_per_s": k * B / pipe_dt,

@@ -603,8 +603,8 @@ void copier_loop(ps_ingest *g) {
     (void)hipSetDevice(g->s->device);
     static const bool timing = getenv("PS_INGEST_TIMING") != nullptr;
     double t_wait = 0, t_sync = 0, t_issue = 0;
-    static const int group_max = getenv("PS_INGEST_GROUP") ? atoi(getenv("PS_INGEST_GROUP")) : 16;      // batches per H2D call at most (1: one call per batch)
-    static const int64_t low_water = getenv("PS_INGEST_LOW") ? atoi(getenv("PS_INGEST_LOW")) : 8;        // ... gathered while the consumer has this many batches ahead of it
+    const int group_max = getenv("PS_INGEST_GROUP") ? atoi(getenv("PS_INGEST_GROUP")) : std::max(1, g->ring / 2);      // batches per H2D call at most (1: one call per batch)
+    const int64_t low_water = getenv("PS_INGEST_LOW") ? atoi(getenv("PS_INGEST_LOW")) : std::max(1, g->ring / 4);        // ... gathered while the consumer has this many batches ahead of it
     for (int64_t b = 0; b < g->nbatches; ++b) {
         ps_ingest::Slot &S = g->slot[(size_t)(b % g->ring)];
         const double c0 = timing ? ing_now() : 0;
