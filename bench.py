@@ -623,9 +623,9 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
     elif out["pipeline_alone_lines_per_s"] < 1.1 * fed:
         out["bounded_by"] = "the pipeline (parse + H2D copy): it delivers no more on its own"
     else:
-        out["bounded_by"] = ("the step itself: beside the pipeline's host activity (parser threads waking and sleeping, the copier's HIP calls) the GPU takes ~0.20 ms per step "
-                             "instead of 0.135 -- measured by events around groups of steps and by the resident step beside unrelated host threads (profiles/r06_ingest_probes.txt); "
-                             "the pipeline alone delivers %.1f M lines/s, the parsers %.0f M" % (out["pipeline_alone_lines_per_s"] / 1e6, out["parser"]["lines_per_s_all_threads"] / 1e6))
+        out["bounded_by"] = ("the step itself, on the GPU: every H2D call the pipeline makes beside the step's 14 launches costs it time whatever the bytes "
+                             "(one call per batch 0.19 ms per step, groups of up to half the ring %.3f, no copies 0.144: profiles/r06_ingest_probes.txt); "
+                             "the pipeline alone delivers %.1f M lines/s, the parsers %.0f M" % (out["ms_per_step"], out["pipeline_alone_lines_per_s"] / 1e6, out["parser"]["lines_per_s_all_threads"] / 1e6))
     return out
 
 
