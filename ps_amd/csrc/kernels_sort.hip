@@ -19,6 +19,10 @@ constexpr int RS_TPB = 256;
 #endif
 constexpr int RS_IPT = PS_RS_IPT;       // keys per thread (tile = 256 x RS_IPT pairs); -DPS_RS_IPT=8 for A/B builds
 constexpr int RS_TILE = RS_TPB * RS_IPT;  // 8192 keys per workgroup
+//  the run-head bits of a thread's keys live in one uint32_t (k_seg_fused, k_seg_emit); k_seg_scatter<., RS_IPT> keeps 2 x RS_TILE
+// words + its cursors in LDS: 75 KB at 32 -- inside gfx950's 160 KB, beyond any 64 KB part's
+static_assert(RS_IPT >= 1 && RS_IPT <= 32, "PS_RS_IPT: at most 32 keys per thread (one head bit each in a uint32_t)");
+static_assert((size_t)RS_TILE * 8 + 16384 <= 160 * 1024, "the staged scatter's LDS footprint must fit gfx950's 160 KB");
 constexpr int RS_WAVE_SPAN = RS_TILE / 4; // 2048 consecutive keys per wave
 constexpr int RS_SB_LOG = 5, RS_SB = 1 << RS_SB_LOG;   // tiles per superblock (second level of the digit counts)
 
