@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_r06
 mkdir -p $OUT
 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_full.log 2>&1; tail -2 $OUT/pytest_gpu_full.log
 python bench.py > $OUT/c2_bench_line.json 2> $OUT/c2_bench.err; cut -c1-300 $OUT/c2_bench_line.json
-python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/c2_bench_line_20steps.json 2> $OUT/c2_bench_20.err; cut -c1-300 $OUT/c2_bench_line_20steps.json
+T0=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/c2_bench_line_20steps.json 2> $OUT/c2_bench_20.err; echo "driver command wall seconds: $(( $(date +%s) - T0 ))" | tee $OUT/driver_command_seconds.txt; cut -c1-300 $OUT/c2_bench_line_20steps.json
 bash tools/profile_round.sh r06 > $OUT/profile_round.log 2>&1; tail -5 $OUT/profile_round.log
 PMC=1 bash tools/r06_adam.sh r06 > $OUT/adam.log 2>&1; tail -12 $OUT/adam.log; cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 python tools/gpu_timeline.py 64 > $OUT/c2_gpu_timeline.txt 2>&1
