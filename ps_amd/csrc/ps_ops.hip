@@ -378,7 +378,10 @@ int stamps_enable(int on) {
     g_stamps_on = false;
     g_stamp_names.clear();
     if (!on) return PS_OK;
-    if (!g_stamp_buf) HIPCHK(hipMalloc((void **)&g_stamp_buf, sizeof(unsigned long long) * 2 * STAMP_SLOTS));
+    // (a stamped kernel still in flight on some store's stream would race with the re-initialisation below -- every enable gets a
+    //  buffer of its own; the previous one is left to whatever still writes to it: 128 KB per enable, a measurement facility)
+    g_stamp_buf = nullptr;
+    HIPCHK(hipMalloc((void **)&g_stamp_buf, sizeof(unsigned long long) * 2 * STAMP_SLOTS));
     std::vector<unsigned long long> init(2 * STAMP_SLOTS);
     for (int i = 0; i < STAMP_SLOTS; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
     // (on a stream of its own, never the null stream -- ps_store.h: the default stream's hardware queue slows every multi-stream step
