@@ -909,7 +909,7 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
             std::vector<uint32_t> agree((size_t)4 * (nsh + 1));
             // (bit 1 of the mode word: this rank wants, and could do, the rows / gradient exchanges over mapped peer memory)
             const bool mp_want = g_mapped_peer && m->cfg.D % 4 == 0 && (nsh > 1 || g_mapped_peer == 2) && shard_push_grouped_ok(s, nsh);
-            agree[0] = (uint32_t)blk_words; agree[1] = (uint32_t)full_words; agree[2] = (uint32_t)ov_want | (mp_want ? 2u : 0u); agree[3] = PS_BLK_HDR;
+            agree[0] = (uint32_t)blk_words; agree[1] = (uint32_t)full_words; agree[2] = (uint32_t)ov_want | (mp_want ? 2u : 0u) | (sh.slot_world ? 4u : 0u); agree[3] = PS_BLK_HDR;      // (bit 2: the wide part of the flat buffer travels as per-worker slots)
             int arc = PS_OK;
             bool mp_all = true;
             if (hipMemcpyAsync(agree_dev, agree.data(), 16, hipMemcpyHostToDevice, s->stream) != hipSuccess) arc = ps_set_err(PS_E_HIP, "upload of the agreement words failed");
@@ -923,6 +923,9 @@ static int shard_step_begin(ps_model_t *m, const ps_batch_t *batch, const ps_com
                 if (a[0] != (uint32_t)blk_words || a[1] != (uint32_t)full_words || a[3] != PS_BLK_HDR)
                     return ps_set_err(PS_E_BAD_ARG, "rank %d exchanges id blocks of %u / %u words, this rank (%d) of %lld / %lld: the ranks' models differ in "
                                       "max_batch / max_nnz (or blk_factor)", r, a[0], a[1], rank, (long long)blk_words, (long long)full_words);
+                if (((a[2] >> 2) & 1u) != (sh.slot_world ? 1u : 0u))      // (ranks that all-reduce flat buffers of two layouts would add slots to dense vectors)
+                    return ps_set_err(PS_E_BAD_ARG, "rank %d reduces the wide part of the flat gradient %s, this rank (%d) %s: the ranks differ in wide_grad_mode or ps_tune_set(\"wide_slots\")",
+                                      r, (a[2] & 4u) ? "as per-worker slots" : "as dense vectors", rank, sh.slot_world ? "as per-worker slots" : "as dense vectors");
                 ov_want = std::min<int>(ov_want, (int)(a[2] & 1u));
                 mp_all = mp_all && (a[2] & 2u) != 0;
             }
