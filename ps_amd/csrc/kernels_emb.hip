@@ -616,6 +616,7 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
                                   // can start in a SEQ_TILE-entry tile); 16 keeps the short role at 64 row registers
 #define SEQ_LONG_GRID 2048        // long-key workgroups when the sort handed over a list of the long runs (round 4: 512 -> 2048, ~1500 runs above 16 entries
                                   // in a configs[1] batch: one run per workgroup instead of three in a row; 0.1333 -> 0.1325 ms / step)
+#define SUPER_LDS_FLOATS 4096     // the chunked order's super role: super partials of one round (16 KB)
 #define SEQ_LDS_FLOATS 4096       // per buffer: D * (3 * (64 / LPR) * SEQ_ILP + 4) <= 768 * VEC + 4 * D
 __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magic, uint32_t &rem) {
     uint32_t q = __umulhi(x, magic);            // magic = floor(2^32 / d): q is the quotient or one less
@@ -803,6 +804,7 @@ __device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_
         // runs above 128 chunks were pre-folded 32 chunks at a time by k_emb_super (one lane group walking the
         // 1968 partials of a 63k-entry key WAS the kernel: ~250 us); their super partials sit in partials2
         const bool two = nch > PS_EMB_SUPER_MIN;
+        if (two && a.super_blocks > 0) return;                  // (round 6: a workgroup of this launch's super role owns the key)
         const uint32_t step = two ? PS_EMB_SUPER : 1u;
         const float *src = two ? a.partials2 : a.partials;
         const uint32_t cnt = (nch + step - 1) / step;
@@ -837,6 +839,68 @@ __device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_
     finish_key<VEC>(a, uo, row, n, S, part);
 }
 
+// Round 6: the runs above PS_EMB_SUPER_MIN chunks as a ROLE of this launch (workgroups [0, a.super_blocks)) instead of a launch of their own
+// (k_emb_super_list, 8 us) in front of it -- at configs[4]'s shape that launch sat between two gaps of 14 and 7 us on the step's main chain,
+// the chip being full of the next step's presort (profiles/r06_c4_gpu_timeline.txt).  One workgroup per run of the sort's list: its lane
+// groups fold the run's chunk partials 32 at a time into super partials (k_emb_super_list's arithmetic, 8 loads in flight instead of 32: this
+// kernel's register budget) into LDS, `cap` super partials per round; lane group 0 folds them in order (reduce_one_key's arithmetic) as they
+// appear; compat mode walks the run a second time.  Same adds in the same order as the two-launch form.
+template <int VEC>
+__device__ __forceinline__ void super_key_run(const EmbBwdArgs &a, float *lds, int lds_floats, uint32_t u, uint32_t s0, uint32_t e0) {
+    const uint32_t CH = PS_EMB_CHUNK;
+    const uint32_t n = e0 - s0, nch = (n + CH - 1) / CH, ngrp = (nch + PS_EMB_SUPER - 1) / PS_EMB_SUPER;
+    const int lane64 = (int)(threadIdx.x & 63), gpw = 64 / a.LPR;
+    const bool act = lane64 / a.LPR < gpw;
+    const int part = lane64 % a.LPR;
+    const uint32_t grp = (threadIdx.x >> 6) * gpw + lane64 / a.LPR, ngl = 4 * gpw;         // this lane group, lane groups per workgroup
+    const uint32_t cap = (uint32_t)(lds_floats / a.D) < ngl ? (uint32_t)(lds_floats / a.D) : ngl;     // super partials per round (one per lane group at most)
+    const int npass = a.grad_mode == PS_GRAD_COMPAT ? 2 : 1;
+    Vec<VEC> S = Vec<VEC>::zero();
+    bool have = false;
+    for (int pass = 0; pass < npass; ++pass) {
+        for (uint32_t g0 = 0; g0 < ngrp; g0 += cap) {
+            const uint32_t g = g0 + grp;
+            if (act && grp < cap && g < ngrp) {
+                const uint32_t j = g * PS_EMB_SUPER, j1 = j + PS_EMB_SUPER < nch ? j + PS_EMB_SUPER : nch;
+                Vec<VEC> acc;
+                bool h = false;
+                for (uint32_t k0 = j; k0 < j1; k0 += PS_EMB_ILP) {
+                    Vec<VEC> p[PS_EMB_ILP];
+#pragma unroll
+                    for (int k = 0; k < PS_EMB_ILP; ++k) {
+                        const uint32_t jj = k0 + k < j1 ? k0 + k : j1 - 1;
+                        const uint32_t sc = s0 + jj * CH;
+                        p[k] = Vec<VEC>::load(a.partials + ((size_t)2 * (sc / CH) + (jj == 0 ? 1 : 0)) * a.D + part * VEC);
+                    }
+#pragma unroll
+                    for (int k = 0; k < PS_EMB_ILP; ++k)
+                        if (k0 + k < j1) {
+                            if (h) { VFOR(i) acc.at(i) = p[k].get(i) + acc.at(i); }
+                            else { acc = p[k]; h = true; }
+                        }
+                }
+                acc.store(lds + (size_t)grp * a.D + part * VEC);
+            }
+            __syncthreads();
+            if (grp == 0 && act) {
+                const uint32_t cnt = ngrp - g0 < cap ? ngrp - g0 : cap;
+                for (uint32_t q = 0; q < cnt; ++q) {
+                    const Vec<VEC> v = Vec<VEC>::load(lds + (size_t)q * a.D + part * VEC);
+                    if (have) { VFOR(i) S.at(i) = v.get(i) + S.at(i); }
+                    else { S = v; have = true; }
+                }
+            }
+            __syncthreads();
+        }
+        if (grp == 0 && act) { VFOR(i) S.at(i) = div_rn(S.get(i), (float)((pass == 0 ? 1u : 2u) * n)); }
+    }
+    if (grp == 0 && act) {
+        const uint32_t row = a.sorted_key[s0];
+        const uint32_t uo = a.out_slot ? a.out_slot[a.sorted_ent[s0]] : u;
+        finish_key<VEC>(a, uo, row, n, S, part);
+    }
+}
+
 // SEQ: the reference's summation order for every key.  Blocks [0, a.long_blocks) are the long-key waves above,
 // the rest handle one key per lane group as before and leave keys above PS_EMB_CHUNK to them.
 #ifdef PS_EMB_TIMING      // (tools/emb_timing.sh: every workgroup's start and end, wall clock; the product build carries none)
@@ -850,7 +914,7 @@ struct EmbWgTimer {};
 #endif
 template <int VEC, bool BAG, bool SEQ>
 __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : 4];
+    __shared__ __attribute__((aligned(16))) float seq_lds[SEQ ? 2 * SEQ_LDS_FLOATS : SUPER_LDS_FLOATS];
     EndWait end_wait(a.end_wait, a.end_val, a.bound);       // (declared first: runs after the stamp's end; every return path)
 #ifdef PS_EMB_TIMING
     EmbWgTimer wg_timer;
@@ -896,11 +960,20 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         long_key_run<VEC, BAG>(a, seq_lds, u, s0, e0);
         return;
     }
+    if (!SEQ && (int)blockIdx.x < a.super_blocks) {
+        const uint32_t nl = *a.nlong;
+        for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.super_blocks) {
+            const uint32_t *ll = a.long_list + 3 * (size_t)i;
+            if ((ll[2] - ll[1] + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK <= PS_EMB_SUPER_MIN) continue;
+            super_key_run<VEC>(a, seq_lds, SUPER_LDS_FLOATS, ll[0], ll[1], ll[2]);
+        }
+        return;
+    }
     if (SEQ && (a.ablate & 4)) return;                          // measurement: the kernel without its short-key role
     // One lane group per key, GRID-STRIDE: the launcher cannot know the number of unique keys (it lives on the device) and
     // used to size the grid for the worst case, one key per entry -- at a multi-hot batch 50 k workgroups of which 40 k
     // found nothing to do; dispatching them was a sixth of the kernel.  Now a bounded grid walks the keys.
-    const int sb = (int)blockIdx.x - (SEQ ? a.long_blocks : 0);
+    const int sb = (int)blockIdx.x - (SEQ ? a.long_blocks : a.super_blocks);
     const int lane64 = (int)(threadIdx.x & 63);
     const int gpw = 64 / a.LPR;
     if (lane64 / a.LPR >= gpw) return;
@@ -1324,6 +1397,7 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_super_in_update = 1;  // ps_tune_set("super_in_update", 0): the very long runs' super partials by a launch of their own (k_emb_super_list) again
 int g_emb_lxcd = 1;         // ps_tune_set("emb_lxcd", 0): the long-key role takes the sort's list in order, any XCD (rounds 4-5)
 int g_emb_xcd = 1;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
 int g_fwd_order = 3;        // ps_tune_set("fwd_order", bits): multi-hot gather's bag order (EmbFwdArgs.order; 0: sample-major round robin -- 0.354 against 0.347 ms / step at configs[4]'s shape, the gather 47.8 -> 42.1 us)
@@ -1549,6 +1623,8 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     // the short-key role: enough workgroups to fill the chip a few times over, never more than one lane group per entry
     a.short_blocks = gr < g_emb_short_grid ? gr : g_emb_short_grid;
     // XCD-affine order (emb_vblock): grids rounded up to multiples of 8 (surplus workgroups find nothing to do)
+    // chunked order: the runs above PS_EMB_SUPER_MIN chunks as a role of the reduce launch (super_key_run) when the sort listed them
+    a.super_blocks = (!a.seq_order && a.long_runs && a.long_list && g_super_in_update) ? 64 : 0;
     a.xcd = (g_emb_xcd && a.short_blocks >= 64 && a.long_blocks % 8 == 0) ? g_emb_xcd : 0;
     // by field pair when the field sort left its table (single-hot batches; ps_tune_set("emb_xcd", 1 | 2): by eighths of the keys / entries again)
     if (a.xcd == 3 && !(a.seq_order && a.long_list && a.ftab && a.F <= 64)) a.xcd = 1;
@@ -1562,9 +1638,10 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
             break;                                                                             \
         }                                                                                      \
         hipLaunchKernelGGL((k_emb_partials<V, BG>), dim3(gpx), dim3(256), 0, st, a);            \
-        if (a.long_runs && a.long_list) hipLaunchKernelGGL((k_emb_super_list<V>), dim3(128), dim3(256), 0, st, a); \
+        if (a.super_blocks) {}                                                                  \
+        else if (a.long_runs && a.long_list) hipLaunchKernelGGL((k_emb_super_list<V>), dim3(128), dim3(256), 0, st, a); \
         else if (a.long_runs) hipLaunchKernelGGL((k_emb_super<V>), dim3(gpx), dim3(256), 0, st, a);  \
-        hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(a.short_blocks), dim3(256), 0, st, a); \
+        hipLaunchKernelGGL((k_emb_reduce_update<V, BG, false>), dim3(a.super_blocks + a.short_blocks), dim3(256), 0, st, a); \
     } while (0)
     if (vec == 4) { if (bag) EMB_BWD_LAUNCH(4, true); else EMB_BWD_LAUNCH(4, false); }
     else { if (bag) EMB_BWD_LAUNCH(1, true); else EMB_BWD_LAUNCH(1, false); }

@@ -284,6 +284,7 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "keys_grid") == 0) { g_keys_grid = value; return PS_OK; }
     if (strcmp(knob, "emb_xcd") == 0) { g_emb_xcd = value; return PS_OK; }
     if (strcmp(knob, "emb_lxcd") == 0) { g_emb_lxcd = value; return PS_OK; }
+    if (strcmp(knob, "super_in_update") == 0) { g_super_in_update = value; return PS_OK; }
     if (strcmp(knob, "mapped_peer") == 0) { g_mapped_peer = value; return PS_OK; }
     if (strcmp(knob, "mapped_ablate") == 0) { g_mapped_ablate = value; return PS_OK; }
     if (strcmp(knob, "mapped_fuse") == 0) { g_mapped_fuse = value; return PS_OK; }
