@@ -1614,7 +1614,6 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     const int gr = cdiv((int64_t)cdiv(a.nnz, gpw) * 64, 256);  // upper bound on unique keys; extra groups exit on *nseg
     const bool bag = a.ent_bag != nullptr;
     a.ablate = g_seq_ablate;
-    if (!a.seq_order) { a.ts_partials = stamp_next("emb_partials"); if (a.long_runs) a.ts_super = stamp_next("emb_super"); }
     a.ts = stamp_next("emb_bwd_update");
     a.flag = lo ? lo->flag : nullptr; a.flag_val = lo ? lo->flag_val : 0;      // "this launch has started" (LaunchOpts, ps_common.h)
     // one workgroup per SEQ_TILE-entry tile looks for a long run starting in it -- or, with the sort's list of the
@@ -1625,6 +1624,7 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     // XCD-affine order (emb_vblock): grids rounded up to multiples of 8 (surplus workgroups find nothing to do)
     // chunked order: the runs above PS_EMB_SUPER_MIN chunks as a role of the reduce launch (super_key_run) when the sort listed them
     a.super_blocks = (!a.seq_order && a.long_runs && a.long_list && g_super_in_update) ? 64 : 0;
+    if (!a.seq_order) { a.ts_partials = stamp_next("emb_partials"); if (a.long_runs && !a.super_blocks) a.ts_super = stamp_next("emb_super"); }
     a.xcd = (g_emb_xcd && a.short_blocks >= 64 && a.long_blocks % 8 == 0) ? g_emb_xcd : 0;
     // by field pair when the field sort left its table (single-hot batches; ps_tune_set("emb_xcd", 1 | 2): by eighths of the keys / entries again)
     if (a.xcd == 3 && !(a.seq_order && a.long_list && a.ftab && a.F <= 64)) a.xcd = 1;
