@@ -475,6 +475,7 @@ struct ps_ingest {
     struct Slot {
         char *host = nullptr, *dev = nullptr;         // pinned | HBM
         hipEvent_t consumed = nullptr;                // the kernels that read the slot were enqueued before this (store stream)
+        hipEvent_t consumed_wait = nullptr;           // ... as recorded for the group of slots released together (the last one's `consumed`)
         hipEvent_t copied = nullptr;                  // the slot's H2D copy has landed (copy stream)
         hipEvent_t wait_ev = nullptr;                 // ... as recorded for the GROUP this batch crossed the link in (its last slot's `copied`)
         bool consumed_recorded = false;
@@ -486,7 +487,7 @@ struct ps_ingest {
     };
     std::vector<Slot> slot;
     char *host_all = nullptr, *dev_all = nullptr;     // the ring's blocks, slot after slot
-    int ring = 0;
+    int ring = 0, release_every = 1;                 // slots go back to the parsers this many at a time (one event on the training stream per group)
     int64_t nbatches = 0;
     // progress, all under mu: batch b may be PARSED into its slot once free_upto > b; it is parsed when parsed[b % ring] == b,
     // in HBM when ready_upto > b
@@ -646,7 +647,7 @@ void copier_loop(ps_ingest *g) {
             hipError_t e = hipSuccess;
             for (int k = 0; k < group && e == hipSuccess; ++k) {
                 ps_ingest::Slot &T = g->slot[(size_t)((b + k) % g->ring)];
-                if (T.consumed_recorded) e = hipEventSynchronize(T.consumed);
+                if (T.consumed_recorded) e = hipEventSynchronize(T.consumed_wait);
             }
             if (S.compact) {
                 const size_t w = g->block - g->off_dense;          // [dense | labels | ids32] to the end of the block
@@ -681,7 +682,7 @@ void copier_loop(ps_ingest *g) {
             // copied, the copy has landed -- the training thread needs no cross-stream event (cross-thread event WAITS proved
             // unreliable in round 2: occasional stale batches)
             hipError_t e = hipSuccess;
-            if (S.consumed_recorded) e = hipEventSynchronize(S.consumed);
+            if (S.consumed_recorded) e = hipEventSynchronize(S.consumed_wait);
             if (timing) t_sync += ing_now() - c1;
             e = issue_copy(g, S, e);
             if (e == hipSuccess) e = hipEventRecord(S.copied, g->copy_stream);
@@ -771,7 +772,9 @@ int ingest_alloc(ps_ingest *g) {
     g->off_ids32 = up(g->off_labels + sizeof(float) * nb);
     g->block = up(g->off_ids32 + sizeof(int32_t) * nb * (c.F > 0 ? c.F : 1));
     const int nt = c.threads > 1 ? c.threads : 1;
-    g->ring = std::max(4, std::min(64, 2 * nt));
+    g->ring = std::max(4, std::min(128, 2 * nt));
+    g->release_every = getenv("PS_INGEST_REL") ? std::max(1, atoi(getenv("PS_INGEST_REL"))) : (g->ring >= 32 ? 4 : 1);
+    if (g->release_every > g->ring / 4) g->release_every = std::max(1, g->ring / 4);
     g->slot.resize((size_t)g->ring);
     g->parsed.assign((size_t)g->ring, -1);
     // ONE pinned and ONE device allocation for the whole ring: neighbouring slots are neighbouring blocks, so a GROUP of parsed batches
@@ -783,7 +786,7 @@ int ingest_alloc(ps_ingest *g) {
         S.host = g->host_all + k * g->block; S.dev = g->dev_all + k * g->block;
         HIPCHK(hipEventCreateWithFlags(&S.consumed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
-        S.wait_ev = S.copied;
+        S.wait_ev = S.copied; S.consumed_wait = S.consumed;
     }
     HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
     return PS_OK;
@@ -876,15 +879,22 @@ extern "C" int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out) {
     ingest_start(g);
     // batch b - 2 goes back to the parsers: its consumers were enqueued on the store's stream before this call; the copier waits
     // (host side) for this event before it overwrites the slot's HBM block
-    if (b >= 2) {
-        ps_ingest::Slot &R = g->slot[(size_t)((b - 2) % g->ring)];
+    // (... `rel` batches at a time: every event recorded on the training stream is a barrier packet between two of its kernels, 3-4 us of the
+    //  step; one event stands for the slots of the `rel` batches handed out before it)
+    const int rel = g->release_every;
+    if (b >= 2 && (b - 1) % rel == 0) {
+        const int64_t last = b - 2, first = std::max<int64_t>(0, last - rel + 1);
+        ps_ingest::Slot &R = g->slot[(size_t)(last % g->ring)];
         static const bool noevent = getenv("PS_INGEST_NOEVENT") != nullptr;      // (measurement only: unsafe)
-        if (!noevent) { HIPCHK(hipEventRecord(R.consumed, g->s->stream)); R.consumed_recorded = true; }
+        if (!noevent) {
+            HIPCHK(hipEventRecord(R.consumed, g->s->stream));
+            for (int64_t q = first; q <= last; ++q) { ps_ingest::Slot &Q = g->slot[(size_t)(q % g->ring)]; Q.consumed_wait = R.consumed; Q.consumed_recorded = true; }
+        }
         {
             std::lock_guard<std::mutex> l(g->mu);
-            g->free_upto = b - 2 + g->ring + 1;
+            g->free_upto = last + g->ring + 1;
         }
-        g->cv_free.notify_one();
+        g->cv_free.notify_all();
     }
     if (g->inline_copy) {
         // Every parsed batch that has not been sent yet is sent NOW, by this thread (the one that enqueues the step): a copier thread's HIP
@@ -905,7 +915,7 @@ extern "C" int ps_ingest_next(ps_ingest_t *g, ps_batch_t *out) {
             ps_ingest::Slot &N = g->slot[(size_t)(nb % g->ring)];
             if (N.rc == PS_OK && N.B > 0 && !nocopy) {
                 hipError_t e = hipSuccess;
-                if (N.consumed_recorded) e = hipStreamWaitEvent(g->copy_stream, N.consumed, 0);
+                if (N.consumed_recorded) e = hipStreamWaitEvent(g->copy_stream, N.consumed_wait, 0);
                 e = issue_copy(g, N, e);
                 if (e == hipSuccess) e = hipEventRecord(N.copied, g->copy_stream);
                 if (e != hipSuccess) { N.rc = PS_E_HIP; snprintf(N.err, sizeof N.err, "ingest H2D: %s", hipGetErrorString(e)); }
@@ -938,7 +948,7 @@ extern "C" int ps_ingest_reset(ps_ingest_t *g) {
     // (the blocks handed out last may still be read by kernels in flight: the next epoch's copies into them wait for the store's stream)
     HIPCHK(hipSetDevice(g->s->device));
     ingest_rewind(g);
-    for (auto &S : g->slot) { HIPCHK(hipEventRecord(S.consumed, g->s->stream)); S.consumed_recorded = true; }
+    for (auto &S : g->slot) { HIPCHK(hipEventRecord(S.consumed, g->s->stream)); S.consumed_wait = S.consumed; S.consumed_recorded = true; }
     return PS_OK;
 }
 
