@@ -511,10 +511,12 @@ def leg_sharded_n1(args):
     cfg["zipf"] = args.zipf
     cfg["idgen"] = args.idgen
     steps = min(args.steps, 1000)
-    ct = {}
-    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2, 3), with_info=True, coll_times=ct)
+    ct, regs = {}, {}
+    res, info = sharded.sharded_n1_modes(cfg, synth_batch, 0, steps, modes=(0, 2, 3), with_info=True, coll_times=ct, regions=regs)
     return {"workload": "configs[2]'s sharded step on 1 GPU (1-rank table), batch %d; %d steps after 300 priming steps (268 + a wait + 32)" % (cfg["B"], steps),
             "ms_per_step": {k: round(v, 5) for k, v in res.items()},
+            # (under 200 steps: the median of five regions of that many steps, all five here)
+            "regions_ms": regs,
             "wire_cost_ms_per_step": round(res["rccl_with_own_keys_in_place"] - res["device_copies"], 5),
             "examples_per_s": {k: cfg["B"] / (1e-3 * v) for k, v in res.items()},
             # device time of every collective of the step by kind (HIP events around each call, a pass of its own)
