@@ -537,8 +537,9 @@ def sharded_n1_leg(args):
         if r.returncode != 0 or not lines:
             return {"error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-400:])}
         return json.loads(lines[-1])
-    except subprocess.TimeoutExpired:
-        return {"error": "the sharded_n1 leg did not finish within 180 s"}
+    except subprocess.TimeoutExpired as e:
+        tail = (e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or ""))[-600:]
+        return {"error": "the sharded_n1 leg did not finish within 180 s", "stderr_tail": tail}
 
 
 def gather_roofline(kv, args):
