@@ -262,4 +262,5 @@ struct PushApplyArgs {
     unsigned long long *ts_mark, *ts_apply;   // stamp slots, set by the launcher
                      // set by the launcher: the mark pass ran in an earlier launch of this push (another updater's)
 };
-int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo = nullptr);      // lo: flag (the first launch announces its start)
+struct PeerPutArgs;
+int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo = nullptr, const PeerPutArgs *put = nullptr);      // put: the mapped-peer gradient put as a role of the mark launch (N >= 2)      // lo: flag (the first launch announces its start)

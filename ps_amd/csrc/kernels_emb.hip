@@ -14,6 +14,7 @@
 
 #include "ps_common.h"
 #include "kernels_emb.h"
+#include "ps_put.h"
 
 #ifndef PS_GEMM_LAB
 #define PS_GEMM_LAB 0
@@ -1093,6 +1094,24 @@ __global__ __launch_bounds__(256) void k_push_mark(PushApplyArgs a) {
 }
 
 // ONE: a single pushing worker (its rows are unique): no mark pass, no mask -- every entry is its row's only push
+// Mapped peer at N >= 2 (round 6): the worker-side gradient put as a ROLE of the owner push's first launch -- workgroups [0, PS_PUT_WGS) store this
+// rank's gradients into the owners' receive regions, raise their flag words and workgroup 0 waits for the peers' (ps_put.h); the rest mark the
+// pushed rows from the id lists, which are here already.  The two roles do not depend on each other and the kernel's end is the join: the
+// apply launch behind it reads gradients that have all landed.  One launch and one boundary less on the step's critical chain than a put of its own.
+__global__ __launch_bounds__(256) void k_push_mark_put(PushApplyArgs a, PeerPutArgs q) {
+    StampScope stamp(a.ts_mark);
+    if (blockIdx.x < PS_PUT_WGS) { peer_put_body(q, blockIdx.x); return; }
+    const unsigned int mb = blockIdx.x - PS_PUT_WGS;
+    if (a.flag && mb == 0 && threadIdx.x == 0) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t e = (int64_t)mb * 256 + threadIdx.x;
+    if (e >= a.n) return;
+    const int p = push_peer_of(a, (uint32_t)e);
+    const uint32_t r = a.rows_p[p][e - a.peer_start[p]];
+    if ((int64_t)r >= a.R) { atomicAdd(a.err, 1); return; }
+    a.pos[(size_t)p * a.R + r] = (uint32_t)e;
+    atomicOr(&a.mask[r], 1u << p);
+}
+
 template <int VEC, bool ONE>
 __global__ __launch_bounds__(256) void k_push_apply(PushApplyArgs a) {
     StampScope stamp(a.ts_apply);
@@ -1851,9 +1870,10 @@ int launch_rows_apply(RowsApplyArgs a, int64_t n, hipStream_t st) {
     return PS_OK;
 }
 
-int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo) {
+int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo, const PeerPutArgs *put) {
     if (lo) lo->launched = false;
-    if (a.n <= 0) return PS_OK;
+    if (put && a.npeers < 2) return ps_set_err(PS_E_BAD_ARG, "the gradient put rides on the mark launch: two workers at least");
+    if (a.n <= 0 && !put) return PS_OK;
     a.flag = lo ? lo->flag : nullptr; a.flag_val = lo ? lo->flag_val : 0u;
     const int vec = a.D % 4 == 0 ? 4 : 1;
     a.LPR = a.D / vec;
@@ -1866,7 +1886,9 @@ int launch_push_apply(PushApplyArgs a, hipStream_t st, LaunchOpts *lo) {
         else hipLaunchKernelGGL((k_push_apply<1, true>), dim3(g), dim3(256), 0, st, a);
     } else {
         a.ts_mark = stamp_next("push_mark"); a.ts_apply = stamp_next("push_apply");
-        hipLaunchKernelGGL(k_push_mark, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
+        if (put) hipLaunchKernelGGL(k_push_mark_put, dim3(PS_PUT_WGS + cdiv(a.n, 256)), dim3(256), 0, st, a, *put);
+        else hipLaunchKernelGGL(k_push_mark, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
+        if (a.n <= 0) { HIPCHK(hipGetLastError()); if (lo) lo->launched = true; return PS_OK; }      // (nothing was pushed to this owner: the put alone)
         if (vec == 4) hipLaunchKernelGGL((k_push_apply<4, false>), dim3(g), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_push_apply<1, false>), dim3(g), dim3(256), 0, st, a);
     }

@@ -898,7 +898,7 @@ bool shard_push_grouped_ok(const ps_store *s, int npeers) {
 // PServer.push + psUpdate for lists that lie grouped by pushing worker, every worker's part where it is (rows_p[p],
 // grads_p[p]: counts[p] entries); lo: the first launch announces its start (LaunchOpts.flag)
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
-                           int is_async, bool bump_step, LaunchOpts *lo) {
+                           int is_async, bool bump_step, LaunchOpts *lo, const PeerPutArgs *put) {
     if (lo) lo->launched = false;
     if (!s->emb.W || !s->emb.state) return ps_set_err(PS_MISSING, "no embedding tables with updater state");
     // (tables reserved earlier -- a model that decided for this push at its first begin -- stay good whatever the knob says now)
@@ -914,12 +914,12 @@ int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const flo
         n += counts[p];
     }
     a.peer_start[npeers] = (uint32_t)n;
-    if (n > 0) {
+    if (n > 0 || put) {        // (put: this rank's gradient put rides on the launch even when nobody pushed anything to this owner)
         if (npeers > 1 && !reserved) PSCHK(shard_push_reserve(s, npeers));      // a no-op after the first step (ps_shard_step_begin reserves up front)
         a.D = s->emb.D; a.is_async = is_async ? 1 : 0; a.npeers = npeers; a.n = n; a.R = s->emb.total_rows;
         a.mask = s->push_mask; a.pos = s->push_pos;
         a.W = s->emb.W; a.state = s->emb.state; a.err = s->err_dev;
-        PSCHK(launch_push_apply(a, s->stream, lo));
+        PSCHK(launch_push_apply(a, s->stream, lo, put));
     }
     if (bump_step) s->global_step++;     // psUpdate: globalStep.incrementAndGet()  (net/PServer.java:213)
     return PS_OK;

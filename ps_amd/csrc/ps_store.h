@@ -376,6 +376,7 @@ void shard_mapped_release(ps_model *m);     // ps_comm.hip: unmap the peers' buf
 extern int g_mapped_peer, g_mapped_ablate, g_mapped_fuse, g_mapped_lists;
 int shard_serve_pull_lists(ps_store *s, const uint32_t *const *rows_p, const int64_t *counts, int npeers, float *rows_out_dev,
                            LaunchOpts *lo, const GatherSlots *gs = nullptr, const GatherPut *gp = nullptr);       // lo: wait (an END wait of the gather's launch)
+struct PeerPutArgs;
 int shard_apply_push_lists(ps_store *s, const uint32_t *const *rows_p, const float *const *grads_p, const int64_t *counts, int npeers,
-                           int is_async, bool bump_step, LaunchOpts *lo);
+                           int is_async, bool bump_step, LaunchOpts *lo, const PeerPutArgs *put = nullptr);     // put: ps_put.h, kernels_emb.h launch_push_apply
 int finish_step(ps_model *m, float *loss);
