@@ -61,12 +61,6 @@ struct LastBwdArgs {                   // FcLayer.backward of the out = 1 layer 
     int prio;                          // raise the waves' priority (the fused step's main chain)
 };
 int launch_last_bwd(const LastBwdArgs &a, int nsplit, hipStream_t st);
-// the head + this layer's backward as the prologue of the first delta GEMM's launch (kernels_gemm.hip k_gemm_nt_head; LaunchOpts.head)
-struct HeadFuse {
-    HeadArgs h; LastBwdArgs q;
-    unsigned int *ctr; unsigned int nowners;      // a device word, zero between launches: counts the workgroups that stored a slab (B / q.chunk of them)
-};
-int gemm_nt_head_ok(int M, int N, int K, const HeadArgs &h, const LastBwdArgs &q);
 // FcLayer.forward x 2 (+ the head and the out = 1 layer's backward) of 16-row panels in one launch (kernels_panel.hip)
 #define PS_PANEL_ROWS 16
 struct FwdPanelArgs {

@@ -26,8 +26,6 @@
 
 namespace {
 
-#include "kernels_head.inc"      // (the head and the out = 1 layer's backward: k_gemm_nt_head runs them for its rows)
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct NtArgs {
@@ -103,14 +101,8 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 //   * the masks / LDS writes / next global loads are dealt out one chunk per MFMA of the first group, so the VALU work sits
 //     in the shadow of a running MFMA instead of between two groups.
 // Same products in the same order per accumulator as PIPE = 0: bit-identical results.
-// HEADA (k_gemm_nt_head, the first delta GEMM of the fused step): the A operand -- the out = 1 layer's delta_prev = (w_last[k] * delta_L[row]) *
-// relu'(x[row][k]), layer/FcLayer.java:108 on one output -- is never read from memory: a.A is that layer's INPUT x, the chunk is turned into
-// delta_prev on its way to LDS from hd[row] (the head's delta_L of this tile's rows) and hw[k] (the layer's weights), both in LDS.  The same two
-// roundings per element as kernels_head.inc last_bwd_body: the products and their order per accumulator are unchanged -- bit-identical.
-template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0, int HEADA = 0>
-__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs,
-                                             const float *const hd = nullptr, const float *const hw = nullptr) {
-    static_assert(!HEADA || PIPE == 3, "HEADA: the default loop");
+template <int WM, int WN, int TM, int TN, int BKT, int KS, int PIPE = 0>
+__device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, const int n0, float *const As, float *const Bs) {
     constexpr int LDB = (PIPE == 3 && BKT == 16 && KS == 1) ? 16 : BKT + 4;              // (row length: see SWZ below)
     constexpr int ASZ = WM * TM * 32 * LDB, BSZ = WN * TN * 32 * LDB;                    // floats per LDS buffer
     constexpr int NTH = WM * WN * 64 * KS;
@@ -133,8 +125,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     // waits in registers for its LDS slot -- one slab of prefetch does not cover the ~1.5 us a
     // load takes under load when a slab is only ~0.4 us of MFMA work (measured: 50 % of peak).
     // The sets are named (not indexed by t) so they stay in registers; the loop is unrolled by 2.
-    constexpr int A_R = A_F4 * (HEADA ? 2 : 1);       // (HEADA: chunk i of x in ra[i], the weights of its four columns in ra[A_F4 + i])
-    float4 ra0[A_R], rb0[B_F4], ra1[A_R], rb1[B_F4];
+    float4 ra0[A_F4], rb0[B_F4], ra1[A_F4], rb1[B_F4];
     // Loads are UNCONDITIONAL and branch-free: rows beyond the operand are clamped to its last row (their products
     // land in output rows/columns the epilogue never stores), columns beyond K are clamped to the last float4 and
     // zeroed with a bit mask.  A select (ok ? v : 0) around the load was turned into exec-masked branches by
@@ -143,7 +134,6 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     // (measured: 42..53 % of the f32 MFMA peak on the FC shapes whatever the tile shape).
     const float *pa[A_F4], *pb[B_F4];
     int ca[A_F4], cb[B_F4], ar[A_F4];
-    float hdr[A_F4];                                  // (HEADA: delta_L of the chunk's row)
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
         const int e = tid + i * NTH;
@@ -152,17 +142,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         ca[i] = (e % RF4) * 4;
         pa[i] = a.A + (size_t)r * a.lda;
         ar[i] = r;
-        hdr[i] = HEADA ? hd[e / RF4 < BM ? e / RF4 : BM - 1] : 0.f;
     }
-    // delta_prev of four columns from x, the weights and the row's delta_L (kernels_head.inc last_bwd_body, op for op)
-    auto atrans = [](const float4 x, const float4 w, const float d) -> float4 {
-        float4 v;
-        v.x = w.x * d; v.x *= x.x > 0.f ? 1.f : 0.f;
-        v.y = w.y * d; v.y *= x.y > 0.f ? 1.f : 0.f;
-        v.z = w.z * d; v.z *= x.z > 0.f ? 1.f : 0.f;
-        v.w = w.w * d; v.w *= x.w > 0.f ? 1.f : 0.f;
-        return v;
-    };
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
         const int e = tid + i * NTH;
@@ -183,14 +163,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
     };
     // (the mask is applied when the registers go to LDS, a slab or two later: touching the loaded value in gload
     // would put the wait for it right behind the load)
-    auto gload = [&](int kt, float4 (&ra)[A_R], float4 (&rb)[B_F4]) {
+    auto gload = [&](int kt, float4 (&ra)[A_F4], float4 (&rb)[B_F4]) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int c = k0 + ca[i];
             if (PS_GEMM_ABLATE & 512) ra[i] = *reinterpret_cast<const float4 *>(emu_src(ar[i], kt, ca[i]));
             else ra[i] = *reinterpret_cast<const float4 *>(pa[i] + (c < a.K ? c : a.K - 4));
-            if constexpr (HEADA) ra[A_F4 + i] = *reinterpret_cast<const float4 *>(hw + (c < a.K ? c : a.K - 4));
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) { const int c = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (c < a.K ? c : a.K - 4)); }
@@ -203,15 +182,13 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         v.z = __int_as_float(__float_as_int(v.z) & m); v.w = __int_as_float(__float_as_int(v.w) & m);
         return v;
     };
-    auto swrite = [&](int buf, int kt, const float4 (&ra)[A_R], const float4 (&rb)[B_F4]) {
+    auto swrite = [&](int buf, int kt, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4]) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int e = tid + i * NTH;
-            float4 v = ra[i];
-            if constexpr (HEADA) v = atrans(ra[i], ra[A_F4 + i], hdr[i]);
             if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(v, k0 + ca[i]);
+                *reinterpret_cast<float4 *>(As + buf * ASZ + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(ra[i], k0 + ca[i]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
@@ -299,24 +276,21 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         constexpr int NCH = A_F4 + B_F4;                    // operand chunks (float4) per thread and slab
         float4 FA[PIPE == 2 ? 4 : 2][TM], FB[PIPE == 2 ? 4 : 2][TN];          // fragment sets (indexed by compile-time constants only: registers)
         // chunk c of a slab: c < A_F4 -> A chunk c, else B chunk c - A_F4
-        auto gload1 = [&](int kt2, float4 (&ra)[A_R], float4 (&rb)[B_F4], int c) {
+        auto gload1 = [&](int kt2, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int c) {
             const int k0 = kt2 * BKT;
             if (c < A_F4) {
                 const int cc = k0 + ca[c];
                 if (PS_GEMM_ABLATE & 512) ra[c] = *reinterpret_cast<const float4 *>(emu_src(ar[c], kt2, ca[c]));
                 else ra[c] = *reinterpret_cast<const float4 *>(pa[c] + (cc < a.K ? cc : a.K - 4));
-                if constexpr (HEADA) ra[A_F4 + c] = *reinterpret_cast<const float4 *>(hw + (cc < a.K ? cc : a.K - 4));     // (LDS; used two slabs later)
             }
             else { const int i = c - A_F4; const int cc = k0 + cb[i]; rb[i] = *reinterpret_cast<const float4 *>(pb[i] + (cc < a.K ? cc : a.K - 4)); }
         };
-        auto swrite1 = [&](int oa, int ob, int kt2, const float4 (&ra)[A_R], const float4 (&rb)[B_F4], int c) {
+        auto swrite1 = [&](int oa, int ob, int kt2, const float4 (&ra)[A_F4], const float4 (&rb)[B_F4], int c) {
             const int k0 = kt2 * BKT;
             if (c < A_F4) {
                 const int e = tid + c * NTH;
-                float4 v = ra[c];
-                if constexpr (HEADA) v = atrans(ra[c], ra[A_F4 + c], hdr[c]);
                 if ((BM * RF4) % NTH == 0 || e < BM * RF4)
-                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(v, k0 + ca[c]);
+                    *reinterpret_cast<float4 *>(As + oa + (e / RF4) * LD + wpos(e / RF4, e % RF4) * 4) = masked(ra[c], k0 + ca[c]);
             } else {
                 const int i = c - A_F4, e = tid + i * NTH;
                 if ((BN * RF4) % NTH == 0 || e < BN * RF4)
@@ -367,7 +341,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
         constexpr bool CROSS = PIPE != 4;                   // fragments of the next slab are read across the barrier
         constexpr int WAHEAD = CROSS ? 2 : 1;               // the slab written while slab kt is multiplied
         static_assert(NG >= LOOK && (2 * NG) % NS == 0, "fragment sets must be back at set 0 after two slabs");
-        auto slab = [&](auto p0c, auto fullc, float4 (&ra)[A_R], float4 (&rb)[B_F4], int kt2, int oca, int ocb, int ona, int onb, int owa, int owb) {
+        auto slab = [&](auto p0c, auto fullc, float4 (&ra)[A_F4], float4 (&rb)[B_F4], int kt2, int oca, int ocb, int ona, int onb, int owa, int owb) {
             constexpr int P0 = decltype(p0c)::value;
             constexpr bool FULL = decltype(fullc)::value;
             static_for<NG>([&](auto gc) {
@@ -421,7 +395,7 @@ __device__ __forceinline__ void gemm_nt_tile(const NtArgs &a, const int m0, cons
             if (kt < nk) slab(I0, NO, ra1, rb1, kt, 0, 0, 0, 0, ASZ, BSZ);
         } else if constexpr (PIPE == 3) {
             static_assert(NG % 2 == 0, "PIPE = 3: an even number of fragment groups per slab (the fragment sets start every slab at set 0)");
-            float4 ra2[A_R], rb2[B_F4];
+            float4 ra2[A_F4], rb2[B_F4];
             gload(0, ra0, rb0);
             gload(1, ra1, rb1);
             gload(2, ra2, rb2);
@@ -540,74 +514,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void k_gemm_nt(NtArgs a) {
     const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     gemm_nt_tile<WM, WN, TM, TN, BKT, KS, PIPE>(a, (wg / tn) * BM, (wg % tn) * BN, As, Bs);     // consecutive ids: the N tiles of one M tile
 }
-
-// The fused step's head + the out = 1 layer's backward + the first delta GEMM in ONE launch (ps_tune_set("head_in_delta", 1); VERDICT r5 next #3a).
-// On the main chain these were two launches, 8.1 + 18.7 us, with a 3.7 us boundary between them (profiles/r06_c2_gpu_timeline.txt).  Here every
-// workgroup of the GEMM runs the head of ITS 64 rows first (eight lanes per sample, kernels_head.inc -- the same operations, so delta_L is the same
-// bits whichever workgroup computes it; the tile columns of a row panel repeat it, which costs loads that hit in L2), keeps delta_L in LDS and
-// builds its A operand from it (gemm_nt_tile HEADA): delta_prev is never read.  It is still WRITTEN, once -- the dW GEMM of that layer reads it on
-// side chain 1 -- together with everything else the two launches left in memory (P, the loss terms, delta_L, the out = 1 layer's dW slabs): tile
-// column c of a panel owns the panel's c-th slab of q.chunk rows (the head's stores for those rows, last_bwd_body for that slab), with stores that
-// go through to memory.  What used to be released by "the first delta GEMM has started" (both side chains' spinners, ps_model.hip) is released by the
-// LAST owner instead: a counter of the owners, the one that completes it raises the launch's flag.
-#define PS_HEADW_MAX 1024
-#ifdef PS_HD_TIMING      // (measurement build: where a workgroup of k_gemm_nt_head spends its time; tools/hd_timing.py)
-__device__ unsigned long long g_hd_t[512 * 8];
-#define HD_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_hd_t[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define HD_T(k) do { } while (0)
-#endif
-template <int WM, int WN, int TM, int TN, int BKT, int PIPE>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt_head(NtArgs a, HeadFuse f) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LD = (PIPE == 3 && BKT == 16) ? 16 : BKT + 4;
-    static_assert(BM == 64 && WM * WN * 64 == 256, "k_gemm_nt_head: 64-row panels, 256 threads (two head sweeps of 32 rows)");
-    __shared__ __attribute__((aligned(16))) float As[3 * BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[3 * BN * LD];
-    __shared__ __attribute__((aligned(16))) float wsh[PS_HEADW_MAX];
-    __shared__ float dsh[BM];
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    EndWait end_wait(a.wait_flag, a.wait_val, a.bound);
-    StampScope stamp(a.ts);
-    const int tn = (a.N + BN - 1) / BN;
-    const int wg = a.xcd_swizzle ? xcd_chunked_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int m0 = (wg / tn) * BM, tc = wg % tn, tid = threadIdx.x;
-    HD_T(0);
-    for (int k = tid * 4; k < a.K; k += 1024) *reinterpret_cast<float4 *>(wsh + k) = *reinterpret_cast<const float4 *>(f.h.w_last + k);
-#pragma unroll 1
-    for (int sw = 0; sw < BM / 32; ++sw) {
-        const int r = sw * 32 + (tid >> 3);
-        const float d = head_one<true>(f.h, m0 + r, tid & 63, r / f.q.chunk == tc);      // (stores: the slab's owner only)
-        if ((tid & 7) == 0) dsh[r] = d;
-        HD_T(1 + sw);
-    }
-    __syncthreads();
-    HD_T(3);
-    if (tc < BM / f.q.chunk) {
-        last_bwd_body<true, true>(f.q, dsh + tc * f.q.chunk, tid, m0 / f.q.chunk + tc);
-        HD_T(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores have reached memory
-        __syncthreads();
-        HD_T(5);
-        if (tid == 0) {
-            const unsigned int old = __hip_atomic_fetch_add(f.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1u == f.nowners) {
-                __hip_atomic_store(f.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for the next launch; nobody adds any more)
-                if (a.flag) __hip_atomic_store(a.flag, a.flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    HD_T(6);
-    gemm_nt_tile<WM, WN, TM, TN, BKT, 1, PIPE, 1>(a, m0, tc * BN, As, Bs, dsh, wsh);
-    HD_T(7);
-}
-#ifdef PS_HD_TIMING
-}   // namespace
-extern "C" int ps_dbg_hd_timing(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hd_t), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -1;
-}
-namespace {
-#endif
 
 #if PS_GEMM_LAB
 #include "lab/kernels_gemm_lab.inc"      // (the rejected variants of rounds 2-3: lab build only)
@@ -916,16 +822,6 @@ int g_gemm_tn_cfg = 0;   // 1 64x64/16, 2 64x64/32, 3 128x128/16, 4 128x32/16, 5
 #define NT_LAUNCH_KS(WM, WN, TM, TN, BKT, KS)                                                            \
     PS_LAUNCH_EV((k_gemm_nt<WM, WN, TM, TN, BKT, KS>), dim3(cdiv(M, WM * TM * 32) * cdiv(N, WN * TN * 32)), dim3(WM * WN * 64 * KS), 0, st, stop_ev, a)
 
-int g_head_in_delta = 0;    // ps_tune_set("head_in_delta", 1): the fused step's head + out = 1 layer's backward inside the first delta GEMM's launch (k_gemm_nt_head)
-// can the delta GEMM [M][N] = (delta_prev of the out = 1 layer q)[M][K] * Bt^T carry the head of its rows?
-int gemm_nt_head_ok(int M, int N, int K, const HeadArgs &h, const LastBwdArgs &q) {
-    if (g_gemm_nt_cfg != 0 || g_gemm_ablate || M <= 0 || (M & 63) || N <= 32) return 0;
-    if ((long long)cdiv(M, 64) * cdiv(N, 128) >= 2048) return 0;             // (gemm_nt would pick another tile)
-    if (K != q.K || q.dprev_cols != q.K || q.mask_cols != q.K || (K & 15) || K > PS_HEADW_MAX) return 0;
-    if (q.B != M || q.chunk < 1 || 64 % q.chunk || 64 / q.chunk > cdiv(N, 64)) return 0;
-    if (!h.a_last || h.a_last != q.A || !h.labels || h.B != M) return 0;
-    return 1;
-}
 int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b_rows, float *C,
             int ldc, int M, int N, int K, int epi, const float *mask, int ldmask, int mask_cols,
             const int *skip_flag, hipStream_t st, LaunchOpts *lo, unsigned int *werr) {
@@ -935,19 +831,10 @@ int gemm_nt(const float *A, int lda, int a_rows, const float *Bt, int ldb, int b
     if (M <= 0 || N <= 0) return PS_OK;
     const LaunchOpts none;
     const LaunchOpts &o = lo ? *lo : none;
-    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next(o.head ? "head_gemm_nt" : "gemm_nt"),
+    NtArgs a{A, lda, a_rows, Bt, ldb, b_rows, C, ldc, M, N, K, epi, mask, ldmask, mask_cols, skip_flag, g_gemm_xcd, g_gemm_ablate, stamp_next("gemm_nt"),
              o.flag, o.flag_val, o.wait, o.wait_val, o.prio, wait_bound(werr, 100)};
     const hipEvent_t stop_ev = o.stop_event;
     int cfg = g_gemm_nt_cfg;
-    if (o.head) {
-        // A = the out = 1 layer's input; its delta_prev is made on the way to LDS
-        if (!gemm_nt_head_ok(M, N, K, o.head->h, o.head->q) || A != o.head->q.A || lda != o.head->q.lda || skip_flag)
-            return ps_set_err(PS_E_BAD_ARG, "gemm_nt: the head cannot ride on this launch");
-        PS_LAUNCH_EV((k_gemm_nt_head<2, 2, 1, 1, 16, 3>), dim3(cdiv(M, 64) * cdiv(N, 64)), dim3(256), 0, st, stop_ev, a, *o.head);
-        HIPCHK(hipGetLastError());
-        if (lo) lo->launched = true;
-        return PS_OK;
-    }
     if (cfg == 30 && (K & 15)) cfg = 0;       // the LDS-DMA kernel multiplies whole or half slabs
     if (cfg == 0) {
         // 64x64 tiles put >= 2 workgroups on every CU for the FC shapes of the CTR models

@@ -122,8 +122,7 @@ int seg_sort_tile();
 bool seg_sort_fits(const int64_t *rows_per_field, int F);
 int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipStream_t st);
 int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st, int which = 3);
-extern int g_head_in_delta;
-extern int g_mh_seg_sort, g_mh_presort, g_mh_presort_at, g_mh_prio, g_slots_in_gather, g_keys_grid, g_emb_xcd, g_emb_lxcd, g_super_in_update, g_fwd_order, g_super_list;
+extern int g_mh_seg_sort, g_mh_presort, g_mh_prio, g_slots_in_gather, g_keys_grid, g_emb_xcd, g_emb_lxcd, g_super_in_update, g_fwd_order, g_super_list;
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap);
 void sort_ws_free(SortWorkspace &ws);
 // Stable LSD radix sort of (key, val) pairs on `key_bits` low bits.
@@ -159,9 +158,7 @@ int field_sort_segments(const uint32_t *keys, const int64_t *keys_base, int key_
 //   wait        the launch's first workgroup ends only once *wait has reached wait_val (a join that costs no launch)
 //   prio        the launch's waves run at raised priority (s_setprio)
 // launched (out): a kernel was launched and took all of the above; false (an empty problem): the caller settles them.
-struct HeadFuse;
 struct LaunchOpts {
-    const HeadFuse *head = nullptr;       // gemm_nt only: the head and the out = 1 layer's backward ride on this launch; flag is then raised when THEY are done (kernels_emb.h)
     hipEvent_t stop_event = nullptr;
     unsigned int *flag = nullptr; unsigned int flag_val = 0;
     const unsigned int *wait = nullptr; unsigned int wait_val = 0;

@@ -331,7 +331,6 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // (single-hot: fused and sharded step).  A multi-hot step is bound by its sort chain and the sum of its kernels, and the
 // priority takes from exactly those: 0.387 against 0.382 ms.
 int g_super_list = 1;   // ps_tune_set("super_list", 0): the chunked order's super partials by the walk over every tile (k_emb_super) instead of the sort's list of very long runs
-int g_mh_presort_at = 0;   // ps_tune_set("mh_presort_at", v): see enqueue_forward
 int g_mh_prio = 0;      // ps_tune_set("mh_prio", 1): raised wave priority for the GEMMs and the head of a MULTI-HOT step too (its sort chain left the critical path with mh_presort)
 static bool gemm_prio(const ps_model *m) { return g_main_prio && (m->cur_offsets == nullptr || g_mh_prio); }
 
@@ -433,10 +432,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         // (host batches are staged in the training stream's order: they keep the join in front of the key kernel)
         // (mh_presort = 2: held back until the previous step's embedding backward has STARTED -- beside the FC chain of that step,
         //  where an idle side chain 0 would otherwise start them at once, they slow its GEMMs: 0.402 against 0.388 ms)
-        // (mh_presort_at: 1 = already at the START of that step's last delta GEMM, 2 = of its first -- measurement knob, profiles/r06_mh_presort_at.txt)
-        if (presort && g_mh_presort >= 2 && g_mh_presort_at && m->delta_started_valid && m->dev_ok)
-            PSCHK(launch_spin_until(m->start_flag, g_mh_presort_at == 2 ? m->delta_first_epoch : m->delta_last_epoch, side_stream(m, 0), s->werr(), 16));
-        else if (presort && g_mh_presort >= 2 && m->emb_started_valid && m->dev_ok)
+        if (presort && g_mh_presort >= 2 && m->emb_started_valid && m->dev_ok)
             PSCHK(launch_spin_until(m->start_flag + 2, m->emb_started_epoch, side_stream(m, 0), s->werr(), 16));
         if (seg_sort) { Prof pf(m, "emb_bag_scan"); PSCHK(seg_sort_scan(m->seg, m->cur_offsets, B, c.F, presort ? side_stream(m, 0) : st)); }
         if (!presort) PSCHK(fork(m, st, side_stream(m, 0)));          // behind the staging of this batch and the previous step
@@ -654,19 +650,8 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         if (pair || panel_l) ++l;          // (layer l + 1 went with this launch)
     }
     if (m->sh.active) PSCHK(shard_launch_deferred_sort(m, false));      // (no GEMM carried the start flag: the sort at once)
-    // head_in_delta: a training step whose backward is enqueued right behind this forward (defer_loss: ps_model_train) leaves the head and the
-    // out = 1 layer's backward to the first delta GEMM's launch (kernels_gemm.hip k_gemm_nt_head): one launch and one boundary less on the chain
-    m->head_deferred = false;
-    if (!panel_head && head_fusable && g_head_in_delta && defer_loss && !m->sh.active && nfc >= 3 && dev_release(m) && m->side[1] != st && !sort_late) {
-        LastBwdArgs q;
-        fill_last_bwd(m, q);
-        m->head_deferred = gemm_nt_head_ok(B, s->fc[nfc - 2].K, m->fc[nfc - 2].ldD, h, q) != 0;
-    }
     if (panel_head) {
         // (went with the panel launch)
-    } else if (m->head_deferred) {
-        m->head_ev = nullptr;
-        m->head_bwd_done = true;          // (as far as the backward's schedule goes: its first delta GEMM does it)
     } else if (head_fusable) {
         // training: the head and the out = 1 layer's backward of the same rows in ONE launch (three tiny kernels
         // of the critical chain become one; the loss reduction leaves the chain altogether, see enqueue_backward)
@@ -763,24 +748,10 @@ int enqueue_backward(ps_model *m, bool apply) {
     // (and not under stream capture: a captured graph needs its side streams joined by events)
     const bool dev_flags = m->dev_ok && !m->cfg.use_graph;
     const bool dev_wait = dev_release(m) && sw != st && m->head_bwd_done;
-    HeadFuse hf;
-    bool head_ride = false;
-    if (m->head_deferred) {
-        m->head_deferred = false;
-        hf.h = m->head_args;
-        fill_last_bwd(m, hf.q);
-        hf.ctr = m->start_flag + 13; hf.nowners = (unsigned int)(B / hf.q.chunk);
-        head_ride = dev_wait && nfc >= 3 && gemm_nt_head_ok(B, s->fc[nfc - 2].K, m->fc[nfc - 2].ldD, hf.h, hf.q);
-        if (!head_ride) {       // (the conditions changed between the two enqueues: the ordinary launch, now)
-            Prof pf(m, "head_last_bwd");
-            PSCHK(launch_head_last_bwd(hf.h, hf.q, m->fc[nfc - 1].nsplit, st, nullptr));
-        }
-    }
     if (dev_wait) {}                                              // both chains: spinners behind the first delta GEMM's launch
     else if (m->head_ev && m->head_bwd_done) { PSCHK(wait_event(m, sw, m->head_ev)); PSCHK(wait_event(m, s0, m->head_ev)); }
     else PSCHK(fork2(m, st, sw, s0));
     bool first_release = dev_wait;
-    bool delta_seen = false;
     // (dw_split needs the fused tail: its dense update is what waits for both chains' GEMMs)
     const bool dw_split = g_dw_split && dev_wait && dev_flags && g_tail_dev && g_tail_fused && sw != st && s0 != st && s0 != sw && sl == s0 &&
                           !m->profile && m->cur_nnz > 0 && !m->sh.active;
@@ -900,8 +871,6 @@ int enqueue_backward(ps_model *m, bool apply) {
             // chain is done" (delta_l included), dW_l sits behind a spinner on that -- no event anywhere on the chain
             if (++m->start_epoch == 0) ++m->start_epoch;
             lo.flag = m->start_flag; lo.flag_val = m->start_epoch;
-            if (!delta_seen) { m->delta_first_epoch = m->start_epoch; delta_seen = true; }
-            m->delta_last_epoch = m->start_epoch;
         } else {
             if (main_dirty) {                               // delta_l was just produced on the main chain
                 if (data_ev) PSCHK(wait_event(m, dws, data_ev)); else PSCHK(fork(m, st, dws));
@@ -914,15 +883,7 @@ int enqueue_backward(ps_model *m, bool apply) {
         // delta_prev = W^T delta, with the previous layer's relu' fused in (its backward's first act)
         static const char *nd[8] = {"fc_bwd_data0", "fc_bwd_data1", "fc_bwd_data2", "fc_bwd_data3", "fc_bwd_data4", "fc_bwd_data5", "fc_bwd_data6", "fc_bwd_data7"};
         static const char *nw[8] = {"fc_bwd_dw0", "fc_bwd_dw1", "fc_bwd_dw2", "fc_bwd_dw3", "fc_bwd_dw4", "fc_bwd_dw5", "fc_bwd_dw6", "fc_bwd_dw7"};
-        if (l > 0 && head_ride && l == nfc - 2) {
-            // ... with the head and the out = 1 layer's backward of its rows in front (the layer's input instead of its delta_prev as operand);
-            // lo.flag is raised when THEY are done, not when the launch starts
-            Prof pf(m, "head_bwd_data");
-            lo.head = &hf;
-            PSCHK(gemm_nt(hf.q.A, hf.q.lda, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
-                          EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st, &lo, werr));
-            if (!lo.launched) return ps_set_err(PS_E_STATE, "the launch that carries the head was not made");
-        } else if (l > 0) {
+        if (l > 0) {
             Prof pf(m, nd[l]);
             PSCHK(gemm_nt(b.dOut, b.ldD, B, p.W, p.ldw, p.K, m->fc[l - 1].dOut, m->fc[l - 1].ldD, B, p.K, b.ldD,
                           EPI_MASK_POS, b.A, b.ldA, p.K, nullptr, st, &lo, werr));
@@ -983,7 +944,6 @@ int enqueue_backward(ps_model *m, bool apply) {
             dw_split_done = true;
         }
     }
-    m->delta_started_valid = delta_seen;
     if (first_release) { PSCHK(fork2(m, st, sw, s0)); PSCHK(small_kernels()); first_release = false; }     // (no delta GEMM at all)
     // tail_dev: the dense update goes to the END OF SIDE CHAIN 1 and both of its edges are device-side flags (no event
     // wait anywhere in the tail): it starts when the embedding update has STARTED (that launch starts only after the

@@ -154,8 +154,6 @@ struct ps_model {
     const int64_t *cur_ids = nullptr, *cur_offsets = nullptr, *cur_wide = nullptr;
     const float *cur_dense = nullptr, *cur_labels = nullptr;
     int cur_B = 0; int64_t cur_nnz = 0; bool fwd_done = false, bwd_done = false;
-    bool head_deferred = false;        // the training step's head + out = 1 layer's backward were left to the first delta GEMM's launch (head_in_delta)
-    bool delta_started_valid = false; unsigned int delta_first_epoch = 0, delta_last_epoch = 0;     // start_flag[0]'s values at the first / last delta GEMM's start (mh_presort_at)
     bool emb_started_valid = false; unsigned int emb_started_epoch = 0;    // the last backward's embedding launch raises start_flag[2] to this when it starts
     bool cur_on_device = false;        // the staged batch is the caller's device-resident batch (complete when handed over: ps_native.h)
     // embedding backward workspaces

@@ -35,7 +35,7 @@ def batches(rng, n, B, F, X, V, WS):
     return out
 
 
-DEFAULTS = {"head_in_delta": 0, "dw_split": 0, "fwd_pair": 0, "fwd_panel": 0, "dw_late": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
+DEFAULTS = {"dw_split": 0, "fwd_pair": 0, "fwd_panel": 0, "dw_late": 0, "gemm_pipe": 5, "gemm_tn_cfg": 0, "gemm_nt_cfg": 0, "gemm_ks": 0, "gemm_8w": 0}      # (every other knob: 1)
 
 
 def run(kind, knobs, profile, data, F, D, X, fc, V, B, WS):
@@ -583,45 +583,3 @@ def test_multi_hot_presort_and_one_launch_segments_change_no_bit():
     for other in res[1:]:
         for x, y in zip(res[0], other):
             np.testing.assert_array_equal(x, y)
-
-
-@pytest.mark.parametrize("kind,fc,B,fused", [("widedeep", [512, 256, 1], 1024, True), ("dnn", [256, 64, 1], 512, True), ("widedeep", [128, 256, 1], 4096, False),
-                                             ("widedeep", [512, 256, 1], 1000, False)])
-def test_head_inside_the_first_delta_gemm_changes_no_bit(kind, fc, B, fused):
-    """head_in_delta: the head (LRLayer + AddLayer + sigmoid + CrossEntropy, layer/LRLayer.java:73-84, loss/CrossEntropy.java:15-25) and the
-    out = 1 FcLayer's backward (layer/FcLayer.java:93-110) as the prologue of the first delta GEMM's launch, that layer's delta_prev made on the
-    operand's way to LDS: every loss and every parameter bit for bit what the two launches leave; shapes the launch cannot carry (a row panel with
-    more slabs than tile columns, a batch that is not whole panels) take the two launches."""
-    import ctypes as C
-    import ps_amd
-    from ps_amd import native as N
-    F, D, X, V, WS = 6, 16, 5, 3000, 97
-    rng = np.random.default_rng(B + len(fc) + fc[0])
-    data = batches(rng, 5, B, F, X, V, WS)
-    ref = run(kind, {}, False, data, F, D, X, fc, V, B, WS)
-    got = run(kind, {"head_in_delta": 1}, False, data, F, D, X, fc, V, B, WS)
-    assert got[0] == ref[0], "losses %s vs %s" % (got[0], ref[0])
-    for a, b in zip(ref[1:], got[1:]):
-        for x, y in zip(a, b) if isinstance(a, list) else [(a, b)]:
-            np.testing.assert_array_equal(x, y)
-    # ... and the launch was the one asked for (the stamps name every stamped launch of a step)
-    L = N.lib()
-    L.ps_dbg_stamps.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int]
-    L.ps_tune_set(b"head_in_delta", 1)
-    try:
-        kv = ps_amd.KVStore(0, SEED)
-        kv.create_embedding([V] * F, D)
-        gm = (ps_amd.WideDeepNN.buildModel(F, D, X, fc, WS, store=kv, max_batch=B) if kind == "widedeep" else ps_amd.DNN.buildModel(F, D, X, fc, store=kv, max_batch=B))
-        E, Xd, Y, W = data[0]
-        gm.train(ps_amd.Batch(E, Xd, Y, W if kind == "widedeep" else None))
-        L.ps_tune_set(b"stamps", 1)
-        gm.train(ps_amd.Batch(E, Xd, Y, W if kind == "widedeep" else None))
-        names = C.create_string_buffer(1 << 16)
-        vals = (C.c_ulonglong * 512)()
-        n = L.ps_dbg_stamps(names, len(names), vals, 256)
-        nm = names.value.decode().split("\n")[:n]
-        gm.close(); kv.close()
-    finally:
-        L.ps_tune_set(b"stamps", 0)
-        L.ps_tune_set(b"head_in_delta", 0)
-    assert ("head_gemm_nt" in nm) == fused and ("head_last_bwd" in nm) == (not fused), nm

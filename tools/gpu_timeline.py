@@ -45,7 +45,7 @@ L.ps_tune_set(b"stamps", 0)
 nm = names.value.decode().split("\n")[:n]
 v = np.array(vals[:2 * n], np.int64).reshape(n, 2) / 100.0      # us
 starts = [i for i, x in enumerate(nm) if x == "emb_fwd"]
-main = {"emb_fwd", "gemm_nt", "head_gemm_nt", "fc_fwd_pair", "fwd_panel", "fwd_panel_head", "head_last_bwd", "emb_bwd_update"}
+main = {"emb_fwd", "gemm_nt", "fc_fwd_pair", "fwd_panel", "fwd_panel_head", "head_last_bwd", "emb_bwd_update"}
 spans = np.diff([v[i, 0] for i in starts])
 print("%d stamped launches, %d steps; step span median %.1f us (min %.1f, max %.1f)" % (n, len(starts) - 1, np.median(spans), spans.min(), spans.max()))
 # average timeline over the steps whose span is within 2%% of the median
