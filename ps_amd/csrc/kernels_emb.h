@@ -28,6 +28,10 @@ struct EmbFwdArgs {
     const unsigned int *end_wait; unsigned int end_val; WaitBound bound;   // the first workgroup ends only once *end_wait reached end_val
     const unsigned int *start_wait; unsigned int start_val;   // no workgroup starts before *start_wait reached start_val (the previous
                                // step's dW GEMMs, on a side chain, still read the activations this launch overwrites)
+    // LRLayer.forward as a role of this launch (wide_in_gather): workgroups behind the gather's and the dense features' leave wide_z[b] = the
+    // sequential sum of sample b's F wide weights + bias (layer/LRLayer.java:73-84) for the head, which then only adds it
+    const int64_t *wide_ids; int64_t wide_rows; const float *wide_w; const float *wide_bias; uint8_t *wide_touched; float *wide_z; int wide_train;
+    int wide_blk0, wide_blocks;    // filled by the launcher
 };
 int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo = nullptr, unsigned int *werr = nullptr);   // lo: stop_event, wait (an END wait)
 int launch_emb_keys(const EmbFwdArgs &a, hipStream_t st);      // multi-hot: key_out / ent_bag from the ids alone
@@ -40,6 +44,7 @@ struct HeadArgs {
     const float *wide_w; const float *wide_bias; uint8_t *touched;
     const float *labels;
     float *P, *wide_z, *terms;
+    const float *wide_z_in;            // when set: LRLayer.forward of this batch was done by the gather's launch (EmbFwdArgs.wide_z): sumW is read, not computed
     float *dlast; int ldd;             // delta at the last FcLayer's output
     int *err;
     // when a_last is set the last FcLayer (out = 1) is computed here as a per-sample dot product

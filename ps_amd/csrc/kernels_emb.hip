@@ -64,12 +64,60 @@ template <> struct Vec<1> {
 #define GATHER_ILP 4
 #endif
 #define GATHER_ILP_MH 1   // measured on a 256 GB table, bags of 32: 1 -> 4.94, 2 -> 4.65, 4 -> 4.8, 8 -> 4.31 TB/s (more in flight per wave only costs occupancy)
+// LRLayer.forward of sample b by its 8-lane group (layer/LRLayer.java:73-84): the head's wide part (kernels_head.inc head_one_t) on its own --
+// the same loads, the same sequential f32 sum in field order, the same + bias, the same touched marks and error count: wide_z[b] has the
+// bits the head would have computed.  As a role of the gather's launch the id -> weight round trip leaves the head, i.e. the step's main chain.
+__device__ __forceinline__ void wide_forward_one(const EmbFwdArgs &a, const int b, const int lane, const bool valid) {
+    const int l8 = lane & 7, gbase = lane & ~7;
+    const bool early = a.F <= 32;
+    float sumW = 0.f;
+    bool wbad = false;
+    for (int j0 = 0; j0 < a.F; j0 += 32) {
+        int64_t wid[4];
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = j0 + 8 * r + l8;
+            wid[r] = a.wide_ids[(size_t)b * a.F + (f < a.F ? f : a.F - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = j0 + 8 * r + l8;
+            const bool bad = wid[r] < 0 || wid[r] >= a.wide_rows;
+            if (bad && f < a.F) { if (early) wbad = true; else if (valid) atomicAdd(a.err, 1); }
+            if (bad) wid[r] = 0;
+            w[r] = a.wide_w[wid[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = a.F - j0 - 8 * r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                                    // field order; the 8 shuffles are independent
+                const float v = __shfl(w[r], gbase + j);
+                if (j < n) sumW += v;
+            }
+        }
+        if (valid && a.wide_touched && a.wide_train) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (j0 + 8 * r + l8 < a.F) a.wide_touched[wid[r]] = 1;   // LRLayer.weights.put (never cleared)
+        }
+    }
+    sumW += a.wide_bias[0];
+    if (valid && wbad) atomicAdd(a.err, 1);
+    if (valid && l8 == 0) a.wide_z[b] = sumW;
+}
+
 template <int VEC, bool MULTI, bool SLOT, int MHI>
 __global__ __launch_bounds__(256) void k_emb_fwd(EmbFwdArgs a) {
     EndWait end_wait(a.end_wait, a.end_val, a.bound);     // (the join with the previous step's dense / replicated update)
     StampScope stamp(a.ts);
     start_wait(a.start_wait, a.start_val, a.bound);
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a.wide_blocks && (int)blockIdx.x >= a.wide_blk0) {
+        const int b = ((int)blockIdx.x - a.wide_blk0) * 32 + (threadIdx.x >> 3);       // eight lanes per sample, like the head
+        wide_forward_one(a, b < a.B ? b : a.B - 1, threadIdx.x & 63, b < a.B);
+        return;
+    }
     if (blockIdx.x >= a.gather_blocks) {
         // ConcatLayer.forward (layer/ConcatLayer.java:30-37): dense features behind the embeddings
         const int64_t t = gt - (int64_t)a.gather_blocks * 256;
@@ -1583,7 +1631,9 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     a.order = (multi && !slot && a.gather_blocks >= 64 && a.table_bytes <= ((size_t)1 << 30)) ? g_fwd_order : 0;
     if (a.order & 1) a.gather_blocks = (a.gather_blocks + 7) & ~7;
     const int dense_blocks = a.dense ? cdiv((int64_t)a.B * a.X, 256) : 0;
-    const int grid = a.gather_blocks + dense_blocks;
+    a.wide_blocks = (a.wide_ids && a.wide_z && a.B > 0) ? cdiv(a.B, 32) : 0;
+    a.wide_blk0 = a.gather_blocks + dense_blocks;
+    const int grid = a.gather_blocks + dense_blocks + a.wide_blocks;
     if (grid == 0) return PS_OK;
     // multi-hot: ids handed round a lane group by shuffle when the group sits inside one wave
     const int mhi = (multi && 64 % a.LPR == 0) ? (a.LPR <= 4 ? a.LPR : a.LPR == 8 ? 2 : (g_mh_ilp16 > 0 ? g_mh_ilp16 : 4)) : 0;      // (D = 64: four row loads in flight per 16-lane group -- 192.8 us against 195.8 with one on the 256 GB table, bags of 32, tools/gather_sweep.py)
@@ -1601,7 +1651,7 @@ int launch_emb_fwd(EmbFwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
                else PS_LAUNCH_EV((k_emb_fwd<V, false, false, 0>), dim3(grid), dim3(256), 0, st, stop_ev, a); }      \
     } while (0)
 #if PS_GEMM_LAB
-    if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && 64 % a.LPR == 0 && !stop_ev && !a.end_wait)
+    if (g_gather_lds && vec == 4 && !multi && !slot && !a.key_out && !a.dense && !a.wide_blocks && 64 % a.LPR == 0 && !stop_ev && !a.end_wait)
         hipLaunchKernelGGL(k_emb_fwd_lds, dim3(grid), dim3(256), 0, st, a);       // (measurement variant: carries no event / end wait)
     else
 #endif

@@ -331,6 +331,7 @@ int stage_batch(ps_model *m, const ps_batch_t *b, bool need_labels) {
 // (single-hot: fused and sharded step).  A multi-hot step is bound by its sort chain and the sum of its kernels, and the
 // priority takes from exactly those: 0.387 against 0.382 ms.
 int g_super_list = 1;   // ps_tune_set("super_list", 0): the chunked order's super partials by the walk over every tile (k_emb_super) instead of the sort's list of very long runs
+int g_wide_in_gather = 1;   // ps_tune_set("wide_in_gather", 0): the head walks the wide ids itself again
 int g_mh_prio = 0;      // ps_tune_set("mh_prio", 1): raised wave priority for the GEMMs and the head of a MULTI-HOT step too (its sort chain left the critical path with mh_presort)
 static bool gemm_prio(const ps_model *m) { return g_main_prio && (m->cur_offsets == nullptr || g_mh_prio); }
 
@@ -487,7 +488,17 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
         }
         m->sh.flat_start_valid = false;
     }
+    // wide_in_gather: LRLayer.forward (sample b's F wide weights summed in field order + bias) as a role of this launch -- the head, three
+    // launches down the main chain, then reads wide_z[b] instead of walking id -> weight itself (one memory round trip less on the chain).
+    // The wide table is what the previous step's wide update left: that update sits on the chain the main chain joined before its embedding
+    // update.  (Sharded worker: the replicated update may still run beside this launch -- the head keeps the walk.)
+    const bool wide_in_gather = g_wide_in_gather && c.kind == PS_MODEL_WIDEDEEP && !m->sh.active && m->cur_wide && B > 0;
+    if (wide_in_gather) {
+        e.wide_ids = m->cur_wide; e.wide_rows = s->wide.rows; e.wide_w = s->wide.W; e.wide_bias = s->wide.bias;
+        e.wide_touched = s->wide.touched; e.wide_z = m->wide_z; e.wide_train = train ? 1 : 0;
+    }
     { Prof pf(m, "emb_fwd"); PSCHK(launch_emb_fwd(e, st, &fwd_lo, s->werr())); }
+    const bool wide_done = wide_in_gather && fwd_lo.launched;
     if (fwd_lo.wait && !m->sh.active) {          // (the fused step's deferred join)
         if (!fwd_lo.launched) PSCHK(store_settle(s));
         s->pending_ev = nullptr; s->pending_flag = nullptr;
@@ -574,6 +585,7 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
     h.touched = s->wide.touched;
     h.labels = m->cur_labels;
     h.P = m->P; h.wide_z = m->wide_z; h.terms = m->terms;
+    h.wide_z_in = wide_done ? m->wide_z : nullptr;
     h.dlast = m->fc[nfc - 1].dOut; h.ldd = m->fc[nfc - 1].ldD;
     h.err = s->err_dev;
     if (s->fc[nfc - 1].N == 1) {

@@ -85,6 +85,7 @@ def test_schedules_agree(kind, F, D, X, fc, V, B):
                 "8-wave 128 x 64 tiles": ({"gemm_8w": 1}, False),
                 "the embedding update holds the join with the dense update": ({"tail_defer": 0}, False),
                 "general sort with scan launches": ({"field_sort": 0, "radix_scan_free": 0}, False),
+                "the head walks the wide ids itself (no LRLayer.forward role in the gather's launch)": ({"wide_in_gather": 0}, False),
                 "no raised wave priority": ({"main_prio": 0}, False), "all plain": ({"dev_wait": 0, "ext_events": 0, "field_sort": 0}, False),
                 "general sort + plain events": ({"field_sort": 0, "ext_events": 0}, False), "one stream": ({}, True)}
     from ps_amd import native as N
