@@ -19,6 +19,8 @@ import pytest
 
 from test_sharded_gloo import CFG, SEED, STEPS, expected, make_batches
 
+STEPS = int(os.environ.get("PS_MULTIPROC_STEPS", STEPS))      # (tools/r06_mapped_soak.py: the same processes over many more steps)
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -165,7 +167,7 @@ def run_processes(world, is_async, device_batches, opts=None):
     for p in procs:
         p.start()
     try:
-        res = [q.get(timeout=170) for _ in procs]
+        res = [q.get(timeout=int(os.environ.get("PS_MULTIPROC_TIMEOUT", "170"))) for _ in procs]
     finally:
         for p in procs:
             p.join(20)
