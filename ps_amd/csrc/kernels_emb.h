@@ -128,7 +128,9 @@ struct EmbBwdArgs {
     float *partials2;                  // same indexing: super partials of runs above PS_EMB_SUPER_MIN chunks
     int long_runs;                     // a run above PS_EMB_SUPER_MIN chunks is possible (launch k_emb_super)
     int seq_order;                     // 1: every key summed in the reference's strict sample order (one launch)
-    int super_blocks;                  // filled by the launcher: workgroups of the chunked order's super role (runs above PS_EMB_SUPER_MIN chunks), or 0
+    int super_blocks;                  // filled by the launcher: workgroups of the chunked order's list role (runs above list_min chunks), or 0
+    int list_min;                      // chunked order: a run above this many chunks belongs to a workgroup of the list role (the sort listed every such run);
+                                       // PS_EMB_SUPER_MIN: only the runs with super partials, as in round 5 (launcher: 0 -> PS_EMB_SUPER_MIN)
     int long_blocks, short_blocks;     // filled by the launcher: workgroups of the long-key role / of the one-key-per-lane-group role
     int ablate;                        // measurement only (g_seq_ablate)
     float *W, *state;                  // [rows][D], [rows][2][D]

@@ -853,7 +853,7 @@ __device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_
         // runs above 128 chunks were pre-folded 32 chunks at a time by k_emb_super (one lane group walking the
         // 1968 partials of a 63k-entry key WAS the kernel: ~250 us); their super partials sit in partials2
         const bool two = nch > PS_EMB_SUPER_MIN;
-        if (two && a.super_blocks > 0) return;                  // (round 6: a workgroup of this launch's super role owns the key)
+        if (a.super_blocks > 0 && nch > (uint32_t)a.list_min) return;      // (round 6: a workgroup of this launch's list role owns the key)
         const uint32_t step = two ? PS_EMB_SUPER : 1u;
         const float *src = two ? a.partials2 : a.partials;
         const uint32_t cnt = (nch + step - 1) / step;
@@ -894,10 +894,14 @@ __device__ __forceinline__ void reduce_one_key(const EmbBwdArgs &a, const int64_
 // groups fold the run's chunk partials 32 at a time into super partials (k_emb_super_list's arithmetic, 8 loads in flight instead of 32: this
 // kernel's register budget) into LDS, `cap` super partials per round; lane group 0 folds them in order (reduce_one_key's arithmetic) as they
 // appear; compat mode walks the run a second time.  Same adds in the same order as the two-launch form.
+// gs = 1 (runs of list_min < chunks <= PS_EMB_SUPER_MIN, the one-level order of reduce_one_key): the lane groups only FETCH the run's chunk
+// partials, `cap` per round and one memory round trip for all of them, and lane group 0 folds them in chunk order from LDS -- one lane group of the
+// short role walked them eight loads at a time (16 dependent round trips for 128 partials: the workgroups holding a 500..4000-entry key ended
+// 20-40 us behind the median one and WERE the launch's tail, tools/emb_timing.sh).  Same adds in the same order.
 template <int VEC>
-__device__ __forceinline__ void super_key_run(const EmbBwdArgs &a, float *lds, int lds_floats, uint32_t u, uint32_t s0, uint32_t e0) {
+__device__ __forceinline__ void super_key_run(const EmbBwdArgs &a, float *lds, int lds_floats, uint32_t u, uint32_t s0, uint32_t e0, const uint32_t gs) {
     const uint32_t CH = PS_EMB_CHUNK;
-    const uint32_t n = e0 - s0, nch = (n + CH - 1) / CH, ngrp = (nch + PS_EMB_SUPER - 1) / PS_EMB_SUPER;
+    const uint32_t n = e0 - s0, nch = (n + CH - 1) / CH, ngrp = (nch + gs - 1) / gs;
     const int lane64 = (int)(threadIdx.x & 63), gpw = 64 / a.LPR;
     const bool act = lane64 / a.LPR < gpw;
     const int part = lane64 % a.LPR;
@@ -910,9 +914,13 @@ __device__ __forceinline__ void super_key_run(const EmbBwdArgs &a, float *lds, i
         for (uint32_t g0 = 0; g0 < ngrp; g0 += cap) {
             const uint32_t g = g0 + grp;
             if (act && grp < cap && g < ngrp) {
-                const uint32_t j = g * PS_EMB_SUPER, j1 = j + PS_EMB_SUPER < nch ? j + PS_EMB_SUPER : nch;
+                const uint32_t j = g * gs, j1 = j + gs < nch ? j + gs : nch;
                 Vec<VEC> acc;
                 bool h = false;
+                if (gs == 1) {
+                    const uint32_t sc = s0 + j * CH;
+                    acc = Vec<VEC>::load(a.partials + ((size_t)2 * (sc / CH) + (j == 0 ? 1 : 0)) * a.D + part * VEC);
+                } else
                 for (uint32_t k0 = j; k0 < j1; k0 += PS_EMB_ILP) {
                     Vec<VEC> p[PS_EMB_ILP];
 #pragma unroll
@@ -1013,8 +1021,9 @@ __global__ __launch_bounds__(256) void k_emb_reduce_update(EmbBwdArgs a) {
         const uint32_t nl = *a.nlong;
         for (uint32_t i = blockIdx.x; i < nl; i += (uint32_t)a.super_blocks) {
             const uint32_t *ll = a.long_list + 3 * (size_t)i;
-            if ((ll[2] - ll[1] + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK <= PS_EMB_SUPER_MIN) continue;
-            super_key_run<VEC>(a, seq_lds, SUPER_LDS_FLOATS, ll[0], ll[1], ll[2]);
+            const uint32_t nch = (ll[2] - ll[1] + PS_EMB_CHUNK - 1) / PS_EMB_CHUNK;
+            if (nch <= (uint32_t)a.list_min) continue;             // (a list with shorter runs in it: the sharded step's)
+            super_key_run<VEC>(a, seq_lds, SUPER_LDS_FLOATS, ll[0], ll[1], ll[2], nch > PS_EMB_SUPER_MIN ? PS_EMB_SUPER : 1u);
         }
         return;
     }
@@ -1464,6 +1473,8 @@ __global__ void k_rows_copy(float *table, int64_t row_stride, int64_t col_off, c
 // launchers
 // ---------------------------------------------------------------------------
 int g_mh_ilp16 = 0;
+int g_emb_list_min = 16;    // ps_tune_set("emb_list_min", chunks): the chunked order's runs above this many 32-entry chunks go to the update launch's list role (128: only the runs with super partials, round 5)
+int g_emb_list_grid = 256;  // ps_tune_set("emb_list_grid", workgroups) of that role
 int g_super_in_update = 1;  // ps_tune_set("super_in_update", 0): the very long runs' super partials by a launch of their own (k_emb_super_list) again
 int g_emb_lxcd = 1;         // ps_tune_set("emb_lxcd", 0): the long-key role takes the sort's list in order, any XCD (rounds 4-5)
 int g_emb_xcd = 1;          // ps_tune_set("emb_xcd", 0): the embedding backward's keys / tiles dealt round robin instead of XCD by XCD (emb_vblock)
@@ -1692,7 +1703,8 @@ int launch_emb_bwd(EmbBwdArgs a, hipStream_t st, LaunchOpts *lo, unsigned int *w
     a.short_blocks = gr < g_emb_short_grid ? gr : g_emb_short_grid;
     // XCD-affine order (emb_vblock): grids rounded up to multiples of 8 (surplus workgroups find nothing to do)
     // chunked order: the runs above PS_EMB_SUPER_MIN chunks as a role of the reduce launch (super_key_run) when the sort listed them
-    a.super_blocks = (!a.seq_order && a.long_runs && a.long_list && g_super_in_update) ? 64 : 0;
+    a.super_blocks = (!a.seq_order && a.long_runs && a.long_list && g_super_in_update) ? (g_emb_list_grid > 0 ? g_emb_list_grid : 64) : 0;
+    if (a.list_min <= 0 || a.list_min > PS_EMB_SUPER_MIN) a.list_min = PS_EMB_SUPER_MIN;
     if (!a.seq_order) { a.ts_partials = stamp_next("emb_partials"); if (a.long_runs && !a.super_blocks) a.ts_super = stamp_next("emb_super"); }
     a.xcd = (g_emb_xcd && a.short_blocks >= 64 && a.long_blocks % 8 == 0) ? g_emb_xcd : 0;
     // by field pair when the field sort left its table (single-hot batches; ps_tune_set("emb_xcd", 1 | 2): by eighths of the keys / entries again)

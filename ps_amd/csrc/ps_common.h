@@ -122,7 +122,7 @@ int seg_sort_tile();
 bool seg_sort_fits(const int64_t *rows_per_field, int F);
 int seg_sort_scan(SegSortWs &ws, const int64_t *offsets_dev, int B, int F, hipStream_t st);
 int seg_sort_pairs(SegSortWs &ws, int64_t n, const int64_t *row_base_dev, uint32_t *keys_out, uint32_t *vals_out, hipStream_t st, int which = 3);
-extern int g_wide_in_gather;
+extern int g_wide_in_gather, g_emb_list_min, g_emb_list_grid;
 extern int g_mh_seg_sort, g_mh_presort, g_mh_prio, g_slots_in_gather, g_keys_grid, g_emb_xcd, g_emb_lxcd, g_super_in_update, g_fwd_order, g_super_list;
 int sort_ws_alloc(SortWorkspace &ws, int64_t cap);
 void sort_ws_free(SortWorkspace &ws);

@@ -557,8 +557,10 @@ int enqueue_forward(ps_model *m, bool train, bool defer_loss) {
                 const bool want_seq = c.emb_sum_order == PS_SUM_SEQUENTIAL || (c.emb_sum_order == PS_SUM_AUTO && !m->cur_offsets);
                 // (chunked order: the runs above PS_EMB_CHUNK * PS_EMB_SUPER_MIN entries, for k_emb_super_list)
                 const bool want_list = want_seq || g_super_list;
+                // (... or, round 6, above emb_list_min chunks: the update launch's list role takes every run a lane group would walk for long)
+                m->list_min = (g_super_in_update && g_emb_list_min > 0 && g_emb_list_min < PS_EMB_SUPER_MIN) ? g_emb_list_min : PS_EMB_SUPER_MIN;
                 PSCHK(build_segments(m->ws, m->sorted_keys, nnz, m->seg_start, m->seg_id, m->nseg_dev, ss, want_list ? m->long_list : nullptr,
-                                     want_seq ? PS_EMB_SEQ_TILE : PS_EMB_CHUNK * PS_EMB_SUPER_MIN));
+                                     want_seq ? PS_EMB_SEQ_TILE : PS_EMB_CHUNK * m->list_min));
                 m->long_list_valid = want_list; m->nlong_ptr = m->nseg_dev + 1;
             }
         }
@@ -979,6 +981,8 @@ int enqueue_backward(ps_model *m, bool apply) {
     g.sorted_key = m->sorted_keys; g.sorted_ent = m->sorted_ents; g.seg_start = m->seg_start; g.seg_id = m->seg_id;
     g.nseg = m->sh.active ? m->nseg_cur : m->nseg_dev;
     g.long_list = m->long_list_valid ? m->long_list : nullptr;
+    // (the sharded step's and the field sort's lists hold every run above PS_EMB_SEQ_TILE entries: any threshold of at least a chunk will do)
+    g.list_min = (m->sh.active || m->field_sorted) ? ((g_emb_list_min > 0 && g_emb_list_min < PS_EMB_SUPER_MIN) ? g_emb_list_min : PS_EMB_SUPER_MIN) : m->list_min;
     g.nlong = m->nlong_ptr;
     g.ftab = (m->long_list_valid && m->field_sorted) ? reinterpret_cast<const uint32_t *>(m->fs_pub + PS_FS_TAB_OFF(c.F)) : nullptr;
     g.out_slot = (m->sh.active && m->field_sorted) ? m->sh.slot : nullptr;     // (runs field by field, gradients in send order)

@@ -280,6 +280,8 @@ extern "C" int ps_tune_set(const char *knob, int value) {
     if (strcmp(knob, "plan_mid") == 0) { g_plan_mid = value; return PS_OK; }
     if (strcmp(knob, "seg_fused") == 0) { g_seg_fused = value; return PS_OK; }
     if (strcmp(knob, "mh_presort") == 0) { g_mh_presort = value; return PS_OK; }
+    if (strcmp(knob, "emb_list_min") == 0) { g_emb_list_min = value; return PS_OK; }
+    if (strcmp(knob, "emb_list_grid") == 0) { g_emb_list_grid = value; return PS_OK; }
     if (strcmp(knob, "wide_in_gather") == 0) { g_wide_in_gather = value; return PS_OK; }
     if (strcmp(knob, "mh_prio") == 0) { g_mh_prio = value; return PS_OK; }
     if (strcmp(knob, "keys_grid") == 0) { g_keys_grid = value; return PS_OK; }

@@ -171,6 +171,7 @@ struct ps_model {
     // single-hot batches: one-launch field sort (kernels_sort.hip field_sort_segments)
     uint32_t *fs_keys = nullptr, *fs_ents = nullptr, *long_list = nullptr;
     unsigned long long *fs_pub = nullptr; uint32_t fs_epoch = 0;
+    int list_min = 0;                                         // chunks: the chunked order's list holds every run above this many (0: PS_EMB_SUPER_MIN)
     bool long_list_valid = false;                             // the last sort filled long_list / *nlong_ptr
     bool field_sorted = false;                                // ... and it was the one-launch field sort
     const uint32_t *nlong_ptr = nullptr;

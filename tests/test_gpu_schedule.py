@@ -562,7 +562,9 @@ def test_multi_hot_presort_and_one_launch_segments_change_no_bit():
     res = []
     L = N.lib()
     try:
-        for knobs in ({}, {"mh_presort": 0}, {"mh_presort": 1}, {"mh_presort": 2}, {"seg_fused": 0}, {"mh_presort": 0, "seg_fused": 0}, {"mh_presort": 3, "mh_prio": 1}):
+        for knobs in ({}, {"mh_presort": 0}, {"mh_presort": 1}, {"mh_presort": 2}, {"seg_fused": 0}, {"mh_presort": 0, "seg_fused": 0}, {"mh_presort": 3, "mh_prio": 1},
+                      # (the update launch's list role: only the runs with super partials as in round 5 / nearly every chunked run on 7 workgroups / no such role)
+                      {"emb_list_min": 128}, {"emb_list_min": 2, "emb_list_grid": 7}, {"super_in_update": 0}):
             for k, v in knobs.items():
                 N.check(L.ps_tune_set(k.encode(), v))
             kv = ps_amd.KVStore(0, SEED)
@@ -578,9 +580,10 @@ def test_multi_hot_presort_and_one_launch_segments_change_no_bit():
                 b.close()
             gm.close(); kv.close()
             for k in knobs:
-                L.ps_tune_set(k.encode(), {"mh_presort": 3, "mh_prio": 0}.get(k, 1))
+                L.ps_tune_set(k.encode(), {"mh_presort": 3, "mh_prio": 0, "emb_list_min": 16, "emb_list_grid": 256}.get(k, 1))
     finally:
         L.ps_tune_set(b"mh_presort", 3); L.ps_tune_set(b"seg_fused", 1); L.ps_tune_set(b"mh_prio", 0)
+        L.ps_tune_set(b"emb_list_min", 16); L.ps_tune_set(b"emb_list_grid", 256); L.ps_tune_set(b"super_in_update", 1)
     for other in res[1:]:
         for x, y in zip(res[0], other):
             np.testing.assert_array_equal(x, y)
