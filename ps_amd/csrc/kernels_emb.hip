@@ -663,8 +663,12 @@ __device__ __forceinline__ void finish_key(const EmbBwdArgs &a, uint32_t u, uint
 #define SEQ_ILP 4
 #define SEQ_TILE PS_EMB_SEQ_TILE  // SEQ mode: keys above this many entries go to a long-key workgroup (at most one such run
                                   // can start in a SEQ_TILE-entry tile); 16 keeps the short role at 64 row registers
-#define SEQ_LONG_GRID 2048        // long-key workgroups when the sort handed over a list of the long runs (round 4: 512 -> 2048, ~1500 runs above 16 entries
-                                  // in a configs[1] batch: one run per workgroup instead of three in a row; 0.1333 -> 0.1325 ms / step)
+#define SEQ_LONG_GRID 1024        // long-key workgroups when the sort handed over a list of the long runs (round 4: 512 -> 2048, ~1500 runs above 16 entries
+                                  // in a configs[1] batch: one run per workgroup instead of three in a row; 0.1333 -> 0.1325 ms / step.  Round 6: 2048 -> 1024.
+                                  // The launch is bound by how fast its workgroups are PLACED (tools/emb_timing.sh: 3712 workgroups, starts spread over
+                                  // 17.6 of its 19.1 us, the short role's first workgroup placed at 12 us behind 2048 long-role ones of which 500 find no
+                                  // run); with the list dealt by eighths since round 6 two runs in a row cost less than the 1024 placements: 0.1341 ->
+                                  // 0.1323 ms / step, flat from 512 to 1024, the clamped id law 0.1401 either way: profiles/r06_emb_list_role.txt)
 #define SUPER_LDS_FLOATS 4096     // the chunked order's super role: super partials of one round (16 KB)
 #define SEQ_LDS_FLOATS 4096       // per buffer: D * (3 * (64 / LPR) * SEQ_ILP + 4) <= 768 * VEC + 4 * D
 __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, uint32_t magic, uint32_t &rem) {
