@@ -569,7 +569,7 @@ def gather_roofline(kv, args):
     return res
 
 
-def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
+def ingest_fed_leg(cfg, resident_examples_per_s, epochs=5):
     """configs[1] trained STRAIGHT FROM libsvm TEXT (data/DataSet.java:77-100's reader threads, data/LibsvmParser.java:13-25,
     CTR.java:47-68) through ps_ingest_*: CTR-shaped lines (label + 26 `idx:1` + 13 `idx:val`) held in memory, parsed by
     min(nproc, 32) host threads into a ring of pinned batches, groups of batches per H2D copy, the same fused step on the batches as they
@@ -604,13 +604,17 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
     # training from the pipeline
     ds.train(gm)                                    # one epoch of warm-up (ps_ingest_train: CTR.java:84-100's loop, in C)
     gm.sync(); ds.reset()
-    t0 = time.perf_counter()
-    steps = 0
+    # (every epoch timed on its own, the MEDIAN reported with all of them beside it: this leg is the one the host's other activity
+    #  reaches -- on one box two runs minutes apart read 0.181 and 0.153 ms per step; the mean of two epochs was whichever it met)
+    steps, ep_ms = 0, []
     for _ in range(epochs):
-        steps += ds.train(gm)
+        t0 = time.perf_counter()
+        n_ep = ds.train(gm)
+        gm.sync()
+        ep_ms.append(1e3 * (time.perf_counter() - t0) / max(n_ep, 1))
+        steps += n_ep
         ds.reset()
-    gm.sync()
-    dt = time.perf_counter() - t0
+    dt = 1e-3 * float(np.median(ep_ms)) * steps
     st1 = ds.stats()
     loss = gm.train(ps_amd.DeviceBatch(kv, *synth_batch(cfg, rng)))
     ds.close(); gm.close(); kv.close()
@@ -618,7 +622,7 @@ def ingest_fed_leg(cfg, resident_examples_per_s, epochs=2):
     block = B * (F * 8 * (2 if cfg["wide"] else 1) + X * 4 + 4)
     fed = B * steps / dt
     out = {"workload": "configs[1] from libsvm text in memory: %d lines (%.1f MB), %d parser threads, ring of pinned batches, groups of batches per H2D copy" % (nbatch * B, len(text) / 1e6, threads),
-           "steps": steps, "ms_per_step": 1e3 * dt / steps, "examples_per_s": fed,
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "epochs_ms_per_step": [round(x, 5) for x in ep_ms], "examples_per_s": fed,
            "resident_examples_per_s": resident_examples_per_s, "fed_over_resident": fed / resident_examples_per_s,
            "pipeline_alone_lines_per_s": k * B / pipe_dt,
            "parser": {"threads": threads, "thread_us_per_line": 1e6 * thread_s_per_line, "lines_per_s_all_threads": threads / thread_s_per_line,
